@@ -1,0 +1,159 @@
+/*
+ * atomdev — C-ABI of the MI355X dynamical-core library (libatomdev.so).
+ *
+ * One handle = one model (atmosphere or hydrosphere) on one GPU: it owns every
+ * field of that model as a flat fp64 array in HBM, index (i*jm + j)*km + k
+ * (i = radius, j = theta, k = phi, phi fastest), plus a derived 1-byte land
+ * mask.  The entry points below are what the reference's per-slice loops call
+ * on its jagged host `Array`s; each comment names the reference method it
+ * replaces.  All functions return 0 on success, non-zero on error (the text is
+ * available from atomdev_last_error()); nothing throws across this boundary.
+ * One caller thread per handle; all work of a handle is ordered on the
+ * handle's own HIP stream, and only atomdev_sync / download / the query
+ * functions wait for it.
+ */
+#ifndef ATOMDEV_H_
+#define ATOMDEV_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct atomdev atomdev_t;
+
+enum atomdev_model {
+    ATOMDEV_ATM = 0, /* cAtmosphereModel fields and operators */
+    ATOMDEV_HYD = 1  /* cHydrosphereModel fields and operators */
+};
+
+/* 3-D fields (im*jm*km doubles each).  Names follow the members of
+ * cAtmosphereModel (atmosphere/cAtmosphereModel.h:179-228) and
+ * cHydrosphereModel (hydrosphere/cHydrosphereModel.h:62-96). */
+enum atomdev_field3d {
+    ATOMDEV_T = 0, ATOMDEV_U, ATOMDEV_V, ATOMDEV_W, ATOMDEV_P_DYN, ATOMDEV_C,
+    ATOMDEV_CLOUD, ATOMDEV_ICE, ATOMDEV_CO2,                       /* 0..8  state            */
+    ATOMDEV_TN = 9, ATOMDEV_UN, ATOMDEV_VN, ATOMDEV_WN, ATOMDEV_P_DYNN, ATOMDEV_CN,
+    ATOMDEV_CLOUDN, ATOMDEV_ICEN, ATOMDEV_CO2N,                    /* 9..17 "new" copies     */
+    ATOMDEV_H = 18,                                                /* 1.0 = solid, else fluid */
+    ATOMDEV_AUX_U = 19, ATOMDEV_AUX_V, ATOMDEV_AUX_W,
+    ATOMDEV_BUOYANCY = 22,       /* BuoyancyForce (atm) / BuoyancyForce_3D (hyd) */
+    ATOMDEV_S_V = 23, ATOMDEV_S_C, ATOMDEV_S_I, ATOMDEV_S_R, ATOMDEV_S_S, /* atm sources */
+    ATOMDEV_SALT_BALANCE = 28, ATOMDEV_SALT_FINGER, ATOMDEV_SALT_DIFFUSION,
+    ATOMDEV_R_WATER, ATOMDEV_R_SALT_WATER,                         /* hyd only */
+    ATOMDEV_RESIDUUM = 33,       /* continuity residuum written by *_residuum3d/2d */
+    ATOMDEV_N3D = 34
+};
+
+/* 2-D fields (jm*km doubles each, index j*km + k). */
+enum atomdev_field2d {
+    ATOMDEV_TOPOGRAPHY = 0,        /* Topography (atm) / Bathymetry (hyd), metres */
+    ATOMDEV_EVAPORATION_DALTON = 1,
+    ATOMDEV_PRECIPITATION = 2,
+    ATOMDEV_N2D = 3
+};
+
+/* Scalars the hot path reads.  Names and meaning are those of the reference's
+ * parameters (param.py:9-178) and grid constants
+ * (atmosphere/cAtmosphereModel.cpp:38-55, hydrosphere/cHydrosphereModel.cpp:145-156). */
+typedef struct atomdev_params {
+    double dt, dr, dthe, dphi;  /* step sizes                                     */
+    double r0, the0, phi0;      /* coordinate origins; rad/the/phi are built by
+                                   repeated addition like Array_1D::Coordinates   */
+    double re, pr, g, Buoyancy, u_0, t_0, c_0;
+    /* atmosphere */
+    double sc_WaterVapour, sc_CO2, gam, r_air, R_Air, R_WaterVapour, L_atm, cp_l,
+           t_tropopause;
+    /* hydrosphere */
+    double sc, L_hyd, r_0_water, ta, pa, ca;
+} atomdev_params;
+
+/* Fills *p with the reference defaults for `model` on the 1-degree grid. */
+void atomdev_default_params(int model, atomdev_params* p);
+
+const char* atomdev_last_error(void);
+
+/* Field store: replaces lib/Array.{h,cpp} + Array_2D + Array_1D for this path.
+ * device < 0 selects the current HIP device. */
+int atomdev_create(int model, int im, int jm, int km, const atomdev_params* p,
+                   int device, atomdev_t** out);
+int atomdev_destroy(atomdev_t* h);
+int atomdev_dims(const atomdev_t* h, int* im, int* jm, int* km);
+int atomdev_upload(atomdev_t* h, int field3d, const double* host);
+int atomdev_download(atomdev_t* h, int field3d, double* host);
+int atomdev_upload2d(atomdev_t* h, int field2d, const double* host);
+int atomdev_download2d(atomdev_t* h, int field2d, double* host);
+int atomdev_fill(atomdev_t* h, int field3d, double value); /* Array::initArray */
+int atomdev_sync(atomdev_t* h);
+
+/* AtomUtils::move_data_to_new_arrays (lib/Utils.cpp:41-68), coeff = 1.
+ * level < 0: the 3-D lists (atm: u v w t p_dyn c cloud ice co2; hyd: u v w t
+ * p_dyn c), every level.  level >= 0: the 2-D lists (v w p_dyn) at that level. */
+int atomdev_move_data_to_new_arrays(atomdev_t* h, int level);
+
+/* ---- atmosphere ---- */
+/* BC_Atmosphere::BC_radius / BC_theta / BC_phi (atmosphere/BC_Atm.cpp:39-150) */
+int atomdev_atm_bc_radius(atomdev_t* h);
+int atomdev_atm_bc_theta(atomdev_t* h);
+int atomdev_atm_bc_phi(atomdev_t* h);
+/* BC_Thermo::Value_Limitation_Atm (atmosphere/BC_Thermo.cpp:3235-3275) */
+int atomdev_atm_value_limitation(atomdev_t* h);
+/* BC_Bathymetry_Atmosphere::BC_SolidGround (atmosphere/BC_Bath_Atm.cpp:94-119) */
+int atomdev_atm_solid_ground(atomdev_t* h);
+/* RungeKutta_Atmosphere::solveRungeKutta_3D_Atmosphere + RHS_Atmosphere::
+ * RK_RHS_3D_Atmosphere (atmosphere/RungeKutta_Atm.cpp:32-156, RHS_Atm.cpp:68-493) */
+int atomdev_atm_rk3d(atomdev_t* h);
+/* solveRungeKutta_2D_Atmosphere + RK_RHS_2D_Atmosphere
+ * (atmosphere/RungeKutta_Atm.cpp:163-217, RHS_Atm.cpp:498-678) */
+int atomdev_atm_rk2d(atomdev_t* h);
+/* Pressure_Atm::computePressure_3D / _2D (atmosphere/Pressure_Atm.cpp:39-301) */
+int atomdev_atm_pressure3d(atomdev_t* h);
+int atomdev_atm_pressure2d(atomdev_t* h);
+/* Accuracy_Atm::residuumQuery_3D / _2D (atmosphere/Accuracy_Atm.cpp:54-116).
+ * *min and loc carry the object's state (min, i_res, j_res, k_res) in and out,
+ * as the reference reuses one object for the before/after calls.  The residuum
+ * field is left in ATOMDEV_RESIDUUM. loc = {i, j, k} ({0, j, k} for 2-D). */
+int atomdev_atm_residuum3d(atomdev_t* h, double* min, int loc[3]);
+int atomdev_atm_residuum2d(atomdev_t* h, double* min, int loc[3]);
+/* Accuracy_Atm::steadyQuery_3D (atmosphere/Accuracy_Atm.cpp:192-337): max |x - xn|
+ * and its first location, order u v w t c cloud ice co2 p_dyn; loc = 9 x {i,j,k}. */
+int atomdev_atm_steady3d(atomdev_t* h, double out[9], int loc[27]);
+/* Accuracy_Atm::steadyQuery_2D (:118-177) on level 0: order v w p_dyn. */
+int atomdev_atm_steady2d(atomdev_t* h, double out[3], int loc[9]);
+
+/* ---- hydrosphere ---- */
+/* BC_Hydrosphere::RB_radius / RB_theta / RB_phi (hydrosphere/BC_Hyd.cpp:38-158) */
+int atomdev_hyd_bc_radius(atomdev_t* h);
+int atomdev_hyd_bc_theta(atomdev_t* h);
+int atomdev_hyd_bc_phi(atomdev_t* h);
+/* BC_Thermohalin::Value_Limitation_Hyd (hydrosphere/BC_Thermohalin.cpp:699-722) */
+int atomdev_hyd_value_limitation(atomdev_t* h);
+/* BC_Bathymetry_Hydrosphere::BC_SolidGround (hydrosphere/BC_Bath_Hyd.cpp:120-139) */
+int atomdev_hyd_solid_ground(atomdev_t* h);
+/* solveRungeKutta_3D_Hydrosphere + RK_RHS_3D_Hydrosphere
+ * (hydrosphere/RungeKutta_Hyd.cpp:30-124, RHS_Hyd.cpp:60-447) */
+int atomdev_hyd_rk3d(atomdev_t* h);
+/* solveRungeKutta_2D_Hydrosphere + RK_RHS_2D_Hydrosphere
+ * (hydrosphere/RungeKutta_Hyd.cpp:130-186, RHS_Hyd.cpp:453-653) */
+int atomdev_hyd_rk2d(atomdev_t* h);
+/* Pressure_Hyd::computePressure_3D / _2D (hydrosphere/Pressure_Hyd.cpp:42-317) */
+int atomdev_hyd_pressure3d(atomdev_t* h);
+int atomdev_hyd_pressure2d(atomdev_t* h);
+/* Accuracy_Hyd::residuumQuery_3D (hydrosphere/Accuracy_Hyd.cpp:88-116): state is
+ * reset on every call and the comparison is >=. */
+int atomdev_hyd_residuum3d(atomdev_t* h, double* min, int loc[3]);
+/* Accuracy_Hyd::steadyQuery_3D (:121-184): order u v w t c p_dyn, >= comparison
+ * (last location of the maximum); loc = 6 x {i,j,k}. */
+int atomdev_hyd_steady3d(atomdev_t* h, double out[6], int loc[18]);
+
+/* HIP-event timing on the handle's stream (for benchmarks): everything enqueued
+ * between start and stop is measured; stop waits for it. */
+int atomdev_timer_start(atomdev_t* h);
+int atomdev_timer_stop(atomdev_t* h, float* milliseconds);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ATOMDEV_H_ */

@@ -1,0 +1,1137 @@
+/*
+ * atom_oracle.c — CPU restatement of ATOM's dynamical-core hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the parity checker for the HIP
+ * library: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may build, load or call it.  Nothing under atom_amd/ links or imports it.
+ *
+ * It restates, on flat (i*jm+j)*km+k arrays and in plain C, the arithmetic of
+ * the reference classes, statement for statement where rounding is concerned
+ * (same association order, same dead terms, same in-place lexicographic sweep
+ * order, same quirks).  Each function cites the reference lines it follows.
+ * Pinned bit-for-bit against the compiled reference (oracle/_ref) by
+ * tests/test_oracle_vs_reference.py and against tests/golden/*.npz, which
+ * oracle/make_golden.py generated from that compiled reference.
+ *
+ * Build: gcc -O2 -ffp-contract=off -fPIC -shared (x86-64 baseline: no FMA, like
+ * the reference's own objects).
+ */
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/atomdev.h"
+
+typedef struct oracle_ctx {
+    int model, im, jm, km;
+    atomdev_params p;
+    double* f[ATOMDEV_N3D]; /* bound by the caller (numpy buffers), not owned */
+    double* g[ATOMDEV_N2D];
+    double *rad, *the, *phi; /* owned */
+} oracle_ctx;
+
+#define IDX(c, i, j, k) (((size_t)(i) * (size_t)(c)->jm + (size_t)(j)) * (size_t)(c)->km + (size_t)(k))
+#define A3(c, F, i, j, k) ((c)->f[F][IDX(c, i, j, k)])
+#define A2(c, G, j, k) ((c)->g[G][(size_t)(j) * (size_t)(c)->km + (size_t)(k)])
+
+/* lib/Array_1D.cpp:54-65 — coordinates by repeated addition */
+static void coordinates(double* z, int n, double z0, double dz) {
+    z[0] = z0;
+    for (int l = 1; l < n; l++) z[l] = z[l - 1] + dz;
+}
+
+oracle_ctx* oracle_create(int model, int im, int jm, int km, const atomdev_params* p) {
+    oracle_ctx* c = (oracle_ctx*)calloc(1, sizeof(oracle_ctx));
+    c->model = model; c->im = im; c->jm = jm; c->km = km; c->p = *p;
+    c->rad = (double*)malloc(sizeof(double) * (size_t)(im > 41 ? im : 41));
+    c->the = (double*)malloc(sizeof(double) * (size_t)jm);
+    c->phi = (double*)malloc(sizeof(double) * (size_t)km);
+    coordinates(c->rad, im > 41 ? im : 41, p->r0, p->dr);
+    coordinates(c->the, jm, p->the0, p->dthe);
+    coordinates(c->phi, km, p->phi0, p->dphi);
+    return c;
+}
+
+void oracle_destroy(oracle_ctx* c) {
+    if (!c) return;
+    free(c->rad); free(c->the); free(c->phi); free(c);
+}
+
+void oracle_bind3d(oracle_ctx* c, int field, double* ptr) { c->f[field] = ptr; }
+void oracle_bind2d(oracle_ctx* c, int field, double* ptr) { c->g[field] = ptr; }
+
+/* lib/Utils.h:22-32 */
+static inline int is_land(const oracle_ctx* c, int i, int j, int k) {
+    return fabs(A3(c, ATOMDEV_H, i, j, k) - 1) < DBL_EPSILON;
+}
+static inline int is_fluid(const oracle_ctx* c, int i, int j, int k) { return !is_land(c, i, j, k); }
+
+/* ------------------------------------------------------------------------- */
+/* Finite differences of RK_RHS_3D_* for a list of fields.                   */
+/* ------------------------------------------------------------------------- */
+
+enum { DIR_R = 0, DIR_THE = 1, DIR_PHI = 2 };
+#define MAXF 9
+
+typedef struct { double d1[3][MAXF], d2[3][MAXF]; } derivs;
+
+static inline double nb(const oracle_ctx* c, int F, int i, int j, int k, int dir, int o) {
+    if (dir == DIR_R) return A3(c, F, i + o, j, k);
+    if (dir == DIR_THE) return A3(c, F, i, j + o, k);
+    return A3(c, F, i, j, k + o);
+}
+
+/* one-sided 3-point forms towards offset s = +1 / -1 */
+static inline double one_sided_d1(const oracle_ctx* c, int F, int i, int j, int k, int dir, int s,
+                                  double hd, double d) {
+    return hd * (-3. * nb(c, F, i, j, k, dir, 0) + 4. * nb(c, F, i, j, k, dir, s) - nb(c, F, i, j, k, dir, 2 * s)) / (2. * d);
+}
+static inline double one_sided_d2(const oracle_ctx* c, int F, int i, int j, int k, int dir, int s,
+                                  double hd, double dd) {
+    return hd * (2 * nb(c, F, i, j, k, dir, 0) - 2. * nb(c, F, i, j, k, dir, s) + nb(c, F, i, j, k, dir, 2 * s)) / dd;
+}
+
+/*
+ * F[0..nf): fields; index ip = position of p_dyn in F (it has no second
+ * derivative), iu / ic = positions of u and c (the radial land branch builds
+ * the c derivatives from u).  hyd selects the hydrosphere variants.
+ * atmosphere/RHS_Atm.cpp:151-381, hydrosphere/RHS_Hyd.cpp:148-341.
+ */
+static void fd_derivatives(const oracle_ctx* c, const int* F, int nf, int ip, int iu, int ic,
+                           int i, int j, int k, const double hd[3], int hyd, derivs* D) {
+    const int im = c->im, jm = c->jm, km = c->km;
+    const double d[3] = { c->p.dr, c->p.dthe, c->p.dphi };
+    const double dd[3] = { c->p.dr * c->p.dr, c->p.dthe * c->p.dthe, c->p.dphi * c->p.dphi };
+
+    for (int dir = 0; dir < 3; dir++)
+        for (int n = 0; n < nf; n++) {
+            D->d1[dir][n] = hd[dir] * (nb(c, F[n], i, j, k, dir, 1) - nb(c, F[n], i, j, k, dir, -1)) / (2. * d[dir]);
+            D->d2[dir][n] = hd[dir] * (nb(c, F[n], i, j, k, dir, 1) - 2. * nb(c, F[n], i, j, k, dir, 0)
+                                        + nb(c, F[n], i, j, k, dir, -1)) / dd[dir];
+        }
+
+    /* radial block: RHS_Atm.cpp:210-243, RHS_Hyd.cpp:191-215 */
+    if (i < im - 2) {
+        int above_is_fluid = hyd ? (A3(c, ATOMDEV_H, i + 1, j, k) == 0.) : is_fluid(c, i + 1, j, k);
+        if (is_land(c, i, j, k) && above_is_fluid) {
+            for (int n = 0; n < nf; n++) {
+                int src = (n == ic) ? F[iu] : F[n]; /* c built from u: RHS_Atm.cpp:217,226; RHS_Hyd.cpp:198,204 */
+                D->d1[DIR_R][n] = one_sided_d1(c, src, i, j, k, DIR_R, +1, hd[DIR_R], d[DIR_R]);
+                if (n != ip) D->d2[DIR_R][n] = one_sided_d2(c, src, i, j, k, DIR_R, +1, hd[DIR_R], dd[DIR_R]);
+            }
+        } else {
+            for (int n = 0; n < nf; n++) {
+                double fwd = (nb(c, F[n], i, j, k, DIR_R, 1) - nb(c, F[n], i, j, k, DIR_R, 0));
+                /* hydrosphere drops h_d_i here: RHS_Hyd.cpp:206-211 */
+                D->d1[DIR_R][n] = hyd ? fwd / d[DIR_R] : hd[DIR_R] * fwd / d[DIR_R];
+                if (n != ip) D->d2[DIR_R][n] = 0.;
+            }
+        }
+    }
+
+    /* theta block: "north" branch, then unconditionally the "south" branch.
+       RHS_Atm.cpp:245-312, RHS_Hyd.cpp:218-278 */
+    if ((j >= 2) && (j < jm - 3)) {
+        for (int s = +1; s >= -1; s -= 2) {
+            if (is_land(c, i, j, k) && (is_fluid(c, i, j + s, k) && is_fluid(c, i, j + 2 * s, k))) {
+                for (int n = 0; n < nf; n++) {
+                    D->d1[DIR_THE][n] = one_sided_d1(c, F[n], i, j, k, DIR_THE, s, hd[DIR_THE], d[DIR_THE]);
+                    if (n != ip) D->d2[DIR_THE][n] = one_sided_d2(c, F[n], i, j, k, DIR_THE, s, hd[DIR_THE], dd[DIR_THE]);
+                }
+            } else {
+                for (int n = 0; n < nf; n++) {
+                    double a = nb(c, F[n], i, j, k, DIR_THE, s > 0 ? 1 : 0);
+                    double b = nb(c, F[n], i, j, k, DIR_THE, s > 0 ? 0 : -1);
+                    D->d1[DIR_THE][n] = hd[DIR_THE] * (a - b) / d[DIR_THE];
+                    if (n != ip) D->d2[DIR_THE][n] = 0.;
+                }
+            }
+        }
+    }
+
+    /* phi block. RHS_Atm.cpp:315-381, RHS_Hyd.cpp:281-341.  The hydrosphere's
+       one-sided branches assign the *theta* second derivatives (RHS_Hyd.cpp:296-300,326-330). */
+    if ((k >= 2) && (k < km - 3)) {
+        for (int s = +1; s >= -1; s -= 2) {
+            if (is_land(c, i, j, k) && is_fluid(c, i, j, k + s) && is_fluid(c, i, j, k + 2 * s)) {
+                for (int n = 0; n < nf; n++) {
+                    D->d1[DIR_PHI][n] = one_sided_d1(c, F[n], i, j, k, DIR_PHI, s, hd[DIR_PHI], d[DIR_PHI]);
+                    if (n != ip) D->d2[hyd ? DIR_THE : DIR_PHI][n] =
+                        one_sided_d2(c, F[n], i, j, k, DIR_PHI, s, hd[DIR_PHI], dd[DIR_PHI]);
+                }
+            } else {
+                for (int n = 0; n < nf; n++) {
+                    double a = nb(c, F[n], i, j, k, DIR_PHI, s > 0 ? 1 : 0);
+                    double b = nb(c, F[n], i, j, k, DIR_PHI, s > 0 ? 0 : -1);
+                    D->d1[DIR_PHI][n] = hd[DIR_PHI] * (a - b) / d[DIR_PHI];
+                    if (n != ip) D->d2[DIR_PHI][n] = 0.;
+                }
+            }
+        }
+    }
+}
+
+/* Immersed-boundary factors. RHS_Atm.cpp:108-149, RHS_Hyd.cpp:94-139.
+ * out: h0[3] = {h_0_i, h_0_j, h_0_k}, hd[3] = {h_d_i, h_d_j, h_d_k}. */
+static void ib_factors(const oracle_ctx* c, int i, int j, int k, int hyd, double L, double h0[3], double hd[3]) {
+    const double cc = 1., dist_coeff = 1.;
+    const double dthe = c->p.dthe, dphi = c->p.dphi;
+    double topo_step = L / (double)(c->im - 1);
+    double hight = (double)i * topo_step;
+    double topo_diff = hyd ? fabs(hight - A2(c, ATOMDEV_TOPOGRAPHY, j, k)) : hight - A2(c, ATOMDEV_TOPOGRAPHY, j, k);
+    double h_0_i = topo_diff / topo_step;
+    double h_d_i = 0, h_0_0 = 0;
+    int below_solid = hyd ? (A3(c, ATOMDEV_H, i - 1, j, k) == 1.) : is_land(c, i - 1, j, k);
+    if ((topo_diff < topo_step) && (is_fluid(c, i, j, k) && below_solid)) {
+        h_0_0 = 1. - h_0_i;
+        h_d_i = cc * (1. - h_0_0);
+    }
+    if ((topo_diff == topo_step) || is_fluid(c, i, j, k)) {
+        h_0_i = 1.;
+        h_d_i = cc * (1. - h_0_i);
+    }
+    double dist = 0, h_0_j = 0, h_d_j = 0;
+    if ((is_fluid(c, i, j, k) && is_land(c, i, j - 1, k)) || (is_fluid(c, i, j, k) && is_land(c, i, j + 1, k))) {
+        dist = dist_coeff * dthe;
+        h_0_j = dist / dthe;
+        h_d_j = cc * (1. - h_0_j);
+    } else {
+        h_0_j = 0.;
+        h_d_j = cc * (1. - h_0_j);
+    }
+    double h_0_k = 0, h_d_k = 0;
+    if ((is_fluid(c, i, j, k) && is_land(c, i, j, k - 1)) || (is_fluid(c, i, j, k) && is_land(c, i, j, k + 1))) {
+        dist = dist_coeff * dphi;
+        h_0_k = dist / dphi;
+        h_d_k = cc * (1. - h_0_k);
+    } else {
+        h_0_k = 0.;
+        h_d_j = cc * (1. - h_0_k); /* assigns h_d_j, not h_d_k: RHS_Atm.cpp:148, RHS_Hyd.cpp:138 */
+    }
+    h0[0] = h_0_i; h0[1] = h_0_j; h0[2] = h_0_k;
+    hd[0] = h_d_i; hd[1] = h_d_j; hd[2] = h_d_k;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Atmosphere                                                                */
+/* ------------------------------------------------------------------------- */
+
+enum { AU = 0, AV, AW, AT, AP, AC, ACL, AIC, ACO };
+static const int ATM_F[9] = { ATOMDEV_U, ATOMDEV_V, ATOMDEV_W, ATOMDEV_T, ATOMDEV_P_DYN,
+                              ATOMDEV_C, ATOMDEV_CLOUD, ATOMDEV_ICE, ATOMDEV_CO2 };
+
+/* RHS_Atmosphere::RK_RHS_3D_Atmosphere, atmosphere/RHS_Atm.cpp:68-493.
+ * rhs order: t u v w c cloud ice co2. */
+static void atm_rhs3d(oracle_ctx* c, int i, int j, int k, double rhs[8]) {
+    const atomdev_params* P = &c->p;
+    const double k_Force = 1.;
+    const double dr = P->dr, dthe = P->dthe, dphi = P->dphi, re = P->re;
+    double dr2 = dr * dr, dthe2 = dthe * dthe, dphi2 = dphi * dphi;
+    double rm = c->rad[i], rm2 = rm * rm;
+    double sinthe = sin(c->the[j]), sinthe2 = sinthe * sinthe, costhe = cos(c->the[j]);
+    double rmsinthe = rm * sinthe, rm2sinthe = rm2 * sinthe, rm2sinthe2 = rm2 * sinthe2;
+
+    double h0[3], hd[3];
+    ib_factors(c, i, j, k, 0, P->L_atm, h0, hd);
+    const double h_0_i = h0[0], h_0_j = h0[1], h_0_k = h0[2];
+    const double h_d_i = hd[0], h_d_j = hd[1], h_d_k = hd[2];
+
+    derivs D;
+    fd_derivatives(c, ATM_F, 9, AP, AU, AC, i, j, k, hd, 0, &D);
+#define DR(n) D.d1[DIR_R][n]
+#define DT(n) D.d1[DIR_THE][n]
+#define DP(n) D.d1[DIR_PHI][n]
+#define D2R(n) D.d2[DIR_R][n]
+#define D2T(n) D.d2[DIR_THE][n]
+#define D2P(n) D.d2[DIR_PHI][n]
+
+    const double u = A3(c, ATOMDEV_U, i, j, k), v = A3(c, ATOMDEV_V, i, j, k), w = A3(c, ATOMDEV_W, i, j, k);
+    const double t0jk = A3(c, ATOMDEV_T, 0, j, k);
+
+    /* RHS_Atm.cpp:384-410 */
+    double exp_pressure = P->g / (1.e-2 * P->gam * P->R_Air);
+    double t_u = A3(c, ATOMDEV_T, i, j, k) * P->t_0;
+    double p_SL = .01 * (P->r_air * P->R_Air * t0jk * P->t_0);
+    double hight = (double)i * (P->L_atm / (double)(c->im - 1));
+    double p_h = pow(((t0jk * P->t_0 - P->gam * hight * 1.e-2) / (t0jk * P->t_0)), exp_pressure) * p_SL;
+    double r_dry = 100. * p_h / (P->R_Air * t_u);
+
+    double coeff_energy = P->L_atm / (P->cp_l * P->t_0 * P->u_0);
+    double coeff_buoy = P->r_air * P->u_0 * P->u_0 / P->L_atm;
+    double coeff_trans = P->L_atm / P->u_0;
+    double vapour_evaporation = 0., vapour_surface = 0., evap_precip = 0.;
+    double coeff_vapour = 1.1574e-5 * P->L_atm / P->u_0;
+
+    double cc_ = A3(c, ATOMDEV_C, i, j, k);
+    double r_humid = r_dry * (1. + cc_) / (1. + P->R_WaterVapour / P->R_Air * cc_);
+    double RS_buoyancy_Momentum = P->Buoyancy * (r_humid - r_dry) / r_dry * P->g;
+
+    A3(c, ATOMDEV_BUOYANCY, i, j, k) = -RS_buoyancy_Momentum * coeff_buoy * 1000.;
+    if (is_land(c, i, j, k)) A3(c, ATOMDEV_BUOYANCY, i, j, k) = 0.;
+
+    /* RHS_Atm.cpp:412-430 (note c at level 3, not 2) */
+    if (i == 1) {
+        evap_precip = A2(c, ATOMDEV_EVAPORATION_DALTON, j, k) - A2(c, ATOMDEV_PRECIPITATION, j, k);
+        if (evap_precip >= 6.) evap_precip = 6.;
+        if (evap_precip <= -6.) evap_precip = -6.;
+        vapour_surface = r_humid * (-3. * A3(c, ATOMDEV_C, 0, j, k) + 4. * A3(c, ATOMDEV_C, 1, j, k)
+                                    - A3(c, ATOMDEV_C, 3, j, k)) / (2. * dr)
+                         * (1. - 2. * A3(c, ATOMDEV_C, 0, j, k)) * evap_precip;
+        vapour_evaporation = +coeff_vapour * vapour_surface;
+        if (is_land(c, i, j, k)) vapour_evaporation = 0.;
+    } else {
+        vapour_evaporation = 0.;
+    }
+
+    const double S_v = A3(c, ATOMDEV_S_V, i, j, k), S_c = A3(c, ATOMDEV_S_C, i, j, k),
+                 S_i = A3(c, ATOMDEV_S_I, i, j, k), S_r = A3(c, ATOMDEV_S_R, i, j, k),
+                 S_s = A3(c, ATOMDEV_S_S, i, j, k);
+
+    /* RHS_Atm.cpp:432-483 */
+    double rhs_t = -(u * DR(AT) + v * DT(AT) / rm + w * DP(AT) / rmsinthe)
+                   + (D2R(AT) + DR(AT) * 2. / rm + D2T(AT) / rm2 + DT(AT) * costhe / rm2sinthe + D2P(AT) / rm2sinthe2) / (re * P->pr)
+                   + coeff_energy * (S_c + S_r)
+                   + coeff_energy * (S_i + S_s);
+
+    double rhs_u = -(u * DR(AU) + v * DT(AU) / rm + w * DP(AU) / rmsinthe)
+                   - h_d_i * DR(AP) / P->r_air
+                   + (D2R(AU) + h_d_i * 2. * u / rm2 + D2T(AU) / rm2 + 4. * DR(AU) / rm + DT(AU) * costhe / rm2sinthe + D2P(AU) / rm2sinthe2) / re
+                   - RS_buoyancy_Momentum
+                   - h_0_i * u * k_Force / dr2;
+
+    double rhs_v = -(u * DR(AV) + v * DT(AV) / rm + w * DP(AV) / rmsinthe)
+                   + -h_d_j * DT(AP) / rm / P->r_air
+                   + (D2R(AV) + DR(AV) * 2. / rm + D2T(AV) / rm2 + DT(AV) / rm2sinthe * costhe
+                      - (1. + costhe * costhe / (rm * sinthe2)) * h_d_j * v + D2P(AV) / rm2sinthe2
+                      + 2. * DT(AU) / rm2 - DP(AW) * 2. * costhe / rm2sinthe2) / re
+                   - h_0_j * v * k_Force / dthe2;
+
+    double rhs_w = -(u * DR(AW) + v * DT(AW) / rm + w * DP(AW) / rmsinthe)
+                   + -h_d_k * DP(AP) / rmsinthe / P->r_air
+                   + (D2R(AW) + DR(AW) * 2. / rm + D2T(AW) / rm2 + DT(AW) / rm2sinthe * costhe
+                      - (1. + costhe * costhe / (rm * sinthe2)) * h_d_k * w
+                      + D2P(AW) / rm2sinthe2 + 2. * DP(AU) / rm2sinthe + DP(AV) * 2. * costhe / rm2sinthe2) / re
+                   - h_0_k * w * k_Force / dphi2;
+
+    double rhs_c = -(u * DR(AC) + v * DT(AC) / rm + w * DP(AC) / rmsinthe)
+                   + (D2R(AC) + DR(AC) * 2. / rm + D2T(AC) / rm2 + DT(AC) * costhe / rm2sinthe + D2P(AC) / rm2sinthe2) / (P->sc_WaterVapour * re)
+                   + S_v * coeff_trans
+                   + vapour_evaporation;
+
+    double cloud = A3(c, ATOMDEV_CLOUD, i, j, k), ice = A3(c, ATOMDEV_ICE, i, j, k), co2 = A3(c, ATOMDEV_CO2, i, j, k);
+    double rhs_cloud = -(u * DR(ACL) + v * DT(ACL) / rm + w * DP(ACL) / rmsinthe)
+                       + (D2R(ACL) + DR(ACL) * 2. / rm + D2T(ACL) / rm2 + DT(ACL) * costhe / rm2sinthe + D2P(ACL) / rm2sinthe2) / (P->sc_WaterVapour * re)
+                       + S_c * coeff_trans
+                       - h_0_i * cloud * k_Force / dr2;
+
+    double rhs_ice = -(u * DR(AIC) + v * DT(AIC) / rm + w * DP(AIC) / rmsinthe)
+                     + (D2R(AIC) + DR(AIC) * 2. / rm + D2T(AIC) / rm2 + DT(AIC) * costhe / rm2sinthe + D2P(AIC) / rm2sinthe2) / (P->sc_WaterVapour * re)
+                     + S_i * coeff_trans
+                     - h_0_i * ice * k_Force / dr2;
+
+    double rhs_co2 = -(u * DR(ACO) + v * DT(ACO) / rm + w * DP(ACO) / rmsinthe)
+                     + (D2R(ACO) + DR(ACO) * 2. / rm + D2T(ACO) / rm2 + DT(ACO) * costhe / rm2sinthe + D2P(ACO) / rm2sinthe2) / (P->sc_CO2 * re)
+                     - h_0_i * co2 * k_Force / dr2;
+
+    /* RHS_Atm.cpp:485-492 */
+    A3(c, ATOMDEV_AUX_U, i, j, k) = rhs_u + h_d_i * DR(AP) / P->r_air;
+    A3(c, ATOMDEV_AUX_V, i, j, k) = rhs_v + h_d_j * DT(AP) / rm / P->r_air;
+    A3(c, ATOMDEV_AUX_W, i, j, k) = rhs_w + h_d_k * DP(AP) / rmsinthe / P->r_air;
+    if (is_land(c, i, j, k))
+        A3(c, ATOMDEV_AUX_U, i, j, k) = A3(c, ATOMDEV_AUX_V, i, j, k) = A3(c, ATOMDEV_AUX_W, i, j, k) = 0.;
+
+    rhs[0] = rhs_t; rhs[1] = rhs_u; rhs[2] = rhs_v; rhs[3] = rhs_w;
+    rhs[4] = rhs_c; rhs[5] = rhs_cloud; rhs[6] = rhs_ice; rhs[7] = rhs_co2;
+}
+
+/* RungeKutta_Atmosphere::solveRungeKutta_3D_Atmosphere, atmosphere/RungeKutta_Atm.cpp:32-156.
+ * In-place, lexicographic (i, j, k): a nonlinear Gauss-Seidel sweep. */
+void oracle_atm_rk3d(oracle_ctx* c) {
+    static const int X[8] = { ATOMDEV_T, ATOMDEV_U, ATOMDEV_V, ATOMDEV_W, ATOMDEV_C, ATOMDEV_CLOUD, ATOMDEV_ICE, ATOMDEV_CO2 };
+    static const int XN[8] = { ATOMDEV_TN, ATOMDEV_UN, ATOMDEV_VN, ATOMDEV_WN, ATOMDEV_CN, ATOMDEV_CLOUDN, ATOMDEV_ICEN, ATOMDEV_CO2N };
+    const double dt = c->p.dt;
+    double k1[8], k2[8], k3[8], k4[8];
+    for (int i = 1; i < c->im - 1; i++)
+        for (int j = 1; j < c->jm - 1; j++)
+            for (int k = 1; k < c->km - 1; k++) {
+                atm_rhs3d(c, i, j, k, k1);
+                for (int n = 0; n < 8; n++) A3(c, X[n], i, j, k) = A3(c, XN[n], i, j, k) + k1[n] * .5 * dt;
+                atm_rhs3d(c, i, j, k, k2);
+                for (int n = 0; n < 8; n++) A3(c, X[n], i, j, k) = A3(c, XN[n], i, j, k) + k2[n] * .5 * dt;
+                atm_rhs3d(c, i, j, k, k3);
+                for (int n = 0; n < 8; n++) A3(c, X[n], i, j, k) = A3(c, XN[n], i, j, k) + k3[n] * dt;
+                atm_rhs3d(c, i, j, k, k4);
+                for (int n = 0; n < 8; n++)
+                    A3(c, X[n], i, j, k) = A3(c, XN[n], i, j, k) + dt * (k1[n] + 2. * k2[n] + 2. * k3[n] + k4[n]) / 6.;
+            }
+}
+
+/*
+ * 2-D surface RHS shared by both models: RHS_Atmosphere::RK_RHS_2D_Atmosphere
+ * (atmosphere/RHS_Atm.cpp:498-678) and RHS_Hydrosphere::RK_RHS_2D_Hydrosphere
+ * (hydrosphere/RHS_Hyd.cpp:453-653).  L = level (0 atm; the hydrosphere object
+ * sets im = 41, so L = 40 there).  fluid_c: the hydrosphere tests h == 0.
+ * where the atmosphere tests !is_land.  sin2_only: the atmosphere divides
+ * cos^2 by sinthe2 too (no rm factor) in the 2-D form — both do.
+ */
+static void rhs2d(oracle_ctx* c, int L, int j, int k, int hyd, double rho, double out[2]) {
+    const atomdev_params* P = &c->p;
+    const double k_Force = 1., cc = 1., dist_coeff = 1.;
+    const double dthe = P->dthe, dphi = P->dphi, re = P->re;
+    const int jm = c->jm, km = c->km;
+    double dthe2 = dthe * dthe, dphi2 = dphi * dphi;
+    double rm = c->rad[L], rm2 = rm * rm;
+    double sinthe = sin(c->the[j]), sinthe2 = sinthe * sinthe, costhe = cos(c->the[j]);
+    double rmsinthe = rm * sinthe, rm2sinthe = rm2 * sinthe, rm2sinthe2 = rm2 * sinthe2;
+
+#define V_(jj, kk) A3(c, ATOMDEV_V, L, jj, kk)
+#define W_(jj, kk) A3(c, ATOMDEV_W, L, jj, kk)
+#define P_(jj, kk) A3(c, ATOMDEV_P_DYN, L, jj, kk)
+#define LAND(jj, kk) is_land(c, L, jj, kk)
+#define FLUID(jj, kk) is_fluid(c, L, jj, kk)
+    int centre_fluid = hyd ? (A3(c, ATOMDEV_H, L, j, k) == 0.) : FLUID(j, k);
+
+    double dist = 0, h_0_j = 0, h_d_j = 0;
+    if ((centre_fluid && LAND(j + 1, k)) || (centre_fluid && LAND(j - 1, k))) {
+        dist = dist_coeff * dthe; h_0_j = dist / dthe; h_d_j = cc * (1. - h_0_j);
+    } else { h_0_j = 0.; h_d_j = cc * (1. - h_0_j); }
+    double h_0_k = 0, h_d_k = 0;
+    if ((centre_fluid && LAND(j, k + 1)) || (centre_fluid && LAND(j, k - 1))) {
+        dist = dist_coeff * dphi; h_0_k = dist / dphi; h_d_k = cc * (1. - h_0_k);
+    } else { h_0_k = 0.; h_d_k = cc * (1. - h_0_k); }
+
+    double dvdthe = h_d_j * (V_(j + 1, k) - V_(j - 1, k)) / (2. * dthe);
+    double dwdthe = h_d_j * (W_(j + 1, k) - W_(j - 1, k)) / (2. * dthe);
+    double dpdthe = h_d_j * (P_(j + 1, k) - P_(j - 1, k)) / (2. * dthe);
+    double dvdphi = h_d_k * (V_(j, k + 1) - V_(j, k - 1)) / (2. * dphi);
+    double dwdphi = h_d_k * (W_(j, k + 1) - W_(j, k - 1)) / (2. * dphi);
+    double dpdphi = h_d_k * (P_(j, k + 1) - P_(j, k - 1)) / (2. * dphi);
+    double d2vdthe2 = h_d_j * (V_(j + 1, k) - 2. * V_(j, k) + V_(j - 1, k)) / dthe2;
+    double d2wdthe2 = h_d_j * (W_(j + 1, k) - 2. * W_(j, k) + W_(j - 1, k)) / dthe2;
+    double d2vdphi2 = h_d_k * (V_(j, k + 1) - 2. * V_(j, k) + V_(j, k - 1)) / dphi2;
+    double d2wdphi2 = h_d_k * (W_(j, k + 1) - 2. * W_(j, k) + W_(j, k - 1)) / dphi2;
+
+    /* RHS_Atm.cpp:559-603, RHS_Hyd.cpp:526-570 */
+    if ((j >= 2) && (j < jm - 3)) {
+        for (int s = +1; s >= -1; s -= 2) {
+            if (LAND(j, k) && (FLUID(j + s, k) && FLUID(j + 2 * s, k))) {
+                dvdthe = h_d_j * (-3. * V_(j, k) + 4. * V_(j + s, k) - V_(j + 2 * s, k)) / (2. * dthe);
+                dwdthe = h_d_j * (-3. * W_(j, k) + 4. * W_(j + s, k) - W_(j + 2 * s, k)) / (2. * dthe);
+                dpdthe = h_d_j * (-3. * P_(j, k) + 4. * P_(j + s, k) - P_(j + 2 * s, k)) / (2. * dthe);
+                d2vdthe2 = h_d_j * (2. * V_(j, k) - 2. * V_(j + s, k) + V_(j + 2 * s, k)) / dthe2;
+                d2wdthe2 = h_d_j * (2. * W_(j, k) - 2. * W_(j + s, k) + W_(j + 2 * s, k)) / dthe2;
+            }
+            if (LAND(j, k) && FLUID(j + s, k)) {
+                int a = s > 0 ? j + 1 : j, b = s > 0 ? j : j - 1;
+                dvdthe = h_d_j * (V_(a, k) - V_(b, k)) / dthe;
+                dwdthe = h_d_j * (W_(a, k) - W_(b, k)) / dthe;
+                dpdthe = h_d_j * (P_(a, k) - P_(b, k)) / dthe;
+                d2vdthe2 = d2wdthe2 = 0.;
+            }
+        }
+        d2vdthe2 = d2wdthe2 = 0.;
+    }
+
+    /* RHS_Atm.cpp:605-662, RHS_Hyd.cpp:573-630; the one-sided branches assign
+       d2vdthe2/d2wdthe2 (sic), and everything second-order ends up 0. */
+    if ((k >= 2) && (k < km - 3)) {
+        for (int s = +1; s >= -1; s -= 2) {
+            if (LAND(j, k) && FLUID(j, k + s) && FLUID(j, k + 2 * s)) {
+                dvdphi = h_d_k * (-3. * V_(j, k) + 4. * V_(j, k + s) - V_(j, k + 2 * s)) / (2. * dphi);
+                dwdphi = h_d_k * (-3. * W_(j, k) + 4. * W_(j, k + s) - W_(j, k + 2 * s)) / (2. * dphi);
+                dpdphi = h_d_k * (-3. * P_(j, k) + 4. * P_(j, k + s) - P_(j, k + 2 * s)) / (2. * dphi);
+                d2vdthe2 = h_d_k * (2. * V_(j, k) - 2. * V_(j, k + s) + V_(j, k + 2 * s)) / dphi2;
+                d2wdthe2 = h_d_k * (2. * W_(j, k) - 2. * W_(j, k + s) + W_(j, k + 2 * s)) / dphi2;
+            }
+            if (LAND(j, k) && FLUID(j, k + s)) {
+                int a = s > 0 ? k + 1 : k, b = s > 0 ? k : k - 1;
+                dvdphi = h_d_k * (V_(j, a) - V_(j, b)) / dphi;
+                dwdphi = h_d_k * (W_(j, a) - W_(j, b)) / dphi;
+                dpdphi = h_d_k * (P_(j, a) - P_(j, b)) / dphi;
+                d2vdphi2 = d2wdphi2 = 0.;
+            }
+        }
+        d2vdphi2 = d2wdphi2 = 0.;
+    } else {
+        if (LAND(j, k) && FLUID(j, k + 1)) {
+            dvdphi = h_d_k * (V_(j, k + 1) - V_(j, k)) / dphi;
+            dwdphi = h_d_k * (W_(j, k + 1) - W_(j, k)) / dphi;
+            dpdphi = h_d_k * (P_(j, k + 1) - P_(j, k)) / dphi;
+        }
+        if (centre_fluid && LAND(j, k - 1)) {
+            dvdphi = h_d_k * (V_(j, k) - V_(j, k - 1)) / dphi;
+            dwdphi = h_d_k * (W_(j, k) - W_(j, k - 1)) / dphi;
+            dpdphi = h_d_k * (P_(j, k) - P_(j, k - 1)) / dphi;
+        }
+        d2vdthe2 = d2wdthe2 = 0.;
+        d2vdphi2 = d2wdphi2 = 0.;
+    }
+
+    double v = V_(j, k), w = W_(j, k);
+    /* RHS_Atm.cpp:664-677, RHS_Hyd.cpp:632-645 */
+    double rhs_v = -(v * dvdthe / rm + w * dvdphi / rmsinthe)
+                   + -h_d_j * dpdthe / rm / rho
+                   - (d2vdthe2 / rm2 + dvdthe / rm2sinthe * costhe
+                      - (1. + costhe * costhe / sinthe2) * h_d_j * v
+                      + d2vdphi2 / rm2sinthe2 - dwdphi * 2. * costhe / rm2sinthe2) / re
+                   - h_0_j * v * k_Force / dthe2;
+    double rhs_w = -(v * dwdthe / rm + w * dwdphi / rmsinthe)
+                   + -h_d_k * dpdphi / rmsinthe / rho
+                   + (d2wdthe2 / rm2 + dwdthe / rm2sinthe * costhe
+                      - (1. + costhe * costhe / sinthe2) * h_d_k * w
+                      + d2wdphi2 / rm2sinthe2 + dvdphi * 2. * costhe / rm2sinthe2) / re
+                   - h_0_k * w * k_Force / dphi2;
+    A3(c, ATOMDEV_AUX_V, L, j, k) = rhs_v + h_d_j * dpdthe / rm / rho;
+    A3(c, ATOMDEV_AUX_W, L, j, k) = rhs_w + h_d_k * dpdphi / rmsinthe / rho;
+    out[0] = rhs_v; out[1] = rhs_w;
+#undef V_
+#undef W_
+#undef P_
+#undef LAND
+#undef FLUID
+}
+
+/* 4-stage in-place sweep over a surface: atmosphere/RungeKutta_Atm.cpp:163-217,
+ * hydrosphere/RungeKutta_Hyd.cpp:130-186.  Lrhs = level the RHS object works
+ * on, Lrk = level the RK driver reads/writes (they differ only if a hydrosphere
+ * grid has im != 41). */
+static void rk2d(oracle_ctx* c, int Lrhs, int Lrk, int hyd, double rho) {
+    const double dt = c->p.dt;
+    double k1[2], k2[2], k3[2], k4[2];
+    for (int j = 1; j < c->jm - 1; j++)
+        for (int k = 1; k < c->km - 1; k++) {
+            rhs2d(c, Lrhs, j, k, hyd, rho, k1);
+            A3(c, ATOMDEV_V, Lrk, j, k) = A3(c, ATOMDEV_VN, Lrk, j, k) + k1[0] * .5 * dt;
+            A3(c, ATOMDEV_W, Lrk, j, k) = A3(c, ATOMDEV_WN, Lrk, j, k) + k1[1] * .5 * dt;
+            rhs2d(c, Lrhs, j, k, hyd, rho, k2);
+            A3(c, ATOMDEV_V, Lrk, j, k) = A3(c, ATOMDEV_VN, Lrk, j, k) + k2[0] * .5 * dt;
+            A3(c, ATOMDEV_W, Lrk, j, k) = A3(c, ATOMDEV_WN, Lrk, j, k) + k2[1] * .5 * dt;
+            rhs2d(c, Lrhs, j, k, hyd, rho, k3);
+            A3(c, ATOMDEV_V, Lrk, j, k) = A3(c, ATOMDEV_VN, Lrk, j, k) + k3[0] * dt;
+            A3(c, ATOMDEV_W, Lrk, j, k) = A3(c, ATOMDEV_WN, Lrk, j, k) + k3[1] * dt;
+            rhs2d(c, Lrhs, j, k, hyd, rho, k4);
+            A3(c, ATOMDEV_V, Lrk, j, k) = A3(c, ATOMDEV_VN, Lrk, j, k) + dt * (k1[0] + 2. * k2[0] + 2. * k3[0] + k4[0]) / 6.;
+            A3(c, ATOMDEV_W, Lrk, j, k) = A3(c, ATOMDEV_WN, Lrk, j, k) + dt * (k1[1] + 2. * k2[1] + 2. * k3[1] + k4[1]) / 6.;
+        }
+}
+
+void oracle_atm_rk2d(oracle_ctx* c) { rk2d(c, 0, 0, 0, c->p.r_air); }
+
+/* ------------------------------------------------------------------------- */
+/* Pressure                                                                  */
+/* ------------------------------------------------------------------------- */
+
+static const double c43 = 4. / 3., c13 = 1. / 3.;
+
+/* Pressure_Atm::computePressure_3D (atmosphere/Pressure_Atm.cpp:39-192) and
+ * Pressure_Hyd::computePressure_3D (hydrosphere/Pressure_Hyd.cpp:42-203). */
+static void pressure3d(oracle_ctx* c, int hyd, double rho) {
+    const int im = c->im, jm = c->jm, km = c->km;
+    const double dr = c->p.dr, dthe = c->p.dthe, dphi = c->p.dphi;
+    static const int AUX[3] = { ATOMDEV_AUX_U, ATOMDEV_AUX_V, ATOMDEV_AUX_W };
+#define AU_(i, j, k) A3(c, ATOMDEV_AUX_U, i, j, k)
+#define AV_(i, j, k) A3(c, ATOMDEV_AUX_V, i, j, k)
+#define AW_(i, j, k) A3(c, ATOMDEV_AUX_W, i, j, k)
+#define PD(i, j, k) A3(c, ATOMDEV_P_DYN, i, j, k)
+#define PN(i, j, k) A3(c, ATOMDEV_P_DYNN, i, j, k)
+    for (int j = 0; j < jm; j++)
+        for (int k = 0; k < km; k++) {
+            AU_(0, j, k) = 0.;
+            AU_(im - 1, j, k) = 0.;
+            AV_(0, j, k) = c43 * AV_(1, j, k) - c13 * AV_(2, j, k);
+            AV_(im - 1, j, k) = c43 * AV_(im - 2, j, k) - c13 * AV_(im - 3, j, k);
+            AW_(0, j, k) = c43 * AW_(1, j, k) - c13 * AW_(2, j, k);
+            AW_(im - 1, j, k) = c43 * AW_(im - 2, j, k) - c13 * AW_(im - 3, j, k);
+        }
+    for (int k = 0; k < km; k++)
+        for (int i = 0; i < im; i++)
+            for (int n = 0; n < 3; n++) {
+                A3(c, AUX[n], i, 0, k) = c43 * A3(c, AUX[n], i, 1, k) - c13 * A3(c, AUX[n], i, 2, k);
+                A3(c, AUX[n], i, jm - 1, k) = c43 * A3(c, AUX[n], i, jm - 2, k) - c13 * A3(c, AUX[n], i, jm - 3, k);
+            }
+    for (int i = 0; i < im; i++)
+        for (int j = 0; j < jm; j++)
+            for (int n = 0; n < 3; n++) {
+                A3(c, AUX[n], i, j, 0) = c43 * A3(c, AUX[n], i, j, 1) - c13 * A3(c, AUX[n], i, j, 2);
+                A3(c, AUX[n], i, j, km - 1) = c43 * A3(c, AUX[n], i, j, km - 2) - c13 * A3(c, AUX[n], i, j, km - 3);
+                A3(c, AUX[n], i, j, 0) = A3(c, AUX[n], i, j, km - 1) = (A3(c, AUX[n], i, j, 0) + A3(c, AUX[n], i, j, km - 1)) / 2.;
+            }
+
+    double dr2 = dr * dr, dthe2 = dthe * dthe, dphi2 = dphi * dphi;
+    /* hydrosphere reads aux_v / aux_w at level im-1 for every i: Pressure_Hyd.cpp:137-163 */
+    for (int i = 1; i < im - 1; i++) {
+        double rm = c->rad[i], rm2 = rm * rm;
+        const int la = hyd ? im - 1 : i;
+        for (int j = 1; j < jm - 1; j++) {
+            double sinthe = sin(c->the[j]);
+            double rmsinthe = rm * sinthe;
+            double rm2sinthe2 = rmsinthe * rmsinthe;
+            double denom = 2. / dr2 + 2. / (rm2 * dthe2) + 2. / (rm2sinthe2 * dphi2);
+            double num1 = 1. / dr2, num2 = 1. / (rm2 * dthe2), num3 = 1. / (rm2sinthe2 * dphi2);
+            for (int k = 1; k < km - 1; k++) {
+                double drhs_udr = (AU_(i + 1, j, k) - AU_(i - 1, j, k)) / (2. * dr);
+                if (i <= im - 3) {
+                    int above = hyd ? (A3(c, ATOMDEV_H, i + 1, j, k) == 0.) : is_fluid(c, i + 1, j, k);
+                    if (is_land(c, i, j, k) && above)
+                        drhs_udr = (-3. * AU_(i, j, k) + 4. * AU_(i + 1, j, k) - AU_(i + 2, j, k)) / (2. * dr);
+                } else drhs_udr = (AU_(i + 1, j, k) - AU_(i, j, k)) / dr;
+
+                double drhs_vdthe = (AV_(la, j + 1, k) - AV_(la, j - 1, k)) / (2. * dthe * rm);
+                if (is_land(c, i, j, k) && is_fluid(c, i, j + 1, k))
+                    drhs_vdthe = (AV_(la, j + 1, k) - AV_(la, j, k)) / (dthe * rm);
+                if (is_land(c, i, j, k) && is_fluid(c, i, j - 1, k))
+                    drhs_vdthe = (AV_(la, j - 1, k) - AV_(la, j, k)) / (dthe * rm);
+                if ((j >= 2) && (j <= jm - 3)) {
+                    if (is_land(c, i, j, k) && (is_fluid(c, i, j + 1, k) && is_fluid(c, i, j + 2, k)))
+                        drhs_vdthe = (-3. * AV_(la, j, k) + 4. * AV_(la, j + 1, k) - AV_(la, j + 2, k)) / (2. * dthe * rm);
+                    if (is_land(c, i, j, k) && is_fluid(c, i, j - 1, k) && is_fluid(c, i, j - 2, k))
+                        drhs_vdthe = (-3. * AV_(la, j, k) + 4. * AV_(la, j - 1, k) - AV_(la, j - 2, k)) / (2. * dthe * rm);
+                }
+
+                /* operand order of the divisor differs: Pressure_Atm.cpp:140 vs Pressure_Hyd.cpp:152 */
+                double drhs_wdphi = hyd ? (AW_(la, j, k + 1) - AW_(la, j, k - 1)) / (2. * dphi * rmsinthe)
+                                        : (AW_(la, j, k + 1) - AW_(la, j, k - 1)) / (2. * rmsinthe * dphi);
+                if (is_land(c, i, j, k) && is_fluid(c, i, j, k + 1))
+                    drhs_wdphi = hyd ? (AW_(la, j, k + 1) - AW_(la, j, k)) / (dphi * rmsinthe)
+                                     : (AW_(la, j, k + 1) - AW_(la, j, k)) / (rmsinthe * dphi);
+                /* atmosphere: air cell with land to the west; hydrosphere: land cell with water to the west */
+                if (hyd ? (is_land(c, i, j, k) && is_fluid(c, i, j, k - 1)) : (is_fluid(c, i, j, k) && is_land(c, i, j, k - 1)))
+                    drhs_wdphi = hyd ? (AW_(la, j, k - 1) - AW_(la, j, k)) / (dphi * rmsinthe)
+                                     : (AW_(la, j, k - 1) - AW_(la, j, k)) / (rmsinthe * dphi);
+                if ((k >= 2) && (k <= km - 3)) {
+                    if (is_land(c, i, j, k) && is_fluid(c, i, j, k + 1) && is_fluid(c, i, j, k + 2))
+                        drhs_wdphi = (-3. * AW_(la, j, k) + 4. * AW_(la, j, k + 1) - AW_(la, j, k + 2)) / (2. * rmsinthe * dphi);
+                    if (is_land(c, i, j, k) && is_fluid(c, i, j, k - 1) && is_fluid(c, i, j, k - 2))
+                        drhs_wdphi = (-3. * AW_(la, j, k) + 4. * AW_(la, j, k - 1) - AW_(la, j, k - 2)) / (2. * rmsinthe * dphi);
+                }
+
+                PD(i, j, k) = ((PN(i + 1, j, k) + PN(i - 1, j, k)) * num1
+                               + (PN(i, j + 1, k) + PN(i, j - 1, k)) * num2
+                               + (PN(i, j, k + 1) + PN(i, j, k - 1)) * num3
+                               - rho * (drhs_udr + drhs_vdthe + drhs_wdphi)) / denom;
+                if (!hyd && is_land(c, i, j, k)) PD(i, j, k) = .0; /* Pressure_Atm.cpp:157 only */
+            }
+        }
+    }
+    for (int j = 0; j < jm; j++)
+        for (int k = 0; k < km; k++) {
+            PD(0, j, k) = PD(3, j, k) - 3. * PD(2, j, k) + 3. * PD(1, j, k);
+            PD(im - 1, j, k) = c43 * PD(im - 2, j, k) - c13 * PD(im - 3, j, k);
+        }
+    for (int i = 0; i < im; i++)
+        for (int j = 0; j < jm; j++) {
+            PD(i, j, 0) = c43 * PD(i, j, 1) - c13 * PD(i, j, 2);
+            PD(i, j, km - 1) = c43 * PD(i, j, km - 2) - c13 * PD(i, j, km - 3);
+            PD(i, j, 0) = PD(i, j, km - 1) = (PD(i, j, 0) + PD(i, j, km - 1)) / 2.;
+        }
+    for (int k = 0; k < km; k++)
+        for (int i = 0; i < im; i++) {
+            PD(i, 0, k) = c43 * PD(i, 1, k) - c13 * PD(i, 2, k);
+            PD(i, jm - 1, k) = c43 * PD(i, jm - 2, k) - c13 * PD(i, jm - 3, k);
+        }
+}
+
+/* Pressure_Atm::computePressure_2D (atmosphere/Pressure_Atm.cpp:195-301) and
+ * Pressure_Hyd::computePressure_2D (hydrosphere/Pressure_Hyd.cpp:206-317), level L. */
+static void pressure2d(oracle_ctx* c, int L, int hyd, double rho) {
+    const int im = c->im, jm = c->jm, km = c->km;
+    const double dthe = c->p.dthe, dphi = c->p.dphi;
+    for (int k = 0; k < km; k++) {
+        AV_(L, 0, k) = c43 * AV_(L, 1, k) - c13 * AV_(L, 2, k);
+        AV_(L, jm - 1, k) = c43 * AV_(L, jm - 2, k) - c13 * AV_(L, jm - 3, k);
+    }
+    for (int j = 0; j < jm; j++) {
+        AV_(L, j, 0) = c43 * AV_(L, j, 1) - c13 * AV_(L, j, 2);
+        AV_(L, j, km - 1) = c43 * AV_(L, j, km - 2) - c13 * AV_(L, j, km - 3);
+        AV_(L, j, 0) = AV_(L, j, km - 1) = (AV_(L, j, 0) + AV_(L, j, km - 1)) / 2.;
+    }
+    double dthe2 = dthe * dthe, dphi2 = dphi * dphi;
+    double rm = c->rad[L], rm2 = rm * rm;
+    for (int j = 1; j < jm - 1; j++) {
+        double sinthe = sin(c->the[j]);
+        double rmsinthe = rm * sinthe;
+        double rm2sinthe2 = rmsinthe * rmsinthe;
+        double denom = 2. / (rm2 * dthe2) + 2. / (rm2sinthe2 * dphi2);
+        double num2 = 1. / (rm2 * dthe2), num3 = 1. / (rm2sinthe2 * dphi2);
+        for (int k = 1; k < km - 1; k++) {
+            double drhs_vdthe = (AV_(L, j + 1, k) - AV_(L, j - 1, k)) / (2. * dthe * rm);
+            if (is_land(c, L, j, k) && is_fluid(c, L, j + 1, k)) {
+                if (j < jm - 2 && is_fluid(c, L, j + 2, k))
+                    drhs_vdthe = (-3. * AV_(L, j, k) + 4. * AV_(L, j + 1, k) - AV_(L, j + 2, k)) / (2. * dthe * rm);
+                else
+                    drhs_vdthe = (AV_(L, j + 1, k) - AV_(L, j, k)) / (dthe * rm);
+            }
+            if (is_land(c, L, j, k) && is_fluid(c, L, j - 1, k)) {
+                if (j > 1 && is_fluid(c, L, j - 2, k))
+                    drhs_vdthe = (-3. * AV_(L, j, k) + 4. * AV_(L, j - 1, k) - AV_(L, j - 2, k)) / (2. * dthe * rm);
+                else
+                    drhs_vdthe = (AV_(L, j - 1, k) - AV_(L, j, k)) / (dthe * rm);
+            }
+            double drhs_wdphi = (AW_(L, j, k + 1) - AW_(L, j, k - 1)) / (2. * dphi * rmsinthe);
+            if (is_land(c, L, j, k) && is_fluid(c, L, j, k + 1)) {
+                if (k < km - 2 && is_fluid(c, L, j, k + 2))
+                    drhs_wdphi = (-3. * AW_(L, j, k) + 4. * AW_(L, j, k + 1) - AW_(L, j, k + 2)) / (2. * rmsinthe * dphi);
+                else
+                    drhs_wdphi = (AW_(L, j, k + 1) - AW_(L, j, k)) / (dphi * rmsinthe);
+            }
+            if (is_land(c, L, j, k) && is_fluid(c, L, j, k - 1)) {
+                /* k >= 2 (atm) and k > 1 (hyd) are the same test */
+                if (k >= 2 && is_fluid(c, L, j, k - 2))
+                    drhs_wdphi = (-3. * AW_(L, j, k) + 4. * AW_(L, j, k - 1) - AW_(L, j, k - 2)) / (2. * rmsinthe * dphi);
+                else
+                    drhs_wdphi = (AW_(L, j, k - 1) - AW_(L, j, k)) / (dphi * rmsinthe);
+            }
+            PD(L, j, k) = ((PN(L, j + 1, k) + PN(L, j - 1, k)) * num2
+                           + (PN(L, j, k + 1) + PN(L, j, k - 1)) * num3
+                           - rho * (drhs_vdthe + drhs_wdphi)) / denom;
+        }
+    }
+    for (int k = 0; k < km; k++) {
+        if (hyd) { /* index slip, Pressure_Hyd.cpp:301-305 */
+            PD(im - 1, im - 1, k) = 0.;
+            PD(0, jm - 1, k) = 0.;
+        } else {
+            PD(0, 0, k) = 0.;
+            PD(0, jm - 1, k) = 0.;
+        }
+    }
+    for (int j = 1; j < jm - 1; j++) {
+        PD(L, j, 0) = c43 * PD(L, j, 1) - c13 * PD(L, j, 2);
+        PD(L, j, km - 1) = c43 * PD(L, j, km - 2) - c13 * PD(L, j, km - 3);
+        PD(L, j, 0) = PD(L, j, km - 1) = (PD(L, j, 0) + PD(L, j, km - 1)) / 2.;
+    }
+}
+#undef AU_
+#undef AV_
+#undef AW_
+#undef PD
+#undef PN
+
+void oracle_atm_pressure3d(oracle_ctx* c) { pressure3d(c, 0, c->p.r_air); }
+void oracle_atm_pressure2d(oracle_ctx* c) { pressure2d(c, 0, 0, c->p.r_air); }
+void oracle_hyd_pressure3d(oracle_ctx* c) { pressure3d(c, 1, c->p.r_0_water); }
+void oracle_hyd_pressure2d(oracle_ctx* c) { pressure2d(c, c->im - 1, 1, c->p.r_0_water); }
+
+/* ------------------------------------------------------------------------- */
+/* Boundary fills                                                            */
+/* ------------------------------------------------------------------------- */
+
+#define NEUMANN_LO(F, a0, a1, a2) (F a0 = c43 * F a1 - c13 * F a2)
+
+/* BC_Atmosphere::BC_radius, atmosphere/BC_Atm.cpp:39-73 */
+void oracle_atm_bc_radius(oracle_ctx* c) {
+    const int im = c->im;
+    static const int EX[5] = { ATOMDEV_P_DYN, ATOMDEV_C, ATOMDEV_CLOUD, ATOMDEV_ICE, ATOMDEV_CO2 };
+    for (int j = 0; j < c->jm; j++)
+        for (int k = 0; k < c->km; k++) {
+            A3(c, ATOMDEV_U, 0, j, k) = 0.;
+            A3(c, ATOMDEV_V, 0, j, k) = c43 * A3(c, ATOMDEV_V, 1, j, k) - c13 * A3(c, ATOMDEV_V, 2, j, k);
+            A3(c, ATOMDEV_W, 0, j, k) = c43 * A3(c, ATOMDEV_W, 1, j, k) - c13 * A3(c, ATOMDEV_W, 2, j, k);
+            A3(c, ATOMDEV_T, im - 1, j, k) = c->p.t_tropopause;
+            A3(c, ATOMDEV_U, im - 1, j, k) = 0.;
+            A3(c, ATOMDEV_V, im - 1, j, k) = 0.;
+            A3(c, ATOMDEV_W, im - 1, j, k) = 0.;
+            for (int n = 0; n < 5; n++)
+                A3(c, EX[n], im - 1, j, k) = A3(c, EX[n], im - 4, j, k) - 3. * A3(c, EX[n], im - 3, j, k) + 3. * A3(c, EX[n], im - 2, j, k);
+        }
+}
+
+/* BC_Atmosphere::BC_theta, atmosphere/BC_Atm.cpp:80-107 */
+void oracle_atm_bc_theta(oracle_ctx* c) {
+    const int jm = c->jm;
+    static const int NE[6] = { ATOMDEV_T, ATOMDEV_U, ATOMDEV_C, ATOMDEV_CLOUD, ATOMDEV_ICE, ATOMDEV_CO2 };
+    static const int ZE[3] = { ATOMDEV_V, ATOMDEV_W, ATOMDEV_P_DYN };
+    for (int k = 0; k < c->km; k++)
+        for (int i = 0; i < c->im; i++) {
+            for (int n = 0; n < 6; n++) {
+                A3(c, NE[n], i, 0, k) = c43 * A3(c, NE[n], i, 1, k) - c13 * A3(c, NE[n], i, 2, k);
+                A3(c, NE[n], i, jm - 1, k) = c43 * A3(c, NE[n], i, jm - 2, k) - c13 * A3(c, NE[n], i, jm - 3, k);
+            }
+            for (int n = 0; n < 3; n++) { A3(c, ZE[n], i, 0, k) = 0.; A3(c, ZE[n], i, jm - 1, k) = 0.; }
+        }
+}
+
+static void phi_seam(oracle_ctx* c, const int* F, int nf, int j0, int j1) {
+    const int km = c->km;
+    for (int i = 0; i < c->im; i++)
+        for (int j = j0; j < j1; j++)
+            for (int n = 0; n < nf; n++) {
+                A3(c, F[n], i, j, 0) = c43 * A3(c, F[n], i, j, 1) - c13 * A3(c, F[n], i, j, 2);
+                A3(c, F[n], i, j, km - 1) = c43 * A3(c, F[n], i, j, km - 2) - c13 * A3(c, F[n], i, j, km - 3);
+                A3(c, F[n], i, j, 0) = A3(c, F[n], i, j, km - 1) = (A3(c, F[n], i, j, 0) + A3(c, F[n], i, j, km - 1)) / 2.;
+            }
+}
+
+/* BC_Atmosphere::BC_phi, atmosphere/BC_Atm.cpp:115-150 (j = 1 .. jm-2 only) */
+void oracle_atm_bc_phi(oracle_ctx* c) {
+    static const int F[9] = { ATOMDEV_T, ATOMDEV_U, ATOMDEV_V, ATOMDEV_W, ATOMDEV_P_DYN, ATOMDEV_C, ATOMDEV_CLOUD, ATOMDEV_ICE, ATOMDEV_CO2 };
+    phi_seam(c, F, 9, 1, c->jm - 1);
+}
+
+/* BC_Hydrosphere::RB_radius, hydrosphere/BC_Hyd.cpp:38-83 */
+void oracle_hyd_bc_radius(oracle_ctx* c) {
+    const int im = c->im;
+    for (int j = 0; j < c->jm; j++)
+        for (int k = 0; k < c->km; k++) {
+            A3(c, ATOMDEV_U, 0, j, k) = c43 * A3(c, ATOMDEV_U, 1, j, k) - c13 * A3(c, ATOMDEV_U, 2, j, k);
+            A3(c, ATOMDEV_T, 0, j, k) = c->p.ta;
+            A3(c, ATOMDEV_C, 0, j, k) = c->p.ca;
+            A3(c, ATOMDEV_V, 0, j, k) = 0.;
+            A3(c, ATOMDEV_W, 0, j, k) = 0.;
+            A3(c, ATOMDEV_P_DYN, 0, j, k) = 0.;
+            A3(c, ATOMDEV_V, im - 1, j, k) = c43 * A3(c, ATOMDEV_V, im - 2, j, k) - c13 * A3(c, ATOMDEV_V, im - 3, j, k);
+            A3(c, ATOMDEV_W, im - 1, j, k) = c43 * A3(c, ATOMDEV_W, im - 2, j, k) - c13 * A3(c, ATOMDEV_W, im - 3, j, k);
+            A3(c, ATOMDEV_U, im - 1, j, k) = A3(c, ATOMDEV_U, im - 4, j, k) - 3. * A3(c, ATOMDEV_U, im - 3, j, k) + 3. * A3(c, ATOMDEV_U, im - 2, j, k);
+            A3(c, ATOMDEV_C, im - 1, j, k) = A3(c, ATOMDEV_C, im - 4, j, k) - 3. * A3(c, ATOMDEV_C, im - 3, j, k) + 3. * A3(c, ATOMDEV_C, im - 2, j, k);
+        }
+}
+
+/* BC_Hydrosphere::RB_theta, hydrosphere/BC_Hyd.cpp:90-118 */
+void oracle_hyd_bc_theta(oracle_ctx* c) {
+    const int jm = c->jm;
+    static const int NE[4] = { ATOMDEV_T, ATOMDEV_U, ATOMDEV_P_DYN, ATOMDEV_C };
+    for (int i = 0; i < c->im; i++)
+        for (int k = 0; k < c->km; k++) {
+            for (int n = 0; n < 4; n++) {
+                A3(c, NE[n], i, 0, k) = c43 * A3(c, NE[n], i, 1, k) - c13 * A3(c, NE[n], i, 2, k);
+                A3(c, NE[n], i, jm - 1, k) = c43 * A3(c, NE[n], i, jm - 2, k) - c13 * A3(c, NE[n], i, jm - 3, k);
+            }
+            A3(c, ATOMDEV_V, i, 0, k) = 0.; A3(c, ATOMDEV_V, i, jm - 1, k) = 0.;
+            A3(c, ATOMDEV_W, i, 0, k) = 0.; A3(c, ATOMDEV_W, i, jm - 1, k) = 0.;
+        }
+}
+
+/* BC_Hydrosphere::RB_phi, hydrosphere/BC_Hyd.cpp:125-158 (all j) */
+void oracle_hyd_bc_phi(oracle_ctx* c) {
+    static const int F[6] = { ATOMDEV_T, ATOMDEV_U, ATOMDEV_V, ATOMDEV_W, ATOMDEV_P_DYN, ATOMDEV_C };
+    phi_seam(c, F, 6, 0, c->jm);
+}
+
+/* ------------------------------------------------------------------------- */
+/* Limiters, solid ground, old -> new copy                                   */
+/* ------------------------------------------------------------------------- */
+
+/* BC_Thermo::Value_Limitation_Atm, atmosphere/BC_Thermo.cpp:3235-3275 */
+void oracle_atm_value_limitation(oracle_ctx* c) {
+    for (int k = 0; k < c->km; k++)
+        for (int j = 0; j < c->jm; j++)
+            for (int i = 0; i < c->im; i++) {
+                double* u = &A3(c, ATOMDEV_U, i, j, k); double* v = &A3(c, ATOMDEV_V, i, j, k);
+                double* w = &A3(c, ATOMDEV_W, i, j, k); double* t = &A3(c, ATOMDEV_T, i, j, k);
+                double* cc = &A3(c, ATOMDEV_C, i, j, k); double* cl = &A3(c, ATOMDEV_CLOUD, i, j, k);
+                double* ic = &A3(c, ATOMDEV_ICE, i, j, k); double* co = &A3(c, ATOMDEV_CO2, i, j, k);
+                if (*u >= .106) *u = .106;
+                if (*u <= -.106) *u = -.106;
+                if (*v >= .125) *v = .125;
+                if (*v <= -.125) *v = -.125;
+                if (*w >= 3.5) *w = 3.5;
+                if (*w <= -.469) *w = -.469;
+                if (*t >= 1.165) *t = 1.165;
+                if (*t <= -.78) *t = -.78;
+                if (*cc >= .03) *cc = .03;
+                if (*cc < 0.) *cc = 0.;
+                if (*cl >= .01) *cl = .01;
+                if (*cl < 0.) *cl = 0.;
+                if (*ic >= .005) *ic = .005;
+                if (*ic < 0.) *ic = 0.;
+                if (*co >= 5.36) *co = 5.36;
+                if (*co <= 1.) *co = 1.;
+                if (is_land(c, i, j, k)) {
+                    *u = 0.; *v = 0.; *w = 0.; *cl = 0.; *ic = 0.; *co = 1.;
+                    A3(c, ATOMDEV_P_DYN, i, j, k) = 0.;
+                }
+            }
+}
+
+/* BC_Bathymetry_Atmosphere::BC_SolidGround, atmosphere/BC_Bath_Atm.cpp:94-119
+ * (levels im-2 .. 0; the top level is left alone) */
+void oracle_atm_solid_ground(oracle_ctx* c) {
+    for (int j = 0; j < c->jm; j++)
+        for (int k = 0; k < c->km; k++)
+            for (int i = c->im - 2; i >= 0; i--)
+                if (is_land(c, i, j, k)) {
+                    A3(c, ATOMDEV_U, i, j, k) = 0.; A3(c, ATOMDEV_V, i, j, k) = 0.; A3(c, ATOMDEV_W, i, j, k) = 0.;
+                    A3(c, ATOMDEV_CLOUD, i, j, k) = 0.; A3(c, ATOMDEV_ICE, i, j, k) = 0.;
+                    A3(c, ATOMDEV_CO2, i, j, k) = 1.; A3(c, ATOMDEV_P_DYN, i, j, k) = 0.;
+                }
+}
+
+/* BC_Thermohalin::Value_Limitation_Hyd, hydrosphere/BC_Thermohalin.cpp:699-722 */
+void oracle_hyd_value_limitation(oracle_ctx* c) {
+    for (int k = 0; k < c->km; k++)
+        for (int j = 0; j < c->jm; j++)
+            for (int i = 0; i < c->im; i++) {
+                double* u = &A3(c, ATOMDEV_U, i, j, k); double* v = &A3(c, ATOMDEV_V, i, j, k);
+                double* w = &A3(c, ATOMDEV_W, i, j, k); double* t = &A3(c, ATOMDEV_T, i, j, k);
+                double* cc = &A3(c, ATOMDEV_C, i, j, k);
+                if (*u >= 11.11) *u = 11.11;
+                if (*u <= -11.11) *u = -11.11;
+                if (*v >= .552) *v = .552;
+                if (*v <= -.552) *v = -.552;
+                if (*w >= .552) *w = .552;
+                if (*w <= -.552) *w = -.552;
+                if (*t >= 1.147) *t = 1.147;
+                if (*t <= -1.01464) *t = -1.01464;
+                if (*cc >= 1.1) *cc = 1.1;
+                if (*cc < .95) *cc = .95;
+            }
+}
+
+/* BC_Bathymetry_Hydrosphere::BC_SolidGround, hydrosphere/BC_Bath_Hyd.cpp:120-139 */
+void oracle_hyd_solid_ground(oracle_ctx* c) {
+    for (int i = 0; i < c->im; i++)
+        for (int j = 0; j < c->jm; j++)
+            for (int k = 0; k < c->km; k++)
+                if (is_land(c, i, j, k)) {
+                    A3(c, ATOMDEV_P_DYN, i, j, k) = A3(c, ATOMDEV_P_DYNN, i, j, k) = c->p.pa;
+                    A3(c, ATOMDEV_T, i, j, k) = A3(c, ATOMDEV_TN, i, j, k) = c->p.ta;
+                    A3(c, ATOMDEV_C, i, j, k) = A3(c, ATOMDEV_CN, i, j, k) = c->p.ca;
+                    A3(c, ATOMDEV_U, i, j, k) = A3(c, ATOMDEV_UN, i, j, k) = 0.;
+                    A3(c, ATOMDEV_V, i, j, k) = A3(c, ATOMDEV_VN, i, j, k) = 0.;
+                    A3(c, ATOMDEV_W, i, j, k) = A3(c, ATOMDEV_WN, i, j, k) = 0.;
+                }
+}
+
+/* AtomUtils::move_data_to_new_arrays, lib/Utils.cpp:41-68, with the lists of
+ * cAtmosphereModel.cpp:60-63 / cHydrosphereModel (u v w t p_dyn c). */
+void oracle_move_data_to_new_arrays(oracle_ctx* c, int level) {
+    static const int O3[9] = { ATOMDEV_U, ATOMDEV_V, ATOMDEV_W, ATOMDEV_T, ATOMDEV_P_DYN, ATOMDEV_C, ATOMDEV_CLOUD, ATOMDEV_ICE, ATOMDEV_CO2 };
+    static const int O2[3] = { ATOMDEV_V, ATOMDEV_W, ATOMDEV_P_DYN };
+    const double coeff = 1.;
+    const int n3 = c->model == ATOMDEV_ATM ? 9 : 6;
+    const int i0 = level < 0 ? 0 : level, i1 = level < 0 ? c->im : level + 1;
+    const int* L = level < 0 ? O3 : O2;
+    const int nl = level < 0 ? n3 : 3;
+    for (int i = i0; i < i1; i++)
+        for (int j = 0; j < c->jm; j++)
+            for (int k = 0; k < c->km; k++)
+                for (int n = 0; n < nl; n++)
+                    A3(c, L[n] + 9, i, j, k) = coeff * A3(c, L[n], i, j, k); /* xn ids = x ids + 9 */
+}
+
+/* ------------------------------------------------------------------------- */
+/* Accuracy                                                                  */
+/* ------------------------------------------------------------------------- */
+
+/* Accuracy_Atm::residuumQuery_3D, atmosphere/Accuracy_Atm.cpp:82-116 (strict >,
+ * state carried by the caller) and Accuracy_Hyd::residuumQuery_3D,
+ * hydrosphere/Accuracy_Hyd.cpp:88-116 (>=, state reset). */
+static void residuum3d(oracle_ctx* c, int hyd, double* min, int loc[3]) {
+    const double dr = c->p.dr, dthe = c->p.dthe, dphi = c->p.dphi;
+    if (hyd) *min = 0.;
+    for (int i = 1; i < c->im - 1; i++)
+        for (int j = 1; j < c->jm - 1; j++) {
+            double sinthe = sin(c->the[j]), costhe = cos(c->the[j]);
+            double rmsinthe = c->rad[i] * sinthe;
+            for (int k = 1; k < c->km - 1; k++) {
+                double dudr = (A3(c, ATOMDEV_U, i + 1, j, k) - A3(c, ATOMDEV_U, i - 1, j, k)) / (2. * dr);
+                double dvdthe = (A3(c, ATOMDEV_V, i, j + 1, k) - A3(c, ATOMDEV_V, i, j - 1, k)) / (2. * dthe);
+                double dwdphi = (A3(c, ATOMDEV_W, i, j, k + 1) - A3(c, ATOMDEV_W, i, j, k - 1)) / (2. * dphi);
+                double residuum = dudr + 2. * A3(c, ATOMDEV_U, i, j, k) / c->rad[i] + dvdthe / c->rad[i]
+                                  + costhe / rmsinthe * A3(c, ATOMDEV_V, i, j, k) + dwdphi / rmsinthe;
+                if (c->f[ATOMDEV_RESIDUUM]) A3(c, ATOMDEV_RESIDUUM, i, j, k) = residuum;
+                if (hyd ? (fabs(residuum) >= *min) : (fabs(residuum) > *min)) {
+                    *min = residuum; loc[0] = i; loc[1] = j; loc[2] = k;
+                }
+            }
+        }
+}
+void oracle_atm_residuum3d(oracle_ctx* c, double* min, int loc[3]) { residuum3d(c, 0, min, loc); }
+void oracle_hyd_residuum3d(oracle_ctx* c, double* min, int loc[3]) { residuum3d(c, 1, min, loc); }
+
+/* Accuracy_Atm::residuumQuery_2D, atmosphere/Accuracy_Atm.cpp:54-80 */
+void oracle_atm_residuum2d(oracle_ctx* c, double* min, int loc[3]) {
+    const double dthe = c->p.dthe, dphi = c->p.dphi;
+    for (int j = 1; j < c->jm - 1; j++) {
+        double sinthe = sin(c->the[j]), costhe = cos(c->the[j]);
+        double rmsinthe = c->rad[0] * sinthe;
+        for (int k = 1; k < c->km - 1; k++) {
+            double dvdthe = (A3(c, ATOMDEV_V, 0, j + 1, k) - A3(c, ATOMDEV_V, 0, j - 1, k)) / (2. * dthe);
+            double dwdphi = (A3(c, ATOMDEV_W, 0, j, k + 1) - A3(c, ATOMDEV_W, 0, j, k - 1)) / (2. * dphi);
+            double residuum = dvdthe / c->rad[0] + costhe / rmsinthe * A3(c, ATOMDEV_V, 0, j, k) + dwdphi / rmsinthe;
+            if (c->f[ATOMDEV_RESIDUUM]) A3(c, ATOMDEV_RESIDUUM, 0, j, k) = residuum;
+            if (fabs(residuum) > *min) { *min = residuum; loc[0] = 0; loc[1] = j; loc[2] = k; }
+        }
+    }
+}
+
+static void steady(oracle_ctx* c, const int* F, int nf, int i0, int i1, int ge, double* out, int* loc) {
+    for (int n = 0; n < nf; n++) { out[n] = 0.; loc[3 * n] = loc[3 * n + 1] = loc[3 * n + 2] = 0; }
+    for (int i = i0; i < i1; i++)
+        for (int j = 0; j < c->jm; j++)
+            for (int k = 0; k < c->km; k++)
+                for (int n = 0; n < nf; n++) {
+                    double tmp = fabs(A3(c, F[n], i, j, k) - A3(c, F[n] + 9, i, j, k));
+                    if (ge ? (tmp >= out[n]) : (tmp > out[n])) {
+                        out[n] = tmp; loc[3 * n] = i; loc[3 * n + 1] = j; loc[3 * n + 2] = k;
+                    }
+                }
+}
+/* Accuracy_Atm::steadyQuery_3D, atmosphere/Accuracy_Atm.cpp:192-305 */
+void oracle_atm_steady3d(oracle_ctx* c, double out[9], int loc[27]) {
+    static const int F[9] = { ATOMDEV_U, ATOMDEV_V, ATOMDEV_W, ATOMDEV_T, ATOMDEV_C, ATOMDEV_CLOUD, ATOMDEV_ICE, ATOMDEV_CO2, ATOMDEV_P_DYN };
+    steady(c, F, 9, 0, c->im, 0, out, loc);
+}
+/* Accuracy_Atm::steadyQuery_2D, atmosphere/Accuracy_Atm.cpp:118-153 */
+void oracle_atm_steady2d(oracle_ctx* c, double out[3], int loc[9]) {
+    static const int F[3] = { ATOMDEV_V, ATOMDEV_W, ATOMDEV_P_DYN };
+    steady(c, F, 3, 0, 1, 0, out, loc);
+}
+/* Accuracy_Hyd::steadyQuery_3D, hydrosphere/Accuracy_Hyd.cpp:121-184 */
+void oracle_hyd_steady3d(oracle_ctx* c, double out[6], int loc[18]) {
+    static const int F[6] = { ATOMDEV_U, ATOMDEV_V, ATOMDEV_W, ATOMDEV_T, ATOMDEV_C, ATOMDEV_P_DYN };
+    steady(c, F, 6, 0, c->im, 1, out, loc);
+}
+
+/* ------------------------------------------------------------------------- */
+/* Hydrosphere RK                                                            */
+/* ------------------------------------------------------------------------- */
+
+enum { HU = 0, HV, HW, HT, HP, HC };
+static const int HYD_F[6] = { ATOMDEV_U, ATOMDEV_V, ATOMDEV_W, ATOMDEV_T, ATOMDEV_P_DYN, ATOMDEV_C };
+
+/* RHS_Hydrosphere::RK_RHS_3D_Hydrosphere, hydrosphere/RHS_Hyd.cpp:60-447.
+ * rhs order: t u v w c. */
+static void hyd_rhs3d(oracle_ctx* c, int i, int j, int k, double rhs[5]) {
+    const atomdev_params* P = &c->p;
+    const int im = c->im;
+    const double k_Force = 1.;
+    const double dr = P->dr, dthe = P->dthe, dphi = P->dphi, re = P->re;
+    double dr2 = dr * dr, dthe2 = dthe * dthe, dphi2 = dphi * dphi;
+    double rm = c->rad[i], rm2 = rm * rm;
+    double sinthe = sin(c->the[j]), sinthe2 = sinthe * sinthe, costhe = cos(c->the[j]);
+    double rmsinthe = rm * sinthe, rm2sinthe = rm2 * sinthe, rm2sinthe2 = rm2 * sinthe2;
+
+    double h0[3], hd[3];
+    ib_factors(c, i, j, k, 1, P->L_hyd, h0, hd);
+    const double h_0_i = h0[0], h_0_j = h0[1], h_0_k = h0[2];
+    const double h_d_i = hd[0], h_d_j = hd[1], h_d_k = hd[2];
+
+    derivs D;
+    fd_derivatives(c, HYD_F, 6, HP, HU, HC, i, j, k, hd, 1, &D);
+
+    const double u = A3(c, ATOMDEV_U, i, j, k), v = A3(c, ATOMDEV_V, i, j, k), w = A3(c, ATOMDEV_W, i, j, k);
+    const double t = A3(c, ATOMDEV_T, i, j, k), cs = A3(c, ATOMDEV_C, i, j, k);
+
+    /* RHS_Hyd.cpp:345-402 */
+    double salinity_evaporation = 0., salinity_surface = 0.;
+    double drodc = .7;
+    double salt_water_ref = A3(c, ATOMDEV_R_WATER, i, j, k) + drodc * cs * P->c_0;
+    double coeff_buoy = P->r_0_water * P->u_0 * P->u_0 / P->L_hyd;
+    double coeff_salinity = 1.1574e-5 * P->L_hyd / P->u_0;
+
+    if (i == im - 2) {
+        salinity_surface = salt_water_ref * (-3. * A3(c, ATOMDEV_C, im - 1, j, k) + 4. * A3(c, ATOMDEV_C, im - 2, j, k)
+                                             - A3(c, ATOMDEV_C, im - 3, j, k)) / (2. * dr)
+                           * (1. - 2. * A3(c, ATOMDEV_C, im - 1, j, k))
+                           * (A2(c, ATOMDEV_EVAPORATION_DALTON, j, k) - A2(c, ATOMDEV_PRECIPITATION, j, k));
+        salinity_evaporation = +coeff_salinity * salinity_surface;
+        if (is_land(c, i, j, k)) salinity_evaporation = 0.;
+        if (salinity_evaporation >= 20.) salinity_evaporation = 20.;
+        if (salinity_evaporation <= -20.) salinity_evaporation = -20.;
+    } else salinity_evaporation = 0.;
+
+    double RS_buoyancy_Momentum = P->Buoyancy * P->g * (A3(c, ATOMDEV_R_SALT_WATER, i, j, k) - salt_water_ref) / salt_water_ref;
+    A3(c, ATOMDEV_BUOYANCY, i, j, k) = RS_buoyancy_Momentum * coeff_buoy * 1000.;
+    A3(c, ATOMDEV_SALT_BALANCE, i, j, k) = salt_water_ref - A3(c, ATOMDEV_R_SALT_WATER, i, j, k);
+    if (A3(c, ATOMDEV_SALT_BALANCE, i, j, k) < 0.) {
+        A3(c, ATOMDEV_SALT_DIFFUSION, i, j, k) = A3(c, ATOMDEV_SALT_BALANCE, i, j, k);
+        A3(c, ATOMDEV_SALT_FINGER, i, j, k) = 0.;
+    } else {
+        A3(c, ATOMDEV_SALT_FINGER, i, j, k) = A3(c, ATOMDEV_SALT_BALANCE, i, j, k);
+        A3(c, ATOMDEV_SALT_DIFFUSION, i, j, k) = 0.;
+    }
+    if (is_land(c, i, j, k)) {
+        A3(c, ATOMDEV_SALT_BALANCE, i, j, k) = 0.;
+        A3(c, ATOMDEV_SALT_FINGER, i, j, k) = 0.;
+        A3(c, ATOMDEV_SALT_DIFFUSION, i, j, k) = 0.;
+        A3(c, ATOMDEV_BUOYANCY, i, j, k) = 0.;
+        A3(c, ATOMDEV_R_WATER, i, j, k) = 1007.;
+        A3(c, ATOMDEV_R_SALT_WATER, i, j, k) = 1032.;
+    }
+
+    /* RHS_Hyd.cpp:404-437 */
+    double rhs_t = -(u * DR(HT) + v * DT(HT) / rm + w * DP(HT) / rmsinthe)
+                   + (D2R(HT) + DR(HT) * 2. / rm + D2T(HT) / rm2 + DT(HT) * costhe / rm2sinthe + D2P(HT) / rm2sinthe2) / (re * P->pr)
+                   - h_0_i * t * k_Force / dr2;
+
+    double rhs_u = -(u * DR(HU) + v * DT(HU) / rm + w * DP(HU) / rmsinthe)
+                   + h_d_i * DR(HP) / salt_water_ref
+                   + (D2R(HU) + h_d_i * 2. * u / rm2 + D2T(HU) / rm2 + 4. * DR(HU) / rm + DT(HU) * costhe / rm2sinthe + D2P(HU) / rm2sinthe2) / re
+                   + RS_buoyancy_Momentum
+                   - h_0_i * u * k_Force / dthe2;
+
+    double rhs_v = -(u * DR(HV) + v * DT(HV) / rm + w * DP(HV) / rmsinthe)
+                   - h_d_j * DT(HP) / rm / salt_water_ref
+                   + (D2R(HV) + DR(HV) * 2. / rm + D2T(HV) / rm2 + DT(HV) / rm2sinthe * costhe
+                      - (1. + costhe * costhe / sinthe2) * h_d_j * v + D2P(HV) / rm2sinthe2
+                      + 2. * DT(HU) / rm2 - DP(HW) * 2. * costhe / rm2sinthe2) / re
+                   - h_0_j * v * k_Force / dthe2;
+
+    double rhs_w = -(u * DR(HW) + v * DT(HW) / rm + w * DP(HW) / rmsinthe)
+                   - h_d_k * DP(HP) / rmsinthe / salt_water_ref
+                   + (D2R(HW) + DR(HW) * 2. / rm + D2T(HW) / rm2 + DT(HW) / rm2sinthe * costhe
+                      - (1. + costhe * costhe / sinthe2) * h_d_k * w + D2P(HW) / rm2sinthe2
+                      + 2. * DP(HU) / rm2sinthe + DP(HV) * 2. * costhe / rm2sinthe2) / re
+                   - h_0_k * w * k_Force / dphi2;
+
+    double rhs_c = -(u * DR(HC) + v * DT(HC) / rm + w * DP(HC) / rmsinthe)
+                   + (D2R(HC) + DR(HC) * 2. / rm + D2T(HC) / rm2 + DT(HC) * costhe / rm2sinthe + D2P(HC) / rm2sinthe2) / (P->sc * re)
+                   + salinity_evaporation
+                   - h_0_i * cs * k_Force / dr2;
+
+    /* RHS_Hyd.cpp:439-446 */
+    A3(c, ATOMDEV_AUX_U, i, j, k) = rhs_u + h_d_i * DR(HP) / salt_water_ref;
+    A3(c, ATOMDEV_AUX_V, i, j, k) = rhs_v + h_d_j * DT(HP) / rm / salt_water_ref;
+    A3(c, ATOMDEV_AUX_W, i, j, k) = rhs_w + h_d_k * DP(HP) / rmsinthe / salt_water_ref;
+    if (is_land(c, i, j, k))
+        A3(c, ATOMDEV_AUX_U, i, j, k) = A3(c, ATOMDEV_AUX_V, i, j, k) = A3(c, ATOMDEV_AUX_W, i, j, k) = 0.;
+
+    rhs[0] = rhs_t; rhs[1] = rhs_u; rhs[2] = rhs_v; rhs[3] = rhs_w; rhs[4] = rhs_c;
+}
+
+/* RungeKutta_Hydrosphere::solveRungeKutta_3D_Hydrosphere, hydrosphere/RungeKutta_Hyd.cpp:30-124.
+ * Stage 3 advances w from its stage-2 value, not from wn (line 101). */
+void oracle_hyd_rk3d(oracle_ctx* c) {
+    static const int X[5] = { ATOMDEV_T, ATOMDEV_U, ATOMDEV_V, ATOMDEV_W, ATOMDEV_C };
+    const double dt = c->p.dt;
+    double k1[5], k2[5], k3[5], k4[5];
+    for (int i = 1; i < c->im - 1; i++)
+        for (int j = 1; j < c->jm - 1; j++)
+            for (int k = 1; k < c->km - 1; k++) {
+                hyd_rhs3d(c, i, j, k, k1);
+                for (int n = 0; n < 5; n++) A3(c, X[n], i, j, k) = A3(c, X[n] + 9, i, j, k) + k1[n] * .5 * dt;
+                hyd_rhs3d(c, i, j, k, k2);
+                for (int n = 0; n < 5; n++) A3(c, X[n], i, j, k) = A3(c, X[n] + 9, i, j, k) + k2[n] * .5 * dt;
+                hyd_rhs3d(c, i, j, k, k3);
+                for (int n = 0; n < 5; n++) {
+                    double base = (n == 3) ? A3(c, ATOMDEV_W, i, j, k) : A3(c, X[n] + 9, i, j, k);
+                    A3(c, X[n], i, j, k) = base + k3[n] * dt;
+                }
+                hyd_rhs3d(c, i, j, k, k4);
+                for (int n = 0; n < 5; n++)
+                    A3(c, X[n], i, j, k) = A3(c, X[n] + 9, i, j, k) + dt * (k1[n] + 2. * k2[n] + 2. * k3[n] + k4[n]) / 6.;
+            }
+}
+
+/* solveRungeKutta_2D_Hydrosphere: the RHS object forces im = 41 (RHS_Hyd.cpp:466),
+ * the RK driver uses the grid's own im-1. */
+void oracle_hyd_rk2d(oracle_ctx* c) { rk2d(c, 40, c->im - 1, 1, c->p.r_0_water); }
+
+/* Reference defaults (param.py:32-177; grid constants cAtmosphereModel.cpp:38-55). */
+void oracle_default_params(int model, atomdev_params* p) {
+    memset(p, 0, sizeof(*p));
+    const double pi180 = 180. / M_PI;
+    p->dt = 0.00001; p->dr = 0.025; p->dthe = 1. / pi180; p->dphi = 1. / pi180;
+    p->r0 = 1.; p->the0 = 0.; p->phi0 = 0.;
+    p->g = 9.8066; p->Buoyancy = 1.0; p->t_0 = 273.15;
+    if (model == ATOMDEV_ATM) {
+        p->re = 1000.; p->pr = .7179; p->u_0 = 8.; p->c_0 = .035;
+    } else {
+        p->re = 10.; p->pr = 6.957; p->u_0 = .25; p->c_0 = 34.6;
+    }
+    p->sc_WaterVapour = .61; p->sc_CO2 = .96; p->gam = .65; p->r_air = 1.2041; p->R_Air = 287.1;
+    p->R_WaterVapour = 461.6; p->L_atm = 16000.; p->cp_l = 1005.; p->t_tropopause = .798;
+    p->sc = 1.7329; p->L_hyd = 1000.; p->r_0_water = 1000.; p->ta = 1.01464; p->pa = 0.; p->ca = 1.;
+}

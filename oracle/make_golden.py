@@ -1,0 +1,125 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz from the COMPILED REFERENCE (oracle/_ref/libatomref.so).
+
+Run in the build container only (needs /root/reference):  python oracle/make_golden.py
+The outputs are data: inputs are re-derived from the seeds by tests/harness.py
+(their SHA-256 is stored so drift of the generator is detected), expected outputs
+are what the reference's own classes computed.
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import harness as H  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+XYZ = "/root/reference/data/Paleotopography_bathymetry/Golonka_rev210/0Ma_Golonka.xyz"
+
+
+def digest(fields, names):
+    h = hashlib.sha256()
+    for k in names:
+        h.update(np.ascontiguousarray(fields[k]).tobytes())
+    return h.hexdigest()
+
+
+def small_case(model, dims, seq, seed, fname, level=None):
+    im, jm, km = dims
+    p = H.default_params(model, im, jm, km)
+    f, g = H.make_inputs(model, im, jm, km, seed, "blobs", p)
+    names = H.ATM_FIELDS if model == H.ATM else H.HYD_FIELDS
+    f = {k: f[k] for k in names}
+    m = H.CpuModel("ref", model, im, jm, km, p, f, g)
+    lvl = None if level is None else (im - 1 if level == "top" else 0)
+    snaps = H.run_sequence(m, seq, names, lvl)
+    snaps["input_sha256"] = np.array(digest(f, names) + digest(g, H.FIELDS2D))
+    snaps["dims"] = np.array(dims)
+    snaps["seed"] = np.array(seed)
+    if model == H.HYD and level == "top":
+        snaps["p_dyn_level0_lastrow"] = m.f["P_DYN"][0, jm - 1, :].copy()  # Pressure_Hyd.cpp:304
+    np.savez_compressed(os.path.join(GOLD, fname), **snaps)
+    print(fname, len(snaps), "entries")
+
+
+def residuum_case():
+    im, jm, km = 7, 13, 17
+    p = H.default_params(H.ATM, im, jm, km)
+    f, g = H.make_inputs(H.ATM, im, jm, km, 77, "blobs", p)
+    f = {k: f[k] for k in H.ATM_FIELDS}
+    # second velocity set for the second query on the same object
+    f["UN"], f["VN"], f["WN"] = -0.5 * f["U"], 0.25 * f["V"], -0.125 * f["W"]
+    m = H.CpuModel("ref", H.ATM, im, jm, km, p, f, g)
+    out = {}
+    mn, loc = m.residuum("atm_residuum3d")
+    out["res3d_min"], out["res3d_loc"], out["res3d_field"] = np.array(mn), np.array(loc), m.f["RESIDUUM"].copy()
+    import ctypes as C
+    mins = (C.c_double * 2)(); locs = (C.c_int * 6)()
+    m.op("atm_residuum3d_twice", mins, locs)
+    out["res3d_twice_min"], out["res3d_twice_loc"] = np.array(mins), np.array(locs)
+    mn, loc = m.residuum("atm_residuum2d")
+    out["res2d_min"], out["res2d_loc"], out["res2d_field"] = np.array(mn), np.array(loc), m.f["RESIDUUM"][0].copy()
+    ph = H.default_params(H.HYD, im, jm, km)
+    fh, gh = H.make_inputs(H.HYD, im, jm, km, 78, "blobs", ph)
+    fh = {k: fh[k] for k in H.HYD_FIELDS}
+    mh = H.CpuModel("ref", H.HYD, im, jm, km, ph, fh, gh)
+    mn, loc = mh.residuum("hyd_residuum3d")
+    out["hyd_res3d_min"], out["hyd_res3d_loc"] = np.array(mn), np.array(loc)
+    np.savez_compressed(os.path.join(GOLD, "residuum_small.npz"), **out)
+    print("residuum_small.npz")
+
+
+def masks():
+    out = {}
+    for model, tag in ((H.ATM, "atm"), (H.HYD, "hyd")):
+        im, jm, km = 41, 181, 361
+        p = H.default_params(model)
+        f = {"H": np.zeros((im, jm, km))}
+        g = {"TOPOGRAPHY": np.zeros((jm, km))}
+        m = H.CpuModel("ref", model, im, jm, km, p, f, g)
+        m.lib.ref_read_mask(m.ctx, XYZ.encode())
+        h = m.f["H"]
+        assert set(np.unique(h)) <= {0.0, 1.0}
+        out[tag + "_h_bits"] = np.packbits(h.astype(np.uint8).ravel())
+        topo = m.g["TOPOGRAPHY"]
+        out[tag + "_topo"] = topo
+        print(tag, "land cells", int(h.sum()))
+    np.savez_compressed(os.path.join(GOLD, "mask_0Ma.npz"), **out)
+
+
+def full_case(model, tag):
+    im, jm, km = 41, 181, 361
+    p = H.default_params(model)
+    f, g = H.make_inputs(model, im, jm, km, 1234, "allfluid", p)
+    names = H.ATM_FIELDS if model == H.ATM else H.HYD_FIELDS
+    f = {k: f[k] for k in names}
+    h, topo = H.load_mask_0Ma(model)
+    f["H"], g["TOPOGRAPHY"] = h, topo
+    m = H.CpuModel("ref", model, im, jm, km, p, f, g)
+    before = {k: m.f[k].copy() for k in names}
+    m.op("atm_rk3d" if model == H.ATM else "hyd_rk3d")
+    out = {"input_sha256": np.array(digest(f, names) + digest(g, H.FIELDS2D))}
+    for k in names:
+        if not np.array_equal(m.f[k], before[k]):
+            a = m.f[k]
+            out[k + "/sha256"] = np.array(hashlib.sha256(a.tobytes()).hexdigest())
+            out[k + "/stats"] = np.array([a.sum(), a.min(), a.max(), np.abs(a).max()])
+            for pk, pv in H.sample_planes(a).items():
+                out[k + "/" + pk] = pv
+    np.savez_compressed(os.path.join(GOLD, "full_1deg_%s_rk3d.npz" % tag), **out)
+    print("full", tag, len(out))
+
+
+if __name__ == "__main__":
+    assert H.have_ref(), "build oracle/_ref first: make -C oracle ref"
+    os.makedirs(GOLD, exist_ok=True)
+    masks()
+    small_case(H.ATM, (7, 13, 17), H.ATM_SEQ, 11, "atm_small.npz")
+    small_case(H.HYD, (7, 13, 17), H.HYD_SEQ, 12, "hyd_small.npz")
+    small_case(H.HYD, (41, 43, 9), H.HYD_SURFACE_SEQ, 13, "hyd_surface.npz", level="top")
+    residuum_case()
+    full_case(H.ATM, "atm")
+    full_case(H.HYD, "hyd")

@@ -1,0 +1,285 @@
+"""Shared test plumbing: ctypes views of the three libraries and seeded inputs.
+
+* ``libatomoracle.so``  — oracle/atom_oracle.c, our CPU restatement (checker)
+* ``_ref/libatomref.so`` — the reference's own classes, compiled from
+  /root/reference by oracle/Makefile (checker; absent where the reference is)
+* ``libatomdev.so``     — the product: HIP kernels behind include/atomdev.h
+
+The CPU libraries work in place on numpy buffers; the device library owns HBM
+and is driven through upload/op/download.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "libatomoracle.so")
+REF_SO = os.path.join(ORACLE_DIR, "_ref", "libatomref.so")
+DEV_SO = os.path.join(ROOT, "atom_amd", "libatomdev.so")
+
+ATM, HYD = 0, 1
+
+# enum atomdev_field3d (include/atomdev.h)
+F3 = dict(T=0, U=1, V=2, W=3, P_DYN=4, C=5, CLOUD=6, ICE=7, CO2=8,
+          TN=9, UN=10, VN=11, WN=12, P_DYNN=13, CN=14, CLOUDN=15, ICEN=16, CO2N=17,
+          H=18, AUX_U=19, AUX_V=20, AUX_W=21, BUOYANCY=22,
+          S_V=23, S_C=24, S_I=25, S_R=26, S_S=27,
+          SALT_BALANCE=28, SALT_FINGER=29, SALT_DIFFUSION=30, R_WATER=31, R_SALT_WATER=32,
+          RESIDUUM=33)
+F2 = dict(TOPOGRAPHY=0, EVAPORATION_DALTON=1, PRECIPITATION=2)
+
+ATM_FIELDS = ["T", "U", "V", "W", "P_DYN", "C", "CLOUD", "ICE", "CO2",
+              "TN", "UN", "VN", "WN", "P_DYNN", "CN", "CLOUDN", "ICEN", "CO2N",
+              "H", "AUX_U", "AUX_V", "AUX_W", "BUOYANCY", "S_V", "S_C", "S_I", "S_R", "S_S", "RESIDUUM"]
+HYD_FIELDS = ["T", "U", "V", "W", "P_DYN", "C", "TN", "UN", "VN", "WN", "P_DYNN", "CN",
+              "H", "AUX_U", "AUX_V", "AUX_W", "BUOYANCY",
+              "SALT_BALANCE", "SALT_FINGER", "SALT_DIFFUSION", "R_WATER", "R_SALT_WATER", "RESIDUUM"]
+FIELDS2D = ["TOPOGRAPHY", "EVAPORATION_DALTON", "PRECIPITATION"]
+
+
+class Params(C.Structure):
+    _fields_ = [(n, C.c_double) for n in (
+        "dt", "dr", "dthe", "dphi", "r0", "the0", "phi0",
+        "re", "pr", "g", "Buoyancy", "u_0", "t_0", "c_0",
+        "sc_WaterVapour", "sc_CO2", "gam", "r_air", "R_Air", "R_WaterVapour", "L_atm", "cp_l", "t_tropopause",
+        "sc", "L_hyd", "r_0_water", "ta", "pa", "ca")]
+
+
+def build_oracle():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "all"])
+    if os.path.isdir("/root/reference"):
+        subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "ref"])
+
+
+_libs = {}
+
+
+def load_oracle():
+    if "oracle" not in _libs:
+        if not os.path.exists(ORACLE_SO):
+            build_oracle()
+        lib = C.CDLL(ORACLE_SO)
+        lib.oracle_create.restype = C.c_void_p
+        lib.oracle_create.argtypes = [C.c_int] * 4 + [C.POINTER(Params)]
+        _libs["oracle"] = lib
+    return _libs["oracle"]
+
+
+def have_ref():
+    return os.path.exists(REF_SO)
+
+
+def load_ref():
+    if "ref" not in _libs:
+        lib = C.CDLL(REF_SO)
+        lib.ref_create.restype = C.c_void_p
+        lib.ref_create.argtypes = [C.c_int] * 4 + [C.POINTER(Params)]
+        _libs["ref"] = lib
+    return _libs["ref"]
+
+
+def default_params(model, im=41, jm=181, km=361):
+    """Reference defaults; dr/dthe/dphi follow the grid like the survey's synthetic configs."""
+    p = Params()
+    load_oracle().oracle_default_params(C.c_int(model), C.byref(p))
+    if (im, jm, km) != (41, 181, 361):
+        p.dr = 1.0 / (im - 1)
+        p.dthe = np.pi / (jm - 1)
+        p.dphi = p.dthe
+    return p
+
+
+class CpuModel:
+    """A model whose fields are numpy arrays, advanced in place by the oracle or
+    by the compiled reference (same call surface: ``m.op("atm_rk3d")``)."""
+
+    def __init__(self, kind, model, im, jm, km, params, fields, fields2d):
+        self.kind = kind
+        self.lib = load_oracle() if kind == "oracle" else load_ref()
+        self.pre = "oracle_" if kind == "oracle" else "ref_"
+        self.model, self.im, self.jm, self.km = model, im, jm, km
+        self.params = params
+        create = getattr(self.lib, self.pre + "create")
+        self.ctx = C.c_void_p(create(model, im, jm, km, C.byref(params)))
+        self.f = {k: np.ascontiguousarray(v, dtype=np.float64).copy() for k, v in fields.items()}
+        self.g = {k: np.ascontiguousarray(v, dtype=np.float64).copy() for k, v in fields2d.items()}
+        for k, a in self.f.items():
+            assert a.shape == (im, jm, km), (k, a.shape)
+            getattr(self.lib, self.pre + "bind3d")(self.ctx, F3[k], a.ctypes.data_as(C.c_void_p))
+        for k, a in self.g.items():
+            assert a.shape == (jm, km)
+            getattr(self.lib, self.pre + "bind2d")(self.ctx, F2[k], a.ctypes.data_as(C.c_void_p))
+
+    def op(self, name, *args):
+        fn = getattr(self.lib, self.pre + name)
+        fn.restype = None
+        fn(self.ctx, *args)
+
+    def residuum(self, name, min0=0.0, loc0=(0, 0, 0)):
+        mn = C.c_double(min0)
+        loc = (C.c_int * 3)(*loc0)
+        self.op(name, C.byref(mn), loc)
+        return mn.value, tuple(loc)
+
+    def steady(self, name, n):
+        out = (C.c_double * n)()
+        loc = (C.c_int * (3 * n))()
+        self.op(name, out, loc)
+        return np.array(out), np.array(loc).reshape(n, 3)
+
+    def close(self):
+        if self.ctx:
+            getattr(self.lib, self.pre + "destroy")(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# --------------------------------------------------------------------------
+# seeded synthetic inputs
+# --------------------------------------------------------------------------
+
+def synthetic_mask(model, im, jm, km, L, rng, kind="blobs"):
+    """Land mask h (exactly 0. / 1.) and the 2-D height field in metres.
+
+    blobs: smooth random terrain thresholded per level plus sprinkled single-cell
+    land and fluid pockets, so that every one-sided / coast branch is reached.
+    allfluid: h = 0 everywhere.
+    """
+    h = np.zeros((im, jm, km))
+    topo = np.zeros((jm, km))
+    if kind == "allfluid":
+        return h, topo
+    step = L / (im - 1)
+    # smooth terrain from a few random cosines
+    jj, kk = np.meshgrid(np.arange(jm), np.arange(km), indexing="ij")
+    z = np.zeros((jm, km))
+    for _ in range(6):
+        a, b = rng.uniform(0.5, 4.0, 2)
+        ph1, ph2 = rng.uniform(0, 2 * np.pi, 2)
+        z += rng.uniform(0.3, 1.0) * np.cos(a * 2 * np.pi * jj / jm + ph1) * np.cos(b * 2 * np.pi * kk / km + ph2)
+    z = (z - z.min()) / (z.max() - z.min())
+    nlev = max(2, im // 3)
+    height_levels = np.where(z > 0.55, (z - 0.55) / 0.45 * nlev, 0.0)  # in levels
+    topo = np.round(height_levels * step * rng.uniform(0.7, 1.3, (jm, km)), 1)
+    topo[height_levels == 0] = 0.0
+    for i in range(im):
+        if model == ATM:
+            h[i] = (height_levels > 0) & (i <= np.floor(height_levels))
+        else:
+            # ocean floor rises from below; continents fill the whole column
+            h[i] = (height_levels > 0) & ((i <= np.floor(height_levels) + im // 3) | (z > 0.85))
+    # sprinkle isolated cells
+    n = max(4, h.size // 200)
+    idx = (rng.integers(0, im, n), rng.integers(0, jm, n), rng.integers(0, km, n))
+    h[idx] = 1.0 - h[idx]
+    return np.ascontiguousarray(h, dtype=np.float64), np.ascontiguousarray(topo)
+
+
+def make_inputs(model, im, jm, km, seed=1234, mask="blobs", params=None):
+    """Fields drawn inside the limiter bounds (ranges: the survey's synthetic spec)."""
+    rng = np.random.default_rng(seed)
+    shp = (im, jm, km)
+    U = lambda lo, hi: rng.uniform(lo, hi, shp)
+    f = {}
+    if model == ATM:
+        L = params.L_atm if params is not None else 16000.0
+        f["T"], f["U"], f["V"], f["W"] = U(0.8, 1.1), U(-0.1, 0.1), U(-0.1, 0.1), U(-0.4, 0.4)
+        f["P_DYN"], f["C"], f["CLOUD"], f["ICE"], f["CO2"] = U(-0.1, 0.1), U(0, 0.03), U(0, 0.01), U(0, 0.005), U(1.0, 1.2)
+        names = ["T", "U", "V", "W", "P_DYN", "C", "CLOUD", "ICE", "CO2"]
+        for s in ["S_V", "S_C", "S_I", "S_R", "S_S"]:
+            f[s] = U(-1e-6, 1e-6)
+    else:
+        L = params.L_hyd if params is not None else 1000.0
+        f["T"], f["U"], f["V"], f["W"] = U(0.98, 1.1), U(-0.1, 0.1), U(-0.1, 0.1), U(-0.1, 0.1)
+        f["P_DYN"], f["C"] = U(-0.1, 0.1), U(0.95, 1.1)
+        names = ["T", "U", "V", "W", "P_DYN", "C"]
+        f["R_WATER"] = U(995.0, 1005.0)
+        f["R_SALT_WATER"] = U(1020.0, 1035.0)
+        for s in ["SALT_BALANCE", "SALT_FINGER", "SALT_DIFFUSION"]:
+            f[s] = np.zeros(shp)
+    for nme in names:
+        f[nme + "N"] = f[nme] + 1e-3 * U(-1, 1) * np.abs(f[nme]).max()
+    for s in ["AUX_U", "AUX_V", "AUX_W"]:
+        f[s] = U(-1, 1)
+    f["BUOYANCY"] = np.zeros(shp)
+    f["RESIDUUM"] = np.zeros(shp)
+    h, topo = synthetic_mask(model, im, jm, km, L, rng, mask)
+    f["H"] = h
+    g = {"TOPOGRAPHY": topo,
+         "EVAPORATION_DALTON": rng.uniform(0.0, 8.0, (jm, km)),
+         "PRECIPITATION": rng.uniform(0.0, 3.0, (jm, km))}
+    return f, g
+
+
+def bits_equal(a, b):
+    """Bitwise equality up to the sign of zero (NaN == NaN)."""
+    a = np.asarray(a); b = np.asarray(b)
+    return bool(np.all((a == b) | (np.isnan(a) & np.isnan(b))))
+
+
+def max_rel_err(a, b):
+    """max |a-b| / max(|b|) over the field — the per-field relative error the
+    1e-10 target is stated in."""
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    scale = np.max(np.abs(b))
+    if scale == 0:
+        return float(np.max(np.abs(a - b)))
+    return float(np.max(np.abs(a - b)) / scale)
+
+
+# --------------------------------------------------------------------------
+# op sequences shared by oracle/make_golden.py and the parity tests
+# --------------------------------------------------------------------------
+
+ATM_SEQ = ["atm_bc_radius", "atm_bc_theta", "atm_bc_phi", "atm_solid_ground", "atm_rk3d",
+           "atm_pressure3d", "atm_rk2d", "atm_pressure2d", "move3d", "atm_rk3d"]
+HYD_SEQ = ["hyd_bc_radius", "hyd_bc_theta", "hyd_bc_phi", "hyd_value_limitation", "hyd_rk3d",
+           "hyd_solid_ground", "hyd_pressure3d", "move3d", "hyd_rk3d"]
+HYD_SURFACE_SEQ = ["hyd_rk2d", "hyd_pressure2d", "move2d", "hyd_rk2d"]
+
+
+def run_op(m, op):
+    if op == "move3d":
+        m.op("move_data_to_new_arrays", C.c_int(-1))
+    elif op == "move2d":
+        m.op("move_data_to_new_arrays", C.c_int(0 if m.model == ATM else m.im - 1))
+    else:
+        m.op(op)
+
+
+def run_sequence(m, seq, names, level=None):
+    """Runs seq on model m; after each op records every field the op changed
+    (whole field, or one level if ``level`` is given).  Keys: '<step>:<op>/<FIELD>'."""
+    snaps = {}
+    prev = {k: m.f[k].copy() for k in names}
+    for step, op in enumerate(seq):
+        run_op(m, op)
+        for k in names:
+            if not np.array_equal(m.f[k], prev[k], equal_nan=True):
+                a = m.f[k] if level is None else m.f[k][level]
+                snaps["%02d:%s/%s" % (step, op, k)] = a.copy()
+                prev[k] = m.f[k].copy()
+    return snaps
+
+
+def sample_planes(a):
+    """The slices of a full 1-degree field kept in the golden file."""
+    return {"j62": a[:, 62, :].copy(), "k87": a[:, :, 87].copy(), "i1s8": a[1, ::8, ::8].copy()}
+
+
+def load_mask_0Ma(model):
+    """The real 0 Ma land mask on the 1-degree grid, as the reference's readers
+    build it from 0Ma_Golonka.xyz (fixture made by oracle/make_golden.py)."""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "mask_0Ma.npz"))
+    tag = "atm" if model == ATM else "hyd"
+    n = 41 * 181 * 361
+    h = np.unpackbits(z[tag + "_h_bits"])[:n].astype(np.float64).reshape(41, 181, 361)
+    return np.ascontiguousarray(h), np.ascontiguousarray(z[tag + "_topo"], dtype=np.float64)

@@ -1,0 +1,145 @@
+"""The CPU restatement (oracle/atom_oracle.c) against the committed golden
+vectors, which oracle/make_golden.py produced with the compiled reference.
+Bar: bit-exact (every op here is +,-,*,/ and one glibc pow on the same host libm)."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import harness as H
+
+GOLD = os.path.join(H.ROOT, "tests", "golden")
+
+
+def _digest(fields, names):
+    h = hashlib.sha256()
+    for k in names:
+        h.update(np.ascontiguousarray(fields[k]).tobytes())
+    return h.hexdigest()
+
+
+def _small(model, fname, seq, level=None):
+    z = np.load(os.path.join(GOLD, fname))
+    im, jm, km = (int(x) for x in z["dims"])
+    p = H.default_params(model, im, jm, km)
+    f, g = H.make_inputs(model, im, jm, km, int(z["seed"]), "blobs", p)
+    names = H.ATM_FIELDS if model == H.ATM else H.HYD_FIELDS
+    f = {k: f[k] for k in names}
+    assert _digest(f, names) + _digest(g, H.FIELDS2D) == str(z["input_sha256"]), "input generator drifted"
+    m = H.CpuModel("oracle", model, im, jm, km, p, f, g)
+    lvl = None if level is None else im - 1
+    snaps = H.run_sequence(m, seq, names, lvl)
+    keys = [k for k in z.files if "/" in k]
+    assert sorted(keys) == sorted(snaps.keys())
+    for k in keys:
+        assert H.bits_equal(snaps[k], z[k]), k
+    return m, z
+
+
+def test_atm_small_sequence_bitexact():
+    _small(H.ATM, "atm_small.npz", H.ATM_SEQ)
+
+
+def test_hyd_small_sequence_bitexact():
+    _small(H.HYD, "hyd_small.npz", H.HYD_SEQ)
+
+
+def test_hyd_surface_sequence_bitexact():
+    m, z = _small(H.HYD, "hyd_surface.npz", H.HYD_SURFACE_SEQ, level="top")
+    # Pressure_Hyd.cpp:304 zeroes p_dyn[0][jm-1][:] from the *surface* routine
+    assert H.bits_equal(m.f["P_DYN"][0, m.jm - 1, :], z["p_dyn_level0_lastrow"])
+
+
+def test_residuum_small():
+    z = np.load(os.path.join(GOLD, "residuum_small.npz"))
+    im, jm, km = 7, 13, 17
+    p = H.default_params(H.ATM, im, jm, km)
+    f, g = H.make_inputs(H.ATM, im, jm, km, 77, "blobs", p)
+    f = {k: f[k] for k in H.ATM_FIELDS}
+    m = H.CpuModel("oracle", H.ATM, im, jm, km, p, f, g)
+    mn, loc = m.residuum("atm_residuum3d")
+    assert mn == float(z["res3d_min"]) and loc == tuple(z["res3d_loc"])
+    assert H.bits_equal(m.f["RESIDUUM"][1:-1, 1:-1, 1:-1], z["res3d_field"][1:-1, 1:-1, 1:-1])
+    # two queries on one Accuracy_Atm object: state carried between the calls
+    m2 = H.CpuModel("oracle", H.ATM, im, jm, km, p,
+                    dict(f, U=-0.5 * f["U"], V=0.25 * f["V"], W=-0.125 * f["W"]), g)
+    mn2, loc2 = m2.residuum("atm_residuum3d", mn, loc)
+    assert np.array_equal([mn, mn2], z["res3d_twice_min"])
+    assert np.array_equal(list(loc) + list(loc2), z["res3d_twice_loc"])
+    mn, loc = m.residuum("atm_residuum2d")
+    assert mn == float(z["res2d_min"]) and loc == tuple(z["res2d_loc"])
+    assert H.bits_equal(m.f["RESIDUUM"][0, 1:-1, 1:-1], z["res2d_field"][1:-1, 1:-1])
+    ph = H.default_params(H.HYD, im, jm, km)
+    fh, gh = H.make_inputs(H.HYD, im, jm, km, 78, "blobs", ph)
+    mh = H.CpuModel("oracle", H.HYD, im, jm, km, ph, {k: fh[k] for k in H.HYD_FIELDS}, gh)
+    mn, loc = mh.residuum("hyd_residuum3d")
+    assert mn == float(z["hyd_res3d_min"]) and loc == tuple(z["hyd_res3d_loc"])
+
+
+@pytest.mark.parametrize("model,tag,op", [(H.ATM, "atm", "atm_rk3d"), (H.HYD, "hyd", "hyd_rk3d")])
+def test_full_1deg_real_mask_rk3d(model, tag, op):
+    """One RK sweep on the full 41x181x361 grid with the real 0 Ma land mask:
+    per-field SHA-256 of the result equals the compiled reference's."""
+    z = np.load(os.path.join(GOLD, "full_1deg_%s_rk3d.npz" % tag))
+    im, jm, km = 41, 181, 361
+    p = H.default_params(model)
+    f, g = H.make_inputs(model, im, jm, km, 1234, "allfluid", p)
+    names = H.ATM_FIELDS if model == H.ATM else H.HYD_FIELDS
+    f = {k: f[k] for k in names}
+    f["H"], g["TOPOGRAPHY"] = H.load_mask_0Ma(model)
+    assert _digest(f, names) + _digest(g, H.FIELDS2D) == str(z["input_sha256"]), "input generator drifted"
+    m = H.CpuModel("oracle", model, im, jm, km, p, f, g)
+    m.op(op)
+    changed = [k[:-7] for k in z.files if k.endswith("/sha256")]
+    assert len(changed) >= 9
+    for k in changed:
+        assert hashlib.sha256(m.f[k].tobytes()).hexdigest() == str(z[k + "/sha256"]), k
+        for pk, pv in H.sample_planes(m.f[k]).items():
+            assert H.bits_equal(pv, z[k + "/" + pk]), (k, pk)
+
+
+def test_value_limitation_atm_against_numpy():
+    """BC_Thermo.cpp cannot be compiled here (it needs generated headers), so the
+    atmosphere limiter is pinned by an independent numpy restatement of
+    atmosphere/BC_Thermo.cpp:3241-3271 instead: parity unpinned by the reference."""
+    im, jm, km = 7, 13, 17
+    p = H.default_params(H.ATM, im, jm, km)
+    f, g = H.make_inputs(H.ATM, im, jm, km, 5, "blobs", p)
+    f = {k: f[k] for k in H.ATM_FIELDS}
+    rng = np.random.default_rng(3)
+    for k in ["U", "V", "W", "T", "C", "CLOUD", "ICE", "CO2"]:
+        f[k] = f[k] + rng.normal(0, 2.0 * np.abs(f[k]).max(), f[k].shape)  # push values past the bounds
+    m = H.CpuModel("oracle", H.ATM, im, jm, km, p, f, g)
+    m.op("atm_value_limitation")
+    land = np.abs(f["H"] - 1) < np.finfo(float).eps
+    exp = {"U": np.clip(f["U"], -.106, .106), "V": np.clip(f["V"], -.125, .125), "W": np.clip(f["W"], -.469, 3.5),
+           "T": np.clip(f["T"], -.78, 1.165), "C": np.clip(f["C"], 0, .03), "CLOUD": np.clip(f["CLOUD"], 0, .01),
+           "ICE": np.clip(f["ICE"], 0, .005), "CO2": np.clip(f["CO2"], 1., 5.36), "P_DYN": f["P_DYN"].copy()}
+    for k in ["U", "V", "W", "CLOUD", "ICE", "P_DYN"]:
+        exp[k][land] = 0.
+    exp["CO2"][land] = 1.
+    for k, v in exp.items():
+        assert H.bits_equal(m.f[k], v), k
+
+
+def test_steady_queries_against_numpy():
+    im, jm, km = 7, 13, 17
+    p = H.default_params(H.ATM, im, jm, km)
+    f, g = H.make_inputs(H.ATM, im, jm, km, 6, "blobs", p)
+    m = H.CpuModel("oracle", H.ATM, im, jm, km, p, {k: f[k] for k in H.ATM_FIELDS}, g)
+    out, loc = m.steady("atm_steady3d", 9)
+    for n, k in enumerate(["U", "V", "W", "T", "C", "CLOUD", "ICE", "CO2", "P_DYN"]):
+        d = np.abs(f[k] - f[k + "N"])
+        assert out[n] == d.max()
+        assert tuple(loc[n]) == np.unravel_index(np.argmax(d), d.shape)  # first maximum
+    out, loc = m.steady("atm_steady2d", 3)
+    for n, k in enumerate(["V", "W", "P_DYN"]):
+        d = np.abs(f[k][0] - f[k + "N"][0])
+        assert out[n] == d.max() and tuple(loc[n][1:]) == np.unravel_index(np.argmax(d), d.shape)
+    ph = H.default_params(H.HYD, im, jm, km)
+    fh, gh = H.make_inputs(H.HYD, im, jm, km, 7, "blobs", ph)
+    fh["UN"] = fh["U"].copy(); fh["UN"][2, 3, 4] += 1.0; fh["UN"][5, 6, 7] += 1.0  # a tie: >= keeps the LAST
+    mh = H.CpuModel("oracle", H.HYD, im, jm, km, ph, {k: fh[k] for k in H.HYD_FIELDS}, gh)
+    out, loc = mh.steady("hyd_steady3d", 6)
+    assert out[0] == 1.0 and tuple(loc[0]) == (5, 6, 7)

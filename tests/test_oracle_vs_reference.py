@@ -1,0 +1,60 @@
+"""atom_oracle.c against the reference's own compiled classes (oracle/_ref),
+on fresh seeds, masks and grid shapes.  Runs only where the reference was
+compiled (the build container); the committed goldens cover the GPU box."""
+import numpy as np
+import pytest
+
+import harness as H
+
+pytestmark = pytest.mark.skipif(not H.have_ref(), reason="oracle/_ref/libatomref.so not built")
+
+
+def _pair(model, dims, seed, mask):
+    im, jm, km = dims
+    p = H.default_params(model, im, jm, km)
+    f, g = H.make_inputs(model, im, jm, km, seed, mask, p)
+    names = H.ATM_FIELDS if model == H.ATM else H.HYD_FIELDS
+    f = {k: f[k] for k in names}
+    return (H.CpuModel("oracle", model, im, jm, km, p, f, g),
+            H.CpuModel("ref", model, im, jm, km, p, f, g), names)
+
+
+@pytest.mark.parametrize("dims,seed,mask", [((9, 21, 31), 1, "blobs"), ((6, 9, 8), 2, "blobs"),
+                                            ((11, 41, 31), 3, "allfluid"), ((5, 7, 7), 4, "blobs")])
+def test_atm_ops(dims, seed, mask):
+    a, b, names = _pair(H.ATM, dims, seed, mask)
+    for op in H.ATM_SEQ + ["move2d", "atm_rk2d"]:
+        H.run_op(a, op); H.run_op(b, op)
+        for k in names:
+            if k != "RESIDUUM":
+                assert H.bits_equal(a.f[k], b.f[k]), (op, k)
+
+
+@pytest.mark.parametrize("dims,seed,mask", [((9, 21, 31), 1, "blobs"), ((6, 9, 8), 2, "blobs"),
+                                            ((11, 41, 31), 3, "allfluid")])
+def test_hyd_ops(dims, seed, mask):
+    a, b, names = _pair(H.HYD, dims, seed, mask)
+    for op in H.HYD_SEQ:
+        H.run_op(a, op); H.run_op(b, op)
+        for k in names:
+            if k != "RESIDUUM":
+                assert H.bits_equal(a.f[k], b.f[k]), (op, k)
+
+
+@pytest.mark.parametrize("dims,seed", [((41, 43, 19), 5), ((41, 45, 12), 6)])
+def test_hyd_surface_ops(dims, seed):
+    """RK_RHS_2D_Hydrosphere hard-codes im = 41 (RHS_Hyd.cpp:466), so these grids keep im = 41."""
+    a, b, names = _pair(H.HYD, dims, seed, "blobs")
+    for op in H.HYD_SURFACE_SEQ + ["hyd_pressure2d"]:
+        H.run_op(a, op); H.run_op(b, op)
+        for k in names:
+            if k != "RESIDUUM":
+                assert H.bits_equal(a.f[k], b.f[k]), (op, k)
+
+
+def test_residuum_queries():
+    a, b, _ = _pair(H.ATM, (9, 21, 31), 9, "blobs")
+    assert a.residuum("atm_residuum3d") == b.residuum("atm_residuum3d")
+    assert a.residuum("atm_residuum2d") == b.residuum("atm_residuum2d")
+    a, b, _ = _pair(H.HYD, (9, 21, 31), 10, "blobs")
+    assert a.residuum("hyd_residuum3d") == b.residuum("hyd_residuum3d")
