@@ -1,0 +1,12 @@
+"""atom_amd — MI355X-native dynamical core for ATOM's atmosphere / hydrosphere models.
+
+The package is a thin ctypes view of ``libatomdev.so`` (HIP kernels for gfx950
+behind the C-ABI declared in ``include/atomdev.h``).  There is no CPU fallback:
+importing works anywhere, but creating a device model raises if the library or
+a GPU is missing.
+"""
+from .device import (ATM, HYD, F2, F3, AtomDevError, DeviceModel, Params, default_params,
+                     library_path, load_library)
+
+__all__ = ["ATM", "HYD", "F2", "F3", "AtomDevError", "DeviceModel", "Params", "default_params",
+           "library_path", "load_library"]

@@ -1,0 +1,237 @@
+// Field store, handle lifetime, transfers, timers: the part of the C-ABI that
+// replaces lib/Array.{h,cpp}, Array_2D and Array_1D for the hot path.
+#include <math.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "atomdev_internal.h"
+
+static thread_local std::string g_last_error;
+
+void atomdev_set_error(const std::string& msg) { g_last_error = msg; }
+
+int atomdev_check(hipError_t e, const char* what) {
+    if (e == hipSuccess) return 0;
+    g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+    return 2;
+}
+
+extern "C" const char* atomdev_last_error(void) { return g_last_error.c_str(); }
+
+// Reference defaults: param.py:32-177; grid constants atmosphere/cAtmosphereModel.cpp:38-55
+// and hydrosphere/cHydrosphereModel.cpp:145-156.
+extern "C" void atomdev_default_params(int model, atomdev_params* p) {
+    memset(p, 0, sizeof(*p));
+    const double pi180 = 180. / M_PI;
+    p->dt = 0.00001; p->dr = 0.025; p->dthe = 1. / pi180; p->dphi = 1. / pi180;
+    p->r0 = 1.; p->the0 = 0.; p->phi0 = 0.;
+    p->g = 9.8066; p->Buoyancy = 1.0; p->t_0 = 273.15;
+    if (model == ATOMDEV_ATM) { p->re = 1000.; p->pr = .7179; p->u_0 = 8.; p->c_0 = .035; }
+    else { p->re = 10.; p->pr = 6.957; p->u_0 = .25; p->c_0 = 34.6; }
+    p->sc_WaterVapour = .61; p->sc_CO2 = .96; p->gam = .65; p->r_air = 1.2041; p->R_Air = 287.1;
+    p->R_WaterVapour = 461.6; p->L_atm = 16000.; p->cp_l = 1005.; p->t_tropopause = .798;
+    p->sc = 1.7329; p->L_hyd = 1000.; p->r_0_water = 1000.; p->ta = 1.01464; p->pa = 0.; p->ca = 1.;
+}
+
+static bool field_used(int model, int f) {
+    if (f < 0 || f >= ATOMDEV_N3D) return false;
+    if (model == ATOMDEV_ATM) return !(f >= ATOMDEV_SALT_BALANCE && f <= ATOMDEV_R_SALT_WATER);
+    // hydrosphere: no cloud / ice / co2 / S_*
+    if (f == ATOMDEV_CLOUD || f == ATOMDEV_ICE || f == ATOMDEV_CO2) return false;
+    if (f == ATOMDEV_CLOUDN || f == ATOMDEV_ICEN || f == ATOMDEV_CO2N) return false;
+    if (f >= ATOMDEV_S_V && f <= ATOMDEV_S_S) return false;
+    return true;
+}
+
+static void fill_constants(atomdev* h) {
+    const atomdev_params& P = h->p;
+    DevConst& k = h->k;
+    const bool atm = h->model == ATOMDEV_ATM;
+    k.im = h->im; k.jm = h->jm; k.km = h->km;
+    k.dt = P.dt; k.dr = P.dr; k.dthe = P.dthe; k.dphi = P.dphi;
+    k.dr2 = P.dr * P.dr; k.dthe2 = P.dthe * P.dthe; k.dphi2 = P.dphi * P.dphi;
+    k.two_dr = 2. * P.dr; k.two_dthe = 2. * P.dthe; k.two_dphi = 2. * P.dphi;
+    k.re = P.re; k.re_pr = P.re * P.pr;
+    k.re_sc_wv = P.sc_WaterVapour * P.re; k.re_sc_co2 = P.sc_CO2 * P.re; k.re_sc = P.sc * P.re;
+    k.r_air = P.r_air; k.g = P.g; k.Buoyancy = P.Buoyancy; k.t_0 = P.t_0; k.c_0 = P.c_0;
+    k.R_Air = P.R_Air; k.R_WV_over_R_Air = P.R_WaterVapour / P.R_Air; k.gam = P.gam;
+    k.L = atm ? P.L_atm : P.L_hyd;
+    k.topo_step = k.L / (double)(h->im - 1);
+    k.exp_pressure = P.g / (1.e-2 * P.gam * P.R_Air);
+    k.p_SL_factor = P.r_air * P.R_Air;
+    k.coeff_energy = P.L_atm / (P.cp_l * P.t_0 * P.u_0);
+    k.coeff_buoy = atm ? P.r_air * P.u_0 * P.u_0 / P.L_atm : P.r_0_water * P.u_0 * P.u_0 / P.L_hyd;
+    k.coeff_trans = P.L_atm / P.u_0;
+    k.coeff_vapour = 1.1574e-5 * P.L_atm / P.u_0;
+    k.coeff_salinity = 1.1574e-5 * P.L_hyd / P.u_0;
+    k.buoy_g = P.Buoyancy * P.g;
+    k.r_0_water = P.r_0_water;
+    k.t_tropopause = P.t_tropopause; k.ta = P.ta; k.pa = P.pa; k.ca = P.ca;
+    k.i_dthe = 1. / k.dthe; k.i_two_dthe = 1. / k.two_dthe; k.i_dthe2 = 1. / k.dthe2;
+    k.i_dr = 1. / k.dr; k.i_two_dr = 1. / k.two_dr; k.i_dr2 = 1. / k.dr2; k.i_dphi2 = 1. / k.dphi2;
+    k.i_re = 1. / k.re; k.i_re_pr = 1. / k.re_pr; k.i_re_sc_wv = 1. / k.re_sc_wv;
+    k.i_re_sc_co2 = 1. / k.re_sc_co2; k.i_re_sc = 1. / k.re_sc;
+    k.i_r_air = 1. / k.r_air; k.i_six = 1. / 6.; k.i_topo_step = 1. / k.topo_step;
+}
+
+extern "C" int atomdev_create(int model, int im, int jm, int km, const atomdev_params* p, int device,
+                              atomdev_t** out) {
+    ATOMDEV_REQUIRE(out != nullptr && p != nullptr, "atomdev_create: null argument");
+    *out = nullptr;
+    ATOMDEV_REQUIRE(model == ATOMDEV_ATM || model == ATOMDEV_HYD, "atomdev_create: unknown model");
+    // the boundary fills read levels 3 and im-4 and rows 2 and jm-3
+    ATOMDEV_REQUIRE(im >= 5 && jm >= 7 && km >= 7, "atomdev_create: grid too small (need im>=5, jm>=7, km>=7)");
+    ATOMDEV_REQUIRE(p->dt > 0 && p->dr > 0 && p->dthe > 0 && p->dphi > 0, "atomdev_create: step sizes must be positive");
+    int ndev = 0;
+    ATOMDEV_TRY(hipGetDeviceCount(&ndev));
+    ATOMDEV_REQUIRE(ndev > 0, "atomdev_create: no HIP device visible");
+    if (device < 0) ATOMDEV_TRY(hipGetDevice(&device));
+    ATOMDEV_REQUIRE(device < ndev, "atomdev_create: device index out of range");
+    ATOMDEV_TRY(hipSetDevice(device));
+
+    atomdev* h = new atomdev();
+    memset(h->f, 0, sizeof(h->f)); memset(h->g, 0, sizeof(h->g)); memset(h->alt, 0, sizeof(h->alt));
+    h->model = model; h->im = im; h->jm = jm; h->km = km; h->device = device;
+    h->n3 = (size_t)im * jm * km; h->n2 = (size_t)jm * km;
+    h->p = *p;
+    h->flags = nullptr; h->flags_dirty = true;
+    h->rad = h->sinthe = h->costhe = h->plane = nullptr; h->red = nullptr;
+    fill_constants(h);
+
+    int rc = 0;
+    auto fail = [&](int code) { atomdev_destroy(h); return code; };
+    if ((rc = atomdev_check(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking), "hipStreamCreate"))) { h->stream = nullptr; return fail(rc); }
+    if ((rc = atomdev_check(hipEventCreate(&h->ev0), "hipEventCreate"))) return fail(rc);
+    if ((rc = atomdev_check(hipEventCreate(&h->ev1), "hipEventCreate"))) return fail(rc);
+    for (int f = 0; f < ATOMDEV_N3D; f++) {
+        if (!field_used(model, f)) continue;
+        if ((rc = atomdev_check(hipMalloc(&h->f[f], h->n3 * sizeof(double)), "hipMalloc(field)"))) return fail(rc);
+        if ((rc = atomdev_check(hipMemsetAsync(h->f[f], 0, h->n3 * sizeof(double), h->stream), "hipMemset"))) return fail(rc);
+    }
+    if (model == ATOMDEV_HYD) {
+        const int pp[5] = { ATOMDEV_T, ATOMDEV_U, ATOMDEV_V, ATOMDEV_W, ATOMDEV_C };
+        for (int n = 0; n < 5; n++)
+            if ((rc = atomdev_check(hipMalloc(&h->alt[pp[n]], h->n3 * sizeof(double)), "hipMalloc(alt)"))) return fail(rc);
+    }
+    for (int g = 0; g < ATOMDEV_N2D; g++) {
+        if ((rc = atomdev_check(hipMalloc(&h->g[g], h->n2 * sizeof(double)), "hipMalloc(field2d)"))) return fail(rc);
+        if ((rc = atomdev_check(hipMemsetAsync(h->g[g], 0, h->n2 * sizeof(double), h->stream), "hipMemset"))) return fail(rc);
+    }
+    if ((rc = atomdev_check(hipMalloc(&h->flags, h->n3), "hipMalloc(flags)"))) return fail(rc);
+    if ((rc = atomdev_check(hipMalloc(&h->plane, h->n2 * sizeof(double)), "hipMalloc(plane)"))) return fail(rc);
+    h->red_bytes = 1 << 20;
+    if ((rc = atomdev_check(hipMalloc(&h->red, h->red_bytes), "hipMalloc(red)"))) return fail(rc);
+
+    // coordinates by repeated addition (lib/Array_1D.cpp:54-65); sin/cos from the host
+    // libm, which is what the reference calls per grid point (e.g. RHS_Atm.cpp:101-103)
+    const int nrad = im > 41 ? im : 41;  // RK_RHS_2D_Hydrosphere reads rad[40] on any grid
+    std::vector<double> rad(nrad), st(jm), ct(jm);
+    rad[0] = p->r0;
+    for (int l = 1; l < nrad; l++) rad[l] = rad[l - 1] + p->dr;
+    double the = p->the0;
+    for (int j = 0; j < jm; j++) { if (j) the = the + p->dthe; st[j] = sin(the); ct[j] = cos(the); }
+    if ((rc = atomdev_check(hipMalloc(&h->rad, nrad * sizeof(double)), "hipMalloc"))) return fail(rc);
+    if ((rc = atomdev_check(hipMalloc(&h->sinthe, jm * sizeof(double)), "hipMalloc"))) return fail(rc);
+    if ((rc = atomdev_check(hipMalloc(&h->costhe, jm * sizeof(double)), "hipMalloc"))) return fail(rc);
+    if ((rc = atomdev_check(hipMemcpy(h->rad, rad.data(), nrad * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy"))) return fail(rc);
+    if ((rc = atomdev_check(hipMemcpy(h->sinthe, st.data(), jm * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy"))) return fail(rc);
+    if ((rc = atomdev_check(hipMemcpy(h->costhe, ct.data(), jm * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy"))) return fail(rc);
+    if ((rc = atomdev_check(hipStreamSynchronize(h->stream), "hipStreamSynchronize"))) return fail(rc);
+    *out = h;
+    return 0;
+}
+
+extern "C" int atomdev_destroy(atomdev_t* h) {
+    if (!h) return 0;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (int f = 0; f < ATOMDEV_N3D; f++) { if (h->f[f]) (void)hipFree(h->f[f]); if (h->alt[f]) (void)hipFree(h->alt[f]); }
+    for (int g = 0; g < ATOMDEV_N2D; g++) if (h->g[g]) (void)hipFree(h->g[g]);
+    if (h->flags) (void)hipFree(h->flags);
+    if (h->plane) (void)hipFree(h->plane);
+    if (h->red) (void)hipFree(h->red);
+    if (h->rad) (void)hipFree(h->rad);
+    if (h->sinthe) (void)hipFree(h->sinthe);
+    if (h->costhe) (void)hipFree(h->costhe);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return 0;
+}
+
+extern "C" int atomdev_dims(const atomdev_t* h, int* im, int* jm, int* km) {
+    ATOMDEV_REQUIRE(h != nullptr, "atomdev_dims: null handle");
+    if (im) *im = h->im;
+    if (jm) *jm = h->jm;
+    if (km) *km = h->km;
+    return 0;
+}
+
+static int check3d(const atomdev_t* h, int field, const void* host, const char* who) {
+    if (!h || !host) { atomdev_set_error(std::string(who) + ": null argument"); return 1; }
+    if (field < 0 || field >= ATOMDEV_N3D || !h->f[field]) {
+        atomdev_set_error(std::string(who) + ": field " + std::to_string(field) + " does not exist in this model");
+        return 1;
+    }
+    return 0;
+}
+
+extern "C" int atomdev_upload(atomdev_t* h, int field, const double* host) {
+    if (int rc = check3d(h, field, host, "atomdev_upload")) return rc;
+    ATOMDEV_TRY(hipSetDevice(h->device));
+    ATOMDEV_TRY(hipMemcpyAsync(h->f[field], host, h->n3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    ATOMDEV_TRY(hipStreamSynchronize(h->stream));  // the host buffer may be reused at once
+    if (field == ATOMDEV_H) h->flags_dirty = true;
+    return 0;
+}
+
+extern "C" int atomdev_download(atomdev_t* h, int field, double* host) {
+    if (int rc = check3d(h, field, host, "atomdev_download")) return rc;
+    ATOMDEV_TRY(hipSetDevice(h->device));
+    ATOMDEV_TRY(hipMemcpyAsync(host, h->f[field], h->n3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    ATOMDEV_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int atomdev_upload2d(atomdev_t* h, int field, const double* host) {
+    ATOMDEV_REQUIRE(h && host && field >= 0 && field < ATOMDEV_N2D, "atomdev_upload2d: bad argument");
+    ATOMDEV_TRY(hipSetDevice(h->device));
+    ATOMDEV_TRY(hipMemcpyAsync(h->g[field], host, h->n2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    ATOMDEV_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int atomdev_download2d(atomdev_t* h, int field, double* host) {
+    ATOMDEV_REQUIRE(h && host && field >= 0 && field < ATOMDEV_N2D, "atomdev_download2d: bad argument");
+    ATOMDEV_TRY(hipSetDevice(h->device));
+    ATOMDEV_TRY(hipMemcpyAsync(host, h->g[field], h->n2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    ATOMDEV_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int atomdev_sync(atomdev_t* h) {
+    ATOMDEV_REQUIRE(h != nullptr, "atomdev_sync: null handle");
+    ATOMDEV_TRY(hipSetDevice(h->device));
+    ATOMDEV_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int atomdev_timer_start(atomdev_t* h) {
+    ATOMDEV_REQUIRE(h != nullptr, "atomdev_timer_start: null handle");
+    ATOMDEV_TRY(hipSetDevice(h->device));
+    ATOMDEV_TRY(hipEventRecord(h->ev0, h->stream));
+    return 0;
+}
+
+extern "C" int atomdev_timer_stop(atomdev_t* h, float* ms) {
+    ATOMDEV_REQUIRE(h != nullptr && ms != nullptr, "atomdev_timer_stop: null argument");
+    ATOMDEV_TRY(hipSetDevice(h->device));
+    ATOMDEV_TRY(hipEventRecord(h->ev1, h->stream));
+    ATOMDEV_TRY(hipEventSynchronize(h->ev1));
+    ATOMDEV_TRY(hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return 0;
+}

@@ -1,0 +1,97 @@
+// Internal definitions shared by the HIP translation units of libatomdev.so.
+#ifndef ATOMDEV_INTERNAL_H_
+#define ATOMDEV_INTERNAL_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "atomdev.h"
+
+// Point flags derived from h once per mask upload (k_flags.hip).
+enum : uint8_t {
+    FL_LAND = 1 << 0,      // |h - 1| < DBL_EPSILON  (AtomUtils::is_land)
+    FL_ONESIDED_S = 1 << 1,// land cell with fluid at j-1 and j-2: one-sided theta differences
+    FL_H0J = 1 << 2,       // fluid cell with land at j-1 or j+1  (h_0_j = 1)
+    FL_H0K = 1 << 3,       // fluid cell with land at k-1 or k+1  (h_0_k = 1)
+    FL_RDEAD = 1 << 4,     // hyd: land cell with h[i+1] == 0.: radial differences multiplied by h_d_i = 0
+    FL_D2ZERO = 1 << 5,    // hyd: land cell with two fluid cells east or west: theta 2nd derivatives zeroed
+    FL_HZERO = 1 << 6      // h == 0. exactly (the hydrosphere surface routine tests this)
+};
+
+// Scalars every kernel may need, computed on the host in the reference's own
+// operation order so that they carry the same bits.
+struct DevConst {
+    int im, jm, km;
+    double dt, dr, dthe, dphi;
+    double dr2, dthe2, dphi2, two_dr, two_dthe, two_dphi;
+    double re, re_pr, re_sc_wv, re_sc_co2, re_sc;   // divisors of the diffusion brackets
+    double r_air, g, Buoyancy, t_0, c_0;
+    double R_Air, R_WV_over_R_Air, gam, L, topo_step;
+    double exp_pressure, p_SL_factor /* r_air*R_Air */, coeff_energy, coeff_buoy, coeff_trans, coeff_vapour;
+    double coeff_salinity, buoy_g /* Buoyancy*g */, r_0_water;
+    double t_tropopause, ta, pa, ca;
+    // reciprocals (correctly rounded 1/x) for the exact-division helper
+    double i_dthe, i_two_dthe, i_dthe2, i_dr, i_two_dr, i_dr2, i_dphi2, i_re, i_re_pr, i_re_sc_wv, i_re_sc_co2, i_re_sc,
+           i_r_air, i_six, i_topo_step;
+};
+
+struct atomdev {
+    int model, im, jm, km, device;
+    size_t n3, n2;
+    atomdev_params p;
+    DevConst k;
+    hipStream_t stream;
+    hipEvent_t ev0, ev1;
+    double* f[ATOMDEV_N3D];
+    double* g[ATOMDEV_N2D];
+    double* alt[ATOMDEV_N3D];  // hyd RK writes out of place into these, then swaps with f[]
+    uint8_t* flags;
+    bool flags_dirty;
+    double *rad, *sinthe, *costhe;  // device tables: rad[max(im,41)], sin/cos(the[j]) from the host libm
+    double* plane;                  // jm*km scratch (atm: snapshot of c at level 3)
+    void* red;                      // reduction scratch
+    size_t red_bytes;
+};
+
+void atomdev_set_error(const std::string& msg);
+int atomdev_check(hipError_t e, const char* what);
+int atomdev_refresh_flags(atomdev* h);  // k_flags.hip
+
+#define ATOMDEV_TRY(expr)                                   \
+    do {                                                    \
+        if (int rc__ = atomdev_check((expr), #expr)) return rc__; \
+    } while (0)
+
+#define ATOMDEV_REQUIRE(cond, msg)        \
+    do {                                  \
+        if (!(cond)) {                    \
+            atomdev_set_error(msg);       \
+            return 1;                     \
+        }                                 \
+    } while (0)
+
+#ifdef __HIPCC__
+// a / b for a divisor whose correctly rounded reciprocal rb is known: one
+// product and two fused corrections give the correctly rounded quotient (the
+// residual a - q*b is exact), at a quarter of the cost of the generic IEEE
+// division sequence.  Valid for finite, normal, non-overflowing operands, which
+// is what the model's bounded fields and grid constants are.
+__device__ __forceinline__ double div_by(double a, double b, double rb) {
+#ifdef ATOMDEV_TRUE_DIV
+    (void)rb;
+    return a / b;
+#else
+    double q = a * rb;
+    double r = __builtin_fma(-q, b, a);
+    return __builtin_fma(r, rb, q);
+#endif
+}
+
+__host__ __device__ __forceinline__ size_t idx3(int jm, int km, int i, int j, int k) {
+    return ((size_t)i * (size_t)jm + (size_t)j) * (size_t)km + (size_t)k;
+}
+#endif
+
+#endif  // ATOMDEV_INTERNAL_H_

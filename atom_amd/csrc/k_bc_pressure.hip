@@ -1,0 +1,373 @@
+// Boundary fills (BC_Atmosphere, BC_Hydrosphere) and the pressure step
+// (Pressure_Atm, Pressure_Hyd): one Jacobi sweep of the pressure Poisson
+// equation framed by boundary fills of aux_u/v/w and p_dyn.
+//
+// Every fill kernel assigns one thread per boundary row/column, and threads of
+// one launch never read what another thread of that launch writes; the
+// reference's r -> theta -> phi order is kept as launch order on the handle's
+// stream, so edges and corners receive the same values.
+#include "atomdev_internal.h"
+
+namespace {
+
+constexpr int TPB = 256;
+constexpr double c43 = 4. / 3., c13 = 1. / 3.;
+
+struct Fields { double* p[9]; int n; };
+
+enum { FILL_NEUMANN = 0, FILL_ZERO = 1 };
+struct ThetaFill { double* p[9]; int mode[9]; int n; };
+
+// rows j = 0 and j = jm-1 for every (i, k): x = 4/3 x1 - 1/3 x2, or 0
+__global__ void k_fill_theta(ThetaFill f, int im, int jm, int km, int i0, int ni) {
+    int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= ni * km) return;
+    int k = id % km, i = i0 + id / km;
+    for (int n = 0; n < f.n; n++) {
+        double* x = f.p[n];
+        if (f.mode[n] == FILL_ZERO) {
+            x[idx3(jm, km, i, 0, k)] = 0.;
+            x[idx3(jm, km, i, jm - 1, k)] = 0.;
+        } else {
+            x[idx3(jm, km, i, 0, k)] = c43 * x[idx3(jm, km, i, 1, k)] - c13 * x[idx3(jm, km, i, 2, k)];
+            x[idx3(jm, km, i, jm - 1, k)] = c43 * x[idx3(jm, km, i, jm - 2, k)] - c13 * x[idx3(jm, km, i, jm - 3, k)];
+        }
+    }
+}
+
+// columns k = 0 and k = km-1 for (i, j), j in [j0, j1): Neumann on both ends, then
+// both set to their mean (e.g. BC_Atm.cpp:121-123)
+__global__ void k_fill_phi_seam(Fields f, int im, int jm, int km, int i0, int ni, int j0, int j1) {
+    int id = blockIdx.x * blockDim.x + threadIdx.x;
+    int nj = j1 - j0;
+    if (id >= ni * nj) return;
+    int j = j0 + id % nj, i = i0 + id / nj;
+    size_t b = idx3(jm, km, i, j, 0);
+    for (int n = 0; n < f.n; n++) {
+        double* x = f.p[n] + b;
+        double lo = c43 * x[1] - c13 * x[2];
+        double hi = c43 * x[km - 2] - c13 * x[km - 3];
+        double m = (lo + hi) / 2.;
+        x[0] = m; x[km - 1] = m;
+    }
+}
+
+// BC_Atmosphere::BC_radius, atmosphere/BC_Atm.cpp:39-73
+__global__ void k_atm_bc_radius(double* t, double* u, double* v, double* w, Fields ex /* p_dyn c cloud ice co2 */,
+                                double t_tropopause, int im, int jm, int km) {
+    size_t n2 = (size_t)jm * km;
+    size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n2) return;
+    const size_t top = (size_t)(im - 1) * n2 + q;
+    u[q] = 0.;
+    v[q] = c43 * v[n2 + q] - c13 * v[2 * n2 + q];
+    w[q] = c43 * w[n2 + q] - c13 * w[2 * n2 + q];
+    t[top] = t_tropopause;
+    u[top] = 0.; v[top] = 0.; w[top] = 0.;
+    for (int n = 0; n < ex.n; n++) {
+        double* x = ex.p[n];
+        x[top] = x[top - 3 * n2] - 3. * x[top - 2 * n2] + 3. * x[top - n2];
+    }
+}
+
+// BC_Hydrosphere::RB_radius, hydrosphere/BC_Hyd.cpp:38-83
+__global__ void k_hyd_bc_radius(double* t, double* u, double* v, double* w, double* p_dyn, double* c, double ta, double ca,
+                                int im, int jm, int km) {
+    size_t n2 = (size_t)jm * km;
+    size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n2) return;
+    const size_t top = (size_t)(im - 1) * n2 + q;
+    u[q] = c43 * u[n2 + q] - c13 * u[2 * n2 + q];
+    t[q] = ta; c[q] = ca; v[q] = 0.; w[q] = 0.; p_dyn[q] = 0.;
+    v[top] = c43 * v[top - n2] - c13 * v[top - 2 * n2];
+    w[top] = c43 * w[top - n2] - c13 * w[top - 2 * n2];
+    u[top] = u[top - 3 * n2] - 3. * u[top - 2 * n2] + 3. * u[top - n2];
+    c[top] = c[top - 3 * n2] - 3. * c[top - 2 * n2] + 3. * c[top - n2];
+}
+
+// radial faces of aux_u/v/w (Pressure_Atm.cpp:47-56, Pressure_Hyd.cpp:51-62)
+__global__ void k_aux_fill_r(double* au, double* av, double* aw, int im, int jm, int km) {
+    size_t n2 = (size_t)jm * km;
+    size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n2) return;
+    const size_t top = (size_t)(im - 1) * n2 + q;
+    au[q] = 0.; au[top] = 0.;
+    av[q] = c43 * av[n2 + q] - c13 * av[2 * n2 + q];
+    av[top] = c43 * av[top - n2] - c13 * av[top - 2 * n2];
+    aw[q] = c43 * aw[n2 + q] - c13 * aw[2 * n2 + q];
+    aw[top] = c43 * aw[top - n2] - c13 * aw[top - 2 * n2];
+}
+
+// radial faces of p_dyn after the sweep (Pressure_Atm.cpp:163-168, Pressure_Hyd.cpp:176-181)
+__global__ void k_p_fill_r(double* p, int im, int jm, int km) {
+    size_t n2 = (size_t)jm * km;
+    size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n2) return;
+    const size_t top = (size_t)(im - 1) * n2 + q;
+    p[q] = p[3 * n2 + q] - 3. * p[2 * n2 + q] + 3. * p[n2 + q];
+    p[top] = c43 * p[top - n2] - c13 * p[top - 2 * n2];
+}
+
+// Interior Jacobi sweep: Pressure_Atm.cpp:104-160 / Pressure_Hyd.cpp:114-173.  Reads
+// p_dynn (old), writes p_dyn.  hyd: aux_v / aux_w are read at level im-1 for every i
+// (Pressure_Hyd.cpp:137-163), the radial land test is h[i+1] == 0., the western
+// phi branch tests a land cell with water to the west, and land is not zeroed.
+template <bool HYD>
+__global__ void k_pressure3d(double* __restrict__ p_dyn, const double* __restrict__ pn, const double* __restrict__ au,
+                             const double* __restrict__ av, const double* __restrict__ aw,
+                             const uint8_t* __restrict__ flags, const double* __restrict__ rad,
+                             const double* __restrict__ sinthe_t, double rho, DevConst K) {
+    const int im = K.im, jm = K.jm, km = K.km;
+    const int k = 1 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = 1 + blockIdx.y, i = 1 + blockIdx.z;
+    if (k > km - 2) return;
+    const size_t row = km, lvl = (size_t)jm * km;
+    const size_t p = idx3(jm, km, i, j, k);
+    const double dr = K.dr, dthe = K.dthe, dphi = K.dphi;
+    const double rm = rad[i], rm2 = rm * rm;
+    const double sinthe = sinthe_t[j];
+    const double rmsinthe = rm * sinthe;
+    const double rm2sinthe2 = rmsinthe * rmsinthe;
+    const double denom = 2. / K.dr2 + 2. / (rm2 * K.dthe2) + 2. / (rm2sinthe2 * K.dphi2);
+    const double num1 = 1. / K.dr2, num2 = 1. / (rm2 * K.dthe2), num3 = 1. / (rm2sinthe2 * K.dphi2);
+
+    auto land = [&](size_t q) { return (flags[q] & FL_LAND) != 0; };
+    const bool lc = land(p);
+
+    double drhs_udr = (au[p + lvl] - au[p - lvl]) / (2. * dr);
+    if (i <= im - 3) {
+        bool above_fluid = HYD ? ((flags[p + lvl] & FL_HZERO) != 0) : !land(p + lvl);
+        if (lc && above_fluid) drhs_udr = (-3. * au[p] + 4. * au[p + lvl] - au[p + 2 * lvl]) / (2. * dr);
+    } else {
+        drhs_udr = (au[p + lvl] - au[p]) / dr;
+    }
+
+    // aux_v / aux_w base: own level (atm) or level im-1 (hyd)
+    const size_t a = HYD ? idx3(jm, km, im - 1, j, k) : p;
+    double drhs_vdthe = (av[a + row] - av[a - row]) / (2. * dthe * rm);
+    if (lc && !land(p + row)) drhs_vdthe = (av[a + row] - av[a]) / (dthe * rm);
+    if (lc && !land(p - row)) drhs_vdthe = (av[a - row] - av[a]) / (dthe * rm);
+    if ((j >= 2) && (j <= jm - 3)) {
+        if (lc && (!land(p + row) && !land(p + 2 * row)))
+            drhs_vdthe = (-3. * av[a] + 4. * av[a + row] - av[a + 2 * row]) / (2. * dthe * rm);
+        if (lc && !land(p - row) && !land(p - 2 * row))
+            drhs_vdthe = (-3. * av[a] + 4. * av[a - row] - av[a - 2 * row]) / (2. * dthe * rm);
+    }
+
+    double drhs_wdphi = HYD ? (aw[a + 1] - aw[a - 1]) / (2. * dphi * rmsinthe) : (aw[a + 1] - aw[a - 1]) / (2. * rmsinthe * dphi);
+    if (lc && !land(p + 1))
+        drhs_wdphi = HYD ? (aw[a + 1] - aw[a]) / (dphi * rmsinthe) : (aw[a + 1] - aw[a]) / (rmsinthe * dphi);
+    if (HYD ? (lc && !land(p - 1)) : (!lc && land(p - 1)))
+        drhs_wdphi = HYD ? (aw[a - 1] - aw[a]) / (dphi * rmsinthe) : (aw[a - 1] - aw[a]) / (rmsinthe * dphi);
+    if ((k >= 2) && (k <= km - 3)) {
+        if (lc && !land(p + 1) && !land(p + 2))
+            drhs_wdphi = (-3. * aw[a] + 4. * aw[a + 1] - aw[a + 2]) / (2. * rmsinthe * dphi);
+        if (lc && !land(p - 1) && !land(p - 2))
+            drhs_wdphi = (-3. * aw[a] + 4. * aw[a - 1] - aw[a - 2]) / (2. * rmsinthe * dphi);
+    }
+
+    double r = ((pn[p + lvl] + pn[p - lvl]) * num1 + (pn[p + row] + pn[p - row]) * num2 + (pn[p + 1] + pn[p - 1]) * num3
+                - rho * (drhs_udr + drhs_vdthe + drhs_wdphi)) / denom;
+    if (!HYD && lc) r = .0;
+    p_dyn[p] = r;
+}
+
+// Surface sweep at level L: Pressure_Atm.cpp:217-281 / Pressure_Hyd.cpp:228-298
+__global__ void k_pressure2d(double* __restrict__ p_dyn, const double* __restrict__ pn, const double* __restrict__ av,
+                             const double* __restrict__ aw, const uint8_t* __restrict__ flags, const double* __restrict__ rad,
+                             const double* __restrict__ sinthe_t, double rho, int L, DevConst K) {
+    const int jm = K.jm, km = K.km;
+    const int k = 1 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = 1 + blockIdx.y;
+    if (k > km - 2) return;
+    const size_t row = km;
+    const size_t p = idx3(jm, km, L, j, k);
+    const double dthe = K.dthe, dphi = K.dphi;
+    const double rm = rad[L], rm2 = rm * rm;
+    const double sinthe = sinthe_t[j];
+    const double rmsinthe = rm * sinthe;
+    const double rm2sinthe2 = rmsinthe * rmsinthe;
+    const double denom = 2. / (rm2 * K.dthe2) + 2. / (rm2sinthe2 * K.dphi2);
+    const double num2 = 1. / (rm2 * K.dthe2), num3 = 1. / (rm2sinthe2 * K.dphi2);
+    auto land = [&](size_t q) { return (flags[q] & FL_LAND) != 0; };
+    const bool lc = land(p);
+
+    double drhs_vdthe = (av[p + row] - av[p - row]) / (2. * dthe * rm);
+    if (lc && !land(p + row)) {
+        if (j < jm - 2 && !land(p + 2 * row)) drhs_vdthe = (-3. * av[p] + 4. * av[p + row] - av[p + 2 * row]) / (2. * dthe * rm);
+        else drhs_vdthe = (av[p + row] - av[p]) / (dthe * rm);
+    }
+    if (lc && !land(p - row)) {
+        if (j > 1 && !land(p - 2 * row)) drhs_vdthe = (-3. * av[p] + 4. * av[p - row] - av[p - 2 * row]) / (2. * dthe * rm);
+        else drhs_vdthe = (av[p - row] - av[p]) / (dthe * rm);
+    }
+    double drhs_wdphi = (aw[p + 1] - aw[p - 1]) / (2. * dphi * rmsinthe);
+    if (lc && !land(p + 1)) {
+        if (k < km - 2 && !land(p + 2)) drhs_wdphi = (-3. * aw[p] + 4. * aw[p + 1] - aw[p + 2]) / (2. * rmsinthe * dphi);
+        else drhs_wdphi = (aw[p + 1] - aw[p]) / (dphi * rmsinthe);
+    }
+    if (lc && !land(p - 1)) {
+        if (k >= 2 && !land(p - 2)) drhs_wdphi = (-3. * aw[p] + 4. * aw[p - 1] - aw[p - 2]) / (2. * rmsinthe * dphi);
+        else drhs_wdphi = (aw[p - 1] - aw[p]) / (dphi * rmsinthe);
+    }
+    p_dyn[p] = ((pn[p + row] + pn[p - row]) * num2 + (pn[p + 1] + pn[p - 1]) * num3 - rho * (drhs_vdthe + drhs_wdphi)) / denom;
+}
+
+// p_dyn = 0 on two rows after the surface sweep: (0, 0, :) and (0, jm-1, :) for the
+// atmosphere (Pressure_Atm.cpp:284-288); (im-1, im-1, :) and (0, jm-1, :) for the
+// hydrosphere, whose row index slips to im-1 (Pressure_Hyd.cpp:301-305).
+__global__ void k_zero_two_rows(double* p, size_t row_a, size_t row_b, int km) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= km) return;
+    p[row_a + k] = 0.;
+    p[row_b + k] = 0.;
+}
+
+inline unsigned nb(size_t n) { return (unsigned)((n + TPB - 1) / TPB); }
+
+int fill_theta(atomdev* h, const int* ids, const int* modes, int n, int i0, int ni) {
+    ThetaFill f; f.n = n;
+    for (int m = 0; m < n; m++) { f.p[m] = h->f[ids[m]]; f.mode[m] = modes[m]; }
+    hipLaunchKernelGGL(k_fill_theta, dim3(nb((size_t)ni * h->km)), dim3(TPB), 0, h->stream, f, h->im, h->jm, h->km, i0, ni);
+    return atomdev_check(hipGetLastError(), "k_fill_theta");
+}
+
+int fill_phi(atomdev* h, const int* ids, int n, int i0, int ni, int j0, int j1) {
+    Fields f; f.n = n;
+    for (int m = 0; m < n; m++) f.p[m] = h->f[ids[m]];
+    hipLaunchKernelGGL(k_fill_phi_seam, dim3(nb((size_t)ni * (j1 - j0))), dim3(TPB), 0, h->stream, f, h->im, h->jm, h->km,
+                       i0, ni, j0, j1);
+    return atomdev_check(hipGetLastError(), "k_fill_phi_seam");
+}
+
+int pressure3d(atomdev* h, bool hyd) {
+    if (int rc = atomdev_refresh_flags(h)) return rc;
+    static const int AUX[3] = { ATOMDEV_AUX_U, ATOMDEV_AUX_V, ATOMDEV_AUX_W };
+    static const int NE3[3] = { FILL_NEUMANN, FILL_NEUMANN, FILL_NEUMANN };
+    const size_t n2 = h->n2;
+    hipLaunchKernelGGL(k_aux_fill_r, dim3(nb(n2)), dim3(TPB), 0, h->stream, h->f[ATOMDEV_AUX_U], h->f[ATOMDEV_AUX_V],
+                       h->f[ATOMDEV_AUX_W], h->im, h->jm, h->km);
+    ATOMDEV_TRY(hipGetLastError());
+    if (int rc = fill_theta(h, AUX, NE3, 3, 0, h->im)) return rc;
+    if (int rc = fill_phi(h, AUX, 3, 0, h->im, 0, h->jm)) return rc;
+    dim3 grid((h->km - 2 + 127) / 128, h->jm - 2, h->im - 2);
+    const double rho = hyd ? h->p.r_0_water : h->p.r_air;
+    if (hyd)
+        hipLaunchKernelGGL(k_pressure3d<true>, grid, dim3(128), 0, h->stream, h->f[ATOMDEV_P_DYN], h->f[ATOMDEV_P_DYNN],
+                           h->f[ATOMDEV_AUX_U], h->f[ATOMDEV_AUX_V], h->f[ATOMDEV_AUX_W], h->flags, h->rad, h->sinthe, rho, h->k);
+    else
+        hipLaunchKernelGGL(k_pressure3d<false>, grid, dim3(128), 0, h->stream, h->f[ATOMDEV_P_DYN], h->f[ATOMDEV_P_DYNN],
+                           h->f[ATOMDEV_AUX_U], h->f[ATOMDEV_AUX_V], h->f[ATOMDEV_AUX_W], h->flags, h->rad, h->sinthe, rho, h->k);
+    ATOMDEV_TRY(hipGetLastError());
+    // p_dyn faces: r, then phi (all j), then theta (Pressure_Atm.cpp:162-186)
+    hipLaunchKernelGGL(k_p_fill_r, dim3(nb(n2)), dim3(TPB), 0, h->stream, h->f[ATOMDEV_P_DYN], h->im, h->jm, h->km);
+    ATOMDEV_TRY(hipGetLastError());
+    static const int PD[1] = { ATOMDEV_P_DYN };
+    if (int rc = fill_phi(h, PD, 1, 0, h->im, 0, h->jm)) return rc;
+    if (int rc = fill_theta(h, PD, NE3, 1, 0, h->im)) return rc;
+    return 0;
+}
+
+int pressure2d(atomdev* h, bool hyd) {
+    if (int rc = atomdev_refresh_flags(h)) return rc;
+    const int L = hyd ? h->im - 1 : 0;
+    static const int AV[1] = { ATOMDEV_AUX_V };
+    static const int NE[1] = { FILL_NEUMANN };
+    static const int PD[1] = { ATOMDEV_P_DYN };
+    // aux_v only: theta rows, then the phi seam for every j (Pressure_Atm.cpp:202-214)
+    if (int rc = fill_theta(h, AV, NE, 1, L, 1)) return rc;
+    if (int rc = fill_phi(h, AV, 1, L, 1, 0, h->jm)) return rc;
+    dim3 grid((h->km - 2 + 127) / 128, h->jm - 2);
+    const double rho = hyd ? h->p.r_0_water : h->p.r_air;
+    hipLaunchKernelGGL(k_pressure2d, grid, dim3(128), 0, h->stream, h->f[ATOMDEV_P_DYN], h->f[ATOMDEV_P_DYNN],
+                       h->f[ATOMDEV_AUX_V], h->f[ATOMDEV_AUX_W], h->flags, h->rad, h->sinthe, rho, L, h->k);
+    ATOMDEV_TRY(hipGetLastError());
+    size_t row_a, row_b = idx3(h->jm, h->km, 0, h->jm - 1, 0);
+    if (hyd) {
+        ATOMDEV_REQUIRE(h->jm > h->im - 1, "atomdev_hyd_pressure2d: the reference writes row j = im-1; the grid needs jm > im-1");
+        row_a = idx3(h->jm, h->km, h->im - 1, h->im - 1, 0);
+    } else {
+        row_a = idx3(h->jm, h->km, 0, 0, 0);
+    }
+    hipLaunchKernelGGL(k_zero_two_rows, dim3(nb(h->km)), dim3(TPB), 0, h->stream, h->f[ATOMDEV_P_DYN], row_a, row_b, h->km);
+    ATOMDEV_TRY(hipGetLastError());
+    if (int rc = fill_phi(h, PD, 1, L, 1, 1, h->jm - 1)) return rc;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int atomdev_atm_bc_radius(atomdev_t* h) {
+    ATOMDEV_REQUIRE(h && h->model == ATOMDEV_ATM, "atomdev_atm_bc_radius: not an atmosphere handle");
+    ATOMDEV_TRY(hipSetDevice(h->device));
+    Fields ex; ex.n = 5;
+    ex.p[0] = h->f[ATOMDEV_P_DYN]; ex.p[1] = h->f[ATOMDEV_C]; ex.p[2] = h->f[ATOMDEV_CLOUD]; ex.p[3] = h->f[ATOMDEV_ICE]; ex.p[4] = h->f[ATOMDEV_CO2];
+    hipLaunchKernelGGL(k_atm_bc_radius, dim3(nb(h->n2)), dim3(TPB), 0, h->stream, h->f[ATOMDEV_T], h->f[ATOMDEV_U],
+                       h->f[ATOMDEV_V], h->f[ATOMDEV_W], ex, h->p.t_tropopause, h->im, h->jm, h->km);
+    ATOMDEV_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int atomdev_atm_bc_theta(atomdev_t* h) {
+    ATOMDEV_REQUIRE(h && h->model == ATOMDEV_ATM, "atomdev_atm_bc_theta: not an atmosphere handle");
+    ATOMDEV_TRY(hipSetDevice(h->device));
+    // BC_Atm.cpp:80-107
+    static const int ids[9] = { ATOMDEV_T, ATOMDEV_U, ATOMDEV_V, ATOMDEV_W, ATOMDEV_P_DYN, ATOMDEV_C, ATOMDEV_CLOUD, ATOMDEV_ICE, ATOMDEV_CO2 };
+    static const int md[9] = { FILL_NEUMANN, FILL_NEUMANN, FILL_ZERO, FILL_ZERO, FILL_ZERO, FILL_NEUMANN, FILL_NEUMANN, FILL_NEUMANN, FILL_NEUMANN };
+    return fill_theta(h, ids, md, 9, 0, h->im);
+}
+
+extern "C" int atomdev_atm_bc_phi(atomdev_t* h) {
+    ATOMDEV_REQUIRE(h && h->model == ATOMDEV_ATM, "atomdev_atm_bc_phi: not an atmosphere handle");
+    ATOMDEV_TRY(hipSetDevice(h->device));
+    // BC_Atm.cpp:115-150: rows j = 1 .. jm-2 only
+    static const int ids[9] = { ATOMDEV_T, ATOMDEV_U, ATOMDEV_V, ATOMDEV_W, ATOMDEV_P_DYN, ATOMDEV_C, ATOMDEV_CLOUD, ATOMDEV_ICE, ATOMDEV_CO2 };
+    return fill_phi(h, ids, 9, 0, h->im, 1, h->jm - 1);
+}
+
+extern "C" int atomdev_hyd_bc_radius(atomdev_t* h) {
+    ATOMDEV_REQUIRE(h && h->model == ATOMDEV_HYD, "atomdev_hyd_bc_radius: not a hydrosphere handle");
+    ATOMDEV_TRY(hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_hyd_bc_radius, dim3(nb(h->n2)), dim3(TPB), 0, h->stream, h->f[ATOMDEV_T], h->f[ATOMDEV_U],
+                       h->f[ATOMDEV_V], h->f[ATOMDEV_W], h->f[ATOMDEV_P_DYN], h->f[ATOMDEV_C], h->p.ta, h->p.ca, h->im, h->jm, h->km);
+    ATOMDEV_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int atomdev_hyd_bc_theta(atomdev_t* h) {
+    ATOMDEV_REQUIRE(h && h->model == ATOMDEV_HYD, "atomdev_hyd_bc_theta: not a hydrosphere handle");
+    ATOMDEV_TRY(hipSetDevice(h->device));
+    // BC_Hyd.cpp:90-118
+    static const int ids[6] = { ATOMDEV_T, ATOMDEV_U, ATOMDEV_V, ATOMDEV_W, ATOMDEV_P_DYN, ATOMDEV_C };
+    static const int md[6] = { FILL_NEUMANN, FILL_NEUMANN, FILL_ZERO, FILL_ZERO, FILL_NEUMANN, FILL_NEUMANN };
+    return fill_theta(h, ids, md, 6, 0, h->im);
+}
+
+extern "C" int atomdev_hyd_bc_phi(atomdev_t* h) {
+    ATOMDEV_REQUIRE(h && h->model == ATOMDEV_HYD, "atomdev_hyd_bc_phi: not a hydrosphere handle");
+    ATOMDEV_TRY(hipSetDevice(h->device));
+    // BC_Hyd.cpp:125-158: every j
+    static const int ids[6] = { ATOMDEV_T, ATOMDEV_U, ATOMDEV_V, ATOMDEV_W, ATOMDEV_P_DYN, ATOMDEV_C };
+    return fill_phi(h, ids, 6, 0, h->im, 0, h->jm);
+}
+
+extern "C" int atomdev_atm_pressure3d(atomdev_t* h) {
+    ATOMDEV_REQUIRE(h && h->model == ATOMDEV_ATM, "atomdev_atm_pressure3d: not an atmosphere handle");
+    ATOMDEV_TRY(hipSetDevice(h->device));
+    return pressure3d(h, false);
+}
+extern "C" int atomdev_hyd_pressure3d(atomdev_t* h) {
+    ATOMDEV_REQUIRE(h && h->model == ATOMDEV_HYD, "atomdev_hyd_pressure3d: not a hydrosphere handle");
+    ATOMDEV_TRY(hipSetDevice(h->device));
+    return pressure3d(h, true);
+}
+extern "C" int atomdev_atm_pressure2d(atomdev_t* h) {
+    ATOMDEV_REQUIRE(h && h->model == ATOMDEV_ATM, "atomdev_atm_pressure2d: not an atmosphere handle");
+    ATOMDEV_TRY(hipSetDevice(h->device));
+    return pressure2d(h, false);
+}
+extern "C" int atomdev_hyd_pressure2d(atomdev_t* h) {
+    ATOMDEV_REQUIRE(h && h->model == ATOMDEV_HYD, "atomdev_hyd_pressure2d: not a hydrosphere handle");
+    ATOMDEV_TRY(hipSetDevice(h->device));
+    return pressure2d(h, true);
+}

@@ -1,0 +1,185 @@
+"""ctypes binding of include/atomdev.h.
+
+``DeviceModel`` mirrors what the reference's per-slice loops do with their
+``Array`` members (atmosphere/cAtmosphereModel.cpp:654-898,
+hydrosphere/cHydrosphereModel.cpp:309-622): fields live on the device, each
+method is one reference operator.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+ATM, HYD = 0, 1
+
+# enum atomdev_field3d / atomdev_field2d
+F3 = dict(T=0, U=1, V=2, W=3, P_DYN=4, C=5, CLOUD=6, ICE=7, CO2=8,
+          TN=9, UN=10, VN=11, WN=12, P_DYNN=13, CN=14, CLOUDN=15, ICEN=16, CO2N=17,
+          H=18, AUX_U=19, AUX_V=20, AUX_W=21, BUOYANCY=22,
+          S_V=23, S_C=24, S_I=25, S_R=26, S_S=27,
+          SALT_BALANCE=28, SALT_FINGER=29, SALT_DIFFUSION=30, R_WATER=31, R_SALT_WATER=32,
+          RESIDUUM=33)
+F2 = dict(TOPOGRAPHY=0, EVAPORATION_DALTON=1, PRECIPITATION=2)
+
+
+class Params(C.Structure):
+    """struct atomdev_params"""
+    _fields_ = [(n, C.c_double) for n in (
+        "dt", "dr", "dthe", "dphi", "r0", "the0", "phi0",
+        "re", "pr", "g", "Buoyancy", "u_0", "t_0", "c_0",
+        "sc_WaterVapour", "sc_CO2", "gam", "r_air", "R_Air", "R_WaterVapour", "L_atm", "cp_l", "t_tropopause",
+        "sc", "L_hyd", "r_0_water", "ta", "pa", "ca")]
+
+
+class AtomDevError(RuntimeError):
+    pass
+
+
+_OPS = ["atm_bc_radius", "atm_bc_theta", "atm_bc_phi", "atm_value_limitation", "atm_solid_ground",
+        "atm_rk3d", "atm_rk2d", "atm_pressure3d", "atm_pressure2d",
+        "hyd_bc_radius", "hyd_bc_theta", "hyd_bc_phi", "hyd_value_limitation", "hyd_solid_ground",
+        "hyd_rk3d", "hyd_rk2d", "hyd_pressure3d", "hyd_pressure2d"]
+
+_lib = None
+
+
+def library_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libatomdev.so")
+
+
+def load_library():
+    """Loads libatomdev.so; raises AtomDevError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise AtomDevError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback)" % path)
+    lib = C.CDLL(path)
+    vp, ip, dp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)
+    lib.atomdev_last_error.restype = C.c_char_p
+    lib.atomdev_default_params.argtypes = [C.c_int, C.POINTER(Params)]
+    lib.atomdev_default_params.restype = None
+    lib.atomdev_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Params), C.c_int, C.POINTER(vp)]
+    lib.atomdev_destroy.argtypes = [vp]
+    lib.atomdev_dims.argtypes = [vp, ip, ip, ip]
+    for name in ("atomdev_upload", "atomdev_download", "atomdev_upload2d", "atomdev_download2d"):
+        getattr(lib, name).argtypes = [vp, C.c_int, vp]
+    lib.atomdev_fill.argtypes = [vp, C.c_int, C.c_double]
+    lib.atomdev_sync.argtypes = [vp]
+    lib.atomdev_move_data_to_new_arrays.argtypes = [vp, C.c_int]
+    for op in _OPS:
+        getattr(lib, "atomdev_" + op).argtypes = [vp]
+    for name in ("atomdev_atm_residuum3d", "atomdev_atm_residuum2d", "atomdev_hyd_residuum3d"):
+        getattr(lib, name).argtypes = [vp, dp, ip]
+    for name in ("atomdev_atm_steady3d", "atomdev_atm_steady2d", "atomdev_hyd_steady3d"):
+        getattr(lib, name).argtypes = [vp, dp, ip]
+    lib.atomdev_timer_start.argtypes = [vp]
+    lib.atomdev_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
+    _lib = lib
+    return lib
+
+
+def default_params(model, im=41, jm=181, km=361):
+    """Reference defaults (param.py); on grids other than 41x181x361 the steps follow the grid."""
+    p = Params()
+    load_library().atomdev_default_params(model, C.byref(p))
+    if (im, jm, km) != (41, 181, 361):
+        p.dr = 1.0 / (im - 1)
+        p.dthe = np.pi / (jm - 1)
+        p.dphi = p.dthe
+    return p
+
+
+class DeviceModel:
+    """One atmosphere or hydrosphere field set resident in HBM."""
+
+    def __init__(self, model, im, jm, km, params=None, device=-1):
+        self.lib = load_library()
+        self.model, self.im, self.jm, self.km = model, im, jm, km
+        self.params = params if params is not None else default_params(model, im, jm, km)
+        self._h = C.c_void_p()
+        self._check(self.lib.atomdev_create(model, im, jm, km, C.byref(self.params), device, C.byref(self._h)))
+
+    def _check(self, rc):
+        if rc != 0:
+            raise AtomDevError(self.lib.atomdev_last_error().decode())
+
+    # ---- field store -----------------------------------------------------
+    def upload(self, name, array):
+        a = np.ascontiguousarray(array, dtype=np.float64)
+        if name in F2:
+            if a.shape != (self.jm, self.km):
+                raise AtomDevError("upload %s: shape %s != %s" % (name, a.shape, (self.jm, self.km)))
+            self._check(self.lib.atomdev_upload2d(self._h, F2[name], a.ctypes.data_as(C.c_void_p)))
+        else:
+            if a.shape != (self.im, self.jm, self.km):
+                raise AtomDevError("upload %s: shape %s != %s" % (name, a.shape, (self.im, self.jm, self.km)))
+            self._check(self.lib.atomdev_upload(self._h, F3[name], a.ctypes.data_as(C.c_void_p)))
+
+    def download(self, name):
+        if name in F2:
+            a = np.empty((self.jm, self.km))
+            self._check(self.lib.atomdev_download2d(self._h, F2[name], a.ctypes.data_as(C.c_void_p)))
+        else:
+            a = np.empty((self.im, self.jm, self.km))
+            self._check(self.lib.atomdev_download(self._h, F3[name], a.ctypes.data_as(C.c_void_p)))
+        return a
+
+    def upload_all(self, fields3d, fields2d=None):
+        for k, v in fields3d.items():
+            self.upload(k, v)
+        for k, v in (fields2d or {}).items():
+            self.upload(k, v)
+
+    def fill(self, name, value):
+        self._check(self.lib.atomdev_fill(self._h, F3[name], float(value)))
+
+    def sync(self):
+        self._check(self.lib.atomdev_sync(self._h))
+
+    # ---- operators ---------------------------------------------------------
+    def op(self, name):
+        """One reference operator, e.g. 'atm_rk3d', 'hyd_pressure3d'."""
+        self._check(getattr(self.lib, "atomdev_" + name)(self._h))
+
+    def move_data_to_new_arrays(self, level=-1):
+        self._check(self.lib.atomdev_move_data_to_new_arrays(self._h, level))
+
+    def residuum(self, name, min0=0.0, loc0=(0, 0, 0)):
+        mn = C.c_double(min0)
+        loc = (C.c_int * 3)(*loc0)
+        self._check(getattr(self.lib, "atomdev_" + name)(self._h, C.byref(mn), loc))
+        return mn.value, tuple(loc)
+
+    def steady(self, name, n):
+        out = (C.c_double * n)()
+        loc = (C.c_int * (3 * n))()
+        self._check(getattr(self.lib, "atomdev_" + name)(self._h, out, loc))
+        return np.array(out), np.array(loc).reshape(n, 3)
+
+    def timer_start(self):
+        self._check(self.lib.atomdev_timer_start(self._h))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        self._check(self.lib.atomdev_timer_stop(self._h, C.byref(ms)))
+        return ms.value
+
+    def close(self):
+        if self._h:
+            self.lib.atomdev_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

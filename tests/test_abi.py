@@ -1,0 +1,55 @@
+"""CPU-side checks of the drop-in boundary: the library loads and exports every
+symbol include/atomdev.h declares; argument errors come back as codes + text."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import atom_amd
+import harness as H
+
+
+def _declared():
+    src = open(os.path.join(H.ROOT, "include", "atomdev.h")).read()
+    return sorted(set(re.findall(r"\b(atomdev_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported():
+    lib = atom_amd.load_library()
+    names = _declared()
+    assert len(names) >= 35
+    for n in names:
+        assert hasattr(lib, n), n
+
+
+def test_default_params_match_reference_defaults():
+    p = atom_amd.default_params(atom_amd.ATM)
+    assert (p.re, p.pr, p.sc_WaterVapour, p.sc_CO2, p.L_atm, p.u_0) == (1000., .7179, .61, .96, 16000., 8.)
+    assert p.dr == 0.025 and p.dt == 0.00001
+    q = atom_amd.default_params(atom_amd.HYD)
+    assert (q.re, q.pr, q.sc, q.L_hyd, q.u_0, q.c_0) == (10., 6.957, 1.7329, 1000., .25, 34.6)
+    o = H.default_params(H.ATM)
+    for name, _ in atom_amd.Params._fields_:
+        assert getattr(p, name) == getattr(o, name), name
+
+
+def test_bad_arguments_are_reported_not_crashed():
+    lib = atom_amd.load_library()
+    h = C.c_void_p()
+    p = atom_amd.default_params(atom_amd.ATM)
+    assert lib.atomdev_create(7, 41, 181, 361, C.byref(p), -1, C.byref(h)) != 0
+    assert b"unknown model" in lib.atomdev_last_error()
+    assert lib.atomdev_create(0, 3, 181, 361, C.byref(p), -1, C.byref(h)) != 0
+    assert b"too small" in lib.atomdev_last_error()
+    assert lib.atomdev_sync(None) != 0
+    assert lib.atomdev_atm_rk3d(None) != 0
+
+
+def test_no_cpu_fallback_in_product():
+    """The product never imports or links the oracle."""
+    for root, _, files in os.walk(os.path.join(H.ROOT, "atom_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
+                txt = open(os.path.join(root, f)).read()
+                assert "oracle" not in txt.lower() or f == "__init__.py" and False, (root, f)
