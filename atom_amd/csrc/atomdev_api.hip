@@ -98,6 +98,7 @@ extern "C" int atomdev_create(int model, int im, int jm, int km, const atomdev_p
     h->n3 = (size_t)im * jm * km; h->n2 = (size_t)jm * km;
     h->p = *p;
     h->flags = nullptr; h->flags_dirty = true;
+    h->profile_rk = false; h->prof_used = 0;
     h->rad = h->sinthe = h->costhe = h->plane = nullptr; h->red = nullptr;
     fill_constants(h);
 
@@ -156,6 +157,7 @@ extern "C" int atomdev_destroy(atomdev_t* h) {
     if (h->rad) (void)hipFree(h->rad);
     if (h->sinthe) (void)hipFree(h->sinthe);
     if (h->costhe) (void)hipFree(h->costhe);
+    for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -233,5 +235,44 @@ extern "C" int atomdev_timer_stop(atomdev_t* h, float* ms) {
     ATOMDEV_TRY(hipEventRecord(h->ev1, h->stream));
     ATOMDEV_TRY(hipEventSynchronize(h->ev1));
     ATOMDEV_TRY(hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return 0;
+}
+
+static int prof_record(atomdev* h) {
+    if (h->prof_used == h->prof_ev.size()) {
+        hipEvent_t e;
+        ATOMDEV_TRY(hipEventCreate(&e));
+        h->prof_ev.push_back(e);
+    }
+    ATOMDEV_TRY(hipEventRecord(h->prof_ev[h->prof_used], h->stream));
+    h->prof_used++;
+    return 0;
+}
+
+int atomdev_prof_begin(atomdev* h) { return h->profile_rk ? prof_record(h) : 0; }
+int atomdev_prof_end(atomdev* h) { return h->profile_rk ? prof_record(h) : 0; }
+
+extern "C" int atomdev_profile_rk(atomdev_t* h, int enable) {
+    ATOMDEV_REQUIRE(h != nullptr, "atomdev_profile_rk: null handle");
+    ATOMDEV_TRY(hipSetDevice(h->device));
+    ATOMDEV_TRY(hipStreamSynchronize(h->stream));
+    h->profile_rk = enable != 0;
+    h->prof_used = 0;
+    return 0;
+}
+
+extern "C" int atomdev_profile_read(atomdev_t* h, float* total_ms, int* sweeps) {
+    ATOMDEV_REQUIRE(h && total_ms && sweeps, "atomdev_profile_read: null argument");
+    ATOMDEV_TRY(hipSetDevice(h->device));
+    ATOMDEV_TRY(hipStreamSynchronize(h->stream));
+    float sum = 0.f;
+    for (size_t i = 0; i + 1 < h->prof_used; i += 2) {
+        float ms = 0.f;
+        ATOMDEV_TRY(hipEventElapsedTime(&ms, h->prof_ev[i], h->prof_ev[i + 1]));
+        sum += ms;
+    }
+    *total_ms = sum;
+    *sweeps = (int)(h->prof_used / 2);
+    h->prof_used = 0;
     return 0;
 }

@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include <string>
+#include <vector>
 
 #include "atomdev.h"
 
@@ -53,7 +54,14 @@ struct atomdev {
     double* plane;                  // jm*km scratch (atm: snapshot of c at level 3)
     void* red;                      // reduction scratch
     size_t red_bytes;
+    bool profile_rk;                // bracket RK sweep kernels with events
+    std::vector<hipEvent_t> prof_ev;  // pairs (start, stop), prof_used of them recorded
+    size_t prof_used;
 };
+
+// Event bracket around the RK sweep kernels when profiling is on (atomdev_api.hip).
+int atomdev_prof_begin(atomdev* h);
+int atomdev_prof_end(atomdev* h);
 
 void atomdev_set_error(const std::string& msg);
 int atomdev_check(hipError_t e, const char* what);

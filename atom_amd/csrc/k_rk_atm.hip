@@ -236,7 +236,9 @@ extern "C" int atomdev_atm_rk3d(atomdev_t* h) {
     a.c3 = h->plane;
     a.rad = h->rad; a.sinthe = h->sinthe; a.costhe = h->costhe;
     dim3 grid((h->km - 2 + 63) / 64, h->im - 2);
+    if (int rc = atomdev_prof_begin(h)) return rc;
     hipLaunchKernelGGL(k_atm_rk3d, grid, dim3(64), 0, h->stream, a, h->k);
     ATOMDEV_TRY(hipGetLastError());
+    if (int rc = atomdev_prof_end(h)) return rc;
     return 0;
 }

@@ -238,6 +238,7 @@ extern "C" int atomdev_hyd_rk3d(atomdev_t* h) {
     a.bathy = h->g[ATOMDEV_TOPOGRAPHY]; a.evap = h->g[ATOMDEV_EVAPORATION_DALTON]; a.precip = h->g[ATOMDEV_PRECIPITATION];
     a.rad = h->rad; a.sinthe = h->sinthe; a.costhe = h->costhe;
     const unsigned gx = (h->km - 2 + 63) / 64;
+    if (int rc = atomdev_prof_begin(h)) return rc;
     if (h->im - 3 >= 1) {  // levels 1 .. im-3
         a.i_begin = 1;
         hipLaunchKernelGGL(k_hyd_rk3d, dim3(gx, h->im - 3), dim3(64), 0, h->stream, a, h->k);
@@ -246,6 +247,7 @@ extern "C" int atomdev_hyd_rk3d(atomdev_t* h) {
     a.i_begin = h->im - 2;  // level im-2, after level im-3 is complete
     hipLaunchKernelGGL(k_hyd_rk3d, dim3(gx, 1), dim3(64), 0, h->stream, a, h->k);
     ATOMDEV_TRY(hipGetLastError());
+    if (int rc = atomdev_prof_end(h)) return rc;
     for (int n = 0; n < 5; n++) { double* t = h->f[X[n]]; h->f[X[n]] = h->alt[X[n]]; h->alt[X[n]] = t; }
     return 0;
 }

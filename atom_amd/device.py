@@ -77,6 +77,8 @@ def load_library():
         getattr(lib, name).argtypes = [vp, dp, ip]
     lib.atomdev_timer_start.argtypes = [vp]
     lib.atomdev_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.atomdev_profile_rk.argtypes = [vp, C.c_int]
+    lib.atomdev_profile_read.argtypes = [vp, C.POINTER(C.c_float), ip]
     _lib = lib
     return lib
 
@@ -166,6 +168,15 @@ class DeviceModel:
         ms = C.c_float()
         self._check(self.lib.atomdev_timer_stop(self._h, C.byref(ms)))
         return ms.value
+
+    def profile_rk(self, enable=True):
+        self._check(self.lib.atomdev_profile_rk(self._h, 1 if enable else 0))
+
+    def profile_read(self):
+        """(summed RK sweep kernel milliseconds, number of sweeps) since the last read."""
+        ms, n = C.c_float(), C.c_int()
+        self._check(self.lib.atomdev_profile_read(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     def close(self):
         if self._h:

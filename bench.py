@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Benchmark of the dynamical-core hot path on MI355X.
+
+Metric (BASELINE.json): grid-point RK updates/s on the 41x181x361 fp64 grid.
+One *step* = one 3-D velocity iteration of the atmosphere's hot path on synthetic
+fields (seed 1234) with the real 0 Ma land mask, in the order of
+cAtmosphereModel::run_3D_loop (atmosphere/cAtmosphereModel.cpp:756-874):
+  BC_radius, BC_theta, BC_phi -> Value_Limitation_Atm -> BC_SolidGround ->
+  solveRungeKutta_3D_Atmosphere -> Value_Limitation_Atm -> move_data_to_new_arrays,
+and computePressure_3D after every second step (velocity_iter_max = 2).
+One step advances 39*179*359 = 2,506,179 grid points through all four RK stages of
+all eight prognostic variables.  Fields are resident in HBM before the timed
+region.  With N > 1 every rank runs an independent slice on its own GPU (the
+140->0 Ma sweep of independent time slices): weak scaling, no data-path collective.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu]
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+IM, JM, KM = 41, 181, 361
+UPDATES = (IM - 2) * (JM - 2) * (KM - 2)
+ATM_BYTES_PER_UPDATE = 280   # reads 9 state + 8 xn + h + 5 sources, writes 8 state + 3 aux + buoyancy
+HYD_BYTES_PER_UPDATE = 208
+HBM_PEAK_GBS = 8000.0
+
+ATM_STEP = ["atm_bc_radius", "atm_bc_theta", "atm_bc_phi", "atm_value_limitation", "atm_solid_ground",
+            "atm_rk3d", "atm_value_limitation", "move3d"]
+HYD_STEP = ["hyd_bc_radius", "hyd_bc_theta", "hyd_bc_phi", "hyd_value_limitation", "hyd_rk3d",
+            "hyd_solid_ground", "move3d"]
+
+
+def make_model(H, atom_amd, model, device, seed):
+    p = H.default_params(model)
+    f, g = H.make_inputs(model, IM, JM, KM, seed, "allfluid", p)
+    names = H.ATM_FIELDS if model == H.ATM else H.HYD_FIELDS
+    f = {k: f[k] for k in names}
+    f["H"], g["TOPOGRAPHY"] = H.load_mask_0Ma(model)
+    d = atom_amd.DeviceModel(model, IM, JM, KM, atom_amd.Params.from_buffer_copy(bytes(p)), device=device)
+    d.upload_all(f, g)
+    d.sync()
+    return d, p, f, g
+
+
+def dev_step(d, seq, s, pressure_op):
+    for op in seq:
+        if op == "move3d":
+            d.move_data_to_new_arrays(-1)
+        else:
+            d.op(op)
+    if (s + 1) % 2 == 0:
+        d.op(pressure_op)
+
+
+def cpu_baseline(H, p, f, g, budget_s=12.0):
+    """The same step on the host, 1 thread, with the C restatement of the reference
+    (oracle/atom_oracle.c, bit-identical to the compiled reference).  Where the
+    compiled reference itself travelled with the tree (oracle/_ref), its own
+    solveRungeKutta_3D_Atmosphere is timed once as well."""
+    m = H.CpuModel("oracle", H.ATM, IM, JM, KM, p, f, g)
+    n, t0 = 0, time.perf_counter()
+    rk_s = 0.0
+    while True:
+        for op in ATM_STEP:
+            t1 = time.perf_counter()
+            H.run_op(m, op)
+            if op == "atm_rk3d":
+                rk_s += time.perf_counter() - t1
+        n += 1
+        if time.perf_counter() - t0 > budget_s or n >= 4:
+            break
+    dt = time.perf_counter() - t0
+    m.close()
+    out = {"value": UPDATES * n / dt, "unit": "grid-point RK updates/s", "cores": 1, "kind": "port",
+           "sample": "%d step(s) of the same workload (41x181x361, 0 Ma mask), %.1f s; RK sweep alone %.2f s/sweep"
+                     % (n, dt, rk_s / n)}
+    if H.have_ref():
+        r = H.CpuModel("ref", H.ATM, IM, JM, KM, p, f, g)
+        t1 = time.perf_counter()
+        r.op("atm_rk3d")
+        out["reference_rk_sweep_s"] = time.perf_counter() - t1  # includes flat<->jagged Array copies of the shim
+        r.close()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+
+    import torch
+    import atom_amd
+    import harness as H
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (there is no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    atm, p, f, g = make_model(H, atom_amd, H.ATM, local_rank, 1234 + rank)
+
+    for s in range(args.warmup):
+        dev_step(atm, ATM_STEP, s, "atm_pressure3d")
+    atm.sync()
+
+    atm.profile_rk(True)
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        dev_step(atm, ATM_STEP, s, "atm_pressure3d")
+    atm.sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    rk_ms, rk_n = atm.profile_read()
+    atm.profile_rk(False)
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # hydrosphere sweep, reported beside the headline (not part of `value`)
+    hyd_info = None
+    if rank == 0:
+        hyd, _, _, _ = make_model(H, atom_amd, H.HYD, local_rank, 4321)
+        for s in range(3):
+            dev_step(hyd, HYD_STEP, s, "hyd_pressure3d")
+        hyd.profile_rk(True)
+        hyd.sync()
+        th = time.perf_counter()
+        nh = 10
+        for s in range(nh):
+            dev_step(hyd, HYD_STEP, s, "hyd_pressure3d")
+        hyd.sync()
+        th = time.perf_counter() - th
+        hms, hn = hyd.profile_read()
+        hyd.close()
+        hyd_info = {"updates_per_s": UPDATES * nh / th, "ms_per_step": 1e3 * th / nh,
+                    "rk_sweep_ms": hms / hn,
+                    "rk_hbm_frac": UPDATES * HYD_BYTES_PER_UPDATE / (hms / hn * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+    if rank == 0:
+        rk_avg_s = rk_ms / rk_n * 1e-3
+        achieved = UPDATES * ATM_BYTES_PER_UPDATE / rk_avg_s / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_atm_rk3d.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "grid-point RK updates/s (41x181x361 fp64)",
+            "value": UPDATES * args.steps * world / elapsed,
+            "unit": "grid-point RK updates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic fields (numpy PCG64 seed 1234+rank), real 0 Ma land mask",
+            "config": {"workload": "atmosphere 3-D hot-path iteration (BC fills, limiter, solid ground, fused RK4+RHS sweep, "
+                                   "limiter, old->new copy; pressure Jacobi every 2nd step), 41x181x361, one slice per GPU",
+                       "grid": [IM, JM, KM], "updates_per_step_per_gpu": UPDATES, "parallelism": "independent slices"},
+            "roofline": {"bound": "hbm", "kernel": "k_atm_rk3d", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "bytes_per_update": ATM_BYTES_PER_UPDATE, "kernel_ms": rk_avg_s * 1e3, "launches": rk_n},
+            "hydrosphere": hyd_info,
+        }
+        if not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(H, p, f, g)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    atm.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -153,6 +153,14 @@ int atomdev_hyd_steady3d(atomdev_t* h, double out[6], int loc[18]);
 int atomdev_timer_start(atomdev_t* h);
 int atomdev_timer_stop(atomdev_t* h, float* milliseconds);
 
+/* Per-launch timing of the 3-D RK sweep kernels, without host synchronisation in
+ * between: while enabled, every atomdev_atm_rk3d / atomdev_hyd_rk3d call brackets
+ * its sweep kernel(s) with HIP events on the handle's stream.  atomdev_profile_read
+ * waits for the stream, returns the summed kernel time and the number of sweeps
+ * since the last read, and resets both. */
+int atomdev_profile_rk(atomdev_t* h, int enable);
+int atomdev_profile_read(atomdev_t* h, float* total_ms, int* sweeps);
+
 #ifdef __cplusplus
 }
 #endif
