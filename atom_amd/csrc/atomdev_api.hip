@@ -1,6 +1,7 @@
 // Field store, handle lifetime, transfers, timers: the part of the C-ABI that
 // replaces lib/Array.{h,cpp}, Array_2D and Array_1D for the hot path.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -99,6 +100,9 @@ extern "C" int atomdev_create(int model, int im, int jm, int km, const atomdev_p
     h->p = *p;
     h->flags = nullptr; h->flags_dirty = true;
     h->profile_rk = false; h->prof_used = 0;
+    h->scr[0] = h->scr[1] = nullptr; h->tab_rm2sin = h->tab_irm2sin = h->tab_coefv = nullptr;
+    h->rk_variant = 0;
+    if (const char* e = getenv("ATOMDEV_RK_VARIANT")) h->rk_variant = atoi(e);
     h->rad = h->sinthe = h->costhe = h->plane = nullptr; h->red = nullptr;
     fill_constants(h);
 
@@ -140,6 +144,29 @@ extern "C" int atomdev_create(int model, int im, int jm, int km, const atomdev_p
     if ((rc = atomdev_check(hipMemcpy(h->rad, rad.data(), nrad * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy"))) return fail(rc);
     if ((rc = atomdev_check(hipMemcpy(h->sinthe, st.data(), jm * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy"))) return fail(rc);
     if ((rc = atomdev_check(hipMemcpy(h->costhe, ct.data(), jm * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy"))) return fail(rc);
+    // per-(i, j) geometry factors of the RK sweeps, in the reference's operation order
+    // (RHS_Atm.cpp:97-106, 450; RHS_Hyd.cpp:83-92, 422); 1/x is the correctly rounded reciprocal
+    {
+        std::vector<double> t1((size_t)im * jm), t2((size_t)im * jm), t3((size_t)im * jm);
+        for (int i = 0; i < im; i++)
+            for (int j = 0; j < jm; j++) {
+                const double rm = rad[i], rm2 = rm * rm, sinthe = st[j], costhe = ct[j], sinthe2 = sinthe * sinthe;
+                const double rm2sinthe = rm2 * sinthe;
+                t1[(size_t)i * jm + j] = rm2sinthe;
+                t2[(size_t)i * jm + j] = 1. / rm2sinthe;
+                t3[(size_t)i * jm + j] = model == ATOMDEV_ATM ? 1. + costhe * costhe / (rm * sinthe2)
+                                                              : 1. + costhe * costhe / sinthe2;
+            }
+        const size_t nb = (size_t)im * jm * sizeof(double);
+        if ((rc = atomdev_check(hipMalloc(&h->tab_rm2sin, nb), "hipMalloc"))) return fail(rc);
+        if ((rc = atomdev_check(hipMalloc(&h->tab_irm2sin, nb), "hipMalloc"))) return fail(rc);
+        if ((rc = atomdev_check(hipMalloc(&h->tab_coefv, nb), "hipMalloc"))) return fail(rc);
+        if ((rc = atomdev_check(hipMemcpy(h->tab_rm2sin, t1.data(), nb, hipMemcpyHostToDevice), "hipMemcpy"))) return fail(rc);
+        if ((rc = atomdev_check(hipMemcpy(h->tab_irm2sin, t2.data(), nb, hipMemcpyHostToDevice), "hipMemcpy"))) return fail(rc);
+        if ((rc = atomdev_check(hipMemcpy(h->tab_coefv, t3.data(), nb, hipMemcpyHostToDevice), "hipMemcpy"))) return fail(rc);
+    }
+    for (int n = 0; n < 2; n++)
+        if ((rc = atomdev_check(hipMalloc(&h->scr[n], h->n3 * sizeof(double)), "hipMalloc(scr)"))) return fail(rc);
     if ((rc = atomdev_check(hipStreamSynchronize(h->stream), "hipStreamSynchronize"))) return fail(rc);
     *out = h;
     return 0;
@@ -157,6 +184,10 @@ extern "C" int atomdev_destroy(atomdev_t* h) {
     if (h->rad) (void)hipFree(h->rad);
     if (h->sinthe) (void)hipFree(h->sinthe);
     if (h->costhe) (void)hipFree(h->costhe);
+    if (h->tab_rm2sin) (void)hipFree(h->tab_rm2sin);
+    if (h->tab_irm2sin) (void)hipFree(h->tab_irm2sin);
+    if (h->tab_coefv) (void)hipFree(h->tab_coefv);
+    for (int n = 0; n < 2; n++) if (h->scr[n]) (void)hipFree(h->scr[n]);
     for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -274,5 +305,12 @@ extern "C" int atomdev_profile_read(atomdev_t* h, float* total_ms, int* sweeps) 
     *total_ms = sum;
     *sweeps = (int)(h->prof_used / 2);
     h->prof_used = 0;
+    return 0;
+}
+
+extern "C" int atomdev_set_rk_variant(atomdev_t* h, int variant) {
+    ATOMDEV_REQUIRE(h != nullptr, "atomdev_set_rk_variant: null handle");
+    ATOMDEV_REQUIRE(variant == 0 || variant == 1, "atomdev_set_rk_variant: variant must be 0 or 1");
+    h->rk_variant = variant;
     return 0;
 }

@@ -54,6 +54,9 @@ struct atomdev {
     double* plane;                  // jm*km scratch (atm: snapshot of c at level 3)
     void* red;                      // reduction scratch
     size_t red_bytes;
+    double* scr[2];                 // 3-D scratch written by the RK prep kernels
+    double *tab_rm2sin, *tab_irm2sin, *tab_coefv;  // [i*jm + j]: rm^2 sin(the), its reciprocal, viscous v coefficient
+    int rk_variant;                 // 0: wave-specialised sweep (default), 1: one thread per theta line
     bool profile_rk;                // bracket RK sweep kernels with events
     std::vector<hipEvent_t> prof_ev;  // pairs (start, stop), prof_used of them recorded
     size_t prof_used;
@@ -65,7 +68,9 @@ int atomdev_prof_end(atomdev* h);
 
 void atomdev_set_error(const std::string& msg);
 int atomdev_check(hipError_t e, const char* what);
-int atomdev_refresh_flags(atomdev* h);  // k_flags.hip
+int atomdev_refresh_flags(atomdev* h);  // k_pointwise.hip
+int atomdev_atm_rk3d_ws(atomdev* h);    // k_rk_atm_ws.hip
+int atomdev_hyd_rk3d_ws(atomdev* h);    // k_rk_hyd_ws.hip
 
 #define ATOMDEV_TRY(expr)                                   \
     do {                                                    \
@@ -95,6 +100,15 @@ __device__ __forceinline__ double div_by(double a, double b, double rb) {
     double r = __builtin_fma(-q, b, a);
     return __builtin_fma(r, rb, q);
 #endif
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every
+// outstanding global load and store of the wave (vmcnt(0)), which would drain the
+// prefetches a sweep kernel keeps in flight across its stage barriers.  LDS operations
+// of a wave complete in issue order, so waiting for them before the barrier is enough
+// for the other waves to read what this wave wrote.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 __host__ __device__ __forceinline__ size_t idx3(int jm, int km, int i, int j, int k) {

@@ -78,6 +78,7 @@ def load_library():
     lib.atomdev_timer_start.argtypes = [vp]
     lib.atomdev_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
     lib.atomdev_profile_rk.argtypes = [vp, C.c_int]
+    lib.atomdev_set_rk_variant.argtypes = [vp, C.c_int]
     lib.atomdev_profile_read.argtypes = [vp, C.POINTER(C.c_float), ip]
     _lib = lib
     return lib
@@ -168,6 +169,10 @@ class DeviceModel:
         ms = C.c_float()
         self._check(self.lib.atomdev_timer_stop(self._h, C.byref(ms)))
         return ms.value
+
+    def set_rk_variant(self, variant):
+        """0: wave-specialised RK sweep (default); 1: one thread per theta line."""
+        self._check(self.lib.atomdev_set_rk_variant(self._h, variant))
 
     def profile_rk(self, enable=True):
         self._check(self.lib.atomdev_profile_rk(self._h, 1 if enable else 0))

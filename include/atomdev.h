@@ -153,6 +153,12 @@ int atomdev_hyd_steady3d(atomdev_t* h, double out[6], int loc[18]);
 int atomdev_timer_start(atomdev_t* h);
 int atomdev_timer_stop(atomdev_t* h, float* milliseconds);
 
+/* Tuning knob without a reference counterpart: which kernel form the 3-D RK sweeps
+ * use.  0 (default): wave-specialised, one prognostic variable per wave, 64 lines
+ * per workgroup.  1: one thread per theta line.  Both give the same bits.  The
+ * environment variable ATOMDEV_RK_VARIANT sets the initial value. */
+int atomdev_set_rk_variant(atomdev_t* h, int variant);
+
 /* Per-launch timing of the 3-D RK sweep kernels, without host synchronisation in
  * between: while enabled, every atomdev_atm_rk3d / atomdev_hyd_rk3d call brackets
  * its sweep kernel(s) with HIP events on the handle's stream.  atomdev_profile_read
