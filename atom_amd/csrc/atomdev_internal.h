@@ -56,6 +56,7 @@ struct atomdev {
     size_t red_bytes;
     double* scr[2];                 // 3-D scratch written by the RK prep kernels
     double *tab_rm2sin, *tab_irm2sin, *tab_coefv;  // [i*jm + j]: rm^2 sin(the), its reciprocal, viscous v coefficient
+    void* ws_params;                // device copy of the wave-specialised sweep's argument block (lazy)
     int rk_variant;                 // 0: wave-specialised sweep (default), 1: one thread per theta line
     bool profile_rk;                // bracket RK sweep kernels with events
     std::vector<hipEvent_t> prof_ev;  // pairs (start, stop), prof_used of them recorded
@@ -108,6 +109,9 @@ __device__ __forceinline__ double div_by(double a, double b, double rb) {
 // of a wave complete in issue order, so waiting for them before the barrier is enough
 // for the other waves to read what this wave wrote.
 __device__ __forceinline__ void lds_barrier() {
+#ifdef ATOMDEV_EXP_NOBARRIER  // timing experiment only: results are wrong
+    return;
+#endif
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 

@@ -25,13 +25,21 @@
 // land height factor h_0_i are computed beforehand for all points in parallel
 // (k_atm_prep), so they are off the sequential path.
 //
-// Pairing.  Waves w and w+4 of a workgroup share a SIMD; roles are numbered so that a
-// heavy variable shares with a light one: (u, co2) (v, ice) (t, cloud) (w, c).
+// Pairing.  Waves w and w+4 of a workgroup share a SIMD, and the SIMD issues one fp64 instruction
+// every ~4 cycles whichever wave it comes from, so the stage time is the largest instruction count
+// of a pair.  Roles are numbered to even the pairs out: (v, w) (t, co2) (u, ice) (c, cloud).
+//
+// Divisions.  The buoyancy term divides by two per-point quantities, 1 + k c and the dry density.
+// The waves that produce c and t also publish the Newton-refined reciprocals of those divisors
+// (the first half of the fp64 division sequence), so that the u wave, which has the most work per
+// stage, only runs the three-instruction quotient step.  The instruction sequence, and therefore
+// every bit of the quotient, is the one the compiler emits for a / b on operands that need no
+// range scaling, which holds for densities and mixing ratios.
 #include "atomdev_internal.h"
 
 namespace {
 
-enum Role { R_U = 0, R_V = 1, R_T = 2, R_W = 3, R_CO2 = 4, R_ICE = 5, R_CLOUD = 6, R_C = 7 };
+enum Role { R_V = 0, R_T = 1, R_U = 2, R_C = 3, R_W = 4, R_CO2 = 5, R_ICE = 6, R_CLOUD = 7 };
 
 struct AtmWsArgs {
     double *t, *u, *v, *w, *c, *cloud, *ice, *co2;
@@ -46,9 +54,20 @@ struct AtmWsArgs {
     const double *tab_rm2sin, *tab_irm2sin, *tab_coefv;   // [i*jm + j]
 };
 
+// Arguments live in device memory, not in the kernel-argument segment: a role then reads the dozen
+// pointers and constants it needs with scalar loads inside its own branch, instead of the compiler
+// loading all ~100 of them ahead of the role switch and spilling them.
+struct AtmWsParams {
+    AtmWsArgs a;
+    DevConst K;
+};
+
 struct Shared {
-    double v[2][64], u[2][64], c[2][64], rdry[2][64];  // stage values, double-buffered by stage parity
-    double ufin[64];                                    // updated u of the row just finished
+    // stage values, double-buffered by stage parity
+    double v[2][64], u[2][64];
+    double opc[2][64], cb[2][64], cy[2][64];  // from c: 1 + c, b = 1 + k c, refined 1/b
+    double rdry[2][64], yr[2][64];            // from t: dry density and its refined reciprocal
+    double ufin[64];                          // updated u of the row just finished
 };
 
 // ---- prep: everything per point that does not change during the sweep -------------------------
@@ -75,9 +94,56 @@ __global__ void k_atm_prep(const double* __restrict__ t, const double* __restric
     h0i[p] = h_0_i;
 }
 
+// Values that every stage of every step needs are pinned into vector registers: the
+// kernel has few waves per SIMD and hundreds of free VGPRs, but only ~100 scalar
+// registers, and a constant evicted from those is re-read from the kernel-argument
+// segment with a full scalar-cache round trip in the middle of the dependent chain.
+#define PIN(x) asm volatile("" : "+v"(x))
+
+#ifdef ATOMDEV_EXP_STAMP  // timing experiment only: cycle stamps of step 60 of one workgroup go to level 0 of aux_w
+#define STAMP(n)                                                                                      \
+    do {                                                                                              \
+        if (j == 60 && blockIdx.x == 2 && blockIdx.y == 10 && lane == 0)                              \
+            a.aux_w[(threadIdx.x >> 6) * 16 + (n)] = (double)(long long)__builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define STAMP(n) do {} while (0)
+#endif
+
+// Field element at byte offset `off` from a (wave-uniform) base pointer: the base stays in scalar
+// registers and the offset is one 32-bit vector register shared by all fields of the role.
+// Pointers read from the argument block are generic to the compiler; typing the access as global
+// keeps it on global_load/global_store (flat instructions would also count against the LDS wait
+// counter of every stage barrier).
+typedef const __attribute__((address_space(1))) char* gcchar_t;
+typedef __attribute__((address_space(1))) char* gchar_t;
+__device__ __forceinline__ double ldg(const double* base, unsigned off) {
+    return *(const __attribute__((address_space(1))) double*)((gcchar_t)base + off);
+}
+__device__ __forceinline__ uint8_t ldg_u8(const uint8_t* base, unsigned idx) {
+    return *(const __attribute__((address_space(1))) uint8_t*)((gcchar_t)base + idx);
+}
+__device__ __forceinline__ void stg(double* base, unsigned off, double x) {
+    *(__attribute__((address_space(1))) double*)((gchar_t)base + off) = x;
+}
+
+// 1/b to the accuracy the fp64 division sequence uses: hardware estimate plus two Newton steps.
+__device__ __forceinline__ double rcp_refined(double b) {
+    double y = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-b, y, 1.0);
+    return __builtin_fma(y, e, y);
+}
+// a / b for operands that need no range scaling (finite, normal, quotient far from overflow and
+// underflow): the compiler's own sequence without its scaling and fix-up instructions.
+__device__ __forceinline__ double fdiv_normal(double a, double b) { return div_by(a, b, rcp_refined(b)); }
+
+struct ThetaK { double dthe, i_dthe, two_dthe, i_two_dthe, dthe2, i_dthe2; };
+
 // theta derivative pair (RHS_Atm.cpp:162-170, 192-199, 245-312); see k_rk_atm.hip
 __device__ __forceinline__ void dtheta(int mode, double hdj, double xm2, double xm1, double x0, double xp1,
-                                       const DevConst& K, double& d1, double& d2) {
+                                       const ThetaK& K, double& d1, double& d2) {
     if (mode == 0) {
         d1 = div_by(hdj * (xp1 - xm1), K.two_dthe, K.i_two_dthe);
         d2 = div_by(hdj * (xp1 - 2. * x0 + xm1), K.dthe2, K.i_dthe2);
@@ -90,222 +156,303 @@ __device__ __forceinline__ void dtheta(int mode, double hdj, double xm2, double 
     }
 }
 
-// Per-step geometry, identical for all lanes of a workgroup.
-struct StepGeo {
-    double costhe, rm, i_rm, rm2, i_rm2, rm2sin, i_rm2sin, coef_v;
-};
-
-// d2/rm2 + d1*cos/rm2sin   (t, u, c, cloud, ice, co2)
-__device__ __forceinline__ double brk_a(bool all_bw, double d1, double d2, const StepGeo& g) {
-    const double x = div_by(d1 * g.costhe, g.rm2sin, g.i_rm2sin);
-    return all_bw ? x : div_by(d2, g.rm2, g.i_rm2) + x;
-}
-// d2/rm2 + d1/rm2sin*cos   (v, w)
-__device__ __forceinline__ double brk_b(bool all_bw, double d1, double d2, const StepGeo& g) {
-    const double x = div_by(d1, g.rm2sin, g.i_rm2sin) * g.costhe;
-    return all_bw ? x : div_by(d2, g.rm2, g.i_rm2) + x;
-}
-
-// RungeKutta_Atm.cpp:58-152 for one variable: returns the next stage value (or the final one)
-__device__ __forceinline__ double rk_advance(int s, double xn, double rhs, double& acc, const DevConst& K) {
-    if (s == 0) { acc = rhs; return xn + rhs * .5 * K.dt; }
-    if (s == 1) { acc = acc + 2. * rhs; return xn + rhs * .5 * K.dt; }
-    if (s == 2) { acc = acc + 2. * rhs; return xn + rhs * K.dt; }
-    return xn + div_by(K.dt * (acc + rhs), 6., K.i_six);
-}
-
 // The whole sweep of one wave.  ROLE is a template parameter so that every wave runs
 // straight-line code for its own variable; all roles execute the same number of barriers
 // (one before the first step, four per step), whatever their lanes do.
+//
+// Memory schedule of a step (row j): every load (xn, flags and source terms of row j+1, row j+2 of the
+// own variable) is issued at the top, the stores of row j-1's results in stage 2, the geometry table
+// of row j+1 is read from LDS in stage 4.  Nothing loaded in a step is used before the next step.
 template <int ROLE>
-__device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K, Shared& sh, double* __restrict__ X,
-                                           const double* __restrict__ XN) {
-    constexpr bool isV = ROLE == R_V, isU = ROLE == R_U, isT = ROLE == R_T, isC = ROLE == R_C;
+__device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K, Shared& sh, const double* tab,
+                                           double* __restrict__ X, const double* __restrict__ XN) {
+    constexpr bool isV = ROLE == R_V, isU = ROLE == R_U, isT = ROLE == R_T, isC = ROLE == R_C, isW = ROLE == R_W;
     constexpr bool hasH0I = ROLE == R_U || ROLE == R_CO2 || ROLE == R_ICE || ROLE == R_CLOUD;
     const int jm = K.jm, km = K.km;
     const int lane = threadIdx.x & 63;
     const int kk = 1 + blockIdx.x * 64 + lane;
-    const bool active = kk <= km - 2;
-    const int k = active ? kk : km - 2;  // idle lanes shadow the last line: loads stay in bounds, stores are masked
+    const int k = kk <= km - 2 ? kk : km - 2;  // idle lanes shadow the last line and reproduce its bits
     const int i = 1 + blockIdx.y;
     const bool lvl1 = isC && (i == 1);
+    constexpr int NST = isU ? 3 : (isV || isW) ? 2 : 1;  // stores per step
 
-    const size_t row = (size_t)km;
-    size_t p = idx3(jm, km, i, 0, k);
-    StepGeo g;
-    g.rm = a.rad[i]; g.rm2 = g.rm * g.rm; g.i_rm = 1. / g.rm; g.i_rm2 = 1. / g.rm2;
+    // ---- constants of the dependent chain, in vector registers ----
+    ThetaK TK = { K.dthe, K.i_dthe, K.two_dthe, K.i_two_dthe, K.dthe2, K.i_dthe2 };
+    PIN(TK.dthe); PIN(TK.i_dthe); PIN(TK.two_dthe); PIN(TK.i_two_dthe); PIN(TK.dthe2); PIN(TK.i_dthe2);
+    double rm = a.rad[i];
+    double rm2 = rm * rm, i_rm = 1. / rm, i_rm2 = 1. / rm2;
+    PIN(rm); PIN(rm2); PIN(i_rm); PIN(i_rm2);
+    // divisor of the diffusion bracket and of the damping term of this variable
+    double dv, i_dv, dm = 1., i_dm = 1.;
+    if constexpr (isT) { dv = K.re_pr; i_dv = K.i_re_pr; }
+    else if constexpr (isU) { dv = K.re; i_dv = K.i_re; dm = K.dr2; i_dm = K.i_dr2; }
+    else if constexpr (isV) { dv = K.re; i_dv = K.i_re; dm = K.dthe2; i_dm = K.i_dthe2; }
+    else if constexpr (isW) { dv = K.re; i_dv = K.i_re; dm = K.dphi2; i_dm = K.i_dphi2; }
+    else if constexpr (ROLE == R_CO2) { dv = K.re_sc_co2; i_dv = K.i_re_sc_co2; dm = K.dr2; i_dm = K.i_dr2; }
+    else if constexpr (isC) { dv = K.re_sc_wv; i_dv = K.i_re_sc_wv; }
+    else { dv = K.re_sc_wv; i_dv = K.i_re_sc_wv; dm = K.dr2; i_dm = K.i_dr2; }
+    PIN(dv); PIN(i_dv); PIN(dm); PIN(i_dm);
+    double dt = K.dt, i_six = K.i_six, six = 6.;
+    PIN(dt); PIN(i_six); PIN(six);
+    double k1 = 0., k2 = 0., k3 = 0., k4 = 0., i_k4 = 0.;  // role-specific scalars
+    if constexpr (isT) { k1 = K.R_Air; k2 = K.t_0; k3 = K.coeff_energy; }
+    if constexpr (isU) { k1 = K.R_WV_over_R_Air; k2 = K.Buoyancy; k3 = K.g; k4 = K.coeff_buoy; }
+    if constexpr (isV) { k1 = K.r_air; k2 = K.i_r_air; }
+    if constexpr (isC) { k1 = K.R_WV_over_R_Air; k2 = K.coeff_trans; k3 = K.coeff_vapour; k4 = K.two_dr; i_k4 = K.i_two_dr; }
+    if constexpr (ROLE == R_ICE || ROLE == R_CLOUD) k2 = K.coeff_trans;
+    PIN(k1); PIN(k2); PIN(k3); PIN(k4); PIN(i_k4);
+    const uint8_t* __restrict__ FL = a.flags;
 
-    double xm2 = 0., xm1 = X[p], x0 = X[p + row], xp1 = X[p + 2 * row];
+    // ---- byte offsets of rows j, j+1, j+2 of this line, advanced by one row per step ----
+    const unsigned rowB = (unsigned)km * 8u;
+    unsigned o0 = (unsigned)(idx3(jm, km, i, 1, k) * 8);
+    unsigned o1 = o0 + rowB, o2 = o1 + rowB;
+    unsigned q1 = (unsigned)(((size_t)2 * km + k) * 8);  // row j+1 of a 2-D field
+    PIN(o0); PIN(o1); PIN(o2); PIN(q1);
+    // source-term fields of the role (bases stay scalar)
+    const double *E1 = nullptr, *E2 = nullptr, *E3 = nullptr, *E4 = nullptr, *E5 = nullptr;
+    if constexpr (isT) { E1 = a.ph100; E2 = a.S_c; E3 = a.S_r; E4 = a.S_i; E5 = a.S_s; }
+    if constexpr (hasH0I) E1 = a.h0i;
+    if constexpr (ROLE == R_ICE) E2 = a.S_i;
+    if constexpr (ROLE == R_CLOUD) E2 = a.S_c;
+    if constexpr (isC) { E2 = a.S_v; E1 = a.evap; E3 = a.precip; E4 = a.c; E5 = a.c3; }
+    if constexpr (isV) { E1 = a.p_dyn; E2 = a.u; }
+    double *O1 = nullptr, *O2 = nullptr;  // side outputs
+    if constexpr (isU) { O1 = a.aux_u; O2 = a.buoy; }
+    if constexpr (isV) O1 = a.aux_v;
+    if constexpr (isW) O1 = a.aux_w;
+
+    double xm2 = 0., xm1 = ldg(X, o0 - rowB), x0 = ldg(X, o0), xp1 = ldg(X, o1);
     double ym2 = 0., ym1 = 0., y0 = 0., yp1 = 0.;  // p_dyn rows (v wave)
     double um2 = 0., um1 = 0., up1 = 0.;            // u rows (v wave): updated j-2, j-1; old j+1
     if constexpr (isV) {
-        ym1 = a.p_dyn[p]; y0 = a.p_dyn[p + row]; yp1 = a.p_dyn[p + 2 * row];
-        um1 = a.u[p]; up1 = a.u[p + 2 * row];
+        ym1 = ldg(E1, o0 - rowB); y0 = ldg(E1, o0); yp1 = ldg(E1, o1);
+        um1 = ldg(E2, o0 - rowB); up1 = ldg(E2, o1);
     }
 
-    // inputs of step j are loaded during step j-1
-    double n_xn, n_a = 0., n_b = 0., n_c = 0., n_c0 = 0., n_c3 = 0.;
+    // raw inputs of the next step, loaded during this one
+    double n_xn, n_r1 = 0., n_r2 = 0., n_r3 = 0., n_r4 = 0., n_r5 = 0.;
     double n_cos, n_rm2sin, n_irm2sin, n_coefv = 0.;
     uint8_t n_fl;
-    auto load_inputs = [&](size_t pp, size_t qq, int jj) {
-        n_xn = XN[pp];
-        n_fl = a.flags[pp];
-        const size_t gi = (size_t)i * jm + jj;
-        n_cos = a.costhe[jj]; n_rm2sin = a.tab_rm2sin[gi]; n_irm2sin = a.tab_irm2sin[gi];
-        if constexpr (isV) n_coefv = a.tab_coefv[gi];
-        if constexpr (isT) {
-            n_a = a.ph100[pp];
-            n_b = K.coeff_energy * (a.S_c[pp] + a.S_r[pp]);
-            n_c = K.coeff_energy * (a.S_i[pp] + a.S_s[pp]);
-        }
-        if constexpr (hasH0I) n_a = a.h0i[pp];
-        if constexpr (ROLE == R_ICE) n_b = a.S_i[pp] * K.coeff_trans;
-        if constexpr (ROLE == R_CLOUD) n_b = a.S_c[pp] * K.coeff_trans;
+    auto load_top = [&](unsigned o) {  // xn, flags
+        n_xn = ldg(XN, o);
+        n_fl = ldg_u8(FL, o >> 3);
+    };
+    auto load_sources = [&](unsigned o, unsigned q) {
+        if constexpr (isT) { n_r2 = ldg(E2, o); n_r3 = ldg(E3, o); n_r4 = ldg(E4, o); n_r5 = ldg(E5, o); }
+        if constexpr (hasH0I) n_r1 = ldg(E1, o);
+        if constexpr (ROLE == R_ICE || ROLE == R_CLOUD || isC) n_r2 = ldg(E2, o);
         if constexpr (isC) {
-            n_b = a.S_v[pp] * K.coeff_trans;
-            if (lvl1) {  // RHS_Atm.cpp:412-421
-                double ep = a.evap[qq] - a.precip[qq];
-                if (ep >= 6.) ep = 6.;
-                if (ep <= -6.) ep = -6.;
-                n_a = ep;
-                n_c0 = a.c[qq];
-                n_c3 = a.c3[qq];
-            }
+            if (lvl1) { n_r1 = ldg(E1, q); n_r3 = ldg(E3, q); n_r4 = ldg(E4, q); n_r5 = ldg(E5, q); }
         }
     };
-    load_inputs(p + row, (size_t)km + k, 1);
+    auto load_table = [&](int jj) {
+        const double* row = tab + 4 * jj;
+        n_cos = row[0]; n_rm2sin = row[1]; n_irm2sin = row[2];
+        if constexpr (isV) n_coefv = row[3];
+    };
+    load_top(o0);
+    load_sources(o0, q1 - rowB);
+    load_table(1);
+    // t wave: 100 p_h of rows j and j+1; row j+2 is fetched at the top of step j
+    double ph_cur = 0., ph_nxt = 0., n_ph2 = 0.;
+    if constexpr (isT) { ph_cur = ldg(E1, o0); ph_nxt = ldg(E1, o1); }
+
+    // what the other waves need of a new t or c value (RHS_Atm.cpp:385, 390-404)
+    auto publish_t = [&](int buf, double tval, double ph) {
+        const double r_dry = fdiv_normal(ph, k1 * (tval * k2));
+        sh.rdry[buf][lane] = r_dry;
+        sh.yr[buf][lane] = rcp_refined(r_dry);
+    };
+    auto publish_c = [&](int buf, double cval) {
+        const double b = 1. + k1 * cval;
+        sh.opc[buf][lane] = 1. + cval;
+        sh.cb[buf][lane] = b;
+        sh.cy[buf][lane] = rcp_refined(b);
+    };
 
     // stage-1 values of row 1
     if constexpr (isV) sh.v[0][lane] = x0;
     if constexpr (isU) sh.u[0][lane] = x0;
-    if constexpr (isC) sh.c[0][lane] = x0;
-    if constexpr (isT) sh.rdry[0][lane] = n_a / (K.R_Air * (x0 * K.t_0));  // r_dry, RHS_Atm.cpp:385, 390
+    if constexpr (isC) publish_c(0, x0);
+    if constexpr (isT) publish_t(0, x0, ph_cur);
     lds_barrier();
 
+    // Everything loaded so far has arrived before the loop starts, so that the only vector-memory
+    // wait inside the loop is the one at the end of a step.
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    double so1 = 0., so2 = 0.;  // side outputs of the previous row, stored with it during the next step
+
     for (int j = 1; j < jm - 1; j++) {
-        p += row;
+        // (Idle lanes shadow the last line: they load what its owner loads and store the same bits.)
+        STAMP(0);
         // ---- take over the prefetched inputs of this step, start loading the next step's ----
         const double xn = n_xn;
         const uint8_t fl = n_fl;
-        const double e_a = n_a, e_b = n_b, e_c = n_c, c_lvl0 = n_c0, c_lvl3 = n_c3;
-        g.costhe = n_cos; g.rm2sin = n_rm2sin; g.i_rm2sin = n_irm2sin; g.coef_v = n_coefv;
-        const int jn = (j + 1 < jm - 1) ? j + 1 : j;  // the last step re-reads its own row (unused)
-        load_inputs(p + (size_t)(jn - j) * row, (size_t)jn * km + k, jn);
+        const double costhe = n_cos, rm2sin = n_rm2sin, i_rm2sin = n_irm2sin, coef_v = n_coefv;
+        double e_a = n_r1, e_b = 0., e_c = 0., c_lvl0 = 0., c_lvl3 = 0.;
+        if constexpr (isT) e_a = ph_cur;
+        if constexpr (isT) { e_b = k3 * (n_r2 + n_r3); e_c = k3 * (n_r4 + n_r5); }
+        if constexpr (ROLE == R_ICE || ROLE == R_CLOUD || isC) e_b = n_r2 * k2;
+        if constexpr (isC) {
+            if (lvl1) {  // RHS_Atm.cpp:412-421
+                double ep = n_r1 - n_r3;
+                if (ep >= 6.) ep = 6.;
+                if (ep <= -6.) ep = -6.;
+                e_a = ep; c_lvl0 = n_r4; c_lvl3 = n_r5;
+            }
+        }
+        load_top(o1);  // row j+1 <= jm-1 always exists
         double xp2 = 0., yp2 = 0., up2 = 0.;
         if (j + 2 < jm) {
-            xp2 = X[p + 2 * row];
-            if constexpr (isV) { yp2 = a.p_dyn[p + 2 * row]; up2 = a.u[p + 2 * row]; }
+            xp2 = ldg(X, o2);
+            if constexpr (isT) n_ph2 = ldg(E1, o2);
+            if constexpr (isV) { yp2 = ldg(E1, o2); up2 = ldg(E2, o2); }
         }
+        load_sources(o1, q1);
+        STAMP(1);
         const bool land = fl & FL_LAND;
         const double h_d_j = ((fl & FL_H0J) && (fl & FL_H0K)) ? 0. : 1.;  // RHS_Atm.cpp:129-149
         const bool window = (j >= 2) && (j < jm - 3);
         const int mode = !window ? 0 : ((fl & FL_ONESIDED_S) ? 2 : 1);
         const bool all_bw = __all(mode == 1);  // whole wave on the two-point backward form: d2 == 0
 
-        double pg_v = 0., h_0_j = 0., h_0_k = 0.;
+        double pg_v = 0., h_0 = 0.;
         if constexpr (isV) {
-            h_0_j = (fl & FL_H0J) ? 1. : 0.;
+            h_0 = (fl & FL_H0J) ? 1. : 0.;
             if (j > 1) um1 = sh.ufin[lane];  // updated u of row j-1 (row 0 is a boundary row)
             double dpdthe, d2p;
-            dtheta(mode, h_d_j, ym2, ym1, y0, yp1, K, dpdthe, d2p);
-            pg_v = div_by(div_by(h_d_j * dpdthe, g.rm, g.i_rm), K.r_air, K.i_r_air);  // h_d_j*dpdthe/rm/r_air
+            dtheta(mode, h_d_j, ym2, ym1, y0, yp1, TK, dpdthe, d2p);
+            pg_v = div_by(div_by(h_d_j * dpdthe, rm, i_rm), k1, k2);  // h_d_j*dpdthe/rm/r_air
         }
-        if constexpr (ROLE == R_W) h_0_k = (fl & FL_H0K) ? 1. : 0.;
+        if constexpr (isW) h_0 = (fl & FL_H0K) ? 1. : 0.;
+        if constexpr (hasH0I) h_0 = e_a;  // h_0_i
 
         double st = x0, acc = 0., rhs = 0., RS = 0.;
 #pragma unroll
         for (int s = 0; s < 4; s++) {
             const int rb = s & 1, wb = rb ^ 1;
+            if (s == 1 && j > 1) {  // results of the previous row
+                stg(X, o0 - rowB, xm1);
+                if constexpr (isU) { stg(O1, o0 - rowB, so1); stg(O2, o0 - rowB, so2); }
+                if constexpr (isV || isW) stg(O1, o0 - rowB, so1);
+            }
+            if (s == 3) load_table(j + 1);
             double v;
             if constexpr (isV) v = st; else v = sh.v[rb][lane];
             double d1, d2 = 0., brk;
             if (all_bw) {
-                d1 = div_by(h_d_j * (st - xm1), K.dthe, K.i_dthe);
-                if constexpr (isV || ROLE == R_W) brk = div_by(d1, g.rm2sin, g.i_rm2sin) * g.costhe;
-                else brk = div_by(d1 * g.costhe, g.rm2sin, g.i_rm2sin);
+                d1 = div_by(h_d_j * (st - xm1), TK.dthe, TK.i_dthe);
+                if constexpr (isV || isW) brk = div_by(d1, rm2sin, i_rm2sin) * costhe;
+                else brk = div_by(d1 * costhe, rm2sin, i_rm2sin);
             } else {
-                dtheta(mode, h_d_j, xm2, xm1, st, xp1, K, d1, d2);
-                if constexpr (isV || ROLE == R_W) brk = div_by(d2, g.rm2, g.i_rm2) + div_by(d1, g.rm2sin, g.i_rm2sin) * g.costhe;
-                else brk = div_by(d2, g.rm2, g.i_rm2) + div_by(d1 * g.costhe, g.rm2sin, g.i_rm2sin);
+                dtheta(mode, h_d_j, xm2, xm1, st, xp1, TK, d1, d2);
+                if constexpr (isV || isW) brk = div_by(d2, rm2, i_rm2) + div_by(d1, rm2sin, i_rm2sin) * costhe;
+                else brk = div_by(d2, rm2, i_rm2) + div_by(d1 * costhe, rm2sin, i_rm2sin);
             }
-            const double adv = div_by(v * d1, g.rm, g.i_rm);
+            const double adv = div_by(v * d1, rm, i_rm);
 
             if constexpr (isT) {
-                rhs = -adv + div_by(brk, K.re_pr, K.i_re_pr) + e_b + e_c;
+                rhs = -adv + div_by(brk, dv, i_dv) + e_b + e_c;
             } else if constexpr (isU) {
                 // buoyancy, RHS_Atm.cpp:390-404, from the current-stage dry density and vapour
-                const double r_dry = sh.rdry[rb][lane], cs = sh.c[rb][lane];
-                const double r_humid = r_dry * (1. + cs) / (1. + K.R_WV_over_R_Air * cs);
-                RS = K.Buoyancy * (r_humid - r_dry) / r_dry * K.g;
-                rhs = -adv + div_by(brk, K.re, K.i_re) - RS - div_by(e_a * st, K.dr2, K.i_dr2);
+                const double r_dry = sh.rdry[rb][lane];
+                const double r_humid = div_by(r_dry * sh.opc[rb][lane], sh.cb[rb][lane], sh.cy[rb][lane]);
+                RS = div_by(k2 * (r_humid - r_dry), r_dry, sh.yr[rb][lane]) * k3;
+                rhs = -adv + div_by(brk, dv, i_dv) - RS - div_by(h_0 * st, dm, i_dm);
             } else if constexpr (isV) {
                 double d1u, d2u;
-                dtheta(mode, h_d_j, um2, um1, sh.u[rb][lane], up1, K, d1u, d2u);
+                dtheta(mode, h_d_j, um2, um1, sh.u[rb][lane], up1, TK, d1u, d2u);
                 rhs = -adv + -pg_v
-                      + div_by(brk - g.coef_v * h_d_j * v + div_by(2. * d1u, g.rm2, g.i_rm2), K.re, K.i_re)
-                      - div_by(h_0_j * v, K.dthe2, K.i_dthe2);
-            } else if constexpr (ROLE == R_W) {
-                rhs = -adv + div_by(brk, K.re, K.i_re) - div_by(h_0_k * st, K.dphi2, K.i_dphi2);
-            } else if constexpr (ROLE == R_CO2) {
-                rhs = -adv + div_by(brk, K.re_sc_co2, K.i_re_sc_co2) - div_by(e_a * st, K.dr2, K.i_dr2);
+                      + div_by(brk - coef_v * h_d_j * v + div_by(2. * d1u, rm2, i_rm2), dv, i_dv)
+                      - div_by(h_0 * v, dm, i_dm);
+            } else if constexpr (isW || ROLE == R_CO2) {
+                rhs = -adv + div_by(brk, dv, i_dv) - div_by(h_0 * st, dm, i_dm);
             } else if constexpr (ROLE == R_ICE || ROLE == R_CLOUD) {
-                rhs = -adv + div_by(brk, K.re_sc_wv, K.i_re_sc_wv) + e_b - div_by(e_a * st, K.dr2, K.i_dr2);
+                rhs = -adv + div_by(brk, dv, i_dv) + e_b - div_by(h_0 * st, dm, i_dm);
             } else {  // R_C
-                rhs = -adv + div_by(brk, K.re_sc_wv, K.i_re_sc_wv) + e_b;
+                rhs = -adv + div_by(brk, dv, i_dv) + e_b;
                 if (lvl1) {  // RHS_Atm.cpp:412-430: surface evaporation source, c at levels 0, 1 (own), 3
                     const double r_dry = sh.rdry[rb][lane];
-                    const double r_humid = r_dry * (1. + st) / (1. + K.R_WV_over_R_Air * st);
-                    double vapour_surface = div_by(r_humid * (-3. * c_lvl0 + 4. * st - c_lvl3), K.two_dr, K.i_two_dr)
+                    const double r_humid = fdiv_normal(r_dry * (1. + st), 1. + k1 * st);
+                    double vapour_surface = div_by(r_humid * (-3. * c_lvl0 + 4. * st - c_lvl3), k4, i_k4)
                                             * (1. - 2. * c_lvl0) * e_a;
-                    double vapour_evaporation = K.coeff_vapour * vapour_surface;
+                    double vapour_evaporation = k3 * vapour_surface;
                     if (land) vapour_evaporation = 0.;
                     rhs = rhs + vapour_evaporation;
                 }
             }
-            st = rk_advance(s, xn, rhs, acc, K);
+            // RungeKutta_Atm.cpp:58-152
+            if (s == 0) { acc = rhs; st = xn + rhs * .5 * dt; }
+            else if (s == 1) { acc = acc + 2. * rhs; st = xn + rhs * .5 * dt; }
+            else if (s == 2) { acc = acc + 2. * rhs; st = xn + rhs * dt; }
+            else st = xn + div_by(dt * (acc + rhs), six, i_six);
 
             // publish: the next stage's value, or (after the last stage) stage 1 of the next row
             const double pub = (s < 3) ? st : xp1;
             if constexpr (isV) sh.v[wb][lane] = pub;
             if constexpr (isU) { sh.u[wb][lane] = pub; if (s == 3) sh.ufin[lane] = st; }
-            if constexpr (isC) sh.c[wb][lane] = pub;
-            if constexpr (isT) sh.rdry[wb][lane] = ((s < 3) ? e_a : n_a) / (K.R_Air * (pub * K.t_0));
+            if constexpr (isC) publish_c(wb, pub);
+            if constexpr (isT) publish_t(wb, pub, (s < 3) ? ph_cur : ph_nxt);
+            STAMP(2 + 2 * s);
             lds_barrier();
+            STAMP(3 + 2 * s);
         }
 
-        // ---- results of this row (side outputs hold the 4th evaluation: RHS_Atm.cpp:406-410, 485-492) ----
-        if (active) {
-            X[p] = st;
-            if constexpr (isU) {
-                a.aux_u[p] = land ? 0. : rhs;
-                a.buoy[p] = land ? 0. : -RS * K.coeff_buoy * 1000.;
-            }
-            if constexpr (isV) a.aux_v[p] = land ? 0. : rhs + pg_v;
-            if constexpr (ROLE == R_W) a.aux_w[p] = land ? 0. : rhs;
-        }
+        // ---- side outputs hold the 4th evaluation (RHS_Atm.cpp:406-410, 485-492) ----
+        if constexpr (isU) { so1 = land ? 0. : rhs; so2 = land ? 0. : -RS * k4 * 1000.; }
+        if constexpr (isV) so1 = land ? 0. : rhs + pg_v;
+        if constexpr (isW) so1 = land ? 0. : rhs;
+        // Vector-memory operations complete in issue order: the step's loads were issued at its top and
+        // its stores after them, so waiting until only the stores may be outstanding completes the loads
+        // (four rounds old) without waiting for the write acknowledgements, and leaves no pending state
+        // for the next step's first uses.
+        if (j > 1) __builtin_amdgcn_s_waitcnt(0x0F70 | NST);  // vmcnt(NST)
+        else __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0): the first step stores nothing
+        STAMP(10);
         xm2 = xm1; xm1 = st; x0 = xp1; xp1 = xp2;
         if constexpr (isV) { ym2 = ym1; ym1 = y0; y0 = yp1; yp1 = yp2; um2 = um1; up1 = up2; }
+        if constexpr (isT) { ph_cur = ph_nxt; ph_nxt = n_ph2; }
+        o0 += rowB; o1 += rowB; o2 += rowB; q1 += rowB;
     }
+    stg(X, o0 - rowB, xm1);  // row jm-2
+    if constexpr (isU) { stg(O1, o0 - rowB, so1); stg(O2, o0 - rowB, so2); }
+    if constexpr (isV || isW) stg(O1, o0 - rowB, so1);
 }
 
-__global__ __launch_bounds__(512) void k_atm_rk3d_ws(AtmWsArgs a, DevConst K) {
+__global__ __launch_bounds__(512) void k_atm_rk3d_ws(const AtmWsParams* __restrict__ P) {
+    const AtmWsArgs& a = P->a;
+    const DevConst& K = P->K;
     __shared__ Shared sh;
+    extern __shared__ double tab[];  // [jm][4]: cos(the), rm^2 sin(the), its reciprocal, viscous v coefficient
+    {
+        const int i = 1 + blockIdx.y;
+        const int jm = K.jm;
+        for (int j = threadIdx.x; j < jm; j += blockDim.x) {
+            tab[4 * j + 0] = a.costhe[j];
+            tab[4 * j + 1] = a.tab_rm2sin[i * jm + j];
+            tab[4 * j + 2] = a.tab_irm2sin[i * jm + j];
+            tab[4 * j + 3] = a.tab_coefv[i * jm + j];
+        }
+        __syncthreads();
+    }
     switch (threadIdx.x >> 6) {
-        case R_U: sweep_role<R_U>(a, K, sh, a.u, a.un); break;
-        case R_V: sweep_role<R_V>(a, K, sh, a.v, a.vn); break;
-        case R_T: sweep_role<R_T>(a, K, sh, a.t, a.tn); break;
-        case R_W: sweep_role<R_W>(a, K, sh, a.w, a.wn); break;
-        case R_CO2: sweep_role<R_CO2>(a, K, sh, a.co2, a.co2n); break;
-        case R_ICE: sweep_role<R_ICE>(a, K, sh, a.ice, a.icen); break;
-        case R_CLOUD: sweep_role<R_CLOUD>(a, K, sh, a.cloud, a.cloudn); break;
-        default: sweep_role<R_C>(a, K, sh, a.c, a.cn); break;
+        case R_U: sweep_role<R_U>(a, K, sh, tab, a.u, a.un); break;
+        case R_V: sweep_role<R_V>(a, K, sh, tab, a.v, a.vn); break;
+        case R_T: sweep_role<R_T>(a, K, sh, tab, a.t, a.tn); break;
+        case R_W: sweep_role<R_W>(a, K, sh, tab, a.w, a.wn); break;
+        case R_CO2: sweep_role<R_CO2>(a, K, sh, tab, a.co2, a.co2n); break;
+        case R_ICE: sweep_role<R_ICE>(a, K, sh, tab, a.ice, a.icen); break;
+        case R_CLOUD: sweep_role<R_CLOUD>(a, K, sh, tab, a.cloud, a.cloudn); break;
+        default: sweep_role<R_C>(a, K, sh, tab, a.c, a.cn); break;
     }
 }
 
 }  // namespace
 
 int atomdev_atm_rk3d_ws(atomdev* h) {
-    AtmWsArgs a;
+    AtmWsParams P;
+    AtmWsArgs& a = P.a;
     a.t = h->f[ATOMDEV_T]; a.u = h->f[ATOMDEV_U]; a.v = h->f[ATOMDEV_V]; a.w = h->f[ATOMDEV_W];
     a.c = h->f[ATOMDEV_C]; a.cloud = h->f[ATOMDEV_CLOUD]; a.ice = h->f[ATOMDEV_ICE]; a.co2 = h->f[ATOMDEV_CO2];
     a.tn = h->f[ATOMDEV_TN]; a.un = h->f[ATOMDEV_UN]; a.vn = h->f[ATOMDEV_VN]; a.wn = h->f[ATOMDEV_WN];
@@ -319,13 +466,21 @@ int atomdev_atm_rk3d_ws(atomdev* h) {
     a.ph100 = h->scr[0]; a.h0i = h->scr[1];
     a.rad = h->rad; a.costhe = h->costhe;
     a.tab_rm2sin = h->tab_rm2sin; a.tab_irm2sin = h->tab_irm2sin; a.tab_coefv = h->tab_coefv;
+    P.K = h->k;
+    // field pointers of the atmosphere never change after creation: one upload per handle
+    if (!h->ws_params) {
+        ATOMDEV_TRY(hipMalloc(&h->ws_params, sizeof(P)));
+        ATOMDEV_TRY(hipMemcpy(h->ws_params, &P, sizeof(P), hipMemcpyHostToDevice));
+    }
     if (int rc = atomdev_prof_begin(h)) return rc;
     dim3 pg((h->km + 127) / 128, h->jm, h->im - 2);
     hipLaunchKernelGGL(k_atm_prep, pg, dim3(128), 0, h->stream, h->f[ATOMDEV_T], h->g[ATOMDEV_TOPOGRAPHY], h->flags,
                        h->scr[0], h->scr[1], h->k);
     ATOMDEV_TRY(hipGetLastError());
     dim3 grid((h->km - 2 + 63) / 64, h->im - 2);
-    hipLaunchKernelGGL(k_atm_rk3d_ws, grid, dim3(512), 0, h->stream, a, h->k);
+    ATOMDEV_REQUIRE(h->n3 * sizeof(double) < ((size_t)1 << 32), "atm_rk3d: field larger than 4 GiB");
+    hipLaunchKernelGGL(k_atm_rk3d_ws, grid, dim3(512), (size_t)h->jm * 4 * sizeof(double), h->stream,
+                       (const AtmWsParams*)h->ws_params);
     ATOMDEV_TRY(hipGetLastError());
     if (int rc = atomdev_prof_end(h)) return rc;
     return 0;

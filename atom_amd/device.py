@@ -44,7 +44,8 @@ _lib = None
 
 
 def library_path():
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libatomdev.so")
+    """In-tree libatomdev.so; ATOMDEV_LIBRARY points experiments at another build of it."""
+    return os.environ.get("ATOMDEV_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libatomdev.so")
 
 
 def load_library():
