@@ -1,0 +1,471 @@
+// Hydrosphere 3-D Runge-Kutta sweep, wave-specialised form (the default).
+//
+// Same arithmetic, statement for statement, as the line kernel in k_rk_hyd.hip
+// (reference: hydrosphere/RungeKutta_Hyd.cpp:30-124, RHS_Hyd.cpp:60-447); the mapping
+// to the machine is the one of the atmosphere sweep (k_rk_atm_ws.hip): a workgroup
+// takes 64 neighbouring theta lines of one level, ONE PROGNOSTIC VARIABLE PER WAVE,
+// and the waves exchange stage values through LDS with one barrier per RK stage:
+//     every variable  <- u, v   (radial and meridional advection velocity)
+//     v               <- u      (2 du/dtheta / r^2 in the viscous bracket)
+//     u, v            <- c      (salt_water_ref = r_water + .7 c c_0 in buoyancy and pressure gradient)
+// The c wave publishes salt_water_ref together with its Newton-refined reciprocal, so that the
+// two divisions by it (u: buoyancy, v: pressure gradient) cost the three-instruction quotient
+// step of the fp64 division sequence instead of the whole sequence; the quotient bits are those
+// of a / b for operands that need no range scaling (a water density is ~1e3).
+//
+// Five waves on four SIMDs: t and w, the two lightest roles, share one (waves 0 and 4).
+//
+// The sweep is out of place (see k_rk_hyd.hip): it reads the current buffers and writes the
+// alternate set, whose boundary shell is refreshed beforehand by k_copy_shell.
+#include "atomdev_internal.h"
+
+namespace {
+
+enum Role { R_T = 0, R_V = 1, R_U = 2, R_C = 3, R_W = 4 };
+
+struct HydWsArgs {
+    const double *t, *u, *v, *w, *c;        // current state (read)
+    double *to, *uo, *vo, *wo, *co;         // next state (written)
+    const double *tn, *un, *vn, *wn, *cn;
+    const double* p_dyn;
+    double *r_water, *r_salt_water;         // read, rewritten on land
+    double *aux_u, *aux_v, *aux_w, *buoy, *salt_balance, *salt_finger, *salt_diffusion;
+    const uint8_t* flags;
+    const double *bathy, *evap, *precip;
+    const double *rad, *sinthe, *costhe;
+};
+
+// Arguments live in device memory (see k_rk_atm_ws.hip): each role reads only what it needs.
+struct HydWsParams {
+    HydWsArgs a;
+    DevConst K;
+};
+
+struct Shared {
+    // stage values, double-buffered by stage parity
+    double u[2][64], v[2][64];
+    double swr[2][64], yswr[2][64];  // salt_water_ref and its refined reciprocal
+    double ufin[64];                 // updated u of the row just finished
+};
+
+#define PIN(x) asm volatile("" : "+v"(x))
+
+typedef const __attribute__((address_space(1))) char* gcchar_t;
+typedef __attribute__((address_space(1))) char* gchar_t;
+__device__ __forceinline__ double ldg(const double* base, unsigned off) {
+    return *(const __attribute__((address_space(1))) double*)((gcchar_t)base + off);
+}
+__device__ __forceinline__ uint8_t ldg_u8(const uint8_t* base, unsigned idx) {
+    return *(const __attribute__((address_space(1))) uint8_t*)((gcchar_t)base + idx);
+}
+__device__ __forceinline__ void stg(double* base, unsigned off, double x) {
+    *(__attribute__((address_space(1))) double*)((gchar_t)base + off) = x;
+}
+
+// 1/b to the accuracy the fp64 division sequence uses: hardware estimate plus two Newton steps.
+__device__ __forceinline__ double rcp_refined(double b) {
+    double y = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-b, y, 1.0);
+    return __builtin_fma(y, e, y);
+}
+
+struct ThetaK { double dthe, i_dthe, two_dthe, i_two_dthe, dthe2, i_dthe2; };
+
+// theta derivative pair (RHS_Hyd.cpp:156-161, 177-181, 250-276)
+__device__ __forceinline__ void dtheta(int mode, double hdj, double xm2, double xm1, double x0, double xp1,
+                                       const ThetaK& K, double& d1, double& d2) {
+    if (mode == 0) {
+        d1 = div_by(hdj * (xp1 - xm1), K.two_dthe, K.i_two_dthe);
+        d2 = div_by(hdj * (xp1 - 2. * x0 + xm1), K.dthe2, K.i_dthe2);
+    } else if (mode == 1) {
+        d1 = div_by(hdj * (x0 - xm1), K.dthe, K.i_dthe);
+        d2 = 0.;
+    } else {
+        d1 = div_by(hdj * (-3. * x0 + 4. * xm1 - xm2), K.two_dthe, K.i_two_dthe);
+        d2 = div_by(hdj * (2 * x0 - 2. * xm1 + xm2), K.dthe2, K.i_dthe2);
+    }
+}
+
+// The whole sweep of one wave.  All roles execute the same number of barriers (one before the
+// first step, four per step).  Memory schedule of a step (row j): every load (row j+1 of xn,
+// flags, the level above and the role's extras, row j+2 of the own variable) is issued at the
+// top, the stores of row j-1's results in stage 2; nothing loaded in a step is used before the
+// next one, and the end-of-step wait leaves only the stores outstanding.
+template <int ROLE>
+__device__ __forceinline__ void sweep_role(const HydWsArgs& a, const DevConst& K, Shared& sh, const double* tab,
+                                           int i, const double* __restrict__ X, double* __restrict__ XO,
+                                           const double* __restrict__ XN) {
+    constexpr bool isT = ROLE == R_T, isU = ROLE == R_U, isV = ROLE == R_V, isW = ROLE == R_W, isC = ROLE == R_C;
+    constexpr bool hasH0I = isT || isU || isC;
+    constexpr int NST = isU ? 7 : (isV || isW || isC) ? 2 : 1;  // stores per step
+    const int im = K.im, jm = K.jm, km = K.km;
+    const int lane = threadIdx.x & 63;
+    const int kk = 1 + blockIdx.x * 64 + lane;
+    const int k = kk <= km - 2 ? kk : km - 2;  // idle lanes shadow the last line and reproduce its bits
+    const bool top = (i == im - 2);
+    const bool kwin = (k >= 2) && (k < km - 3);
+
+    // ---- constants of the dependent chain, in vector registers ----
+    ThetaK TK = { K.dthe, K.i_dthe, K.two_dthe, K.i_two_dthe, K.dthe2, K.i_dthe2 };
+    PIN(TK.dthe); PIN(TK.i_dthe); PIN(TK.two_dthe); PIN(TK.i_two_dthe); PIN(TK.dthe2); PIN(TK.i_dthe2);
+    double rm = a.rad[i];
+    double rm2 = rm * rm, i_rm = 1. / rm, i_rm2 = 1. / rm2;
+    PIN(rm); PIN(rm2); PIN(i_rm); PIN(i_rm2);
+    double dr = K.dr, i_dr = K.i_dr;
+    PIN(dr); PIN(i_dr);
+    // divisor of the diffusion bracket and of the damping term of this variable
+    double dv, i_dv, dm, i_dm;
+    if constexpr (isT) { dv = K.re_pr; i_dv = K.i_re_pr; dm = K.dr2; i_dm = K.i_dr2; }
+    else if constexpr (isU) { dv = K.re; i_dv = K.i_re; dm = K.dthe2; i_dm = K.i_dthe2; }
+    else if constexpr (isV) { dv = K.re; i_dv = K.i_re; dm = K.dthe2; i_dm = K.i_dthe2; }
+    else if constexpr (isW) { dv = K.re; i_dv = K.i_re; dm = K.dphi2; i_dm = K.i_dphi2; }
+    else { dv = K.re_sc; i_dv = K.i_re_sc; dm = K.dr2; i_dm = K.i_dr2; }
+    PIN(dv); PIN(i_dv); PIN(dm); PIN(i_dm);
+    double dt = K.dt, i_six = K.i_six, six = 6.;
+    PIN(dt); PIN(i_six); PIN(six);
+    double k1 = 0., k2 = 0., k3 = 0., k4 = 0.;  // role-specific scalars
+    if constexpr (isU) { k1 = K.buoy_g; k2 = K.coeff_buoy; }
+    if constexpr (isC) { k1 = K.c_0; k2 = K.coeff_salinity; k3 = K.two_dr; k4 = K.i_two_dr; }
+    PIN(k1); PIN(k2); PIN(k3); PIN(k4);
+    double topo_step = K.topo_step, i_topo_step = K.i_topo_step;
+    const double hight = (double)i * topo_step;
+    const uint8_t* __restrict__ FL = a.flags;
+
+    // ---- byte offsets of rows j, j+1, j+2 of this line, advanced by one row per step ----
+    const unsigned rowB = (unsigned)km * 8u;
+    const unsigned lvlB = (unsigned)jm * rowB;
+    unsigned o0 = (unsigned)(idx3(jm, km, i, 1, k) * 8);
+    unsigned o1 = o0 + rowB, o2 = o1 + rowB;
+    unsigned q1 = (unsigned)(((size_t)2 * km + k) * 8);  // row j+1 of a 2-D field
+    PIN(o0); PIN(o1); PIN(o2); PIN(q1);
+    const double *E1 = nullptr, *E2 = nullptr, *E3 = nullptr;
+    if constexpr (isV) { E1 = a.p_dyn; E2 = a.u; }
+    if constexpr (isU) E1 = a.r_salt_water;
+    if constexpr (isC) { E1 = a.r_water; E2 = a.evap; E3 = a.precip; }
+    const double* BA = a.bathy;
+    // side-output fields of the role
+    double *O1 = nullptr, *O2 = nullptr, *O3 = nullptr, *O4 = nullptr, *O5 = nullptr, *O6 = nullptr;
+    if constexpr (isU) { O1 = a.aux_u; O2 = a.buoy; O3 = a.salt_balance; O4 = a.salt_finger; O5 = a.salt_diffusion; O6 = a.r_salt_water; }
+    if constexpr (isV) O1 = a.aux_v;
+    if constexpr (isW) O1 = a.aux_w;
+    if constexpr (isC) O1 = a.r_water;
+
+    double xm2 = 0., xm1 = ldg(X, o0 - rowB), x0 = ldg(X, o0), xp1 = ldg(X, o1);
+    double ym2 = 0., ym1 = 0., y0 = 0., yp1 = 0.;  // p_dyn rows (v wave)
+    double um2 = 0., um1 = 0., up1 = 0.;            // u rows (v wave): updated j-2, j-1; old j+1
+    if constexpr (isV) {
+        ym1 = ldg(E1, o0 - rowB); y0 = ldg(E1, o0); yp1 = ldg(E1, o1);
+        um1 = ldg(E2, o0 - rowB); up1 = ldg(E2, o1);
+    }
+
+    // raw inputs of the next step, loaded during this one
+    double n_xn, n_xa, n_bathy = 0., n_r1 = 0., n_cb = 0., n_ev = 0., n_pr = 0.;
+    double n_cos, n_rm2sin, n_irm2sin, n_coefv = 0.;
+    uint8_t n_fl;
+    auto load_next = [&](unsigned o, unsigned q) {
+        n_xn = ldg(XN, o);
+        n_fl = ldg_u8(FL, o >> 3);
+        n_xa = ldg(X, o + lvlB);  // level i+1 <= im-1 always exists
+        if constexpr (hasH0I) n_bathy = ldg(BA, q);
+        if constexpr (isU) n_r1 = ldg(E1, o);
+        if constexpr (isC) {
+            if (top) {  // RHS_Hyd.cpp:355-359
+                n_cb = ldg(XO, o - lvlB);    // c at level im-3: already updated (level im-1, in n_xa, never is)
+                n_ev = ldg(E2, q); n_pr = ldg(E3, q);
+            }
+        }
+    };
+    auto load_table = [&](int jj) {
+        const double* row = tab + 4 * jj;
+        n_cos = row[0]; n_rm2sin = row[1]; n_irm2sin = row[2];
+        if constexpr (isV) n_coefv = row[3];
+    };
+    load_next(o0, q1 - rowB);
+    load_table(1);
+    // c wave: r_water of rows j and j+1; row j+2 is fetched at the top of step j
+    double rw_cur = 0., rw_nxt = 0., n_rw2 = 0.;
+    if constexpr (isC) { rw_cur = ldg(E1, o0); rw_nxt = ldg(E1, o1); }
+
+    // what the u and v waves need of a new c value (RHS_Hyd.cpp:345)
+    auto publish_c = [&](int buf, double cval, double rw) {
+        const double swr = rw + .7 * cval * k1;
+        sh.swr[buf][lane] = swr;
+        sh.yswr[buf][lane] = rcp_refined(swr);
+    };
+
+    // stage-1 values of row 1
+    if constexpr (isU) sh.u[0][lane] = x0;
+    if constexpr (isV) sh.v[0][lane] = x0;
+    if constexpr (isC) publish_c(0, x0, rw_cur);
+    lds_barrier();
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): nothing pending when the loop starts
+
+    double so1 = 0., so2 = 0., so3 = 0., so4 = 0., so5 = 0., so6 = 0.;  // side outputs of the previous row
+
+    for (int j = 1; j < jm - 1; j++) {
+        // ---- take over the prefetched inputs of this step, start loading the next step's ----
+        const double xn = n_xn, xa_raw = n_xa;
+        const uint8_t fl = n_fl;
+        const double costhe = n_cos, rm2sin = n_rm2sin, i_rm2sin = n_irm2sin, coef_v = n_coefv;
+        const double bathy = n_bathy, rsw_in = n_r1;
+        const double c_top = xa_raw, c_below = n_cb, ep = n_ev - n_pr;
+        load_next(o1, q1);  // row j+1 <= jm-1 always exists
+        double xp2 = 0., yp2 = 0., up2 = 0.;
+        if (j + 2 < jm) {
+            xp2 = ldg(X, o2);
+            if constexpr (isC) n_rw2 = ldg(E1, o2);
+            if constexpr (isV) { yp2 = ldg(E1, o2); up2 = ldg(E2, o2); }
+        }
+
+        const bool land = fl & FL_LAND;
+        const double h_d_j = ((fl & FL_H0J) && (fl & FL_H0K)) ? 0. : 1.;  // RHS_Hyd.cpp:117-139
+        const bool window = (j >= 2) && (j < jm - 3);
+        const int mode = !window ? 0 : ((fl & FL_ONESIDED_S) ? 2 : 1);
+        const bool all_bw = __all(mode == 1);                    // whole wave on the two-point backward form: d2 == 0
+        const bool d2zero = kwin && (fl & FL_D2ZERO);            // RHS_Hyd.cpp:296-300, 326-330
+        const bool rlive = (i < im - 2) && !(fl & FL_RDEAD);     // RHS_Hyd.cpp:191-214
+        const double xa = rlive ? xa_raw : 0.;
+
+        double h_0 = 0.;
+        if constexpr (hasH0I) {  // h_0_i, RHS_Hyd.cpp:96-111
+            h_0 = 1.;
+            if (land) {
+                const double topo_diff = fabs(hight - bathy);
+                if (!(topo_diff == topo_step)) h_0 = div_by(topo_diff, topo_step, i_topo_step);
+            }
+        }
+        if constexpr (isV) h_0 = (fl & FL_H0J) ? 1. : 0.;
+        if constexpr (isW) h_0 = (fl & FL_H0K) ? 1. : 0.;
+
+        double pg_num = 0.;
+        if constexpr (isV) {
+            if (j > 1) um1 = sh.ufin[lane];  // updated u of row j-1 (row 0 is a boundary row)
+            double dpdthe, d2p;
+            dtheta(mode, h_d_j, ym2, ym1, y0, yp1, TK, dpdthe, d2p);
+            pg_num = div_by(h_d_j * dpdthe, rm, i_rm);  // h_d_j*dpdthe/rm, then / salt_water_ref per stage
+        }
+        double rsw = rsw_in;  // u wave: r_salt_water, overwritten on land after the first evaluation
+        double rw = rw_cur;   // c wave: r_water, likewise
+
+        double st = x0, acc = 0., rhs = 0., RS = 0., pg_v = 0., sb = 0.;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const int rb = s & 1, wb = rb ^ 1;
+            if (s == 1 && j > 1) {  // results of the previous row
+                stg(XO, o0 - rowB, xm1);
+                if constexpr (isU) {
+                    stg(O1, o0 - rowB, so1); stg(O2, o0 - rowB, so2); stg(O3, o0 - rowB, so3);
+                    stg(O4, o0 - rowB, so4); stg(O5, o0 - rowB, so5); stg(O6, o0 - rowB, so6);
+                }
+                if constexpr (isV || isW || isC) stg(O1, o0 - rowB, so1);
+            }
+            if (s == 3) load_table(j + 1);
+            double u, v;
+            if constexpr (isU) u = st; else u = sh.u[rb][lane];
+            if constexpr (isV) v = st; else v = sh.v[rb][lane];
+
+            double d1, d2 = 0.;
+            if (all_bw) {
+                d1 = div_by(h_d_j * (st - xm1), TK.dthe, TK.i_dthe);
+            } else {
+                dtheta(mode, h_d_j, xm2, xm1, st, xp1, TK, d1, d2);
+                if (d2zero) d2 = 0.;
+            }
+            const double dr1 = rlive ? div_by(xa - st, dr, i_dr) : 0.;  // RHS_Hyd.cpp:206-211
+            const double adv = u * dr1 + div_by(v * d1, rm, i_rm);
+
+            // RHS_Hyd.cpp:406-437 with the exact-zero terms removed
+            if constexpr (isT || isC) {
+                double brk;
+                if (all_bw) brk = div_by(dr1 * 2., rm, i_rm) + div_by(d1 * costhe, rm2sin, i_rm2sin);
+                else brk = div_by(dr1 * 2., rm, i_rm) + div_by(d2, rm2, i_rm2) + div_by(d1 * costhe, rm2sin, i_rm2sin);
+                rhs = -adv + div_by(brk, dv, i_dv);
+                if constexpr (isC) {
+                    if (top) {  // RHS_Hyd.cpp:355-372
+                        const double swr = rw + .7 * st * k1;
+                        double salinity_surface = div_by(swr * (-3. * c_top + 4. * st - c_below), k3, k4)
+                                                  * (1. - 2. * c_top) * ep;
+                        double salinity_evaporation = k2 * salinity_surface;
+                        if (land) salinity_evaporation = 0.;
+                        if (salinity_evaporation >= 20.) salinity_evaporation = 20.;
+                        if (salinity_evaporation <= -20.) salinity_evaporation = -20.;
+                        rhs = rhs + salinity_evaporation;
+                    }
+                    if (land) rw = 1007.;  // seen by the following stages (RHS_Hyd.cpp:395-402)
+                }
+                rhs = rhs - div_by(h_0 * st, dm, i_dm);
+            } else if constexpr (isU) {
+                double brk;
+                if (all_bw) brk = div_by(4. * dr1, rm, i_rm) + div_by(d1 * costhe, rm2sin, i_rm2sin);
+                else brk = div_by(d2, rm2, i_rm2) + div_by(4. * dr1, rm, i_rm) + div_by(d1 * costhe, rm2sin, i_rm2sin);
+                const double swr = sh.swr[rb][lane];
+                RS = div_by(k1 * (rsw - swr), swr, sh.yswr[rb][lane]);  // RHS_Hyd.cpp:374
+                sb = swr - rsw;
+                if (land) rsw = 1032.;
+                rhs = -adv + div_by(brk, dv, i_dv) + RS - div_by(h_0 * u, dm, i_dm);
+            } else if constexpr (isV) {
+                double d1u, d2u;
+                dtheta(mode, h_d_j, um2, um1, u, up1, TK, d1u, d2u);
+                pg_v = div_by(pg_num, sh.swr[rb][lane], sh.yswr[rb][lane]);
+                double brk;
+                if (all_bw) brk = div_by(dr1 * 2., rm, i_rm) + div_by(d1, rm2sin, i_rm2sin) * costhe;
+                else brk = div_by(dr1 * 2., rm, i_rm) + div_by(d2, rm2, i_rm2) + div_by(d1, rm2sin, i_rm2sin) * costhe;
+                rhs = -adv - pg_v
+                      + div_by(brk - coef_v * h_d_j * v + div_by(2. * d1u, rm2, i_rm2), dv, i_dv)
+                      - div_by(h_0 * v, dm, i_dm);
+            } else {  // R_W
+                double brk;
+                if (all_bw) brk = div_by(dr1 * 2., rm, i_rm) + div_by(d1, rm2sin, i_rm2sin) * costhe;
+                else brk = div_by(dr1 * 2., rm, i_rm) + div_by(d2, rm2, i_rm2) + div_by(d1, rm2sin, i_rm2sin) * costhe;
+                rhs = -adv + div_by(brk, dv, i_dv) - div_by(h_0 * st, dm, i_dm);
+            }
+
+            // RungeKutta_Hyd.cpp:56-120 (stage 3 advances w from its stage-2 value, :101)
+            if (s == 0) { acc = rhs; st = xn + rhs * .5 * dt; }
+            else if (s == 1) { acc = acc + 2. * rhs; st = xn + rhs * .5 * dt; }
+            else if (s == 2) { acc = acc + 2. * rhs; st = (isW ? st : xn) + rhs * dt; }
+            else st = xn + div_by(dt * (acc + rhs), six, i_six);
+
+            // publish: the next stage's value, or (after the last stage) stage 1 of the next row
+            const double pub = (s < 3) ? st : xp1;
+            if constexpr (isU) { sh.u[wb][lane] = pub; if (s == 3) sh.ufin[lane] = st; }
+            if constexpr (isV) sh.v[wb][lane] = pub;
+            if constexpr (isC) publish_c(wb, pub, (s < 3) ? rw : rw_nxt);
+            lds_barrier();
+        }
+
+        // ---- side outputs of the 4th evaluation (RHS_Hyd.cpp:379-402, 440-446) ----
+        if constexpr (isU) {
+            double sfinger, sdiff;
+            if (sb < 0.) { sdiff = sb; sfinger = 0.; } else { sfinger = sb; sdiff = 0.; }
+            so1 = land ? 0. : rhs;
+            so2 = land ? 0. : RS * k2 * 1000.;
+            so3 = land ? 0. : sb; so4 = land ? 0. : sfinger; so5 = land ? 0. : sdiff;
+            so6 = land ? 1032. : rsw_in;
+        }
+        if constexpr (isV) so1 = land ? 0. : rhs + pg_v;
+        if constexpr (isW) so1 = land ? 0. : rhs;
+        if constexpr (isC) so1 = land ? 1007. : rw_cur;
+        // Vector-memory operations complete in issue order: waiting until only this step's stores may
+        // be outstanding completes its loads without waiting for the write acknowledgements.
+        if (j > 1) __builtin_amdgcn_s_waitcnt(0x0F70 | NST);  // vmcnt(NST)
+        else __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0): the first step stores nothing
+        xm2 = xm1; xm1 = st; x0 = xp1; xp1 = xp2;
+        if constexpr (isV) { ym2 = ym1; ym1 = y0; y0 = yp1; yp1 = yp2; um2 = um1; up1 = up2; }
+        if constexpr (isC) { rw_cur = rw_nxt; rw_nxt = n_rw2; }
+        o0 += rowB; o1 += rowB; o2 += rowB; q1 += rowB;
+    }
+    // row jm-2
+    stg(XO, o0 - rowB, xm1);
+    if constexpr (isU) {
+        stg(O1, o0 - rowB, so1); stg(O2, o0 - rowB, so2); stg(O3, o0 - rowB, so3);
+        stg(O4, o0 - rowB, so4); stg(O5, o0 - rowB, so5); stg(O6, o0 - rowB, so6);
+    }
+    if constexpr (isV || isW || isC) stg(O1, o0 - rowB, so1);
+}
+
+__global__ __launch_bounds__(320) void k_hyd_rk3d_ws(const HydWsParams* __restrict__ P, int i_begin) {
+    const HydWsArgs& a = P->a;
+    const DevConst& K = P->K;
+    __shared__ Shared sh;
+    extern __shared__ double tab[];  // [jm][4]: cos(the), rm^2 sin(the), its reciprocal, viscous v coefficient
+    const int i = i_begin + blockIdx.y;
+    {
+        const int jm = K.jm;
+        const double rm = a.rad[i], rm2 = rm * rm;
+        for (int j = threadIdx.x; j < jm; j += blockDim.x) {
+            const double sinthe = a.sinthe[j], costhe = a.costhe[j];
+            const double rm2sinthe = rm2 * sinthe;
+            tab[4 * j + 0] = costhe;
+            tab[4 * j + 1] = rm2sinthe;
+            tab[4 * j + 2] = 1. / rm2sinthe;
+            tab[4 * j + 3] = 1. + costhe * costhe / (sinthe * sinthe);  // RHS_Hyd.cpp:422 (no rm here)
+        }
+        __syncthreads();
+    }
+    switch (threadIdx.x >> 6) {
+        case R_T: sweep_role<R_T>(a, K, sh, tab, i, a.t, a.to, a.tn); break;
+        case R_V: sweep_role<R_V>(a, K, sh, tab, i, a.v, a.vo, a.vn); break;
+        case R_U: sweep_role<R_U>(a, K, sh, tab, i, a.u, a.uo, a.un); break;
+        case R_C: sweep_role<R_C>(a, K, sh, tab, i, a.c, a.co, a.cn); break;
+        default: sweep_role<R_W>(a, K, sh, tab, i, a.w, a.wo, a.wn); break;
+    }
+}
+
+// Copies the boundary shell (i, j or k on a face) of src to dst: the sweep writes interior points only.
+__global__ void k_copy_shell(const double* const* __restrict__ src, double* const* __restrict__ dst, int im, int jm, int km) {
+    const double* __restrict__ s = src[blockIdx.z];
+    double* __restrict__ d = dst[blockIdx.z];
+    const int i = blockIdx.y;
+    const size_t base = (size_t)i * jm * km;
+    if (i == 0 || i == im - 1) {  // whole level
+        for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < jm * km; q += gridDim.x * blockDim.x) d[base + q] = s[base + q];
+        return;
+    }
+    // rows j = 0, jm-1 and columns k = 0, km-1 of an interior level
+    const int n = 2 * km + 2 * jm;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+        size_t q;
+        if (e < km) q = e;
+        else if (e < 2 * km) q = (size_t)(jm - 1) * km + (e - km);
+        else if (e < 2 * km + jm) q = (size_t)(e - 2 * km) * km;
+        else q = (size_t)(e - 2 * km - jm) * km + (km - 1);
+        d[base + q] = s[base + q];
+    }
+}
+
+}  // namespace
+
+int atomdev_hyd_rk3d_ws(atomdev* h) {
+    static const int X[5] = { ATOMDEV_T, ATOMDEV_U, ATOMDEV_V, ATOMDEV_W, ATOMDEV_C };
+    ATOMDEV_REQUIRE(h->n3 * sizeof(double) < ((size_t)1 << 32), "hyd_rk3d: field larger than 4 GiB");
+    // Two argument blocks, one per orientation of the (current, alternate) buffer pair; the sweep
+    // swaps the pair, so consecutive sweeps alternate between them.
+    struct Blocks { HydWsParams p[2]; const double* src[2][5]; double* dst[2][5]; };
+    if (!h->ws_params) {
+        Blocks* B = new Blocks;
+        for (int o = 0; o < 2; o++) {
+            HydWsArgs& a = B->p[o].a;
+            double* cur[5]; double* alt[5];
+            for (int n = 0; n < 5; n++) { cur[n] = o ? h->alt[X[n]] : h->f[X[n]]; alt[n] = o ? h->f[X[n]] : h->alt[X[n]]; }
+            a.t = cur[0]; a.u = cur[1]; a.v = cur[2]; a.w = cur[3]; a.c = cur[4];
+            a.to = alt[0]; a.uo = alt[1]; a.vo = alt[2]; a.wo = alt[3]; a.co = alt[4];
+            a.tn = h->f[ATOMDEV_TN]; a.un = h->f[ATOMDEV_UN]; a.vn = h->f[ATOMDEV_VN]; a.wn = h->f[ATOMDEV_WN]; a.cn = h->f[ATOMDEV_CN];
+            a.p_dyn = h->f[ATOMDEV_P_DYN];
+            a.r_water = h->f[ATOMDEV_R_WATER]; a.r_salt_water = h->f[ATOMDEV_R_SALT_WATER];
+            a.aux_u = h->f[ATOMDEV_AUX_U]; a.aux_v = h->f[ATOMDEV_AUX_V]; a.aux_w = h->f[ATOMDEV_AUX_W]; a.buoy = h->f[ATOMDEV_BUOYANCY];
+            a.salt_balance = h->f[ATOMDEV_SALT_BALANCE]; a.salt_finger = h->f[ATOMDEV_SALT_FINGER];
+            a.salt_diffusion = h->f[ATOMDEV_SALT_DIFFUSION];
+            a.flags = h->flags;
+            a.bathy = h->g[ATOMDEV_TOPOGRAPHY]; a.evap = h->g[ATOMDEV_EVAPORATION_DALTON]; a.precip = h->g[ATOMDEV_PRECIPITATION];
+            a.rad = h->rad; a.sinthe = h->sinthe; a.costhe = h->costhe;
+            B->p[o].K = h->k;
+            for (int n = 0; n < 5; n++) { B->src[o][n] = cur[n]; B->dst[o][n] = alt[n]; }
+        }
+        hipError_t e = hipMalloc(&h->ws_params, sizeof(Blocks));
+        if (e == hipSuccess) e = hipMemcpy(h->ws_params, B, sizeof(Blocks), hipMemcpyHostToDevice);
+        h->ws_cur0 = h->f[ATOMDEV_T];
+        delete B;
+        ATOMDEV_TRY(e);
+    }
+    const int o = (h->f[ATOMDEV_T] == h->ws_cur0) ? 0 : 1;
+    const Blocks* D = (const Blocks*)h->ws_params;
+    const HydWsParams* P = &D->p[o];
+    if (int rc = atomdev_prof_begin(h)) return rc;
+    hipLaunchKernelGGL(k_copy_shell, dim3(8, h->im, 5), dim3(256), 0, h->stream, &D->src[o][0], &D->dst[o][0], h->im, h->jm, h->km);
+    ATOMDEV_TRY(hipGetLastError());
+    const unsigned gx = (h->km - 2 + 63) / 64;
+    const size_t lds = (size_t)h->jm * 4 * sizeof(double);
+    if (h->im - 3 >= 1) {  // levels 1 .. im-3
+        hipLaunchKernelGGL(k_hyd_rk3d_ws, dim3(gx, h->im - 3), dim3(320), lds, h->stream, P, 1);
+        ATOMDEV_TRY(hipGetLastError());
+    }
+    // level im-2 reads the updated salinity of level im-3 (RHS_Hyd.cpp:356-357): second launch
+    hipLaunchKernelGGL(k_hyd_rk3d_ws, dim3(gx, 1), dim3(320), lds, h->stream, P, h->im - 2);
+    ATOMDEV_TRY(hipGetLastError());
+    if (int rc = atomdev_prof_end(h)) return rc;
+    for (int n = 0; n < 5; n++) { double* t = h->f[X[n]]; h->f[X[n]] = h->alt[X[n]]; h->alt[X[n]] = t; }
+    return 0;
+}

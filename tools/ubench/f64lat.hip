@@ -125,6 +125,32 @@ __global__ void k_long(double* out, long long* cyc, double a, double b, int iter
     if (threadIdx.x == 0 && blockIdx.x == 0) { cyc[0] = t1 - t0; cyc[1] = w1 - w0; }
 }
 
+__global__ void k_long_masked(double* out, long long* cyc, double a, double b, int iters, int active) {
+    double x = out[threadIdx.x];
+    if ((threadIdx.x & 63) < active) {
+        for (int it = 0; it < iters; it++) {
+#pragma unroll
+            for (int i = 0; i < 64; i++) x = __builtin_fma(x, a, b);
+        }
+    }
+    out[threadIdx.x + blockIdx.x * blockDim.x] = x;
+}
+static void run_masked(int blocks, int threads, int iters, int active) {
+    double* out; long long* cyc;
+    hipMalloc(&out, sizeof(double) * blocks * threads + 4096);
+    hipMalloc(&cyc, 2 * sizeof(long long));
+    hipMemset(out, 0, sizeof(double) * blocks * threads + 4096);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k_long_masked, dim3(blocks), dim3(threads), 0, 0, out, cyc, 1.0000001, 1e-9, iters, active);
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(k_long_masked, dim3(blocks), dim3(threads), 0, 0, out, cyc, 1.0000001, 1e-9, iters, active);
+    hipEventRecord(e1, 0);
+    hipDeviceSynchronize();
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("masked fma chain blocks=%d threads=%d active lanes=%d: %.3f ms, %.2f ns/op/wave\n", blocks, threads, active, ms, ms * 1e6 / (64.0 * iters));
+    hipFree(out); hipFree(cyc);
+}
+
 static void run_long(int blocks, int threads, int iters) {
     double* out; long long* cyc;
     hipMalloc(&out, sizeof(double) * blocks * threads + 4096);
@@ -165,6 +191,7 @@ int main() {
     int wclk = 0;
     hipDeviceGetAttribute(&wclk, hipDeviceAttributeWallClockRate, 0);
     printf("clockRate %d kHz  wallClockRate %d kHz\n", clk, wclk);
+    for (int act : {64, 48, 32, 16, 1}) run_masked(234, 512, 10000, act);
     run_long(1, 64, 20000);
     run_long(1, 512, 20000);
     run_long(234, 512, 20000);
