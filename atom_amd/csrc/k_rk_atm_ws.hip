@@ -472,11 +472,11 @@ int atomdev_atm_rk3d_ws(atomdev* h) {
         ATOMDEV_TRY(hipMalloc(&h->ws_params, sizeof(P)));
         ATOMDEV_TRY(hipMemcpy(h->ws_params, &P, sizeof(P), hipMemcpyHostToDevice));
     }
-    if (int rc = atomdev_prof_begin(h)) return rc;
     dim3 pg((h->km + 127) / 128, h->jm, h->im - 2);
     hipLaunchKernelGGL(k_atm_prep, pg, dim3(128), 0, h->stream, h->f[ATOMDEV_T], h->g[ATOMDEV_TOPOGRAPHY], h->flags,
                        h->scr[0], h->scr[1], h->k);
     ATOMDEV_TRY(hipGetLastError());
+    if (int rc = atomdev_prof_begin(h)) return rc;  // the event bracket times the sweep kernel alone
     dim3 grid((h->km - 2 + 63) / 64, h->im - 2);
     ATOMDEV_REQUIRE(h->n3 * sizeof(double) < ((size_t)1 << 32), "atm_rk3d: field larger than 4 GiB");
     hipLaunchKernelGGL(k_atm_rk3d_ws, grid, dim3(512), (size_t)h->jm * 4 * sizeof(double), h->stream,

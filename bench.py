@@ -191,7 +191,7 @@ def main():
             "config": {"workload": "atmosphere 3-D hot-path iteration (BC fills, limiter, solid ground, fused RK4+RHS sweep, "
                                    "limiter, old->new copy; pressure Jacobi every 2nd step), 41x181x361, one slice per GPU",
                        "grid": [IM, JM, KM], "updates_per_step_per_gpu": UPDATES, "parallelism": "independent slices"},
-            "roofline": {"bound": "hbm", "kernel": "k_atm_rk3d", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_atm_rk3d_ws", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "bytes_per_update": ATM_BYTES_PER_UPDATE, "kernel_ms": rk_avg_s * 1e3, "launches": rk_n},
             "hydrosphere": hyd_info,

@@ -1,6 +1,7 @@
 #!/bin/bash
 # usage (on the GPU box, from the repo root): tools/pmc.sh <tag> <model> -- one rocprofv3 --pmc pass per counter group
 set -u
+export RUN_RK_MOVE=1
 tag=$1; model=$2
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT

@@ -25,6 +25,8 @@ d.upload_all(f, g)
 d.profile_rk(True)
 for _ in range(n):
     d.op("atm_rk3d" if model == H.ATM else "hyd_rk3d")
+    if os.environ.get("RUN_RK_MOVE"):  # a streaming copy of known size, to calibrate byte counters against
+        d.move_data_to_new_arrays(-1)
 ms, cnt = d.profile_read()
 print("%s %s: %.3f ms per sweep (%d sweeps)" % (sys.argv[1], "x".join(map(str, dims)), ms / cnt, cnt))
 d.close()
