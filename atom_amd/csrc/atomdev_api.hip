@@ -248,6 +248,28 @@ extern "C" int atomdev_download2d(atomdev_t* h, int field, double* host) {
     return 0;
 }
 
+// Columns k0 .. k0+nk-1 of a 3-D field <-> a dense [im*jm][nk] buffer in host or device memory.
+static int copy_columns(atomdev_t* h, int field, int k0, int nk, void* buf, bool to_buf, const char* who) {
+    ATOMDEV_REQUIRE(h && buf && field >= 0 && field < ATOMDEV_N3D && h->f[field], std::string(who) + ": bad argument");
+    ATOMDEV_REQUIRE(k0 >= 0 && nk >= 1 && k0 + nk <= h->km, std::string(who) + ": column range outside the grid");
+    ATOMDEV_TRY(hipSetDevice(h->device));
+    const size_t rows = (size_t)h->im * h->jm, pitch = (size_t)h->km * sizeof(double), w = (size_t)nk * sizeof(double);
+    double* f = h->f[field] + k0;
+    if (to_buf) ATOMDEV_TRY(hipMemcpy2DAsync(buf, w, f, pitch, w, rows, hipMemcpyDefault, h->stream));
+    else ATOMDEV_TRY(hipMemcpy2DAsync(f, pitch, buf, w, w, rows, hipMemcpyDefault, h->stream));
+    ATOMDEV_TRY(hipStreamSynchronize(h->stream));
+    if (!to_buf && field == ATOMDEV_H) h->flags_dirty = true;
+    return 0;
+}
+
+extern "C" int atomdev_get_columns(atomdev_t* h, int field3d, int k0, int nk, void* dst) {
+    return copy_columns(h, field3d, k0, nk, dst, true, "atomdev_get_columns");
+}
+
+extern "C" int atomdev_set_columns(atomdev_t* h, int field3d, int k0, int nk, const void* src) {
+    return copy_columns(h, field3d, k0, nk, const_cast<void*>(src), false, "atomdev_set_columns");
+}
+
 extern "C" int atomdev_sync(atomdev_t* h) {
     ATOMDEV_REQUIRE(h != nullptr, "atomdev_sync: null handle");
     ATOMDEV_TRY(hipSetDevice(h->device));

@@ -67,6 +67,8 @@ def load_library():
     lib.atomdev_dims.argtypes = [vp, ip, ip, ip]
     for name in ("atomdev_upload", "atomdev_download", "atomdev_upload2d", "atomdev_download2d"):
         getattr(lib, name).argtypes = [vp, C.c_int, vp]
+    for name in ("atomdev_get_columns", "atomdev_set_columns"):
+        getattr(lib, name).argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
     lib.atomdev_fill.argtypes = [vp, C.c_int, C.c_double]
     lib.atomdev_sync.argtypes = [vp]
     lib.atomdev_move_data_to_new_arrays.argtypes = [vp, C.c_int]
@@ -136,6 +138,31 @@ class DeviceModel:
             self.upload(k, v)
         for k, v in (fields2d or {}).items():
             self.upload(k, v)
+
+    @staticmethod
+    def _buffer_pointer(buf, nbytes):
+        """Address of a dense fp64 buffer: a numpy array or anything with data_ptr() (a torch tensor, host or device)."""
+        if isinstance(buf, np.ndarray):
+            if buf.dtype != np.float64 or not buf.flags["C_CONTIGUOUS"] or buf.nbytes != nbytes:
+                raise AtomDevError("column buffer must be C-contiguous float64 of %d bytes" % nbytes)
+            return buf.ctypes.data_as(C.c_void_p)
+        if not buf.is_contiguous() or buf.element_size() != 8 or buf.numel() * 8 != nbytes:
+            raise AtomDevError("column buffer must be a contiguous 8-byte tensor of %d bytes" % nbytes)
+        return C.c_void_p(buf.data_ptr())
+
+    def get_columns(self, name, k0, nk, out=None):
+        """Columns k0..k0+nk-1 of a 3-D field as an (im, jm, nk) block (halo send side of a phi-slab split)."""
+        if out is None:
+            out = np.empty((self.im, self.jm, nk))
+        ptr = self._buffer_pointer(out, self.im * self.jm * nk * 8)
+        self._check(self.lib.atomdev_get_columns(self._h, F3[name], k0, nk, ptr))
+        return out
+
+    def set_columns(self, name, k0, block):
+        """Overwrites columns k0.. of a 3-D field with an (im, jm, nk) block (halo receive side)."""
+        nk = int(block.shape[-1])
+        ptr = self._buffer_pointer(block, self.im * self.jm * nk * 8)
+        self._check(self.lib.atomdev_set_columns(self._h, F3[name], k0, nk, ptr))
 
     def fill(self, name, value):
         self._check(self.lib.atomdev_fill(self._h, F3[name], float(value)))

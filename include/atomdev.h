@@ -86,6 +86,13 @@ int atomdev_download(atomdev_t* h, int field3d, double* host);
 int atomdev_upload2d(atomdev_t* h, int field2d, const double* host);
 int atomdev_download2d(atomdev_t* h, int field2d, double* host);
 int atomdev_fill(atomdev_t* h, int field3d, double value); /* Array::initArray */
+/* Columns k0 .. k0+nk-1 (all i, j) of a 3-D field to / from a dense buffer of im*jm rows of nk
+ * doubles, in host or device memory.  This is the halo transfer of a phi-slab decomposition
+ * (one slab of longitudes per GPU); the reference is single-domain and has no counterpart, the
+ * operators it would feed are Pressure_Atm.cpp:140-155 (k+-1, k+-2 reads) and the phi-seam fills
+ * BC_Atm.cpp:115-150.  Both calls wait for the handle's stream. */
+int atomdev_get_columns(atomdev_t* h, int field3d, int k0, int nk, void* dst);
+int atomdev_set_columns(atomdev_t* h, int field3d, int k0, int nk, const void* src);
 int atomdev_sync(atomdev_t* h);
 
 /* AtomUtils::move_data_to_new_arrays (lib/Utils.cpp:41-68), coeff = 1.

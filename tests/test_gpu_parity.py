@@ -211,3 +211,22 @@ def test_errors_surface_as_exceptions():
     with pytest.raises(atom_amd.AtomDevError):
         d.upload("R_WATER", np.zeros((7, 13, 17)))
     d.close()
+
+
+@pytest.mark.parametrize("model,op,dims,seed", [(H.ATM, "atm_rk3d", (9, 21, 70), 41), (H.ATM, "atm_rk3d", (6, 9, 131), 42),
+                                                (H.HYD, "hyd_rk3d", (9, 21, 70), 43), (H.HYD, "hyd_rk3d", (6, 9, 131), 44)])
+def test_rk_variants_same_bits(model, op, dims, seed):
+    """The wave-specialised sweep (variant 0, default) and the one-thread-per-line sweep
+    (variant 1) are the same arithmetic on a different mapping: every field bit for bit, over
+    two consecutive sweeps (the hydrosphere swaps its buffer pair in between)."""
+    out = []
+    for variant in (0, 1):
+        o, d, names = _pair(model, dims, seed, "blobs")
+        o.close()
+        d.set_rk_variant(variant)
+        d.op(op)
+        d.op(op)
+        out.append({k: d.download(k) for k in names})
+        d.close()
+    for k in out[0]:
+        assert H.bits_equal(out[0][k], out[1][k]), (op, k, H.max_rel_err(out[0][k], out[1][k]))
