@@ -103,7 +103,7 @@ __global__ void k_atm_prep(const double* __restrict__ t, const double* __restric
 #ifdef ATOMDEV_EXP_STAMP  // timing experiment only: cycle stamps of step 60 of one workgroup go to level 0 of aux_w
 #define STAMP(n)                                                                                      \
     do {                                                                                              \
-        if (j == 60 && blockIdx.x == 2 && blockIdx.y == 10 && lane == 0)                              \
+        if (j == 60 && bx == 2 && i == 11 && lane == 0)                                           \
             a.aux_w[(threadIdx.x >> 6) * 16 + (n)] = (double)(long long)__builtin_readcyclecounter(); \
     } while (0)
 #else
@@ -165,14 +165,13 @@ __device__ __forceinline__ void dtheta(int mode, double hdj, double xm2, double 
 // of row j+1 is read from LDS in stage 4.  Nothing loaded in a step is used before the next step.
 template <int ROLE>
 __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K, Shared& sh, const double* tab,
-                                           double* __restrict__ X, const double* __restrict__ XN) {
+                                           int bx, int i, double* __restrict__ X, const double* __restrict__ XN) {
     constexpr bool isV = ROLE == R_V, isU = ROLE == R_U, isT = ROLE == R_T, isC = ROLE == R_C, isW = ROLE == R_W;
     constexpr bool hasH0I = ROLE == R_U || ROLE == R_CO2 || ROLE == R_ICE || ROLE == R_CLOUD;
     const int jm = K.jm, km = K.km;
     const int lane = threadIdx.x & 63;
-    const int kk = 1 + blockIdx.x * 64 + lane;
+    const int kk = 1 + bx * 64 + lane;
     const int k = kk <= km - 2 ? kk : km - 2;  // idle lanes shadow the last line and reproduce its bits
-    const int i = 1 + blockIdx.y;
     const bool lvl1 = isC && (i == 1);
     constexpr int NST = isU ? 3 : (isV || isW) ? 2 : 1;  // stores per step
 
@@ -192,8 +191,8 @@ __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K
     else if constexpr (isC) { dv = K.re_sc_wv; i_dv = K.i_re_sc_wv; }
     else { dv = K.re_sc_wv; i_dv = K.i_re_sc_wv; dm = K.dr2; i_dm = K.i_dr2; }
     PIN(dv); PIN(i_dv); PIN(dm); PIN(i_dm);
-    double dt = K.dt, i_six = K.i_six, six = 6.;
-    PIN(dt); PIN(i_six); PIN(six);
+    double dt = K.dt, hdt = .5 * K.dt, i_six = K.i_six, six = 6.;
+    PIN(dt); PIN(hdt); PIN(i_six); PIN(six);
     double k1 = 0., k2 = 0., k3 = 0., k4 = 0., i_k4 = 0.;  // role-specific scalars
     if constexpr (isT) { k1 = K.R_Air; k2 = K.t_0; k3 = K.coeff_energy; }
     if constexpr (isU) { k1 = K.R_WV_over_R_Air; k2 = K.Buoyancy; k3 = K.g; k4 = K.coeff_buoy; }
@@ -302,14 +301,19 @@ __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K
                 e_a = ep; c_lvl0 = n_r4; c_lvl3 = n_r5;
             }
         }
-        load_top(o1);  // row j+1 <= jm-1 always exists
+#ifdef ATOMDEV_EXP_NOMEM  // timing experiment only (results are wrong): bit 0 no loads, bit 1 no stores inside the loop
+        const bool exp_mem = !(ATOMDEV_EXP_NOMEM & 1) || jm < 0, exp_st = !(ATOMDEV_EXP_NOMEM & 2) || jm < 0;
+#else
+        const bool exp_mem = true, exp_st = true;
+#endif
+        if (exp_mem) load_top(o1);  // row j+1 <= jm-1 always exists
         double xp2 = 0., yp2 = 0., up2 = 0.;
-        if (j + 2 < jm) {
+        if (exp_mem && j + 2 < jm) {
             xp2 = ldg(X, o2);
             if constexpr (isT) n_ph2 = ldg(E1, o2);
             if constexpr (isV) { yp2 = ldg(E1, o2); up2 = ldg(E2, o2); }
         }
-        load_sources(o1, q1);
+        if (exp_mem) load_sources(o1, q1);
         STAMP(1);
         const bool land = fl & FL_LAND;
         const double h_d_j = ((fl & FL_H0J) && (fl & FL_H0K)) ? 0. : 1.;  // RHS_Atm.cpp:129-149
@@ -332,7 +336,7 @@ __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K
 #pragma unroll
         for (int s = 0; s < 4; s++) {
             const int rb = s & 1, wb = rb ^ 1;
-            if (s == 1 && j > 1) {  // results of the previous row
+            if (exp_st && s == 1 && j > 1) {  // results of the previous row
                 stg(X, o0 - rowB, xm1);
                 if constexpr (isU) { stg(O1, o0 - rowB, so1); stg(O2, o0 - rowB, so2); }
                 if constexpr (isV || isW) stg(O1, o0 - rowB, so1);
@@ -382,10 +386,11 @@ __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K
                     rhs = rhs + vapour_evaporation;
                 }
             }
-            // RungeKutta_Atm.cpp:58-152
-            if (s == 0) { acc = rhs; st = xn + rhs * .5 * dt; }
-            else if (s == 1) { acc = acc + 2. * rhs; st = xn + rhs * .5 * dt; }
-            else if (s == 2) { acc = acc + 2. * rhs; st = xn + rhs * dt; }
+            // RungeKutta_Atm.cpp:58-152.  rhs * .5 * dt == rhs * (.5 * dt) and acc + 2. * rhs == fma(2, rhs, acc)
+            // bit for bit (scaling by a power of two is exact), one instruction less each.
+            if (s == 0) { acc = rhs; st = xn + rhs * hdt; }
+            else if (s == 1) { acc = __builtin_fma(2., rhs, acc); st = xn + rhs * hdt; }
+            else if (s == 2) { acc = __builtin_fma(2., rhs, acc); st = xn + rhs * dt; }
             else st = xn + div_by(dt * (acc + rhs), six, i_six);
 
             // publish: the next stage's value, or (after the last stage) stage 1 of the next row
@@ -425,8 +430,15 @@ __global__ __launch_bounds__(512) void k_atm_rk3d_ws(const AtmWsParams* __restri
     const DevConst& K = P->K;
     __shared__ Shared sh;
     extern __shared__ double tab[];  // [jm][4]: cos(the), rm^2 sin(the), its reciprocal, viscous v coefficient
+    // Workgroup -> (level, longitude block).  Consecutive workgroup ids go to consecutive XCDs, each
+    // with its own L2; the 512-byte row segments of neighbouring longitude blocks share cache lines
+    // (rows are not line-aligned), so all blocks of one level are given to the same XCD.
+    const int gx = (K.km - 2 + 63) / 64;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int lev = xcd + 8 * (idx / gx), bx = idx % gx;
+    if (lev >= K.im - 2) return;  // padding workgroups of the last round of levels
+    const int i = 1 + lev;
     {
-        const int i = 1 + blockIdx.y;
         const int jm = K.jm;
         for (int j = threadIdx.x; j < jm; j += blockDim.x) {
             tab[4 * j + 0] = a.costhe[j];
@@ -437,14 +449,14 @@ __global__ __launch_bounds__(512) void k_atm_rk3d_ws(const AtmWsParams* __restri
         __syncthreads();
     }
     switch (threadIdx.x >> 6) {
-        case R_U: sweep_role<R_U>(a, K, sh, tab, a.u, a.un); break;
-        case R_V: sweep_role<R_V>(a, K, sh, tab, a.v, a.vn); break;
-        case R_T: sweep_role<R_T>(a, K, sh, tab, a.t, a.tn); break;
-        case R_W: sweep_role<R_W>(a, K, sh, tab, a.w, a.wn); break;
-        case R_CO2: sweep_role<R_CO2>(a, K, sh, tab, a.co2, a.co2n); break;
-        case R_ICE: sweep_role<R_ICE>(a, K, sh, tab, a.ice, a.icen); break;
-        case R_CLOUD: sweep_role<R_CLOUD>(a, K, sh, tab, a.cloud, a.cloudn); break;
-        default: sweep_role<R_C>(a, K, sh, tab, a.c, a.cn); break;
+        case R_U: sweep_role<R_U>(a, K, sh, tab, bx, i, a.u, a.un); break;
+        case R_V: sweep_role<R_V>(a, K, sh, tab, bx, i, a.v, a.vn); break;
+        case R_T: sweep_role<R_T>(a, K, sh, tab, bx, i, a.t, a.tn); break;
+        case R_W: sweep_role<R_W>(a, K, sh, tab, bx, i, a.w, a.wn); break;
+        case R_CO2: sweep_role<R_CO2>(a, K, sh, tab, bx, i, a.co2, a.co2n); break;
+        case R_ICE: sweep_role<R_ICE>(a, K, sh, tab, bx, i, a.ice, a.icen); break;
+        case R_CLOUD: sweep_role<R_CLOUD>(a, K, sh, tab, bx, i, a.cloud, a.cloudn); break;
+        default: sweep_role<R_C>(a, K, sh, tab, bx, i, a.c, a.cn); break;
     }
 }
 
@@ -477,8 +489,14 @@ int atomdev_atm_rk3d_ws(atomdev* h) {
                        h->scr[0], h->scr[1], h->k);
     ATOMDEV_TRY(hipGetLastError());
     if (int rc = atomdev_prof_begin(h)) return rc;  // the event bracket times the sweep kernel alone
-    dim3 grid((h->km - 2 + 63) / 64, h->im - 2);
+    const unsigned gx = (h->km - 2 + 63) / 64, rounds = (h->im - 2 + 7) / 8;
+    dim3 grid(8 * rounds * gx);
     ATOMDEV_REQUIRE(h->n3 * sizeof(double) < ((size_t)1 << 32), "atm_rk3d: field larger than 4 GiB");
+#ifdef ATOMDEV_EXP_COREONLY  // timing experiment only: the four coupled roles alone (w, co2, ice, cloud not advanced)
+    hipLaunchKernelGGL(k_atm_rk3d_ws, grid, dim3(256), (size_t)h->jm * 4 * sizeof(double), h->stream,
+                       (const AtmWsParams*)h->ws_params);
+    if (0)
+#endif
     hipLaunchKernelGGL(k_atm_rk3d_ws, grid, dim3(512), (size_t)h->jm * 4 * sizeof(double), h->stream,
                        (const AtmWsParams*)h->ws_params);
     ATOMDEV_TRY(hipGetLastError());

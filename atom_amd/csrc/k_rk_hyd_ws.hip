@@ -95,14 +95,14 @@ __device__ __forceinline__ void dtheta(int mode, double hdj, double xm2, double 
 // next one, and the end-of-step wait leaves only the stores outstanding.
 template <int ROLE>
 __device__ __forceinline__ void sweep_role(const HydWsArgs& a, const DevConst& K, Shared& sh, const double* tab,
-                                           int i, const double* __restrict__ X, double* __restrict__ XO,
+                                           int bx, int i, const double* __restrict__ X, double* __restrict__ XO,
                                            const double* __restrict__ XN) {
     constexpr bool isT = ROLE == R_T, isU = ROLE == R_U, isV = ROLE == R_V, isW = ROLE == R_W, isC = ROLE == R_C;
     constexpr bool hasH0I = isT || isU || isC;
     constexpr int NST = isU ? 7 : (isV || isW || isC) ? 2 : 1;  // stores per step
     const int im = K.im, jm = K.jm, km = K.km;
     const int lane = threadIdx.x & 63;
-    const int kk = 1 + blockIdx.x * 64 + lane;
+    const int kk = 1 + bx * 64 + lane;
     const int k = kk <= km - 2 ? kk : km - 2;  // idle lanes shadow the last line and reproduce its bits
     const bool top = (i == im - 2);
     const bool kwin = (k >= 2) && (k < km - 3);
@@ -123,8 +123,8 @@ __device__ __forceinline__ void sweep_role(const HydWsArgs& a, const DevConst& K
     else if constexpr (isW) { dv = K.re; i_dv = K.i_re; dm = K.dphi2; i_dm = K.i_dphi2; }
     else { dv = K.re_sc; i_dv = K.i_re_sc; dm = K.dr2; i_dm = K.i_dr2; }
     PIN(dv); PIN(i_dv); PIN(dm); PIN(i_dm);
-    double dt = K.dt, i_six = K.i_six, six = 6.;
-    PIN(dt); PIN(i_six); PIN(six);
+    double dt = K.dt, hdt = .5 * K.dt, i_six = K.i_six, six = 6.;
+    PIN(dt); PIN(hdt); PIN(i_six); PIN(six);
     double k1 = 0., k2 = 0., k3 = 0., k4 = 0.;  // role-specific scalars
     if constexpr (isU) { k1 = K.buoy_g; k2 = K.coeff_buoy; }
     if constexpr (isC) { k1 = K.c_0; k2 = K.coeff_salinity; k3 = K.two_dr; k4 = K.i_two_dr; }
@@ -323,9 +323,11 @@ __device__ __forceinline__ void sweep_role(const HydWsArgs& a, const DevConst& K
             }
 
             // RungeKutta_Hyd.cpp:56-120 (stage 3 advances w from its stage-2 value, :101)
-            if (s == 0) { acc = rhs; st = xn + rhs * .5 * dt; }
-            else if (s == 1) { acc = acc + 2. * rhs; st = xn + rhs * .5 * dt; }
-            else if (s == 2) { acc = acc + 2. * rhs; st = (isW ? st : xn) + rhs * dt; }
+            // rhs * .5 * dt == rhs * (.5 * dt) and acc + 2. * rhs == fma(2, rhs, acc) bit for bit (scaling by a
+            // power of two is exact), one instruction less each
+            if (s == 0) { acc = rhs; st = xn + rhs * hdt; }
+            else if (s == 1) { acc = __builtin_fma(2., rhs, acc); st = xn + rhs * hdt; }
+            else if (s == 2) { acc = __builtin_fma(2., rhs, acc); st = (isW ? st : xn) + rhs * dt; }
             else st = xn + div_by(dt * (acc + rhs), six, i_six);
 
             // publish: the next stage's value, or (after the last stage) stage 1 of the next row
@@ -366,12 +368,17 @@ __device__ __forceinline__ void sweep_role(const HydWsArgs& a, const DevConst& K
     if constexpr (isV || isW || isC) stg(O1, o0 - rowB, so1);
 }
 
-__global__ __launch_bounds__(320) void k_hyd_rk3d_ws(const HydWsParams* __restrict__ P, int i_begin) {
+__global__ __launch_bounds__(320) void k_hyd_rk3d_ws(const HydWsParams* __restrict__ P, int i_begin, int nlev) {
     const HydWsArgs& a = P->a;
     const DevConst& K = P->K;
     __shared__ Shared sh;
     extern __shared__ double tab[];  // [jm][4]: cos(the), rm^2 sin(the), its reciprocal, viscous v coefficient
-    const int i = i_begin + blockIdx.y;
+    // all longitude blocks of a level on one XCD (they share cache lines; see k_rk_atm_ws.hip)
+    const int gx = (K.km - 2 + 63) / 64;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int lev = xcd + 8 * (idx / gx), bx = idx % gx;
+    if (lev >= nlev) return;
+    const int i = i_begin + lev;
     {
         const int jm = K.jm;
         const double rm = a.rad[i], rm2 = rm * rm;
@@ -386,11 +393,11 @@ __global__ __launch_bounds__(320) void k_hyd_rk3d_ws(const HydWsParams* __restri
         __syncthreads();
     }
     switch (threadIdx.x >> 6) {
-        case R_T: sweep_role<R_T>(a, K, sh, tab, i, a.t, a.to, a.tn); break;
-        case R_V: sweep_role<R_V>(a, K, sh, tab, i, a.v, a.vo, a.vn); break;
-        case R_U: sweep_role<R_U>(a, K, sh, tab, i, a.u, a.uo, a.un); break;
-        case R_C: sweep_role<R_C>(a, K, sh, tab, i, a.c, a.co, a.cn); break;
-        default: sweep_role<R_W>(a, K, sh, tab, i, a.w, a.wo, a.wn); break;
+        case R_T: sweep_role<R_T>(a, K, sh, tab, bx, i, a.t, a.to, a.tn); break;
+        case R_V: sweep_role<R_V>(a, K, sh, tab, bx, i, a.v, a.vo, a.vn); break;
+        case R_U: sweep_role<R_U>(a, K, sh, tab, bx, i, a.u, a.uo, a.un); break;
+        case R_C: sweep_role<R_C>(a, K, sh, tab, bx, i, a.c, a.co, a.cn); break;
+        default: sweep_role<R_W>(a, K, sh, tab, bx, i, a.w, a.wo, a.wn); break;
     }
 }
 
@@ -459,11 +466,11 @@ int atomdev_hyd_rk3d_ws(atomdev* h) {
     const unsigned gx = (h->km - 2 + 63) / 64;
     const size_t lds = (size_t)h->jm * 4 * sizeof(double);
     if (h->im - 3 >= 1) {  // levels 1 .. im-3
-        hipLaunchKernelGGL(k_hyd_rk3d_ws, dim3(gx, h->im - 3), dim3(320), lds, h->stream, P, 1);
+        hipLaunchKernelGGL(k_hyd_rk3d_ws, dim3(8 * ((h->im - 3 + 7) / 8) * gx), dim3(320), lds, h->stream, P, 1, h->im - 3);
         ATOMDEV_TRY(hipGetLastError());
     }
     // level im-2 reads the updated salinity of level im-3 (RHS_Hyd.cpp:356-357): second launch
-    hipLaunchKernelGGL(k_hyd_rk3d_ws, dim3(gx, 1), dim3(320), lds, h->stream, P, h->im - 2);
+    hipLaunchKernelGGL(k_hyd_rk3d_ws, dim3(8 * gx), dim3(320), lds, h->stream, P, h->im - 2, 1);
     ATOMDEV_TRY(hipGetLastError());
     if (int rc = atomdev_prof_end(h)) return rc;
     for (int n = 0; n < 5; n++) { double* t = h->f[X[n]]; h->f[X[n]] = h->alt[X[n]]; h->alt[X[n]] = t; }

@@ -16,8 +16,8 @@ for _ in range(3):
     d.op("atm_rk3d")
 st = d.download("AUX_W").reshape(-1)[:128].reshape(8, 16)
 names = ["V", "T", "U", "C", "W", "CO2", "ICE", "CLOUD"]
-t0 = st[:, 0].min()
-print("role  " + " ".join("%6s" % x for x in ["top", "loads", "s0 arr", "s0 go", "s1 arr", "s1 go", "s2 arr", "s2 go", "s3 arr", "s3 go", "vmwait"]))
+t0 = st[:4, 0].min()
+print("role  " + " ".join("%6s" % x for x in ["top", "loads", "s0 arr", "s0 go", "s1 arr", "s1 go", "s2 arr", "s2 go", "s3 arr", "s3 go", "vmwait", "s1 adv", "s1 rhs"]))
 for w in range(8):
-    print("%-5s " % names[w] + " ".join("%6d" % (st[w, n] - t0) for n in range(11)))
+    print("%-5s " % names[w] + " ".join("%6d" % (st[w, n] - t0) for n in range(13)))
 d.close()

@@ -170,6 +170,36 @@ static void run_long(int blocks, int threads, int iters) {
     hipFree(out); hipFree(cyc);
 }
 
+// one "stage round": read a peer's value from LDS, NOPS dependent div_by-like ops (mul, fma, fma), publish, barrier
+template <int NOPS>
+__global__ void k_round(double* out, long long* cyc, double a, double b) {
+    __shared__ double sh[2][512];
+    double x = out[threadIdx.x];
+    const int peer = (threadIdx.x + 64) % blockDim.x;
+    sh[1][threadIdx.x] = x;
+    __syncthreads();
+    asm volatile("" : "+v"(x));
+    long long t0 = __builtin_readcyclecounter();
+    asm volatile("" : "+v"(x));
+    for (int i = 0; i < 256; i++) {
+        double y = sh[(i & 1) ^ 1][peer];
+#pragma unroll
+        for (int n = 0; n < NOPS / 3; n++) {
+            double q = x * a;
+            double r = __builtin_fma(-q, b, x);
+            x = __builtin_fma(r, a, q);
+        }
+        x = x + y;
+        sh[i & 1][threadIdx.x] = x;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    asm volatile("" : "+v"(x));
+    long long t1 = __builtin_readcyclecounter();
+    asm volatile("" : "+v"(x));
+    out[threadIdx.x + blockIdx.x * blockDim.x] = x;
+    if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+}
+
 template <class K>
 static void run(const char* name, K k, int blocks, int threads, int ops) {
     double* out; long long* cyc;
@@ -206,6 +236,11 @@ int main() {
     run("div_f64 dependent", k_div_dep, 1, 64, N / 8);
     run("div_f64 dependent 2w/SIMD", k_div_dep, 1, 512, N / 8);
     run("rcp_f64 dependent", k_rcp_dep, 1, 64, N / 8);
+    run("round 0 ops, 4 waves", k_round<0>, 234, 256, 256);
+    run("round 30 ops, 4 waves", k_round<30>, 234, 256, 256);
+    run("round 60 ops, 4 waves", k_round<60>, 234, 256, 256);
+    run("round 30 ops, 8 waves", k_round<30>, 234, 512, 256);
+    run("round 60 ops, 8 waves", k_round<60>, 234, 512, 256);
     run("lds round 8 waves", k_lds_round, 1, 512, N / 8);
     run("lds round 8 waves chip full", k_lds_round, 256, 512, N / 8);
     return 0;
