@@ -15,6 +15,11 @@
 //
 // Five waves on four SIMDs: t and w, the two lightest roles, share one (waves 0 and 4).
 //
+// Level im-2 reads the salinity level im-3 has just computed (RHS_Hyd.cpp:356-357).  The workgroups of
+// level im-3 therefore carry five more waves that sweep level im-2 ONE STEP BEHIND, in the same barrier
+// rhythm: the c wave of level im-3 leaves its new row in LDS, the c wave of level im-2 picks it up one
+// step later.  (As a launch of its own, level im-2 costs a whole second sweep time on six workgroups.)
+//
 // The sweep is out of place (see k_rk_hyd.hip): it reads the current buffers and writes the
 // alternate set, whose boundary shell is refreshed beforehand by k_copy_shell.
 #include "atomdev_internal.h"
@@ -95,8 +100,12 @@ __device__ __forceinline__ void dtheta(int mode, double hdj, double xm2, double 
 // next one, and the end-of-step wait leaves only the stores outstanding.
 template <int ROLE>
 __device__ __forceinline__ void sweep_role(const HydWsArgs& a, const DevConst& K, Shared& sh, const double* tab,
-                                           int bx, int i, const double* __restrict__ X, double* __restrict__ XO,
+                                           int bx, int i, int lag, int extra, double (*cfin)[64],
+                                           const double* __restrict__ X, double* __restrict__ XO,
                                            const double* __restrict__ XN) {
+    // lag: steps this wave runs behind the workgroup's clock (1 for the waves of level im-2 in a paired
+    // workgroup); extra: additional clock ticks of the workgroup (1 when paired); cfin: the paired
+    // levels' hand-over buffer for the new salinity row, or null.
     constexpr bool isT = ROLE == R_T, isU = ROLE == R_U, isV = ROLE == R_V, isW = ROLE == R_W, isC = ROLE == R_C;
     constexpr bool hasH0I = isT || isU || isC;
     constexpr int NST = isU ? 7 : (isV || isW || isC) ? 2 : 1;  // stores per step
@@ -172,7 +181,7 @@ __device__ __forceinline__ void sweep_role(const HydWsArgs& a, const DevConst& K
         if constexpr (isU) n_r1 = ldg(E1, o);
         if constexpr (isC) {
             if (top) {  // RHS_Hyd.cpp:355-359
-                n_cb = ldg(XO, o - lvlB);    // c at level im-3: already updated (level im-1, in n_xa, never is)
+                if (!cfin) n_cb = ldg(XO, o - lvlB);  // c at level im-3: already updated (level im-1, in n_xa, never is)
                 n_ev = ldg(E2, q); n_pr = ldg(E3, q);
             }
         }
@@ -204,13 +213,23 @@ __device__ __forceinline__ void sweep_role(const HydWsArgs& a, const DevConst& K
 
     double so1 = 0., so2 = 0., so3 = 0., so4 = 0., so5 = 0., so6 = 0.;  // side outputs of the previous row
 
-    for (int j = 1; j < jm - 1; j++) {
+    for (int tick = 1; tick < jm - 1 + extra; tick++) {
+        const int j = tick - lag;
+        if (j < 1 || j > jm - 2) {  // this level idles: keep the barrier rhythm of the workgroup
+#pragma unroll
+            for (int s = 0; s < 4; s++) lds_barrier();
+            continue;
+        }
         // ---- take over the prefetched inputs of this step, start loading the next step's ----
         const double xn = n_xn, xa_raw = n_xa;
         const uint8_t fl = n_fl;
         const double costhe = n_cos, rm2sin = n_rm2sin, i_rm2sin = n_irm2sin, coef_v = n_coefv;
         const double bathy = n_bathy, rsw_in = n_r1;
-        const double c_top = xa_raw, c_below = n_cb, ep = n_ev - n_pr;
+        double c_below = n_cb;
+        if constexpr (isC) {
+            if (top && cfin) c_below = cfin[j & 1][lane];  // row j of level im-3, finished one tick ago
+        }
+        const double c_top = xa_raw, ep = n_ev - n_pr;
         load_next(o1, q1);  // row j+1 <= jm-1 always exists
         double xp2 = 0., yp2 = 0., up2 = 0.;
         if (j + 2 < jm) {
@@ -334,7 +353,10 @@ __device__ __forceinline__ void sweep_role(const HydWsArgs& a, const DevConst& K
             const double pub = (s < 3) ? st : xp1;
             if constexpr (isU) { sh.u[wb][lane] = pub; if (s == 3) sh.ufin[lane] = st; }
             if constexpr (isV) sh.v[wb][lane] = pub;
-            if constexpr (isC) publish_c(wb, pub, (s < 3) ? rw : rw_nxt);
+            if constexpr (isC) {
+                publish_c(wb, pub, (s < 3) ? rw : rw_nxt);
+                if (s == 3 && cfin && !top) cfin[j & 1][lane] = st;  // hand the new row to level im-2
+            }
             lds_barrier();
         }
 
@@ -368,21 +390,32 @@ __device__ __forceinline__ void sweep_role(const HydWsArgs& a, const DevConst& K
     if constexpr (isV || isW || isC) stg(O1, o0 - rowB, so1);
 }
 
-__global__ __launch_bounds__(320) void k_hyd_rk3d_ws(const HydWsParams* __restrict__ P, int i_begin, int nlev) {
+__global__ __launch_bounds__(640) void k_hyd_rk3d_ws(const HydWsParams* __restrict__ P, int nlev) {
     const HydWsArgs& a = P->a;
     const DevConst& K = P->K;
-    __shared__ Shared sh;
-    extern __shared__ double tab[];  // [jm][4]: cos(the), rm^2 sin(the), its reciprocal, viscous v coefficient
+    __shared__ Shared sh2[2];
+    __shared__ double cfin[2][64];
+    extern __shared__ double tab2[];  // 2 x [jm][4]: cos(the), rm^2 sin(the), its reciprocal, viscous v coefficient
     // all longitude blocks of a level on one XCD (they share cache lines; see k_rk_atm_ws.hip)
     const int gx = (K.km - 2 + 63) / 64;
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     const int lev = xcd + 8 * (idx / gx), bx = idx % gx;
     if (lev >= nlev) return;
-    const int i = i_begin + lev;
+    // Levels 1 .. im-3 have a workgroup each; the one of level im-3 also sweeps level im-2 with waves 5-9.
+    const int wave = threadIdx.x >> 6;
+    const int grp = wave >= 5 ? 1 : 0;
+#ifdef ATOMDEV_EXP_NOPAIR  // timing experiment only: level im-2 is not swept
+    const bool paired = false;
+#else
+    const bool paired = (1 + lev == K.im - 3);
+#endif
+    if (grp == 1 && !paired) return;  // before any barrier: a barrier only counts the waves still running
+    const int i = 1 + lev + grp;
+    const int jm = K.jm;
+    double* tab = tab2 + grp * 4 * jm;
     {
-        const int jm = K.jm;
         const double rm = a.rad[i], rm2 = rm * rm;
-        for (int j = threadIdx.x; j < jm; j += blockDim.x) {
+        for (int j = threadIdx.x - grp * 320; j < jm; j += 320) {
             const double sinthe = a.sinthe[j], costhe = a.costhe[j];
             const double rm2sinthe = rm2 * sinthe;
             tab[4 * j + 0] = costhe;
@@ -392,12 +425,15 @@ __global__ __launch_bounds__(320) void k_hyd_rk3d_ws(const HydWsParams* __restri
         }
         __syncthreads();
     }
-    switch (threadIdx.x >> 6) {
-        case R_T: sweep_role<R_T>(a, K, sh, tab, bx, i, a.t, a.to, a.tn); break;
-        case R_V: sweep_role<R_V>(a, K, sh, tab, bx, i, a.v, a.vo, a.vn); break;
-        case R_U: sweep_role<R_U>(a, K, sh, tab, bx, i, a.u, a.uo, a.un); break;
-        case R_C: sweep_role<R_C>(a, K, sh, tab, bx, i, a.c, a.co, a.cn); break;
-        default: sweep_role<R_W>(a, K, sh, tab, bx, i, a.w, a.wo, a.wn); break;
+    Shared& sh = sh2[grp];
+    double (*cf)[64] = paired ? cfin : nullptr;
+    const int lag = grp, extra = paired ? 1 : 0;
+    switch (wave - 5 * grp) {
+        case R_T: sweep_role<R_T>(a, K, sh, tab, bx, i, lag, extra, cf, a.t, a.to, a.tn); break;
+        case R_V: sweep_role<R_V>(a, K, sh, tab, bx, i, lag, extra, cf, a.v, a.vo, a.vn); break;
+        case R_U: sweep_role<R_U>(a, K, sh, tab, bx, i, lag, extra, cf, a.u, a.uo, a.un); break;
+        case R_C: sweep_role<R_C>(a, K, sh, tab, bx, i, lag, extra, cf, a.c, a.co, a.cn); break;
+        default: sweep_role<R_W>(a, K, sh, tab, bx, i, lag, extra, cf, a.w, a.wo, a.wn); break;
     }
 }
 
@@ -464,13 +500,10 @@ int atomdev_hyd_rk3d_ws(atomdev* h) {
     hipLaunchKernelGGL(k_copy_shell, dim3(8, h->im, 5), dim3(256), 0, h->stream, &D->src[o][0], &D->dst[o][0], h->im, h->jm, h->km);
     ATOMDEV_TRY(hipGetLastError());
     const unsigned gx = (h->km - 2 + 63) / 64;
-    const size_t lds = (size_t)h->jm * 4 * sizeof(double);
-    if (h->im - 3 >= 1) {  // levels 1 .. im-3
-        hipLaunchKernelGGL(k_hyd_rk3d_ws, dim3(8 * ((h->im - 3 + 7) / 8) * gx), dim3(320), lds, h->stream, P, 1, h->im - 3);
-        ATOMDEV_TRY(hipGetLastError());
-    }
-    // level im-2 reads the updated salinity of level im-3 (RHS_Hyd.cpp:356-357): second launch
-    hipLaunchKernelGGL(k_hyd_rk3d_ws, dim3(8 * gx), dim3(320), lds, h->stream, P, h->im - 2, 1);
+    const size_t lds = (size_t)h->jm * 8 * sizeof(double);
+    ATOMDEV_REQUIRE(h->im >= 5, "hyd_rk3d: the grid needs at least 5 levels");
+    // levels 1 .. im-3, one workgroup per 64 lines; the workgroups of level im-3 sweep level im-2 as well
+    hipLaunchKernelGGL(k_hyd_rk3d_ws, dim3(8 * ((h->im - 3 + 7) / 8) * gx), dim3(640), lds, h->stream, P, h->im - 3);
     ATOMDEV_TRY(hipGetLastError());
     if (int rc = atomdev_prof_end(h)) return rc;
     for (int n = 0; n < 5; n++) { double* t = h->f[X[n]]; h->f[X[n]] = h->alt[X[n]]; h->alt[X[n]] = t; }
