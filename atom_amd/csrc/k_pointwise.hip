@@ -56,22 +56,30 @@ __global__ void k_copy_lists(CPtrList src, PtrList dst, int nf, size_t off, size
     for (int f = 0; f < nf; f++) dst.p[f][off + id] = 1. * src.p[f][off + id];
 }
 
+// Stores x only where its bits differ from what the field holds: a limiter changes few points, and the
+// write-back of unchanged values would double the kernel's HBM traffic.
+__device__ __forceinline__ void store_if_changed(double* p, double was, double x) {
+    if (__double_as_longlong(was) != __double_as_longlong(x)) *p = x;
+}
+
 // BC_Thermo::Value_Limitation_Atm (atmosphere/BC_Thermo.cpp:3235-3275)
 __global__ void k_atm_value_limitation(double* u, double* v, double* w, double* t, double* c, double* cloud, double* ice,
                                        double* co2, double* p_dyn, const uint8_t* __restrict__ flags, size_t n) {
     size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= n) return;
+    const double u0 = u[id], v0 = v[id], w0 = w[id], t0 = t[id], c0 = c[id], cl0 = cloud[id], ic0 = ice[id], co0 = co2[id];
     double x;
-    x = u[id]; if (x >= .106) x = .106; if (x <= -.106) x = -.106; double uu = x;
-    x = v[id]; if (x >= .125) x = .125; if (x <= -.125) x = -.125; double vv = x;
-    x = w[id]; if (x >= 3.5) x = 3.5; if (x <= -.469) x = -.469; double ww = x;
-    x = t[id]; if (x >= 1.165) x = 1.165; if (x <= -.78) x = -.78; t[id] = x;
-    x = c[id]; if (x >= .03) x = .03; if (x < 0.) x = 0.; c[id] = x;
-    x = cloud[id]; if (x >= .01) x = .01; if (x < 0.) x = 0.; double cl = x;
-    x = ice[id]; if (x >= .005) x = .005; if (x < 0.) x = 0.; double ic = x;
-    x = co2[id]; if (x >= 5.36) x = 5.36; if (x <= 1.) x = 1.; double co = x;
+    x = u0; if (x >= .106) x = .106; if (x <= -.106) x = -.106; double uu = x;
+    x = v0; if (x >= .125) x = .125; if (x <= -.125) x = -.125; double vv = x;
+    x = w0; if (x >= 3.5) x = 3.5; if (x <= -.469) x = -.469; double ww = x;
+    x = t0; if (x >= 1.165) x = 1.165; if (x <= -.78) x = -.78; store_if_changed(t + id, t0, x);
+    x = c0; if (x >= .03) x = .03; if (x < 0.) x = 0.; store_if_changed(c + id, c0, x);
+    x = cl0; if (x >= .01) x = .01; if (x < 0.) x = 0.; double cl = x;
+    x = ic0; if (x >= .005) x = .005; if (x < 0.) x = 0.; double ic = x;
+    x = co0; if (x >= 5.36) x = 5.36; if (x <= 1.) x = 1.; double co = x;
     if (flags[id] & FL_LAND) { uu = 0.; vv = 0.; ww = 0.; cl = 0.; ic = 0.; co = 1.; p_dyn[id] = 0.; }
-    u[id] = uu; v[id] = vv; w[id] = ww; cloud[id] = cl; ice[id] = ic; co2[id] = co;
+    store_if_changed(u + id, u0, uu); store_if_changed(v + id, v0, vv); store_if_changed(w + id, w0, ww);
+    store_if_changed(cloud + id, cl0, cl); store_if_changed(ice + id, ic0, ic); store_if_changed(co2 + id, co0, co);
 }
 
 // BC_Bathymetry_Atmosphere::BC_SolidGround (atmosphere/BC_Bath_Atm.cpp:94-119): levels 0 .. im-2
@@ -86,12 +94,13 @@ __global__ void k_atm_solid_ground(double* u, double* v, double* w, double* clou
 __global__ void k_hyd_value_limitation(double* u, double* v, double* w, double* t, double* c, size_t n) {
     size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= n) return;
+    const double u0 = u[id], v0 = v[id], w0 = w[id], t0 = t[id], c0 = c[id];
     double x;
-    x = u[id]; if (x >= 11.11) x = 11.11; if (x <= -11.11) x = -11.11; u[id] = x;
-    x = v[id]; if (x >= .552) x = .552; if (x <= -.552) x = -.552; v[id] = x;
-    x = w[id]; if (x >= .552) x = .552; if (x <= -.552) x = -.552; w[id] = x;
-    x = t[id]; if (x >= 1.147) x = 1.147; if (x <= -1.01464) x = -1.01464; t[id] = x;
-    x = c[id]; if (x >= 1.1) x = 1.1; if (x < .95) x = .95; c[id] = x;
+    x = u0; if (x >= 11.11) x = 11.11; if (x <= -11.11) x = -11.11; store_if_changed(u + id, u0, x);
+    x = v0; if (x >= .552) x = .552; if (x <= -.552) x = -.552; store_if_changed(v + id, v0, x);
+    x = w0; if (x >= .552) x = .552; if (x <= -.552) x = -.552; store_if_changed(w + id, w0, x);
+    x = t0; if (x >= 1.147) x = 1.147; if (x <= -1.01464) x = -1.01464; store_if_changed(t + id, t0, x);
+    x = c0; if (x >= 1.1) x = 1.1; if (x < .95) x = .95; store_if_changed(c + id, c0, x);
 }
 
 // BC_Bathymetry_Hydrosphere::BC_SolidGround (hydrosphere/BC_Bath_Hyd.cpp:120-139): old and new arrays
