@@ -98,7 +98,7 @@ extern "C" int atomdev_create(int model, int im, int jm, int km, const atomdev_p
     h->model = model; h->im = im; h->jm = jm; h->km = km; h->device = device;
     h->n3 = (size_t)im * jm * km; h->n2 = (size_t)jm * km;
     h->p = *p;
-    h->flags = nullptr; h->flags_dirty = true;
+    h->flags = nullptr; h->flags_dirty = true; h->h0i_valid = false;
     h->profile_rk = false; h->prof_used = 0;
     h->scr[0] = h->scr[1] = nullptr; h->tab_rm2sin = h->tab_irm2sin = h->tab_coefv = nullptr;
     h->rk_variant = 0;
@@ -237,6 +237,7 @@ extern "C" int atomdev_upload2d(atomdev_t* h, int field, const double* host) {
     ATOMDEV_TRY(hipSetDevice(h->device));
     ATOMDEV_TRY(hipMemcpyAsync(h->g[field], host, h->n2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
     ATOMDEV_TRY(hipStreamSynchronize(h->stream));
+    if (field == ATOMDEV_TOPOGRAPHY) h->h0i_valid = false;
     return 0;
 }
 

@@ -50,6 +50,7 @@ struct atomdev {
     double* alt[ATOMDEV_N3D];  // hyd RK writes out of place into these, then swaps with f[]
     uint8_t* flags;
     bool flags_dirty;
+    bool h0i_valid;                 // atm: scr[1] holds h_0_i for the current mask and topography
     double *rad, *sinthe, *costhe;  // device tables: rad[max(im,41)], sin/cos(the[j]) from the host libm
     double* plane;                  // jm*km scratch (atm: snapshot of c at level 3)
     void* red;                      // reduction scratch

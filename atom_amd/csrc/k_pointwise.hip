@@ -124,6 +124,7 @@ int atomdev_refresh_flags(atomdev* h) {
                        h->im, h->jm, h->km);
     ATOMDEV_TRY(hipGetLastError());
     h->flags_dirty = false;
+    h->h0i_valid = false;
     return 0;
 }
 

@@ -72,6 +72,7 @@ struct Shared {
 
 // ---- prep: everything per point that does not change during the sweep -------------------------
 // ph100 = 100 * p_h, p_h from RHS_Atm.cpp:384-389; h0i = h_0_i from RHS_Atm.cpp:110-124.
+template <bool WITH_H0I>
 __global__ void k_atm_prep(const double* __restrict__ t, const double* __restrict__ topo, const uint8_t* __restrict__ flags,
                            double* __restrict__ ph100, double* __restrict__ h0i, DevConst K) {
     const int jm = K.jm, km = K.km;
@@ -86,12 +87,14 @@ __global__ void k_atm_prep(const double* __restrict__ t, const double* __restric
     const double p_SL = .01 * (K.p_SL_factor * t0jk * K.t_0);
     const double p_h = pow((t0K - K.gam * hight * 1.e-2) / t0K, K.exp_pressure) * p_SL;
     ph100[p] = 100. * p_h;
-    double h_0_i = 1.;
-    if (flags[p] & FL_LAND) {
-        double topo_diff = hight - topo[q];
-        if (!(topo_diff == K.topo_step)) h_0_i = div_by(topo_diff, K.topo_step, K.i_topo_step);
+    if constexpr (WITH_H0I) {  // static: depends on the mask and the topography only
+        double h_0_i = 1.;
+        if (flags[p] & FL_LAND) {
+            double topo_diff = hight - topo[q];
+            if (!(topo_diff == K.topo_step)) h_0_i = div_by(topo_diff, K.topo_step, K.i_topo_step);
+        }
+        h0i[p] = h_0_i;
     }
-    h0i[p] = h_0_i;
 }
 
 // Values that every stage of every step needs are pinned into vector registers: the
@@ -485,9 +488,14 @@ int atomdev_atm_rk3d_ws(atomdev* h) {
         ATOMDEV_TRY(hipMemcpy(h->ws_params, &P, sizeof(P), hipMemcpyHostToDevice));
     }
     dim3 pg((h->km + 127) / 128, h->jm, h->im - 2);
-    hipLaunchKernelGGL(k_atm_prep, pg, dim3(128), 0, h->stream, h->f[ATOMDEV_T], h->g[ATOMDEV_TOPOGRAPHY], h->flags,
-                       h->scr[0], h->scr[1], h->k);
+    if (h->h0i_valid)
+        hipLaunchKernelGGL(k_atm_prep<false>, pg, dim3(128), 0, h->stream, h->f[ATOMDEV_T], h->g[ATOMDEV_TOPOGRAPHY], h->flags,
+                           h->scr[0], h->scr[1], h->k);
+    else
+        hipLaunchKernelGGL(k_atm_prep<true>, pg, dim3(128), 0, h->stream, h->f[ATOMDEV_T], h->g[ATOMDEV_TOPOGRAPHY], h->flags,
+                           h->scr[0], h->scr[1], h->k);
     ATOMDEV_TRY(hipGetLastError());
+    h->h0i_valid = true;
     if (int rc = atomdev_prof_begin(h)) return rc;  // the event bracket times the sweep kernel alone
     const unsigned gx = (h->km - 2 + 63) / 64, rounds = (h->im - 2 + 7) / 8;
     dim3 grid(8 * rounds * gx);
