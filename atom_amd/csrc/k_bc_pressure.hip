@@ -18,38 +18,34 @@ struct Fields { double* p[9]; int n; };
 enum { FILL_NEUMANN = 0, FILL_ZERO = 1 };
 struct ThetaFill { double* p[9]; int mode[9]; int n; };
 
-// rows j = 0 and j = jm-1 for every (i, k): x = 4/3 x1 - 1/3 x2, or 0
+// rows j = 0 and j = jm-1 for every (i, k): x = 4/3 x1 - 1/3 x2, or 0; blockIdx.y = field
 __global__ void k_fill_theta(ThetaFill f, int im, int jm, int km, int i0, int ni) {
     int id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= ni * km) return;
     int k = id % km, i = i0 + id / km;
-    for (int n = 0; n < f.n; n++) {
-        double* x = f.p[n];
-        if (f.mode[n] == FILL_ZERO) {
-            x[idx3(jm, km, i, 0, k)] = 0.;
-            x[idx3(jm, km, i, jm - 1, k)] = 0.;
-        } else {
-            x[idx3(jm, km, i, 0, k)] = c43 * x[idx3(jm, km, i, 1, k)] - c13 * x[idx3(jm, km, i, 2, k)];
-            x[idx3(jm, km, i, jm - 1, k)] = c43 * x[idx3(jm, km, i, jm - 2, k)] - c13 * x[idx3(jm, km, i, jm - 3, k)];
-        }
+    const int n = blockIdx.y;
+    double* x = f.p[n];
+    if (f.mode[n] == FILL_ZERO) {
+        x[idx3(jm, km, i, 0, k)] = 0.;
+        x[idx3(jm, km, i, jm - 1, k)] = 0.;
+    } else {
+        x[idx3(jm, km, i, 0, k)] = c43 * x[idx3(jm, km, i, 1, k)] - c13 * x[idx3(jm, km, i, 2, k)];
+        x[idx3(jm, km, i, jm - 1, k)] = c43 * x[idx3(jm, km, i, jm - 2, k)] - c13 * x[idx3(jm, km, i, jm - 3, k)];
     }
 }
 
 // columns k = 0 and k = km-1 for (i, j), j in [j0, j1): Neumann on both ends, then
-// both set to their mean (e.g. BC_Atm.cpp:121-123)
+// both set to their mean (e.g. BC_Atm.cpp:121-123); blockIdx.y = field
 __global__ void k_fill_phi_seam(Fields f, int im, int jm, int km, int i0, int ni, int j0, int j1) {
     int id = blockIdx.x * blockDim.x + threadIdx.x;
     int nj = j1 - j0;
     if (id >= ni * nj) return;
     int j = j0 + id % nj, i = i0 + id / nj;
-    size_t b = idx3(jm, km, i, j, 0);
-    for (int n = 0; n < f.n; n++) {
-        double* x = f.p[n] + b;
-        double lo = c43 * x[1] - c13 * x[2];
-        double hi = c43 * x[km - 2] - c13 * x[km - 3];
-        double m = (lo + hi) / 2.;
-        x[0] = m; x[km - 1] = m;
-    }
+    double* x = f.p[blockIdx.y] + idx3(jm, km, i, j, 0);
+    double lo = c43 * x[1] - c13 * x[2];
+    double hi = c43 * x[km - 2] - c13 * x[km - 3];
+    double m = (lo + hi) / 2.;
+    x[0] = m; x[km - 1] = m;
 }
 
 // BC_Atmosphere::BC_radius, atmosphere/BC_Atm.cpp:39-73
@@ -228,14 +224,14 @@ inline unsigned nb(size_t n) { return (unsigned)((n + TPB - 1) / TPB); }
 int fill_theta(atomdev* h, const int* ids, const int* modes, int n, int i0, int ni) {
     ThetaFill f; f.n = n;
     for (int m = 0; m < n; m++) { f.p[m] = h->f[ids[m]]; f.mode[m] = modes[m]; }
-    hipLaunchKernelGGL(k_fill_theta, dim3(nb((size_t)ni * h->km)), dim3(TPB), 0, h->stream, f, h->im, h->jm, h->km, i0, ni);
+    hipLaunchKernelGGL(k_fill_theta, dim3(nb((size_t)ni * h->km), n), dim3(TPB), 0, h->stream, f, h->im, h->jm, h->km, i0, ni);
     return atomdev_check(hipGetLastError(), "k_fill_theta");
 }
 
 int fill_phi(atomdev* h, const int* ids, int n, int i0, int ni, int j0, int j1) {
     Fields f; f.n = n;
     for (int m = 0; m < n; m++) f.p[m] = h->f[ids[m]];
-    hipLaunchKernelGGL(k_fill_phi_seam, dim3(nb((size_t)ni * (j1 - j0))), dim3(TPB), 0, h->stream, f, h->im, h->jm, h->km,
+    hipLaunchKernelGGL(k_fill_phi_seam, dim3(nb((size_t)ni * (j1 - j0)), n), dim3(TPB), 0, h->stream, f, h->im, h->jm, h->km,
                        i0, ni, j0, j1);
     return atomdev_check(hipGetLastError(), "k_fill_phi_seam");
 }
