@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo to rehearse "
+                                                      "several ranks on one GPU)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -115,12 +117,16 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (there is no CPU fallback for the product path)")
+    local_rank %= torch.cuda.device_count()  # ranks beyond the GPU count share cards (rehearsal with --backend gloo)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.backend)
 
     def barrier():
         torch.cuda.synchronize()
@@ -146,7 +152,7 @@ def main():
     atm.profile_rk(False)
 
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
