@@ -78,6 +78,46 @@ static void fill_constants(atomdev* h) {
     k.i_r_air = 1. / k.r_air; k.i_six = 1. / 6.; k.i_topo_step = 1. / k.topo_step;
 }
 
+// Coordinate and geometry tables of a handle, (re)built from its parameters.
+static int upload_tables(atomdev* h) {
+    const atomdev_params* p = &h->p;
+    const int im = h->im, jm = h->jm, model = h->model;
+    // coordinates by repeated addition (lib/Array_1D.cpp:54-65); sin/cos from the host
+    // libm, which is what the reference calls per grid point (e.g. RHS_Atm.cpp:101-103)
+    const int nrad = im > 41 ? im : 41;  // RK_RHS_2D_Hydrosphere reads rad[40] on any grid
+    std::vector<double> rad(nrad), st(jm), ct(jm);
+    rad[0] = p->r0;
+    for (int l = 1; l < nrad; l++) rad[l] = rad[l - 1] + p->dr;
+    double the = p->the0;
+    for (int j = 0; j < jm; j++) { if (j) the = the + p->dthe; st[j] = sin(the); ct[j] = cos(the); }
+    const size_t nb = (size_t)im * jm * sizeof(double);
+    if (!h->rad) ATOMDEV_TRY(hipMalloc(&h->rad, nrad * sizeof(double)));
+    if (!h->sinthe) ATOMDEV_TRY(hipMalloc(&h->sinthe, jm * sizeof(double)));
+    if (!h->costhe) ATOMDEV_TRY(hipMalloc(&h->costhe, jm * sizeof(double)));
+    if (!h->tab_rm2sin) ATOMDEV_TRY(hipMalloc(&h->tab_rm2sin, nb));
+    if (!h->tab_irm2sin) ATOMDEV_TRY(hipMalloc(&h->tab_irm2sin, nb));
+    if (!h->tab_coefv) ATOMDEV_TRY(hipMalloc(&h->tab_coefv, nb));
+    ATOMDEV_TRY(hipMemcpy(h->rad, rad.data(), nrad * sizeof(double), hipMemcpyHostToDevice));
+    ATOMDEV_TRY(hipMemcpy(h->sinthe, st.data(), jm * sizeof(double), hipMemcpyHostToDevice));
+    ATOMDEV_TRY(hipMemcpy(h->costhe, ct.data(), jm * sizeof(double), hipMemcpyHostToDevice));
+    // per-(i, j) geometry factors of the RK sweeps, in the reference's operation order
+    // (RHS_Atm.cpp:97-106, 450; RHS_Hyd.cpp:83-92, 422); 1/x is the correctly rounded reciprocal
+    std::vector<double> t1((size_t)im * jm), t2((size_t)im * jm), t3((size_t)im * jm);
+    for (int i = 0; i < im; i++)
+        for (int j = 0; j < jm; j++) {
+            const double rm = rad[i], rm2 = rm * rm, sinthe = st[j], costhe = ct[j], sinthe2 = sinthe * sinthe;
+            const double rm2sinthe = rm2 * sinthe;
+            t1[(size_t)i * jm + j] = rm2sinthe;
+            t2[(size_t)i * jm + j] = 1. / rm2sinthe;
+            t3[(size_t)i * jm + j] = model == ATOMDEV_ATM ? 1. + costhe * costhe / (rm * sinthe2)
+                                                          : 1. + costhe * costhe / sinthe2;
+        }
+    ATOMDEV_TRY(hipMemcpy(h->tab_rm2sin, t1.data(), nb, hipMemcpyHostToDevice));
+    ATOMDEV_TRY(hipMemcpy(h->tab_irm2sin, t2.data(), nb, hipMemcpyHostToDevice));
+    ATOMDEV_TRY(hipMemcpy(h->tab_coefv, t3.data(), nb, hipMemcpyHostToDevice));
+    return 0;
+}
+
 extern "C" int atomdev_create(int model, int im, int jm, int km, const atomdev_params* p, int device,
                               atomdev_t** out) {
     ATOMDEV_REQUIRE(out != nullptr && p != nullptr, "atomdev_create: null argument");
@@ -131,45 +171,24 @@ extern "C" int atomdev_create(int model, int im, int jm, int km, const atomdev_p
     h->red_bytes = 1 << 20;
     if ((rc = atomdev_check(hipMalloc(&h->red, h->red_bytes), "hipMalloc(red)"))) return fail(rc);
 
-    // coordinates by repeated addition (lib/Array_1D.cpp:54-65); sin/cos from the host
-    // libm, which is what the reference calls per grid point (e.g. RHS_Atm.cpp:101-103)
-    const int nrad = im > 41 ? im : 41;  // RK_RHS_2D_Hydrosphere reads rad[40] on any grid
-    std::vector<double> rad(nrad), st(jm), ct(jm);
-    rad[0] = p->r0;
-    for (int l = 1; l < nrad; l++) rad[l] = rad[l - 1] + p->dr;
-    double the = p->the0;
-    for (int j = 0; j < jm; j++) { if (j) the = the + p->dthe; st[j] = sin(the); ct[j] = cos(the); }
-    if ((rc = atomdev_check(hipMalloc(&h->rad, nrad * sizeof(double)), "hipMalloc"))) return fail(rc);
-    if ((rc = atomdev_check(hipMalloc(&h->sinthe, jm * sizeof(double)), "hipMalloc"))) return fail(rc);
-    if ((rc = atomdev_check(hipMalloc(&h->costhe, jm * sizeof(double)), "hipMalloc"))) return fail(rc);
-    if ((rc = atomdev_check(hipMemcpy(h->rad, rad.data(), nrad * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy"))) return fail(rc);
-    if ((rc = atomdev_check(hipMemcpy(h->sinthe, st.data(), jm * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy"))) return fail(rc);
-    if ((rc = atomdev_check(hipMemcpy(h->costhe, ct.data(), jm * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy"))) return fail(rc);
-    // per-(i, j) geometry factors of the RK sweeps, in the reference's operation order
-    // (RHS_Atm.cpp:97-106, 450; RHS_Hyd.cpp:83-92, 422); 1/x is the correctly rounded reciprocal
-    {
-        std::vector<double> t1((size_t)im * jm), t2((size_t)im * jm), t3((size_t)im * jm);
-        for (int i = 0; i < im; i++)
-            for (int j = 0; j < jm; j++) {
-                const double rm = rad[i], rm2 = rm * rm, sinthe = st[j], costhe = ct[j], sinthe2 = sinthe * sinthe;
-                const double rm2sinthe = rm2 * sinthe;
-                t1[(size_t)i * jm + j] = rm2sinthe;
-                t2[(size_t)i * jm + j] = 1. / rm2sinthe;
-                t3[(size_t)i * jm + j] = model == ATOMDEV_ATM ? 1. + costhe * costhe / (rm * sinthe2)
-                                                              : 1. + costhe * costhe / sinthe2;
-            }
-        const size_t nb = (size_t)im * jm * sizeof(double);
-        if ((rc = atomdev_check(hipMalloc(&h->tab_rm2sin, nb), "hipMalloc"))) return fail(rc);
-        if ((rc = atomdev_check(hipMalloc(&h->tab_irm2sin, nb), "hipMalloc"))) return fail(rc);
-        if ((rc = atomdev_check(hipMalloc(&h->tab_coefv, nb), "hipMalloc"))) return fail(rc);
-        if ((rc = atomdev_check(hipMemcpy(h->tab_rm2sin, t1.data(), nb, hipMemcpyHostToDevice), "hipMemcpy"))) return fail(rc);
-        if ((rc = atomdev_check(hipMemcpy(h->tab_irm2sin, t2.data(), nb, hipMemcpyHostToDevice), "hipMemcpy"))) return fail(rc);
-        if ((rc = atomdev_check(hipMemcpy(h->tab_coefv, t3.data(), nb, hipMemcpyHostToDevice), "hipMemcpy"))) return fail(rc);
-    }
+    if ((rc = upload_tables(h))) return fail(rc);
     for (int n = 0; n < 2; n++)
         if ((rc = atomdev_check(hipMalloc(&h->scr[n], h->n3 * sizeof(double)), "hipMalloc(scr)"))) return fail(rc);
     if ((rc = atomdev_check(hipStreamSynchronize(h->stream), "hipStreamSynchronize"))) return fail(rc);
     *out = h;
+    return 0;
+}
+
+extern "C" int atomdev_set_params(atomdev_t* h, const atomdev_params* p) {
+    ATOMDEV_REQUIRE(h != nullptr && p != nullptr, "atomdev_set_params: null argument");
+    ATOMDEV_REQUIRE(p->dt > 0 && p->dr > 0 && p->dthe > 0 && p->dphi > 0, "atomdev_set_params: step sizes must be positive");
+    ATOMDEV_TRY(hipSetDevice(h->device));
+    ATOMDEV_TRY(hipStreamSynchronize(h->stream));
+    h->p = *p;
+    fill_constants(h);
+    if (int rc = upload_tables(h)) return rc;
+    if (h->ws_params) { ATOMDEV_TRY(hipFree(h->ws_params)); h->ws_params = nullptr; }  // holds a copy of the constants
+    h->h0i_valid = false;
     return 0;
 }
 

@@ -64,6 +64,7 @@ def load_library():
     lib.atomdev_default_params.restype = None
     lib.atomdev_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Params), C.c_int, C.POINTER(vp)]
     lib.atomdev_destroy.argtypes = [vp]
+    lib.atomdev_set_params.argtypes = [vp, C.POINTER(Params)]
     lib.atomdev_dims.argtypes = [vp, ip, ip, ip]
     for name in ("atomdev_upload", "atomdev_download", "atomdev_upload2d", "atomdev_download2d"):
         getattr(lib, name).argtypes = [vp, C.c_int, vp]
@@ -163,6 +164,11 @@ class DeviceModel:
         nk = int(block.shape[-1])
         ptr = self._buffer_pointer(block, self.im * self.jm * nk * 8)
         self._check(self.lib.atomdev_set_columns(self._h, F3[name], k0, nk, ptr))
+
+    def set_params(self, params):
+        """Replaces the scalars of the model; the fields stay."""
+        self._check(self.lib.atomdev_set_params(self._h, C.byref(params)))
+        self.params = params
 
     def fill(self, name, value):
         self._check(self.lib.atomdev_fill(self._h, F3[name], float(value)))

@@ -80,6 +80,10 @@ const char* atomdev_last_error(void);
 int atomdev_create(int model, int im, int jm, int km, const atomdev_params* p,
                    int device, atomdev_t** out);
 int atomdev_destroy(atomdev_t* h);
+/* Replaces the scalars of an existing handle (fields stay as they are).  The reference passes its
+ * scalars with every operator call (e.g. u_0, r_air to Pressure_Atm::computePressure_3D,
+ * atmosphere/Pressure_Atm.cpp:39-41); a caller that mirrors those signatures sets them here. */
+int atomdev_set_params(atomdev_t* h, const atomdev_params* p);
 int atomdev_dims(const atomdev_t* h, int* im, int* jm, int* km);
 int atomdev_upload(atomdev_t* h, int field3d, const double* host);
 int atomdev_download(atomdev_t* h, int field3d, double* host);

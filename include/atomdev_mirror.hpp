@@ -1,0 +1,389 @@
+// atomdev_mirror — the reference's dynamical-core operator classes, same names, same
+// constructor and method signatures, executing on the GPU through libatomdev.so.
+//
+// For a maintainer of the reference: include this header next to lib/Array.h,
+// lib/Array_1D.h and lib/Array_2D.h (it only uses their public members x, y, z) and
+// replace e.g. `RungeKutta_Atmosphere result(...)` by
+// `atomdev_mirror::RungeKutta_Atmosphere result(...)`; the call sites in
+// cAtmosphereModel::run_3D_loop (atmosphere/cAtmosphereModel.cpp:777-874) and
+// cHydrosphereModel::RunTimeSlice (hydrosphere/cHydrosphereModel.cpp:437-610) stay as
+// they are.  Every call uploads the arrays the operator reads, runs it, and downloads the
+// arrays it writes, so the classes are drop-in but pay two PCIe transfers per call; a port
+// that keeps the fields resident uses the C-ABI (atomdev.h) directly.
+//
+// Scalars.  The reference hands each operator only the scalars it needs, with every call.
+// The mirror keeps one parameter block per model, updates it from whatever a constructor
+// or method receives, and pushes it to the device handle (atomdev_set_params) before the
+// operator runs.  Scalars an operator never reads (lv, ls, ep, hp, co2_0, p_0, ...) are
+// accepted and ignored, like the reference's own bodies ignore them.
+//
+// Errors.  The reference prints and aborts (e.g. atmosphere/cAtmosphereModel.cpp:132-135);
+// so does the mirror, with the library's error text.
+#ifndef ATOMDEV_MIRROR_HPP_
+#define ATOMDEV_MIRROR_HPP_
+
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <vector>
+
+#include "Array.h"
+#include "Array_1D.h"
+#include "Array_2D.h"
+#include "atomdev.h"
+
+namespace atomdev_mirror {
+
+// One device handle per model, created on first use and re-created when the grid changes.
+class Device {
+public:
+    static Device& of(int model) {
+        static Device dev[2];
+        dev[model].model_ = model;
+        return dev[model];
+    }
+    atomdev_params& params() {
+        if (!have_params_) { atomdev_default_params(model_, &p_); have_params_ = true; }
+        return p_;
+    }
+    // coordinates as the reference builds them: z[0] and the step (lib/Array_1D.cpp:54-65)
+    void grid(int im, int jm, int km) {
+        if (h_ && (im != im_ || jm != jm_ || km != km_)) { atomdev_destroy(h_); h_ = nullptr; }
+        im_ = im; jm_ = jm; km_ = km;
+    }
+    void origin(Array_1D& rad, Array_1D& the) { params().r0 = rad.z[0]; params().the0 = the.z[0]; }
+    atomdev_t* handle() {
+        if (!h_) {
+            if (atomdev_create(model_, im_, jm_, km_, &params(), -1, &h_)) die("atomdev_create");
+            stage_.resize((size_t)im_ * jm_ * km_);
+            std::memcpy(&sent_, &p_, sizeof(p_));
+        } else if (std::memcmp(&sent_, &p_, sizeof(p_)) != 0) {
+            if (atomdev_set_params(h_, &p_)) die("atomdev_set_params");
+            std::memcpy(&sent_, &p_, sizeof(p_));
+        }
+        return h_;
+    }
+    void push(int field, Array& a) {
+        atomdev_t* h = handle();
+        for (int i = 0; i < im_; i++)
+            for (int j = 0; j < jm_; j++)
+                std::memcpy(&stage_[((size_t)i * jm_ + j) * km_], a.x[i][j], sizeof(double) * km_);
+        if (atomdev_upload(h, field, stage_.data())) die("atomdev_upload");
+    }
+    void pull(int field, Array& a) {
+        if (atomdev_download(handle(), field, stage_.data())) die("atomdev_download");
+        for (int i = 0; i < im_; i++)
+            for (int j = 0; j < jm_; j++)
+                std::memcpy(a.x[i][j], &stage_[((size_t)i * jm_ + j) * km_], sizeof(double) * km_);
+    }
+    void push2d(int field, Array_2D& a) {
+        atomdev_t* h = handle();
+        for (int j = 0; j < jm_; j++) std::memcpy(&stage_[(size_t)j * km_], a.y[j], sizeof(double) * km_);
+        if (atomdev_upload2d(h, field, stage_.data())) die("atomdev_upload2d");
+    }
+    void run(int rc, const char* what) { if (rc) die(what); }
+    static void die(const char* where) {
+        std::cerr << "ERROR: " << where << ": " << atomdev_last_error() << std::endl;
+        std::abort();
+    }
+    int im() const { return im_; }
+
+private:
+    int model_ = 0, im_ = 0, jm_ = 0, km_ = 0;
+    bool have_params_ = false;
+    atomdev_params p_, sent_;
+    atomdev_t* h_ = nullptr;
+    std::vector<double> stage_;
+};
+
+struct FieldRef { int id; Array* a; };
+
+inline void push_all(Device& d, std::initializer_list<FieldRef> l) { for (const FieldRef& f : l) d.push(f.id, *f.a); }
+inline void pull_all(Device& d, std::initializer_list<FieldRef> l) { for (const FieldRef& f : l) d.pull(f.id, *f.a); }
+
+// ---------------------------------------------------------------------------------------------
+// atmosphere
+// ---------------------------------------------------------------------------------------------
+
+// atmosphere/RHS_Atm.h:23-60.  Holds the scalars of the right-hand sides; the evaluation itself is
+// fused into the sweeps of RungeKutta_Atmosphere on the device.
+class RHS_Atmosphere {
+public:
+    RHS_Atmosphere(int jm, int km, double dthe, double dphi, double re) {
+        atomdev_params& p = Device::of(ATOMDEV_ATM).params();
+        (void)jm; (void)km; p.dthe = dthe; p.dphi = dphi; p.re = re;
+    }
+    RHS_Atmosphere(int im, int jm, int km, double dt, double dr, double dthe, double dphi, double re,
+                   double sc_WaterVapour, double sc_CO2, double g, double pr, double WaterVapour, double Buoyancy,
+                   double CO2, double gam, double sigma, double lamda) {
+        atomdev_params& p = Device::of(ATOMDEV_ATM).params();
+        (void)im; (void)jm; (void)km; (void)WaterVapour; (void)CO2; (void)sigma; (void)lamda;
+        p.dt = dt; p.dr = dr; p.dthe = dthe; p.dphi = dphi; p.re = re; p.sc_WaterVapour = sc_WaterVapour;
+        p.sc_CO2 = sc_CO2; p.g = g; p.pr = pr; p.Buoyancy = Buoyancy; p.gam = gam;
+    }
+};
+
+// atmosphere/RungeKutta_Atm.h:22-52
+class RungeKutta_Atmosphere {
+public:
+    RungeKutta_Atmosphere(int im, int jm, int km, double dt, double dr, double dphi, double dthe)
+        : im_(im), jm_(jm), km_(km) {
+        atomdev_params& p = Device::of(ATOMDEV_ATM).params();
+        p.dt = dt; p.dr = dr; p.dphi = dphi; p.dthe = dthe;
+    }
+
+    // atmosphere/RungeKutta_Atm.cpp:32-156
+    void solveRungeKutta_3D_Atmosphere(RHS_Atmosphere&, int&, double, double, double, double, double u_0, double t_0,
+                                       double c_0, double, double, double r_air, double, double, double L_atm, double cp_l,
+                                       double R_Air, double R_WaterVapour, double, Array_1D& rad, Array_1D& the, Array_1D&,
+                                       Array&, Array&, Array&, Array&, Array&, Array&, Array&, Array&, Array& h, Array& t,
+                                       Array& u, Array& v, Array& w, Array& p_dyn, Array&, Array& c, Array& cloud, Array& ice,
+                                       Array& co2, Array& tn, Array& un, Array& vn, Array& wn, Array& p_dynn, Array& cn,
+                                       Array& cloudn, Array& icen, Array& co2n, Array& aux_u, Array& aux_v, Array& aux_w,
+                                       Array&, Array& BuoyancyForce, Array&, Array&, Array&, Array& S_v, Array& S_c,
+                                       Array& S_i, Array& S_r, Array& S_s, Array&, Array_2D& Topography,
+                                       Array_2D& Evaporation_Dalton, Array_2D& Precipitation) {
+        Device& d = Device::of(ATOMDEV_ATM);
+        d.grid(im_, jm_, km_); d.origin(rad, the);
+        atomdev_params& p = d.params();
+        p.u_0 = u_0; p.t_0 = t_0; p.c_0 = c_0; p.r_air = r_air; p.L_atm = L_atm; p.cp_l = cp_l; p.R_Air = R_Air;
+        p.R_WaterVapour = R_WaterVapour;
+        push_all(d, { { ATOMDEV_H, &h }, { ATOMDEV_T, &t }, { ATOMDEV_U, &u }, { ATOMDEV_V, &v }, { ATOMDEV_W, &w },
+                      { ATOMDEV_P_DYN, &p_dyn }, { ATOMDEV_C, &c }, { ATOMDEV_CLOUD, &cloud }, { ATOMDEV_ICE, &ice },
+                      { ATOMDEV_CO2, &co2 }, { ATOMDEV_TN, &tn }, { ATOMDEV_UN, &un }, { ATOMDEV_VN, &vn },
+                      { ATOMDEV_WN, &wn }, { ATOMDEV_P_DYNN, &p_dynn }, { ATOMDEV_CN, &cn }, { ATOMDEV_CLOUDN, &cloudn },
+                      { ATOMDEV_ICEN, &icen }, { ATOMDEV_CO2N, &co2n }, { ATOMDEV_S_V, &S_v }, { ATOMDEV_S_C, &S_c },
+                      { ATOMDEV_S_I, &S_i }, { ATOMDEV_S_R, &S_r }, { ATOMDEV_S_S, &S_s } });
+        d.push2d(ATOMDEV_TOPOGRAPHY, Topography);
+        d.push2d(ATOMDEV_EVAPORATION_DALTON, Evaporation_Dalton);
+        d.push2d(ATOMDEV_PRECIPITATION, Precipitation);
+        d.run(atomdev_atm_rk3d(d.handle()), "atomdev_atm_rk3d");
+        pull_all(d, { { ATOMDEV_T, &t }, { ATOMDEV_U, &u }, { ATOMDEV_V, &v }, { ATOMDEV_W, &w }, { ATOMDEV_C, &c },
+                      { ATOMDEV_CLOUD, &cloud }, { ATOMDEV_ICE, &ice }, { ATOMDEV_CO2, &co2 }, { ATOMDEV_AUX_U, &aux_u },
+                      { ATOMDEV_AUX_V, &aux_v }, { ATOMDEV_AUX_W, &aux_w }, { ATOMDEV_BUOYANCY, &BuoyancyForce } });
+    }
+
+    // atmosphere/RungeKutta_Atm.cpp:163-217
+    void solveRungeKutta_2D_Atmosphere(RHS_Atmosphere&, int&, double r_air, double u_0, double, double L_atm, Array_1D& rad,
+                                       Array_1D& the, Array_1D&, Array&, Array&, Array& h, Array& v, Array& w, Array& p_dyn,
+                                       Array& vn, Array& wn, Array& p_dynn, Array& aux_v, Array& aux_w) {
+        Device& d = Device::of(ATOMDEV_ATM);
+        d.grid(im_, jm_, km_); d.origin(rad, the);
+        atomdev_params& p = d.params();
+        p.r_air = r_air; p.u_0 = u_0; p.L_atm = L_atm;
+        push_all(d, { { ATOMDEV_H, &h }, { ATOMDEV_V, &v }, { ATOMDEV_W, &w }, { ATOMDEV_P_DYN, &p_dyn }, { ATOMDEV_VN, &vn },
+                      { ATOMDEV_WN, &wn }, { ATOMDEV_P_DYNN, &p_dynn }, { ATOMDEV_AUX_V, &aux_v }, { ATOMDEV_AUX_W, &aux_w } });
+        d.run(atomdev_atm_rk2d(d.handle()), "atomdev_atm_rk2d");
+        pull_all(d, { { ATOMDEV_V, &v }, { ATOMDEV_W, &w }, { ATOMDEV_AUX_V, &aux_v }, { ATOMDEV_AUX_W, &aux_w } });
+    }
+
+private:
+    int im_, jm_, km_;
+};
+
+// atmosphere/Pressure_Atm.h
+class Pressure_Atm {
+public:
+    Pressure_Atm(int im, int jm, int km, double dr, double dthe, double dphi) : im_(im), jm_(jm), km_(km) {
+        atomdev_params& p = Device::of(ATOMDEV_ATM).params();
+        p.dr = dr; p.dthe = dthe; p.dphi = dphi;
+    }
+    // atmosphere/Pressure_Atm.cpp:39-190
+    void computePressure_3D(double u_0, double r_air, Array_1D& rad, Array_1D& the, Array& p_dyn, Array& p_dynn, Array& h,
+                            Array& aux_u, Array& aux_v, Array& aux_w) {
+        Device& d = begin(u_0, r_air, rad, the);
+        push_all(d, { { ATOMDEV_P_DYN, &p_dyn }, { ATOMDEV_P_DYNN, &p_dynn }, { ATOMDEV_H, &h }, { ATOMDEV_AUX_U, &aux_u },
+                      { ATOMDEV_AUX_V, &aux_v }, { ATOMDEV_AUX_W, &aux_w } });
+        d.run(atomdev_atm_pressure3d(d.handle()), "atomdev_atm_pressure3d");
+        pull_all(d, { { ATOMDEV_P_DYN, &p_dyn }, { ATOMDEV_AUX_U, &aux_u }, { ATOMDEV_AUX_V, &aux_v }, { ATOMDEV_AUX_W, &aux_w } });
+    }
+    // atmosphere/Pressure_Atm.cpp:195-301
+    void computePressure_2D(double u_0, double r_air, Array_1D& rad, Array_1D& the, Array& p_dyn, Array& p_dynn, Array& h,
+                            Array& aux_v, Array& aux_w) {
+        Device& d = begin(u_0, r_air, rad, the);
+        push_all(d, { { ATOMDEV_P_DYN, &p_dyn }, { ATOMDEV_P_DYNN, &p_dynn }, { ATOMDEV_H, &h }, { ATOMDEV_AUX_V, &aux_v },
+                      { ATOMDEV_AUX_W, &aux_w } });
+        d.run(atomdev_atm_pressure2d(d.handle()), "atomdev_atm_pressure2d");
+        pull_all(d, { { ATOMDEV_P_DYN, &p_dyn }, { ATOMDEV_AUX_V, &aux_v } });
+    }
+
+private:
+    Device& begin(double u_0, double r_air, Array_1D& rad, Array_1D& the) {
+        Device& d = Device::of(ATOMDEV_ATM);
+        d.grid(im_, jm_, km_); d.origin(rad, the);
+        d.params().u_0 = u_0; d.params().r_air = r_air;
+        return d;
+    }
+    int im_, jm_, km_;
+};
+
+// atmosphere/BC_Atm.h
+class BC_Atmosphere {
+public:
+    BC_Atmosphere(int im, int jm, int km, double t_tropopause) : im_(im), jm_(jm), km_(km) {
+        Device::of(ATOMDEV_ATM).params().t_tropopause = t_tropopause;
+    }
+#define ATOMDEV_MIRROR_ATM_BC(NAME, ENTRY)                                                                             \
+    void NAME(Array& t, Array& u, Array& v, Array& w, Array& p_dyn, Array& c, Array& cloud, Array& ice, Array& co2) { \
+        Device& d = Device::of(ATOMDEV_ATM);                                                                           \
+        d.grid(im_, jm_, km_);                                                                                         \
+        push_all(d, { { ATOMDEV_T, &t }, { ATOMDEV_U, &u }, { ATOMDEV_V, &v }, { ATOMDEV_W, &w }, { ATOMDEV_P_DYN, &p_dyn }, \
+                      { ATOMDEV_C, &c }, { ATOMDEV_CLOUD, &cloud }, { ATOMDEV_ICE, &ice }, { ATOMDEV_CO2, &co2 } });    \
+        d.run(ENTRY(d.handle()), #ENTRY);                                                                              \
+        pull_all(d, { { ATOMDEV_T, &t }, { ATOMDEV_U, &u }, { ATOMDEV_V, &v }, { ATOMDEV_W, &w }, { ATOMDEV_P_DYN, &p_dyn }, \
+                      { ATOMDEV_C, &c }, { ATOMDEV_CLOUD, &cloud }, { ATOMDEV_ICE, &ice }, { ATOMDEV_CO2, &co2 } });    \
+    }
+    ATOMDEV_MIRROR_ATM_BC(BC_radius, atomdev_atm_bc_radius)  // atmosphere/BC_Atm.cpp:39-73
+    ATOMDEV_MIRROR_ATM_BC(BC_theta, atomdev_atm_bc_theta)    // atmosphere/BC_Atm.cpp:80-107
+    ATOMDEV_MIRROR_ATM_BC(BC_phi, atomdev_atm_bc_phi)        // atmosphere/BC_Atm.cpp:115-150
+#undef ATOMDEV_MIRROR_ATM_BC
+
+private:
+    int im_, jm_, km_;
+};
+
+// ---------------------------------------------------------------------------------------------
+// hydrosphere
+// ---------------------------------------------------------------------------------------------
+
+// hydrosphere/RHS_Hyd.h
+class RHS_Hydrosphere {
+public:
+    RHS_Hydrosphere(int jm, int km, double dthe, double dphi, double re) {
+        atomdev_params& p = Device::of(ATOMDEV_HYD).params();
+        (void)jm; (void)km; p.dthe = dthe; p.dphi = dphi; p.re = re;
+    }
+    RHS_Hydrosphere(int im, int jm, int km, double dt, double dr, double dthe, double dphi, double re, double sc, double g,
+                    double pr, double buoyancy) {
+        atomdev_params& p = Device::of(ATOMDEV_HYD).params();
+        (void)im; (void)jm; (void)km;
+        p.dt = dt; p.dr = dr; p.dthe = dthe; p.dphi = dphi; p.re = re; p.sc = sc; p.g = g; p.pr = pr; p.Buoyancy = buoyancy;
+    }
+};
+
+// hydrosphere/RungeKutta_Hyd.h
+class RungeKutta_Hydrosphere {
+public:
+    RungeKutta_Hydrosphere(int im, int jm, int km, double dt) : im_(im), jm_(jm), km_(km) {
+        Device::of(ATOMDEV_HYD).params().dt = dt;
+    }
+
+    // hydrosphere/RungeKutta_Hyd.cpp:30-124
+    void solveRungeKutta_3D_Hydrosphere(RHS_Hydrosphere&, int&, double L_hyd, double g, double, double u_0, double t_0,
+                                        double c_0, double r_0_water, double ta, double pa, double ca, Array_1D& rad,
+                                        Array_1D& the, Array_1D&, Array_2D& Evaporation_Dalton, Array_2D& Precipitation,
+                                        Array& h, Array&, Array&, Array&, Array&, Array&, Array& t, Array& u, Array& v,
+                                        Array& w, Array& p_dyn, Array& c, Array& tn, Array& un, Array& vn, Array& wn,
+                                        Array& p_dynn, Array& cn, Array& aux_u, Array& aux_v, Array& aux_w, Array& Salt_Finger,
+                                        Array& Salt_Diffusion, Array& Buoyancy_Force, Array& Salt_Balance, Array&,
+                                        Array& r_water, Array& r_salt_water, Array_2D& Bathymetry) {
+        Device& d = Device::of(ATOMDEV_HYD);
+        d.grid(im_, jm_, km_); d.origin(rad, the);
+        atomdev_params& p = d.params();
+        p.L_hyd = L_hyd; p.g = g; p.u_0 = u_0; p.t_0 = t_0; p.c_0 = c_0; p.r_0_water = r_0_water; p.ta = ta; p.pa = pa; p.ca = ca;
+        push_all(d, { { ATOMDEV_H, &h }, { ATOMDEV_T, &t }, { ATOMDEV_U, &u }, { ATOMDEV_V, &v }, { ATOMDEV_W, &w },
+                      { ATOMDEV_P_DYN, &p_dyn }, { ATOMDEV_C, &c }, { ATOMDEV_TN, &tn }, { ATOMDEV_UN, &un }, { ATOMDEV_VN, &vn },
+                      { ATOMDEV_WN, &wn }, { ATOMDEV_P_DYNN, &p_dynn }, { ATOMDEV_CN, &cn }, { ATOMDEV_R_WATER, &r_water },
+                      { ATOMDEV_R_SALT_WATER, &r_salt_water } });
+        d.push2d(ATOMDEV_TOPOGRAPHY, Bathymetry);
+        d.push2d(ATOMDEV_EVAPORATION_DALTON, Evaporation_Dalton);
+        d.push2d(ATOMDEV_PRECIPITATION, Precipitation);
+        d.run(atomdev_hyd_rk3d(d.handle()), "atomdev_hyd_rk3d");
+        pull_all(d, { { ATOMDEV_T, &t }, { ATOMDEV_U, &u }, { ATOMDEV_V, &v }, { ATOMDEV_W, &w }, { ATOMDEV_C, &c },
+                      { ATOMDEV_AUX_U, &aux_u }, { ATOMDEV_AUX_V, &aux_v }, { ATOMDEV_AUX_W, &aux_w },
+                      { ATOMDEV_SALT_FINGER, &Salt_Finger }, { ATOMDEV_SALT_DIFFUSION, &Salt_Diffusion },
+                      { ATOMDEV_BUOYANCY, &Buoyancy_Force }, { ATOMDEV_SALT_BALANCE, &Salt_Balance },
+                      { ATOMDEV_R_WATER, &r_water }, { ATOMDEV_R_SALT_WATER, &r_salt_water } });
+    }
+
+    // hydrosphere/RungeKutta_Hyd.cpp:130-186
+    void solveRungeKutta_2D_Hydrosphere(RHS_Hydrosphere&, int&, double r_0_water, Array_1D& rad, Array_1D& the, Array_1D&,
+                                        Array&, Array&, Array& h, Array& v, Array& w, Array& p_dyn, Array& vn, Array& wn,
+                                        Array& p_dynn, Array& aux_v, Array& aux_w) {
+        Device& d = Device::of(ATOMDEV_HYD);
+        d.grid(im_, jm_, km_); d.origin(rad, the);
+        d.params().r_0_water = r_0_water;
+        push_all(d, { { ATOMDEV_H, &h }, { ATOMDEV_V, &v }, { ATOMDEV_W, &w }, { ATOMDEV_P_DYN, &p_dyn }, { ATOMDEV_VN, &vn },
+                      { ATOMDEV_WN, &wn }, { ATOMDEV_P_DYNN, &p_dynn }, { ATOMDEV_AUX_V, &aux_v }, { ATOMDEV_AUX_W, &aux_w } });
+        d.run(atomdev_hyd_rk2d(d.handle()), "atomdev_hyd_rk2d");
+        pull_all(d, { { ATOMDEV_V, &v }, { ATOMDEV_W, &w }, { ATOMDEV_AUX_V, &aux_v }, { ATOMDEV_AUX_W, &aux_w } });
+    }
+
+private:
+    int im_, jm_, km_;
+};
+
+// hydrosphere/Pressure_Hyd.h
+class Pressure_Hyd {
+public:
+    Pressure_Hyd(int im, int jm, int km, double dr, double dthe, double dphi) : im_(im), jm_(jm), km_(km) {
+        atomdev_params& p = Device::of(ATOMDEV_HYD).params();
+        p.dr = dr; p.dthe = dthe; p.dphi = dphi;
+    }
+    // hydrosphere/Pressure_Hyd.cpp:42-200
+    void computePressure_3D(double u_0, double r_0_water, Array_1D& rad, Array_1D& the, Array& p_dyn, Array& p_dynn, Array& h,
+                            Array& aux_u, Array& aux_v, Array& aux_w) {
+        Device& d = begin(u_0, r_0_water, rad, the);
+        push_all(d, { { ATOMDEV_P_DYN, &p_dyn }, { ATOMDEV_P_DYNN, &p_dynn }, { ATOMDEV_H, &h }, { ATOMDEV_AUX_U, &aux_u },
+                      { ATOMDEV_AUX_V, &aux_v }, { ATOMDEV_AUX_W, &aux_w } });
+        d.run(atomdev_hyd_pressure3d(d.handle()), "atomdev_hyd_pressure3d");
+        pull_all(d, { { ATOMDEV_P_DYN, &p_dyn }, { ATOMDEV_AUX_U, &aux_u }, { ATOMDEV_AUX_V, &aux_v }, { ATOMDEV_AUX_W, &aux_w } });
+    }
+    // hydrosphere/Pressure_Hyd.cpp:206-317
+    void computePressure_2D(double u_0, double r_0_water, Array_1D& rad, Array_1D& the, Array& p_dyn, Array& p_dynn, Array& h,
+                            Array& aux_v, Array& aux_w) {
+        Device& d = begin(u_0, r_0_water, rad, the);
+        push_all(d, { { ATOMDEV_P_DYN, &p_dyn }, { ATOMDEV_P_DYNN, &p_dynn }, { ATOMDEV_H, &h }, { ATOMDEV_AUX_V, &aux_v },
+                      { ATOMDEV_AUX_W, &aux_w } });
+        d.run(atomdev_hyd_pressure2d(d.handle()), "atomdev_hyd_pressure2d");
+        pull_all(d, { { ATOMDEV_P_DYN, &p_dyn }, { ATOMDEV_AUX_V, &aux_v } });
+    }
+
+private:
+    Device& begin(double u_0, double r_0_water, Array_1D& rad, Array_1D& the) {
+        Device& d = Device::of(ATOMDEV_HYD);
+        d.grid(im_, jm_, km_); d.origin(rad, the);
+        d.params().u_0 = u_0; d.params().r_0_water = r_0_water;
+        return d;
+    }
+    int im_, jm_, km_;
+};
+
+// hydrosphere/BC_Hyd.h
+class BC_Hydrosphere {
+public:
+    BC_Hydrosphere(int im, int jm, int km) : im_(im), jm_(jm), km_(km) {}
+    // hydrosphere/BC_Hyd.cpp:38-83
+    void RB_radius(double ca, double ta, double pa, double dr, Array_1D& rad, Array& t, Array& u, Array& v, Array& w,
+                   Array& p_dyn, Array& c) {
+        Device& d = Device::of(ATOMDEV_HYD);
+        d.params().ca = ca; d.params().ta = ta; d.params().pa = pa; d.params().dr = dr; d.params().r0 = rad.z[0];
+        apply(atomdev_hyd_bc_radius, "atomdev_hyd_bc_radius", t, u, v, w, p_dyn, c);
+    }
+    // hydrosphere/BC_Hyd.cpp:90-118
+    void RB_theta(double ca, double ta, double pa, Array& t, Array& u, Array& v, Array& w, Array& p_dyn, Array& c) {
+        Device& d = Device::of(ATOMDEV_HYD);
+        d.params().ca = ca; d.params().ta = ta; d.params().pa = pa;
+        apply(atomdev_hyd_bc_theta, "atomdev_hyd_bc_theta", t, u, v, w, p_dyn, c);
+    }
+    // hydrosphere/BC_Hyd.cpp:125-158
+    void RB_phi(Array& t, Array& u, Array& v, Array& w, Array& p_dyn, Array& c) {
+        apply(atomdev_hyd_bc_phi, "atomdev_hyd_bc_phi", t, u, v, w, p_dyn, c);
+    }
+
+private:
+    void apply(int (*entry)(atomdev_t*), const char* name, Array& t, Array& u, Array& v, Array& w, Array& p_dyn, Array& c) {
+        Device& d = Device::of(ATOMDEV_HYD);
+        d.grid(im_, jm_, km_);
+        push_all(d, { { ATOMDEV_T, &t }, { ATOMDEV_U, &u }, { ATOMDEV_V, &v }, { ATOMDEV_W, &w }, { ATOMDEV_P_DYN, &p_dyn },
+                      { ATOMDEV_C, &c } });
+        d.run(entry(d.handle()), name);
+        pull_all(d, { { ATOMDEV_T, &t }, { ATOMDEV_U, &u }, { ATOMDEV_V, &v }, { ATOMDEV_W, &w }, { ATOMDEV_P_DYN, &p_dyn },
+                      { ATOMDEV_C, &c } });
+    }
+    int im_, jm_, km_;
+};
+
+}  // namespace atomdev_mirror
+
+#endif  // ATOMDEV_MIRROR_HPP_

@@ -1,0 +1,236 @@
+/*
+ * bridge_test.cpp — the reference's call sites, once with the reference's own classes and once with
+ * the same-named classes of include/atomdev_mirror.hpp, on the same seeded fields.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Our own code; built here (oracle/Makefile, target bridge) against the
+ * reference's sources where they lie under /root/reference and against atom_amd/libatomdev.so; the
+ * binary oracle/_ref/bridge_test travels to the GPU box with the tree and is run by
+ * tests/test_bridge.py.  One function template holds the call text; it is instantiated with the two
+ * sets of class names, so what is compared is exactly "same source, other classes".
+ *
+ * Bars: hydrosphere and every atmosphere operator except the 3-D RK sweep bit for bit; the
+ * atmosphere sweep and what follows it 1e-10 relative per field (host and device pow differ in the
+ * last place).
+ */
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <iostream>
+#include <random>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "Array.h"
+#include "Array_1D.h"
+#include "Array_2D.h"
+#include "RHS_Atm.h"
+#include "RungeKutta_Atm.h"
+#include "Pressure_Atm.h"
+#include "BC_Atm.h"
+#undef _PRESSURE_
+#include "RHS_Hyd.h"
+#include "RungeKutta_Hyd.h"
+#include "Pressure_Hyd.h"
+#include "BC_Hyd.h"
+
+#include "../include/atomdev_mirror.hpp"
+
+namespace {
+
+struct RefClasses {
+    typedef ::RHS_Atmosphere RHS_A; typedef ::RungeKutta_Atmosphere RK_A; typedef ::Pressure_Atm P_A; typedef ::BC_Atmosphere BC_A;
+    typedef ::RHS_Hydrosphere RHS_H; typedef ::RungeKutta_Hydrosphere RK_H; typedef ::Pressure_Hyd P_H; typedef ::BC_Hydrosphere BC_H;
+};
+struct DevClasses {
+    typedef atomdev_mirror::RHS_Atmosphere RHS_A; typedef atomdev_mirror::RungeKutta_Atmosphere RK_A;
+    typedef atomdev_mirror::Pressure_Atm P_A; typedef atomdev_mirror::BC_Atmosphere BC_A;
+    typedef atomdev_mirror::RHS_Hydrosphere RHS_H; typedef atomdev_mirror::RungeKutta_Hydrosphere RK_H;
+    typedef atomdev_mirror::Pressure_Hyd P_H; typedef atomdev_mirror::BC_Hydrosphere BC_H;
+};
+
+struct Scalars {
+    double dt = 0.00001, dr, dthe, dphi, re, pr, g = 9.8066, Buoyancy = 1., u_0, t_0 = 273.15, c_0;
+    double sc_WaterVapour = .61, sc_CO2 = .96, gam = .65, r_air = 1.2041, R_Air = 287.1, R_WaterVapour = 461.6,
+           L_atm = 16000., cp_l = 1005., t_tropopause = .798;
+    double sc = 1.7329, L_hyd = 1000., r_0_water = 1000., ta = 1.01464, pa = 0., ca = 1.;
+};
+
+struct Fields {
+    int im, jm, km;
+    std::vector<std::string> names;
+    std::vector<Array*> arr;
+    Array_2D topo, evap, precip;
+    Array_1D rad, the, phi;
+    Array& operator[](const char* n) {
+        for (size_t i = 0; i < names.size(); i++) if (names[i] == n) return *arr[i];
+        names.push_back(n); arr.push_back(new Array(im, jm, km, 0.));
+        return *arr.back();
+    }
+    Fields(int im_, int jm_, int km_, const Scalars& s) : im(im_), jm(jm_), km(km_), topo(jm_, km_, 0.), evap(jm_, km_, 1.), precip(jm_, km_, .5) {
+        const int nrad = im > 41 ? im : 41;
+        rad.initArray_1D(nrad, 0.); the.initArray_1D(jm, 0.); phi.initArray_1D(km, 0.);
+        rad.Coordinates(nrad, 1., s.dr); the.Coordinates(jm, 0., s.dthe); phi.Coordinates(km, 0., s.dphi);
+    }
+    ~Fields() { for (Array* a : arr) delete a; }
+};
+
+void fill(Array& a, int im, int jm, int km, std::mt19937_64& rng, double lo, double hi) {
+    std::uniform_real_distribution<double> d(lo, hi);
+    for (int i = 0; i < im; i++) for (int j = 0; j < jm; j++) for (int k = 0; k < km; k++) a.x[i][j][k] = d(rng);
+}
+
+// columns of solid cells rising from level 0, a third of the columns, up to half the levels
+void make_mask(Fields& F, std::mt19937_64& rng, double L) {
+    std::uniform_real_distribution<double> u01(0., 1.);
+    Array& h = F["h"];
+    for (int j = 0; j < F.jm; j++)
+        for (int k = 0; k < F.km; k++) {
+            int top = u01(rng) < .33 ? 1 + (int)(u01(rng) * (F.im / 2)) : 0;
+            F.topo.y[j][k] = top * (L / (double)(F.im - 1));
+            for (int i = 0; i < F.im; i++) h.x[i][j][k] = i < top ? 1. : 0.;
+        }
+}
+
+void init_atm(Fields& F, unsigned seed, const Scalars& s) {
+    std::mt19937_64 rng(seed);
+    const int im = F.im, jm = F.jm, km = F.km;
+    make_mask(F, rng, s.L_atm);
+    const char* st[9] = { "t", "u", "v", "w", "p_dyn", "c", "cloud", "ice", "co2" };
+    const double lo[9] = { .8, -.1, -.1, -.4, -.1, 0., 0., 0., 1. }, hi[9] = { 1.1, .1, .1, .4, .1, .03, .01, .005, 1.2 };
+    for (int n = 0; n < 9; n++) {
+        fill(F[st[n]], im, jm, km, rng, lo[n], hi[n]);
+        fill(F[(std::string(st[n]) + "n").c_str()], im, jm, km, rng, lo[n], hi[n]);
+    }
+    for (const char* n : { "S_v", "S_c", "S_i", "S_r", "S_s" }) fill(F[n], im, jm, km, rng, -1e-6, 1e-6);
+    for (const char* n : { "aux_u", "aux_v", "aux_w" }) fill(F[n], im, jm, km, rng, -1., 1.);
+    for (const char* n : { "BuoyancyForce", "spare" }) (void)F[n];
+    for (int n = 0; n < 8; n++) (void)F[("rhs" + std::to_string(n)).c_str()];
+}
+
+void init_hyd(Fields& F, unsigned seed, const Scalars& s) {
+    std::mt19937_64 rng(seed);
+    const int im = F.im, jm = F.jm, km = F.km;
+    make_mask(F, rng, s.L_hyd);
+    const char* st[6] = { "t", "u", "v", "w", "p_dyn", "c" };
+    const double lo[6] = { .9, -.1, -.1, -.1, -.1, .95 }, hi[6] = { 1.1, .1, .1, .1, .1, 1.1 };
+    for (int n = 0; n < 6; n++) {
+        fill(F[st[n]], im, jm, km, rng, lo[n], hi[n]);
+        fill(F[(std::string(st[n]) + "n").c_str()], im, jm, km, rng, lo[n], hi[n]);
+    }
+    fill(F["r_water"], im, jm, km, rng, 995., 1005.);
+    fill(F["r_salt_water"], im, jm, km, rng, 1020., 1035.);
+    for (const char* n : { "aux_u", "aux_v", "aux_w" }) fill(F[n], im, jm, km, rng, -1., 1.);
+    for (const char* n : { "Salt_Finger", "Salt_Diffusion", "Buoyancy_Force", "Salt_Balance", "spare" }) (void)F[n];
+    for (int n = 0; n < 5; n++) (void)F[("rhs" + std::to_string(n)).c_str()];
+}
+
+// ---- the reference's call text (cAtmosphereModel.cpp:777-874), for either set of classes ----
+template <class NS>
+void atmosphere_calls(Fields& F, const Scalars& s, bool with_rk3d) {
+    const int im = F.im, jm = F.jm, km = F.km;
+    typename NS::BC_A boundary(im, jm, km, s.t_tropopause);
+    typename NS::RHS_A prepare(im, jm, km, s.dt, s.dr, s.dthe, s.dphi, s.re, s.sc_WaterVapour, s.sc_CO2, s.g, s.pr, 1., s.Buoyancy,
+                               1., s.gam, 5.670280e-8, 0.0262);
+    typename NS::RHS_A prepare_2D(jm, km, s.dthe, s.dphi, s.re);
+    typename NS::RK_A result(im, jm, km, s.dt, s.dr, s.dphi, s.dthe);
+    typename NS::P_A startPressure(im, jm, km, s.dr, s.dthe, s.dphi);
+    int n = 1;
+    boundary.BC_radius(F["t"], F["u"], F["v"], F["w"], F["p_dyn"], F["c"], F["cloud"], F["ice"], F["co2"]);
+    boundary.BC_theta(F["t"], F["u"], F["v"], F["w"], F["p_dyn"], F["c"], F["cloud"], F["ice"], F["co2"]);
+    boundary.BC_phi(F["t"], F["u"], F["v"], F["w"], F["p_dyn"], F["c"], F["cloud"], F["ice"], F["co2"]);
+    if (with_rk3d)
+        result.solveRungeKutta_3D_Atmosphere(prepare, n, 2.52e6, 2.83e6, 0.623, 6.1078, s.u_0, s.t_0, s.c_0, 280.0, 1013.25,
+            s.r_air, 0.0094, 0.0019767, s.L_atm, s.cp_l, s.R_Air, s.R_WaterVapour, 188.91, F.rad, F.the, F.phi,
+            F["rhs0"], F["rhs1"], F["rhs2"], F["rhs3"], F["rhs4"], F["rhs5"], F["rhs6"], F["rhs7"],
+            F["h"], F["t"], F["u"], F["v"], F["w"], F["p_dyn"], F["spare"], F["c"], F["cloud"], F["ice"], F["co2"],
+            F["tn"], F["un"], F["vn"], F["wn"], F["p_dynn"], F["cn"], F["cloudn"], F["icen"], F["co2n"],
+            F["aux_u"], F["aux_v"], F["aux_w"], F["spare"], F["BuoyancyForce"], F["spare"], F["spare"], F["spare"],
+            F["S_v"], F["S_c"], F["S_i"], F["S_r"], F["S_s"], F["spare"], F.topo, F.evap, F.precip);
+    startPressure.computePressure_3D(s.u_0, s.r_air, F.rad, F.the, F["p_dyn"], F["p_dynn"], F["h"], F["aux_u"], F["aux_v"], F["aux_w"]);
+    result.solveRungeKutta_2D_Atmosphere(prepare_2D, n, s.r_air, s.u_0, 1013.25, s.L_atm, F.rad, F.the, F.phi, F["rhs2"], F["rhs3"],
+        F["h"], F["v"], F["w"], F["p_dyn"], F["vn"], F["wn"], F["p_dynn"], F["aux_v"], F["aux_w"]);
+    startPressure.computePressure_2D(s.u_0, s.r_air, F.rad, F.the, F["p_dyn"], F["p_dynn"], F["h"], F["aux_v"], F["aux_w"]);
+}
+
+// ---- cHydrosphereModel.cpp:437-610 ----
+template <class NS>
+void hydrosphere_calls(Fields& F, const Scalars& s) {
+    const int im = F.im, jm = F.jm, km = F.km;
+    typename NS::BC_H boundary(im, jm, km);
+    typename NS::RHS_H prepare(im, jm, km, s.dt, s.dr, s.dthe, s.dphi, s.re, s.sc, s.g, s.pr, s.Buoyancy);
+    typename NS::RHS_H prepare_2D(jm, km, s.dthe, s.dphi, s.re);
+    typename NS::RK_H result(im, jm, km, s.dt);
+    typename NS::P_H startPressure(im, jm, km, s.dr, s.dthe, s.dphi);
+    int n = 1;
+    boundary.RB_radius(s.ca, s.ta, s.pa, s.dr, F.rad, F["t"], F["u"], F["v"], F["w"], F["p_dyn"], F["c"]);
+    boundary.RB_theta(s.ca, s.ta, s.pa, F["t"], F["u"], F["v"], F["w"], F["p_dyn"], F["c"]);
+    boundary.RB_phi(F["t"], F["u"], F["v"], F["w"], F["p_dyn"], F["c"]);
+    result.solveRungeKutta_3D_Hydrosphere(prepare, n, s.L_hyd, s.g, 4182.0, s.u_0, s.t_0, s.c_0, s.r_0_water, s.ta, s.pa, s.ca,
+        F.rad, F.the, F.phi, F.evap, F.precip, F["h"], F["rhs0"], F["rhs1"], F["rhs2"], F["rhs3"], F["rhs4"],
+        F["t"], F["u"], F["v"], F["w"], F["p_dyn"], F["c"], F["tn"], F["un"], F["vn"], F["wn"], F["p_dynn"], F["cn"],
+        F["aux_u"], F["aux_v"], F["aux_w"], F["Salt_Finger"], F["Salt_Diffusion"], F["Buoyancy_Force"], F["Salt_Balance"],
+        F["spare"], F["r_water"], F["r_salt_water"], F.topo);
+    startPressure.computePressure_3D(s.u_0, s.r_0_water, F.rad, F.the, F["p_dyn"], F["p_dynn"], F["h"], F["aux_u"], F["aux_v"], F["aux_w"]);
+    result.solveRungeKutta_2D_Hydrosphere(prepare_2D, n, s.r_0_water, F.rad, F.the, F.phi, F["rhs2"], F["rhs3"],
+        F["h"], F["v"], F["w"], F["p_dyn"], F["vn"], F["wn"], F["p_dynn"], F["aux_v"], F["aux_w"]);
+    startPressure.computePressure_2D(s.u_0, s.r_0_water, F.rad, F.the, F["p_dyn"], F["p_dynn"], F["h"], F["aux_v"], F["aux_w"]);
+}
+
+int compare(Fields& A, Fields& B, double tol, const char* what) {
+    int bad = 0;
+    for (size_t n = 0; n < A.names.size(); n++) {
+        if (A.names[n].compare(0, 3, "rhs") == 0 || A.names[n] == "spare") continue;  // scratch of the reference's RHS
+        Array& a = *A.arr[n]; Array& b = B[A.names[n].c_str()];
+        double maxd = 0., maxa = 0.; bool bits = true;
+        for (int i = 0; i < A.im; i++) for (int j = 0; j < A.jm; j++) for (int k = 0; k < A.km; k++) {
+            const double x = a.x[i][j][k], y = b.x[i][j][k];
+            if (std::memcmp(&x, &y, 8) != 0 && !(x == 0. && y == 0.)) bits = false;
+            maxd = std::fmax(maxd, std::fabs(x - y)); maxa = std::fmax(maxa, std::fabs(x));
+        }
+        const double rel = maxa > 0. ? maxd / maxa : maxd;
+        const bool ok = tol == 0. ? bits : rel <= tol;
+        if (!ok) { bad++; std::printf("  %s %-16s MISMATCH rel %.3e bits %d\n", what, A.names[n].c_str(), rel, (int)bits); }
+    }
+    std::printf("%s: %zu fields, %s (%s)\n", what, A.names.size(), bad ? "FAIL" : "ok", tol == 0. ? "bit-exact" : "<= 1e-10 relative");
+    return bad;
+}
+
+struct Quiet {  // the reference prints progress on std::cout
+    std::streambuf* old; std::ostringstream sink;
+    Quiet() : old(std::cout.rdbuf(sink.rdbuf())) {}
+    ~Quiet() { std::cout.rdbuf(old); }
+};
+
+}  // namespace
+
+int main() {
+    int bad = 0;
+    {   // atmosphere without the pow-dependent sweep: bit-exact
+        Scalars s; s.re = 1000.; s.pr = .7179; s.u_0 = 8.; s.c_0 = .035;
+        const int im = 9, jm = 21, km = 70;
+        s.dr = 1. / (im - 1); s.dthe = M_PI / (jm - 1); s.dphi = s.dthe;
+        Fields R(im, jm, km, s), D(im, jm, km, s);
+        init_atm(R, 7, s); init_atm(D, 7, s);
+        { Quiet q; atmosphere_calls<RefClasses>(R, s, false); }
+        atmosphere_calls<DevClasses>(D, s, false);
+        bad += compare(R, D, 0., "atmosphere, fills + pressure + surface loop");
+        Fields R2(im, jm, km, s), D2(im, jm, km, s);
+        init_atm(R2, 8, s); init_atm(D2, 8, s);
+        { Quiet q; atmosphere_calls<RefClasses>(R2, s, true); }
+        atmosphere_calls<DevClasses>(D2, s, true);
+        bad += compare(R2, D2, 1e-10, "atmosphere, with the 3-D RK sweep");
+    }
+    {   // hydrosphere (the surface RHS hard-codes im = 41, RHS_Hyd.cpp:466)
+        Scalars s; s.re = 10.; s.pr = 6.957; s.u_0 = .25; s.c_0 = 34.6;
+        const int im = 41, jm = 43, km = 24;
+        s.dr = 1. / (im - 1); s.dthe = M_PI / (jm - 1); s.dphi = s.dthe;
+        Fields R(im, jm, km, s), D(im, jm, km, s);
+        init_hyd(R, 9, s); init_hyd(D, 9, s);
+        { Quiet q; hydrosphere_calls<RefClasses>(R, s); }
+        hydrosphere_calls<DevClasses>(D, s);
+        bad += compare(R, D, 0., "hydrosphere");
+    }
+    std::printf(bad ? "BRIDGE FAIL\n" : "BRIDGE PASS\n");
+    return bad ? 1 : 0;
+}
