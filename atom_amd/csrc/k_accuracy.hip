@@ -7,13 +7,22 @@
 // The residuum "minimum" of the reference is an order-dependent scan,
 //     if (fabs(res) > min) { min = res; loc = here; }      (>= for the hydrosphere)
 // with a SIGNED store and an unsigned compare: after a negative value is stored
-// every following point replaces it.  It is not a max-reduction, so it is
-// evaluated as what it is, a state machine over the lexicographic sequence, in
-// three steps: (1) every point's residuum in parallel; (2) per chunk of the
-// sequence, in parallel, the chunk's transfer function: for an incoming state m
-// the first point that replaces it is the first strict prefix maximum of |res|
-// that beats m, and what the chunk leaves behind from there on does not depend on
-// m any more; (3) one thread chains the chunk functions.
+// the next point replaces it whatever it is.  It is not a max-reduction, so it is
+// evaluated as what it is, a state machine over the lexicographic sequence — but the
+// machine can jump:
+//   * state m >= 0 at position s: let P be the FIRST position of the maximum of |res|
+//     over [s, n).  If that maximum does not beat m, nothing in the suffix does and the
+//     scan is over.  Otherwise P replaces whatever state reaches it (every earlier
+//     point of the suffix is strictly smaller in magnitude, a negative state is always
+//     replaced), so the points in between do not matter: continue at P+1 with state res[P].
+//   * state m < 0 at position s: every point replaces it until the first non-negative
+//     one, q; continue at q+1 with state res[q] (if there is none, the last point wins).
+// Each jump is two block-wide searches over a per-chunk summary table plus one partial
+// chunk; the number of jumps is the number of sign changes along the chain of suffix
+// maxima, a handful on any field (logarithmic in expectation on random data).
+// Steps: (1) every point's residuum in parallel; (2) per chunk, in parallel: first
+// position of the maximum magnitude and first non-negative position; (3) one workgroup
+// runs the jumps.  NaNs never compare true: they neither replace nor are they stored.
 #include <math.h>
 
 #include "atomdev_internal.h"
@@ -22,13 +31,11 @@ namespace {
 
 constexpr int TPB = 256;
 constexpr int CHUNK = 2048;    // sequence elements per chunk
-constexpr int MAXREC = 24;     // prefix-maximum records kept per chunk; more -> the chain step walks the chunk itself
 
-struct ChunkFn {
-    int nrec;                  // -1: too many records
-    double thr[MAXREC];        // |res| at the record
-    double out_val[MAXREC];    // state after the chunk if the record is the first replacement
-    int out_pos[MAXREC];       // sequence index of that state
+struct ChunkSum {
+    double amax;               // maximum |res| of the chunk (-1: none, all NaN)
+    int pmax;                  // first position (sequence index) attaining it
+    int pnn;                   // first position with res >= 0 (-1: none)
 };
 
 template <bool GE>
@@ -75,61 +82,84 @@ __global__ void k_residuum2d(const double* __restrict__ v, const double* __restr
     (void)jm;
 }
 
-template <bool GE>
-__global__ void k_chunk_functions(const double* __restrict__ seq, size_t n, ChunkFn* __restrict__ fn, int nchunks) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= nchunks) return;
-    const size_t b = (size_t)c * CHUNK;
-    const size_t e = (b + CHUNK < n) ? b + CHUNK : n;
-    ChunkFn f;
-    f.nrec = 0;
-    double best = -1.;
-    size_t rec_pos[MAXREC];
-    for (size_t q = b; q < e; q++) {
-        double a = fabs(seq[q]);
-        if (a > best) {  // strict prefix maximum (NaN never is)
-            best = a;
-            if (f.nrec < MAXREC) { f.thr[f.nrec] = a; rec_pos[f.nrec] = q; }
-            f.nrec++;
-        }
-    }
-    if (f.nrec > MAXREC) { fn[c].nrec = -1; return; }
-    for (int r = 0; r < f.nrec; r++) {
-        double m = seq[rec_pos[r]];
-        size_t pos = rec_pos[r];
-        for (size_t q = rec_pos[r] + 1; q < e; q++) {
-            double x = seq[q];
-            if (beats<GE>(x, m)) { m = x; pos = q; }
-        }
-        f.out_val[r] = m; f.out_pos[r] = (int)pos;
-    }
-    fn[c] = f;
+// first-argmax / first-position combiners
+__device__ __forceinline__ void take_max(double& v, long& p, double v2, long p2) {
+    if (v2 > v || (v2 == v && p2 >= 0 && (p < 0 || p2 < p))) { v = v2; p = p2; }
+}
+__device__ __forceinline__ void take_first(long& p, long p2) {
+    if (p2 >= 0 && (p < 0 || p2 < p)) p = p2;
 }
 
-template <bool GE>
-__global__ void k_chain_chunks(const double* __restrict__ seq, size_t n, const ChunkFn* __restrict__ fn, int nchunks,
-                               double m_in, long pos_in, double* __restrict__ out /* {min, pos} */) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    double m = m_in;
-    long pos = pos_in;  // -1: state carried in from the caller, location unchanged
-    for (int c = 0; c < nchunks; c++) {
-        const ChunkFn& f = fn[c];
-        if (f.nrec >= 0) {
-            for (int r = 0; r < f.nrec; r++) {
-                // first record that replaces m: records are increasing in |res|
-                if (GE ? (f.thr[r] >= m) : (f.thr[r] > m)) { m = f.out_val[r]; pos = f.out_pos[r]; break; }
-            }
-        } else {
-            const size_t b = (size_t)c * CHUNK;
-            const size_t e = (b + CHUNK < n) ? b + CHUNK : n;
-            for (size_t q = b; q < e; q++) {
-                double x = seq[q];
-                if (beats<GE>(x, m)) { m = x; pos = (long)q; }
-            }
-        }
+__global__ __launch_bounds__(TPB) void k_chunk_summary(const double* __restrict__ seq, size_t n, ChunkSum* __restrict__ sum) {
+    __shared__ double sv[TPB];
+    __shared__ long sp[TPB], sq[TPB];
+    const size_t b = (size_t)blockIdx.x * CHUNK;
+    const size_t e = (b + CHUNK < n) ? b + CHUNK : n;
+    double v = -1.; long p = -1, q = -1;
+    for (size_t t = b + threadIdx.x; t < e; t += TPB) {
+        const double x = seq[t];
+        take_max(v, p, fabs(x), (long)t);  // NaN: both compares false
+        if (x >= 0.) take_first(q, (long)t);
     }
-    out[0] = m;
-    out[1] = (double)pos;
+    sv[threadIdx.x] = v; sp[threadIdx.x] = p; sq[threadIdx.x] = q;
+    __syncthreads();
+    for (int st = TPB / 2; st > 0; st >>= 1) {
+        if (threadIdx.x < st) {
+            take_max(sv[threadIdx.x], sp[threadIdx.x], sv[threadIdx.x + st], sp[threadIdx.x + st]);
+            take_first(sq[threadIdx.x], sq[threadIdx.x + st]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { sum[blockIdx.x].amax = sv[0]; sum[blockIdx.x].pmax = (int)sp[0]; sum[blockIdx.x].pnn = (int)sq[0]; }
+}
+
+// One workgroup: the jumps described at the top of the file.
+template <bool GE>
+__global__ __launch_bounds__(TPB) void k_scan_jumps(const double* __restrict__ seq, size_t n, const ChunkSum* __restrict__ sum,
+                                                    int nchunks, double m_in, double* __restrict__ out /* {min, pos} */) {
+    __shared__ double sv[TPB];
+    __shared__ long sp[TPB], sq[TPB];
+    double m = m_in;
+    long pos = -1;  // -1: the carried-in state survives, the caller's location stays
+    long s = 0;
+    const long N = (long)n;
+    while (s < N) {
+        // suffix [s, N): the rest of the chunk s lies in, element by element, then whole chunks from the table
+        const long c0 = s / CHUNK;
+        const long e0 = ((c0 + 1) * CHUNK < N) ? (c0 + 1) * CHUNK : N;
+        double v = -1.; long p = -1, q = -1;
+        for (long t = s + threadIdx.x; t < e0; t += TPB) {
+            const double x = seq[t];
+            take_max(v, p, fabs(x), t);
+            if (x >= 0.) take_first(q, t);
+        }
+        for (long c = c0 + 1 + threadIdx.x; c < nchunks; c += TPB) {
+            take_max(v, p, sum[c].amax, (long)sum[c].pmax);
+            take_first(q, (long)sum[c].pnn);
+        }
+        sv[threadIdx.x] = v; sp[threadIdx.x] = p; sq[threadIdx.x] = q;
+        __syncthreads();
+        for (int st = TPB / 2; st > 0; st >>= 1) {
+            if (threadIdx.x < st) {
+                take_max(sv[threadIdx.x], sp[threadIdx.x], sv[threadIdx.x + st], sp[threadIdx.x + st]);
+                take_first(sq[threadIdx.x], sq[threadIdx.x + st]);
+            }
+            __syncthreads();
+        }
+        const double g = sv[0]; const long P = sp[0], Q = sq[0];
+        __syncthreads();  // everyone has read the results before the next round overwrites them
+        if (m < 0.) {
+            // every (non-NaN) point replaces a negative state, up to and including the first non-negative one
+            if (Q >= 0) { m = seq[Q]; pos = Q; s = Q + 1; continue; }
+            long t = N - 1;  // no non-negative point left: the last non-NaN point of the suffix wins
+            while (t >= s && !(fabs(seq[t]) >= 0.)) t--;
+            if (t >= s) { m = seq[t]; pos = t; }
+            break;
+        }
+        if (P < 0 || !(GE ? (g >= m) : (g > m))) break;  // nothing in the suffix beats m (also: m is NaN)
+        m = seq[P]; pos = P; s = P + 1;
+    }
+    if (threadIdx.x == 0) { out[0] = m; out[1] = (double)pos; }
 }
 
 // ---- steady queries: max |x - xn| and its first (atm, strict >) or last (hyd, >=) location ----
@@ -176,7 +206,7 @@ int residuum(atomdev* h, bool three_d, bool ge, double* min, int loc[3]) {
     const size_t n = three_d ? (size_t)(im - 2) * (jm - 2) * (km - 2) : (size_t)(jm - 2) * (km - 2);
     const int nchunks = (int)((n + CHUNK - 1) / CHUNK);
     // scratch: seq | chunk functions | result
-    const size_t need = n * sizeof(double) + (size_t)nchunks * sizeof(ChunkFn) + 64;
+    const size_t need = n * sizeof(double) + (size_t)nchunks * sizeof(ChunkSum) + 128;
     if (need > h->red_bytes) {
         ATOMDEV_TRY(hipStreamSynchronize(h->stream));
         ATOMDEV_TRY(hipFree(h->red));
@@ -185,8 +215,8 @@ int residuum(atomdev* h, bool three_d, bool ge, double* min, int loc[3]) {
         h->red_bytes = need;
     }
     double* seq = (double*)h->red;
-    ChunkFn* fn = (ChunkFn*)((char*)h->red + ((n * sizeof(double) + 63) / 64) * 64);
-    double* out = (double*)((char*)fn + (size_t)nchunks * sizeof(ChunkFn));
+    ChunkSum* fn = (ChunkSum*)((char*)h->red + ((n * sizeof(double) + 63) / 64) * 64);
+    double* out = (double*)((char*)fn + (size_t)nchunks * sizeof(ChunkSum));
     if ((char*)(out + 2) > (char*)h->red + h->red_bytes) { atomdev_set_error("residuum: scratch layout"); return 1; }
     if (three_d) {
         dim3 grid((km - 2 + 127) / 128, jm - 2, im - 2);
@@ -199,14 +229,9 @@ int residuum(atomdev* h, bool three_d, bool ge, double* min, int loc[3]) {
     }
     ATOMDEV_TRY(hipGetLastError());
     const double m_in = ge ? 0. : *min;  // the hydrosphere object resets its state (Accuracy_Hyd.cpp:91)
-    const unsigned cb = (unsigned)((nchunks + 63) / 64);
-    if (ge) {
-        hipLaunchKernelGGL(k_chunk_functions<true>, dim3(cb), dim3(64), 0, h->stream, seq, n, fn, nchunks);
-        hipLaunchKernelGGL(k_chain_chunks<true>, dim3(1), dim3(64), 0, h->stream, seq, n, fn, nchunks, m_in, -1L, out);
-    } else {
-        hipLaunchKernelGGL(k_chunk_functions<false>, dim3(cb), dim3(64), 0, h->stream, seq, n, fn, nchunks);
-        hipLaunchKernelGGL(k_chain_chunks<false>, dim3(1), dim3(64), 0, h->stream, seq, n, fn, nchunks, m_in, -1L, out);
-    }
+    hipLaunchKernelGGL(k_chunk_summary, dim3(nchunks), dim3(TPB), 0, h->stream, seq, n, fn);
+    if (ge) hipLaunchKernelGGL(k_scan_jumps<true>, dim3(1), dim3(TPB), 0, h->stream, seq, n, fn, nchunks, m_in, out);
+    else hipLaunchKernelGGL(k_scan_jumps<false>, dim3(1), dim3(TPB), 0, h->stream, seq, n, fn, nchunks, m_in, out);
     ATOMDEV_TRY(hipGetLastError());
     double res[2];
     ATOMDEV_TRY(hipMemcpyAsync(res, out, sizeof(res), hipMemcpyDeviceToHost, h->stream));
