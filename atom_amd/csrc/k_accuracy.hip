@@ -175,30 +175,37 @@ __device__ __forceinline__ void take(Best& a, double v, long long idx) {
 template <bool LAST>
 __global__ void k_steady_partial(SteadyArgs s, size_t off, size_t n, Best* __restrict__ part) {
     __shared__ Best sh[TPB];
-    for (int f = 0; f < s.n; f++) {
-        Best b; b.v = -1.; b.idx = LAST ? -1 : (long long)n;
-        for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (size_t)gridDim.x * blockDim.x) {
-            double d = fabs(s.x[f][off + q] - s.xn[f][off + q]);
-            take<LAST>(b, d, (long long)q);
-        }
-        sh[threadIdx.x] = b;
-        __syncthreads();
-        for (int st = TPB / 2; st > 0; st >>= 1) {
-            if (threadIdx.x < st) take<LAST>(sh[threadIdx.x], sh[threadIdx.x + st].v, sh[threadIdx.x + st].idx);
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) part[(size_t)f * gridDim.x + blockIdx.x] = sh[0];
+    const int f = blockIdx.y;  // one field per grid row: all fields stream concurrently
+    const double* __restrict__ x = s.x[f] + off;
+    const double* __restrict__ xn = s.xn[f] + off;
+    Best b; b.v = -1.; b.idx = LAST ? -1 : (long long)n;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (size_t)gridDim.x * blockDim.x) {
+        double d = fabs(x[q] - xn[q]);
+        take<LAST>(b, d, (long long)q);
+    }
+    sh[threadIdx.x] = b;
+    __syncthreads();
+    for (int st = TPB / 2; st > 0; st >>= 1) {
+        if (threadIdx.x < st) take<LAST>(sh[threadIdx.x], sh[threadIdx.x + st].v, sh[threadIdx.x + st].idx);
         __syncthreads();
     }
+    if (threadIdx.x == 0) part[(size_t)f * gridDim.x + blockIdx.x] = sh[0];
 }
 
 template <bool LAST>
 __global__ void k_steady_final(const Best* __restrict__ part, int nblocks, int nf, Best* __restrict__ out) {
-    int f = threadIdx.x;
-    if (f >= nf) return;
+    __shared__ Best sh[TPB];
+    const int f = blockIdx.x;  // one workgroup per field
     Best b; b.v = -1.; b.idx = LAST ? -1 : (1LL << 62);
-    for (int i = 0; i < nblocks; i++) take<LAST>(b, part[(size_t)f * nblocks + i].v, part[(size_t)f * nblocks + i].idx);
-    out[f] = b;
+    for (int i = threadIdx.x; i < nblocks; i += blockDim.x) take<LAST>(b, part[(size_t)f * nblocks + i].v, part[(size_t)f * nblocks + i].idx);
+    sh[threadIdx.x] = b;
+    __syncthreads();
+    for (int st = TPB / 2; st > 0; st >>= 1) {
+        if (threadIdx.x < st) take<LAST>(sh[threadIdx.x], sh[threadIdx.x + st].v, sh[threadIdx.x + st].idx);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[f] = sh[0];
+    (void)nf;
 }
 
 int residuum(atomdev* h, bool three_d, bool ge, double* min, int loc[3]) {
@@ -255,11 +262,11 @@ int steady(atomdev* h, const int* ids, int nf, size_t off, size_t n, bool last, 
     SteadyArgs s; s.n = nf;
     for (int f = 0; f < nf; f++) { s.x[f] = h->f[ids[f]]; s.xn[f] = h->f[ids[f] + 9]; }
     if (last) {
-        hipLaunchKernelGGL(k_steady_partial<true>, dim3(nblocks), dim3(TPB), 0, h->stream, s, off, n, part);
-        hipLaunchKernelGGL(k_steady_final<true>, dim3(1), dim3(64), 0, h->stream, part, nblocks, nf, fin);
+        hipLaunchKernelGGL(k_steady_partial<true>, dim3(nblocks, nf), dim3(TPB), 0, h->stream, s, off, n, part);
+        hipLaunchKernelGGL(k_steady_final<true>, dim3(nf), dim3(TPB), 0, h->stream, part, nblocks, nf, fin);
     } else {
-        hipLaunchKernelGGL(k_steady_partial<false>, dim3(nblocks), dim3(TPB), 0, h->stream, s, off, n, part);
-        hipLaunchKernelGGL(k_steady_final<false>, dim3(1), dim3(64), 0, h->stream, part, nblocks, nf, fin);
+        hipLaunchKernelGGL(k_steady_partial<false>, dim3(nblocks, nf), dim3(TPB), 0, h->stream, s, off, n, part);
+        hipLaunchKernelGGL(k_steady_final<false>, dim3(nf), dim3(TPB), 0, h->stream, part, nblocks, nf, fin);
     }
     ATOMDEV_TRY(hipGetLastError());
     Best res[9];
