@@ -230,3 +230,41 @@ def test_rk_variants_same_bits(model, op, dims, seed):
         d.close()
     for k in out[0]:
         assert H.bits_equal(out[0][k], out[1][k]), (op, k, H.max_rel_err(out[0][k], out[1][k]))
+
+
+def test_residuum_scan_adversarial_fields():
+    """The residuum scan (signed store, unsigned compare) on fields built to stress its jump logic:
+    many sign changes, long runs of negative values, exact ties and zeros, magnitudes that shrink or
+    grow along the sequence, and a carried-in state that nothing or everything beats.  Grid 6 x 9 x 1100:
+    every level is several scan chunks, with a ragged last one."""
+    im, jm, km = 6, 9, 1100
+    rng = np.random.default_rng(77)
+    kk = np.arange(km, dtype=np.float64)[None, None, :]
+    ii = np.arange(im, dtype=np.float64)[:, None, None]
+    shapes = {
+        "random": lambda: rng.uniform(-1, 1, (im, jm, km)),
+        "integers_with_ties": lambda: rng.integers(-3, 4, (im, jm, km)).astype(np.float64),
+        "mostly_zero": lambda: np.where(rng.uniform(0, 1, (im, jm, km)) < .01, rng.uniform(-1, 1, (im, jm, km)), 0.),
+        "shrinking_negative": lambda: -np.exp(-kk / 300.) * (1. + ii) * np.ones((im, jm, km)),
+        "growing_alternating": lambda: (1. + kk / km) * np.where((np.arange(km) % 2) == 0, 1., -1.)[None, None, :] * np.ones((im, jm, km)),
+        "all_negative_random": lambda: -rng.uniform(0, 1, (im, jm, km)),
+    }
+    for model, op, ge in ((H.ATM, "atm_residuum3d", False), (H.HYD, "hyd_residuum3d", True)):
+        p = H.default_params(model, im, jm, km)
+        f, g = H.make_inputs(model, im, jm, km, 5, "allfluid", p)
+        names = H.ATM_FIELDS if model == H.ATM else H.HYD_FIELDS
+        f = {k: f[k] for k in names}
+        o = H.CpuModel("oracle", model, im, jm, km, p, f, g)
+        d = atom_amd.DeviceModel(model, im, jm, km, atom_amd.Params.from_buffer_copy(bytes(p)))
+        d.upload_all(f, g)
+        for name, make in shapes.items():
+            for fld in ("U", "V", "W"):
+                a = make() if fld == "U" else (make() * .1 if name == "random" else np.zeros((im, jm, km)))
+                o.f[fld][...] = a
+                d.upload(fld, a)
+            for carried in ((0.0, (0, 0, 0)), (1e30, (1, 2, 3)), (-5.0, (1, 1, 1))):
+                ro = o.residuum(op, *carried)
+                rd = d.residuum(op, *carried)
+                assert ro == rd, (op, name, carried, ro, rd)
+        o.close()
+        d.close()
