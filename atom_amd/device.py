@@ -18,7 +18,7 @@ F3 = dict(T=0, U=1, V=2, W=3, P_DYN=4, C=5, CLOUD=6, ICE=7, CO2=8,
           H=18, AUX_U=19, AUX_V=20, AUX_W=21, BUOYANCY=22,
           S_V=23, S_C=24, S_I=25, S_R=26, S_S=27,
           SALT_BALANCE=28, SALT_FINGER=29, SALT_DIFFUSION=30, R_WATER=31, R_SALT_WATER=32,
-          RESIDUUM=33)
+          RESIDUUM=33, P_STAT=34)
 F2 = dict(TOPOGRAPHY=0, EVAPORATION_DALTON=1, PRECIPITATION=2)
 
 
@@ -28,7 +28,7 @@ class Params(C.Structure):
         "dt", "dr", "dthe", "dphi", "r0", "the0", "phi0",
         "re", "pr", "g", "Buoyancy", "u_0", "t_0", "c_0",
         "sc_WaterVapour", "sc_CO2", "gam", "r_air", "R_Air", "R_WaterVapour", "L_atm", "cp_l", "t_tropopause",
-        "sc", "L_hyd", "r_0_water", "ta", "pa", "ca")]
+        "sc", "L_hyd", "r_0_water", "ta", "pa", "ca", "p_0")]
 
 
 class AtomDevError(RuntimeError):
@@ -38,7 +38,7 @@ class AtomDevError(RuntimeError):
 _OPS = ["atm_bc_radius", "atm_bc_theta", "atm_bc_phi", "atm_value_limitation", "atm_solid_ground",
         "atm_rk3d", "atm_rk2d", "atm_pressure3d", "atm_pressure2d",
         "hyd_bc_radius", "hyd_bc_theta", "hyd_bc_phi", "hyd_value_limitation", "hyd_solid_ground",
-        "hyd_rk3d", "hyd_rk2d", "hyd_pressure3d", "hyd_pressure2d"]
+        "hyd_rk3d", "hyd_rk2d", "hyd_pressure3d", "hyd_pressure2d", "hyd_pressure_density"]
 
 _lib = None
 

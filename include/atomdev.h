@@ -44,7 +44,8 @@ enum atomdev_field3d {
     ATOMDEV_SALT_BALANCE = 28, ATOMDEV_SALT_FINGER, ATOMDEV_SALT_DIFFUSION,
     ATOMDEV_R_WATER, ATOMDEV_R_SALT_WATER,                         /* hyd only */
     ATOMDEV_RESIDUUM = 33,       /* continuity residuum written by *_residuum3d/2d */
-    ATOMDEV_N3D = 34
+    ATOMDEV_P_STAT = 34,         /* hydrostatic pressure: bar in the hydrosphere, hPa in the atmosphere */
+    ATOMDEV_N3D = 35
 };
 
 /* 2-D fields (jm*km doubles each, index j*km + k). */
@@ -68,6 +69,8 @@ typedef struct atomdev_params {
            t_tropopause;
     /* hydrosphere */
     double sc, L_hyd, r_0_water, ta, pa, ca;
+    /* both models */
+    double p_0;                 /* reference pressure in hPa */
 } atomdev_params;
 
 /* Fills *p with the reference defaults for `model` on the 1-degree grid. */
@@ -143,6 +146,10 @@ int atomdev_hyd_bc_phi(atomdev_t* h);
 int atomdev_hyd_value_limitation(atomdev_t* h);
 /* BC_Bathymetry_Hydrosphere::BC_SolidGround (hydrosphere/BC_Bath_Hyd.cpp:120-139) */
 int atomdev_hyd_solid_ground(atomdev_t* h);
+/* BC_Thermohalin::BC_Pressure_Density (hydrosphere/BC_Thermohalin.cpp:518-583): hydrostatic
+ * pressure and the densities of water and salt water, integrated down each column from the
+ * surface level im-1.  Reads t, c; writes p_stat, r_water, r_salt_water at every point. */
+int atomdev_hyd_pressure_density(atomdev_t* h);
 /* solveRungeKutta_3D_Hydrosphere + RK_RHS_3D_Hydrosphere
  * (hydrosphere/RungeKutta_Hyd.cpp:30-124, RHS_Hyd.cpp:60-447) */
 int atomdev_hyd_rk3d(atomdev_t* h);

@@ -25,6 +25,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <string>
 #include <vector>
 
 #include "Array.h"
@@ -381,6 +382,39 @@ private:
         pull_all(d, { { ATOMDEV_T, &t }, { ATOMDEV_U, &u }, { ATOMDEV_V, &v }, { ATOMDEV_W, &w }, { ATOMDEV_P_DYN, &p_dyn },
                       { ATOMDEV_C, &c } });
     }
+    int im_, jm_, km_;
+};
+
+// hydrosphere/BC_Thermohalin.h: the two members the 3-D loop calls every iteration
+// (hydrosphere/cHydrosphereModel.cpp:448-451); the initial-condition builders stay on the host.
+class BC_Thermohalin {
+public:
+    BC_Thermohalin(int im, int jm, int km, int, int, int, int, int, double dr, double g, double r_0_water, double, double, double,
+                   double ta, double ca, double pa, double u_0, double p_0, double t_0, double c_0, double, double L_hyd, double,
+                   double, double, double, const std::string&)
+        : im_(im), jm_(jm), km_(km) {
+        atomdev_params& p = Device::of(ATOMDEV_HYD).params();
+        p.dr = dr; p.g = g; p.r_0_water = r_0_water; p.ta = ta; p.ca = ca; p.pa = pa; p.u_0 = u_0; p.p_0 = p_0; p.t_0 = t_0;
+        p.c_0 = c_0; p.L_hyd = L_hyd;
+    }
+    // hydrosphere/BC_Thermohalin.cpp:518-583 (h is an argument the reference never reads)
+    void BC_Pressure_Density(Array& p_stat, Array& r_water, Array& r_salt_water, Array& t, Array& c, Array&) {
+        Device& d = Device::of(ATOMDEV_HYD);
+        d.grid(im_, jm_, km_);
+        push_all(d, { { ATOMDEV_T, &t }, { ATOMDEV_C, &c } });
+        d.run(atomdev_hyd_pressure_density(d.handle()), "atomdev_hyd_pressure_density");
+        pull_all(d, { { ATOMDEV_P_STAT, &p_stat }, { ATOMDEV_R_WATER, &r_water }, { ATOMDEV_R_SALT_WATER, &r_salt_water } });
+    }
+    // hydrosphere/BC_Thermohalin.cpp:699-722 (h and p_dyn are not touched)
+    void Value_Limitation_Hyd(Array&, Array& u, Array& v, Array& w, Array&, Array& t, Array& c) {
+        Device& d = Device::of(ATOMDEV_HYD);
+        d.grid(im_, jm_, km_);
+        push_all(d, { { ATOMDEV_U, &u }, { ATOMDEV_V, &v }, { ATOMDEV_W, &w }, { ATOMDEV_T, &t }, { ATOMDEV_C, &c } });
+        d.run(atomdev_hyd_value_limitation(d.handle()), "atomdev_hyd_value_limitation");
+        pull_all(d, { { ATOMDEV_U, &u }, { ATOMDEV_V, &v }, { ATOMDEV_W, &w }, { ATOMDEV_T, &t }, { ATOMDEV_C, &c } });
+    }
+
+private:
     int im_, jm_, km_;
 };
 

@@ -878,6 +878,47 @@ void oracle_hyd_value_limitation(oracle_ctx* c) {
             }
 }
 
+/* BC_Thermohalin::BC_Pressure_Density, hydrosphere/BC_Thermohalin.cpp:518-583.  The local
+ * r_air / R_Air of the reference function (:533-534) shadow the model parameters. */
+void oracle_hyd_pressure_density(oracle_ctx* c) {
+    const atomdev_params* P = &c->p;
+    const int im = c->im;
+    const double E_water = 2.15e9, beta_water = 8.8e-5, r_air = 1.2041, R_Air = 287.1;
+    const double t_0 = P->t_0, c_0 = P->c_0;
+    for (int k = 0; k < c->km; k++)
+        for (int j = 0; j < c->jm; j++) {
+            double t1 = A3(c, ATOMDEV_T, im - 1, j, k), cc = A3(c, ATOMDEV_C, im - 1, j, k);
+            A3(c, ATOMDEV_P_STAT, im - 1, j, k) = .01 * (r_air * R_Air * t1 * t_0) / 1000.;
+            A3(c, ATOMDEV_R_WATER, im - 1, j, k) = P->r_0_water;
+            double t_Celsius_1 = t1 * t_0 - t_0;
+            double C_p = 999.83, beta_p = .808;
+            double alfa_t_p = .0708 * (1. + .068 * t_Celsius_1);
+            double gamma_t_p = .003 * (1. - .012 * t_Celsius_1);
+            A3(c, ATOMDEV_R_SALT_WATER, im - 1, j, k) = C_p + beta_p * cc * c_0 - alfa_t_p * t_Celsius_1
+                                                        - gamma_t_p * (c_0 - cc * c_0) * t_Celsius_1;
+        }
+    for (int k = 0; k < c->km; k++)
+        for (int j = 0; j < c->jm; j++)
+            for (int i = im - 2; i >= 0; i--) {
+                double d_i = (double)(im - 1 - i);
+                double cc = A3(c, ATOMDEV_C, i, j, k);
+                double t_Celsius_1 = A3(c, ATOMDEV_T, i, j, k) * t_0 - t_0;
+                double t_Celsius_0 = A3(c, ATOMDEV_T, i + 1, j, k) * t_0 - t_0;
+                double rw1 = A3(c, ATOMDEV_R_WATER, i + 1, j, k);
+                double ps = rw1 * P->g * d_i * (P->L_hyd / (double)(im - 1)) / 100000. + P->p_0 / 1000.;
+                A3(c, ATOMDEV_P_STAT, i, j, k) = ps;
+                A3(c, ATOMDEV_R_WATER, i, j, k) = rw1 / (1. + beta_water * (t_Celsius_1 - t_Celsius_0))
+                                                  / (1. - (ps - A3(c, ATOMDEV_P_STAT, i + 1, j, k)) / E_water * 1e5);
+                double p_km = (double)(im - 1 - i) * (P->L_hyd / (double)(im - 1)) / 1000.;
+                double C_p = 999.83 + 5.053 * p_km - .048 * p_km * p_km;
+                double beta_p = .808 - .0085 * p_km;
+                double alfa_t_p = .0708 * (1. + .351 * p_km + .068 * (1. - .0683 * p_km) * t_Celsius_1);
+                double gamma_t_p = .003 * (1. - .059 * p_km - .012 * (1. - .064 * p_km) * t_Celsius_1);
+                A3(c, ATOMDEV_R_SALT_WATER, i, j, k) = C_p + beta_p * cc * c_0 - alfa_t_p * t_Celsius_1
+                                                       - gamma_t_p * (c_0 - cc * c_0) * t_Celsius_1;
+            }
+}
+
 /* BC_Bathymetry_Hydrosphere::BC_SolidGround, hydrosphere/BC_Bath_Hyd.cpp:120-139 */
 void oracle_hyd_solid_ground(oracle_ctx* c) {
     for (int i = 0; i < c->im; i++)
@@ -1125,7 +1166,7 @@ void oracle_default_params(int model, atomdev_params* p) {
     const double pi180 = 180. / M_PI;
     p->dt = 0.00001; p->dr = 0.025; p->dthe = 1. / pi180; p->dphi = 1. / pi180;
     p->r0 = 1.; p->the0 = 0.; p->phi0 = 0.;
-    p->g = 9.8066; p->Buoyancy = 1.0; p->t_0 = 273.15;
+    p->g = 9.8066; p->Buoyancy = 1.0; p->t_0 = 273.15; p->p_0 = 1013.25; /* param.py:92,151 */
     if (model == ATOMDEV_ATM) {
         p->re = 1000.; p->pr = .7179; p->u_0 = 8.; p->c_0 = .035;
     } else {

@@ -33,6 +33,7 @@
 #include "RungeKutta_Hyd.h"
 #include "Pressure_Hyd.h"
 #include "BC_Hyd.h"
+#include "BC_Thermohalin.h"
 
 #include "../include/atomdev_mirror.hpp"
 
@@ -41,12 +42,14 @@ namespace {
 struct RefClasses {
     typedef ::RHS_Atmosphere RHS_A; typedef ::RungeKutta_Atmosphere RK_A; typedef ::Pressure_Atm P_A; typedef ::BC_Atmosphere BC_A;
     typedef ::RHS_Hydrosphere RHS_H; typedef ::RungeKutta_Hydrosphere RK_H; typedef ::Pressure_Hyd P_H; typedef ::BC_Hydrosphere BC_H;
+    typedef ::BC_Thermohalin TH_H;
 };
 struct DevClasses {
     typedef atomdev_mirror::RHS_Atmosphere RHS_A; typedef atomdev_mirror::RungeKutta_Atmosphere RK_A;
     typedef atomdev_mirror::Pressure_Atm P_A; typedef atomdev_mirror::BC_Atmosphere BC_A;
     typedef atomdev_mirror::RHS_Hydrosphere RHS_H; typedef atomdev_mirror::RungeKutta_Hydrosphere RK_H;
     typedef atomdev_mirror::Pressure_Hyd P_H; typedef atomdev_mirror::BC_Hydrosphere BC_H;
+    typedef atomdev_mirror::BC_Thermohalin TH_H;
 };
 
 struct Scalars {
@@ -166,11 +169,15 @@ void hydrosphere_calls(Fields& F, const Scalars& s) {
     boundary.RB_radius(s.ca, s.ta, s.pa, s.dr, F.rad, F["t"], F["u"], F["v"], F["w"], F["p_dyn"], F["c"]);
     boundary.RB_theta(s.ca, s.ta, s.pa, F["t"], F["u"], F["v"], F["w"], F["p_dyn"], F["c"]);
     boundary.RB_phi(F["t"], F["u"], F["v"], F["w"], F["p_dyn"], F["c"]);
+    typename NS::TH_H oceanflow(im, jm, km, 0, im - 1, 0, 300, 150, s.dr, s.g, s.r_0_water, 0., 0., 0., s.ta, s.ca, s.pa, s.u_0,
+                                1013.25, s.t_0, s.c_0, 4182.0, s.L_hyd, 15.0, 10.0, 1.1355, 1.0146, "");
+    oceanflow.BC_Pressure_Density(F["p_stat"], F["r_water"], F["r_salt_water"], F["t"], F["c"], F["h"]);
+    oceanflow.Value_Limitation_Hyd(F["h"], F["u"], F["v"], F["w"], F["p_dyn"], F["t"], F["c"]);
     result.solveRungeKutta_3D_Hydrosphere(prepare, n, s.L_hyd, s.g, 4182.0, s.u_0, s.t_0, s.c_0, s.r_0_water, s.ta, s.pa, s.ca,
         F.rad, F.the, F.phi, F.evap, F.precip, F["h"], F["rhs0"], F["rhs1"], F["rhs2"], F["rhs3"], F["rhs4"],
         F["t"], F["u"], F["v"], F["w"], F["p_dyn"], F["c"], F["tn"], F["un"], F["vn"], F["wn"], F["p_dynn"], F["cn"],
         F["aux_u"], F["aux_v"], F["aux_w"], F["Salt_Finger"], F["Salt_Diffusion"], F["Buoyancy_Force"], F["Salt_Balance"],
-        F["spare"], F["r_water"], F["r_salt_water"], F.topo);
+        F["p_stat"], F["r_water"], F["r_salt_water"], F.topo);
     startPressure.computePressure_3D(s.u_0, s.r_0_water, F.rad, F.the, F["p_dyn"], F["p_dynn"], F["h"], F["aux_u"], F["aux_v"], F["aux_w"]);
     result.solveRungeKutta_2D_Hydrosphere(prepare_2D, n, s.r_0_water, F.rad, F.the, F.phi, F["rhs2"], F["rhs3"],
         F["h"], F["v"], F["w"], F["p_dyn"], F["vn"], F["wn"], F["p_dynn"], F["aux_v"], F["aux_w"]);

@@ -299,6 +299,15 @@ void ref_hyd_value_limitation(void* v) {
     copy_out(c);
 }
 
+void ref_hyd_pressure_density(void* v) {
+    RefCtx* c = (RefCtx*)v; CoutSilencer s; copy_in(c);
+    const atomdev_params& P = c->p;
+    BC_Thermohalin oceanflow(c->im, c->jm, c->km, 0, c->im - 1, 0, 300, 150, P.dr, P.g, P.r_0_water, 0., 0., 0., P.ta,
+                             P.ca, P.pa, P.u_0, P.p_0, P.t_0, P.c_0, 4182.0, P.L_hyd, 15.0, 10.0, 1.1355, 1.0146, "");
+    oceanflow.BC_Pressure_Density(A(P_STAT), A(R_WATER), A(R_SALT_WATER), A(T), A(C), A(H));
+    copy_out(c);
+}
+
 void ref_hyd_solid_ground(void* v) {
     RefCtx* c = (RefCtx*)v; CoutSilencer s; copy_in(c);
     BC_Bathymetry_Hydrosphere depth(c->im, c->jm, c->km);

@@ -28,7 +28,7 @@ F3 = dict(T=0, U=1, V=2, W=3, P_DYN=4, C=5, CLOUD=6, ICE=7, CO2=8,
           H=18, AUX_U=19, AUX_V=20, AUX_W=21, BUOYANCY=22,
           S_V=23, S_C=24, S_I=25, S_R=26, S_S=27,
           SALT_BALANCE=28, SALT_FINGER=29, SALT_DIFFUSION=30, R_WATER=31, R_SALT_WATER=32,
-          RESIDUUM=33)
+          RESIDUUM=33, P_STAT=34)
 F2 = dict(TOPOGRAPHY=0, EVAPORATION_DALTON=1, PRECIPITATION=2)
 
 ATM_FIELDS = ["T", "U", "V", "W", "P_DYN", "C", "CLOUD", "ICE", "CO2",
@@ -36,7 +36,7 @@ ATM_FIELDS = ["T", "U", "V", "W", "P_DYN", "C", "CLOUD", "ICE", "CO2",
               "H", "AUX_U", "AUX_V", "AUX_W", "BUOYANCY", "S_V", "S_C", "S_I", "S_R", "S_S", "RESIDUUM"]
 HYD_FIELDS = ["T", "U", "V", "W", "P_DYN", "C", "TN", "UN", "VN", "WN", "P_DYNN", "CN",
               "H", "AUX_U", "AUX_V", "AUX_W", "BUOYANCY",
-              "SALT_BALANCE", "SALT_FINGER", "SALT_DIFFUSION", "R_WATER", "R_SALT_WATER", "RESIDUUM"]
+              "SALT_BALANCE", "SALT_FINGER", "SALT_DIFFUSION", "R_WATER", "R_SALT_WATER", "RESIDUUM", "P_STAT"]
 FIELDS2D = ["TOPOGRAPHY", "EVAPORATION_DALTON", "PRECIPITATION"]
 
 
@@ -45,7 +45,7 @@ class Params(C.Structure):
         "dt", "dr", "dthe", "dphi", "r0", "the0", "phi0",
         "re", "pr", "g", "Buoyancy", "u_0", "t_0", "c_0",
         "sc_WaterVapour", "sc_CO2", "gam", "r_air", "R_Air", "R_WaterVapour", "L_atm", "cp_l", "t_tropopause",
-        "sc", "L_hyd", "r_0_water", "ta", "pa", "ca")]
+        "sc", "L_hyd", "r_0_water", "ta", "pa", "ca", "p_0")]
 
 
 def build_oracle():
@@ -203,6 +203,7 @@ def make_inputs(model, im, jm, km, seed=1234, mask="blobs", params=None):
         names = ["T", "U", "V", "W", "P_DYN", "C"]
         f["R_WATER"] = U(995.0, 1005.0)
         f["R_SALT_WATER"] = U(1020.0, 1035.0)
+        f["P_STAT"] = np.random.default_rng(seed + 7919).uniform(1.0, 100.0, shp)  # own stream: the other draws stay as they were
         for s in ["SALT_BALANCE", "SALT_FINGER", "SALT_DIFFUSION"]:
             f[s] = np.zeros(shp)
     for nme in names:
@@ -241,7 +242,7 @@ def max_rel_err(a, b):
 
 ATM_SEQ = ["atm_bc_radius", "atm_bc_theta", "atm_bc_phi", "atm_solid_ground", "atm_rk3d",
            "atm_pressure3d", "atm_rk2d", "atm_pressure2d", "move3d", "atm_rk3d"]
-HYD_SEQ = ["hyd_bc_radius", "hyd_bc_theta", "hyd_bc_phi", "hyd_value_limitation", "hyd_rk3d",
+HYD_SEQ = ["hyd_bc_radius", "hyd_bc_theta", "hyd_bc_phi", "hyd_pressure_density", "hyd_value_limitation", "hyd_rk3d",
            "hyd_solid_ground", "hyd_pressure3d", "move3d", "hyd_rk3d"]
 HYD_SURFACE_SEQ = ["hyd_rk2d", "hyd_pressure2d", "move2d", "hyd_rk2d"]
 

@@ -20,6 +20,7 @@ BYTES = {
     "atm_pressure3d": upd * 48, "hyd_pressure3d": upd * 48,
     "atm_value_limitation": n3 * 152, "hyd_value_limitation": n3 * 88,
     "move3d(atm)": n3 * 16 * 9, "move3d(hyd)": n3 * 16 * 6,
+    "hyd_pressure_density": n3 * 40,
 }
 print("| operator | ms per call | algorithmic GB/s | % of 8 TB/s |")
 print("|---|---|---|---|")
@@ -33,6 +34,8 @@ for model, pre in ((H.ATM, "atm"), (H.HYD, "hyd")):
     d.upload_all(f, g)
     ops = [pre + "_" + o for o in ("bc_radius", "bc_theta", "bc_phi", "value_limitation", "solid_ground", "rk3d",
                                     "pressure3d", "rk2d", "pressure2d")] + ["move3d(%s)" % pre, "residuum3d", "steady3d"]
+    if model == H.HYD:
+        ops.append("hyd_pressure_density")
     for op in ops:
         def call():
             if op.startswith("move3d"):
