@@ -88,8 +88,13 @@ static int upload_tables(atomdev* h) {
     std::vector<double> rad(nrad), st(jm), ct(jm);
     rad[0] = p->r0;
     for (int l = 1; l < nrad; l++) rad[l] = rad[l - 1] + p->dr;
-    double the = p->the0;
-    for (int j = 0; j < jm; j++) { if (j) the = the + p->dthe; st[j] = sin(the); ct[j] = cos(the); }
+    // sin and cos in loops of their own: a compiler that sees both calls on one argument may merge them
+    // into sincos(), whose sine differs from sin() in the last place for some angles
+    std::vector<double> the(jm);
+    the[0] = p->the0;
+    for (int j = 1; j < jm; j++) the[j] = the[j - 1] + p->dthe;
+    for (int j = 0; j < jm; j++) st[j] = sin(the[j]);
+    for (int j = 0; j < jm; j++) ct[j] = cos(the[j]);
     const size_t nb = (size_t)im * jm * sizeof(double);
     if (!h->rad) ATOMDEV_TRY(hipMalloc(&h->rad, nrad * sizeof(double)));
     if (!h->sinthe) ATOMDEV_TRY(hipMalloc(&h->sinthe, jm * sizeof(double)));
@@ -142,7 +147,7 @@ extern "C" int atomdev_create(int model, int im, int jm, int km, const atomdev_p
     h->profile_rk = false; h->prof_used = 0;
     h->scr[0] = h->scr[1] = nullptr; h->tab_rm2sin = h->tab_irm2sin = h->tab_coefv = nullptr;
     h->rk_variant = 0;
-    h->ws_params = nullptr;
+    h->ws_params = nullptr; h->surf = nullptr;
     if (const char* e = getenv("ATOMDEV_RK_VARIANT")) h->rk_variant = atoi(e);
     h->rad = h->sinthe = h->costhe = h->plane = nullptr; h->red = nullptr;
     fill_constants(h);
@@ -208,6 +213,7 @@ extern "C" int atomdev_destroy(atomdev_t* h) {
     if (h->tab_irm2sin) (void)hipFree(h->tab_irm2sin);
     if (h->tab_coefv) (void)hipFree(h->tab_coefv);
     if (h->ws_params) (void)hipFree(h->ws_params);
+    if (h->surf) (void)hipFree(h->surf);
     for (int n = 0; n < 2; n++) if (h->scr[n]) (void)hipFree(h->scr[n]);
     for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
     if (h->ev0) (void)hipEventDestroy(h->ev0);

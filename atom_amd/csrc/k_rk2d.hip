@@ -49,23 +49,118 @@ __device__ __forceinline__ double diff(const Diff& D, double centre, double nA, 
 //   theta second derivatives: central outside window_j, zero inside; then, inside window_k, replaced by the
 //       PHI one-sided form h_d_k (2 x - 2 x(k+-1) + x(k+-2)) / dphi2 where L && f(+-1) && f(+-2) (the reference
 //       assigns d2vdthe2 there: RHS_Atm.cpp:616-617, 637-638; the s = -1 side wins); outside window_k zero.
+struct PointIn {
+    double vc, wc, vn, wn;                                   // centre: current and "new"-array values
+    double v_tp, v_tm, v_pp, v_pm, w_tp, w_tm, w_pp, w_pm;   // theta +-1, phi +-1 neighbours
+    double v_pp2, v_pm2, w_pp2, w_pm2;                       // phi +-2 (read only inside window_k)
+    double p_c, p_tp, p_tm, p_pp, p_pm;
+    unsigned m;                                              // land tests, M_* bits (the +-2 ones set outside window_k)
+};
+enum : unsigned { M_L = 1, M_FLUID_C = 2, M_TP = 4, M_TM = 8, M_PP = 16, M_PM = 32, M_PP2 = 64, M_PM2 = 128 };
+struct PointOut { double v, w, aux_v, aux_w; };
+
+// All four RK stages at one surface point (RungeKutta_Atm.cpp:176-214 around RHS_Atm.cpp:498-678).
+__device__ __forceinline__ PointOut rk_point(const PointIn& in, const RowGeo& G, bool win_j, bool win_k,
+                                             const Rk2dArgs& a, const DevConst& K) {
+    const double dt = K.dt;
+    const double rm = a.rm, rm2 = rm * rm;
+    const bool L = in.m & M_L, fluid_c = in.m & M_FLUID_C;
+    const bool l_tp = in.m & M_TP, l_tm = in.m & M_TM, l_pp = in.m & M_PP, l_pm = in.m & M_PM, l_pp2 = in.m & M_PP2, l_pm2 = in.m & M_PM2;
+    double h_0_j, h_d_j, h_0_k, h_d_k;
+    if (fluid_c && (l_tp || l_tm)) { h_0_j = 1.; h_d_j = 0.; } else { h_0_j = 0.; h_d_j = 1.; }
+    if (fluid_c && (l_pp || l_pm)) { h_0_k = 1.; h_d_k = 0.; } else { h_0_k = 0.; h_d_k = 1.; }
+
+    // ---- the surviving variant of every difference ----
+    // central {0, 1, -1} / 2 d; forward two-point {-1, 1, 0} / d; backward two-point {1, 0, -1} / d (wins)
+    const bool t_fwd = win_j && L && !l_tp, t_bwd = win_j && L && !l_tm;
+    const bool p_fwd = L && !l_pp, p_bwd = win_k ? (L && !l_pm) : (fluid_c && l_pm);
+    const int t_sel = t_bwd ? 2 : (t_fwd ? 1 : 0), p_sel = p_bwd ? 2 : (p_fwd ? 1 : 0);
+    Diff T1, P1, T2;
+    T1.cc = t_sel == 2 ? 1. : (t_sel == 1 ? -1. : 0.); T1.c1 = t_sel == 2 ? 0. : 1.; T1.c2 = t_sel == 1 ? 0. : -1.;
+    T1.h = h_d_j; T1.div = t_sel ? K.dthe : K.two_dthe; T1.idiv = t_sel ? K.i_dthe : K.i_two_dthe;
+    P1.cc = p_sel == 2 ? 1. : (p_sel == 1 ? -1. : 0.); P1.c1 = p_sel == 2 ? 0. : 1.; P1.c2 = p_sel == 1 ? 0. : -1.;
+    P1.h = h_d_k; P1.div = p_sel ? K.dphi : K.two_dphi; P1.idiv = p_sel ? a.i_dphi : a.i_two_dphi;
+    // theta second derivative and its two neighbour operands: zero {0, 0, 0} inside window_j, central {-2, 1, 1}
+    // outside it, zero again outside window_k; inside window_k the PHI one-sided form {2, -2, 1} on (k, k+-1, k+-2)
+    // where the centre is land and both cells on that side are fluid (the s = -1 side wins)
+    const bool o_fwd = win_k && L && !l_pp && !l_pp2, o_bwd = win_k && L && !l_pm && !l_pm2;
+    const bool one_sided = o_fwd || o_bwd, central2 = !win_j && win_k && !one_sided;
+    T2.cc = one_sided ? 2. : (central2 ? -2. : 0.); T2.c1 = one_sided ? -2. : (central2 ? 1. : 0.);
+    T2.c2 = (one_sided || central2) ? 1. : 0.;
+    T2.h = one_sided ? h_d_k : h_d_j; T2.div = one_sided ? K.dphi2 : K.dthe2; T2.idiv = one_sided ? K.i_dphi2 : K.i_dthe2;
+    // (operands copied out of the struct as opaque values: a select between two struct members otherwise becomes a
+    // load through a selected address and pins the whole struct in scratch memory)
+    double s_tp[2] = { in.v_tp, in.w_tp }, s_tm[2] = { in.v_tm, in.w_tm }, s_pp[2] = { in.v_pp, in.w_pp };
+    double s_pm[2] = { in.v_pm, in.w_pm }, s_pp2[2] = { in.v_pp2, in.w_pp2 }, s_pm2[2] = { in.v_pm2, in.w_pm2 };
+#pragma unroll
+    for (int n = 0; n < 2; n++) {
+        asm volatile("" : "+v"(s_tp[n]), "+v"(s_tm[n]), "+v"(s_pp[n]), "+v"(s_pm[n]), "+v"(s_pp2[n]), "+v"(s_pm2[n]));
+    }
+    const double v2A = o_bwd ? s_pm[0] : (o_fwd ? s_pp[0] : s_tp[0]), v2B = o_bwd ? s_pm2[0] : (o_fwd ? s_pp2[0] : s_tm[0]);
+    const double w2A = o_bwd ? s_pm[1] : (o_fwd ? s_pp[1] : s_tp[1]), w2B = o_bwd ? s_pm2[1] : (o_fwd ? s_pp2[1] : s_tm[1]);
+    // pressure gradient terms do not change during the stages
+    const double dpdthe = diff(T1, in.p_c, in.p_tp, in.p_tm), dpdphi = diff(P1, in.p_c, in.p_pp, in.p_pm);
+    const double pg_v = div_by(div_by(h_d_j * dpdthe, rm, a.i_rm), a.rho, a.i_rho);         // h_d_j * dpdthe / rm / rho
+    const double pg_w = div_by(div_by(h_d_k * dpdphi, G.rmsin, G.i_rmsin), a.rho, a.i_rho);
+
+    double vc = in.vc, wc = in.wc;
+    const double vn = in.vn, wn = in.wn;
+    double kv[4], kw[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const double dvdthe = diff(T1, vc, in.v_tp, in.v_tm), dwdthe = diff(T1, wc, in.w_tp, in.w_tm);
+        const double dvdphi = diff(P1, vc, in.v_pp, in.v_pm), dwdphi = diff(P1, wc, in.w_pp, in.w_pm);
+        const double d2vdthe2 = diff(T2, vc, v2A, v2B), d2wdthe2 = diff(T2, wc, w2A, w2B);
+        // RHS_Atm.cpp:664-677 / RHS_Hyd.cpp:632-645 (k_Force = 1; the phi second derivatives are zero)
+        kv[s] = -(div_by(vc * dvdthe, rm, a.i_rm) + div_by(wc * dvdphi, G.rmsin, G.i_rmsin))
+                + -pg_v
+                - div_by(div_by(d2vdthe2, rm2, a.i_rm2) + div_by(dvdthe, G.rm2sin, G.i_rm2sin) * G.costhe
+                         - G.coef * h_d_j * vc
+                         - div_by(dwdphi * 2. * G.costhe, G.rm2sin2, G.i_rm2sin2), K.re, K.i_re)
+                - div_by(h_0_j * vc, K.dthe2, K.i_dthe2);
+        kw[s] = -(div_by(vc * dwdthe, rm, a.i_rm) + div_by(wc * dwdphi, G.rmsin, G.i_rmsin))
+                + -pg_w
+                + div_by(div_by(d2wdthe2, rm2, a.i_rm2) + div_by(dwdthe, G.rm2sin, G.i_rm2sin) * G.costhe
+                         - G.coef * h_d_k * wc
+                         + div_by(dvdphi * 2. * G.costhe, G.rm2sin2, G.i_rm2sin2), K.re, K.i_re)
+                - div_by(h_0_k * wc, K.dphi2, K.i_dphi2);
+        if (s < 2) { vc = vn + kv[s] * .5 * dt; wc = wn + kw[s] * .5 * dt; }
+        else if (s == 2) { vc = vn + kv[s] * dt; wc = wn + kw[s] * dt; }
+    }
+    PointOut o;
+    o.v = vn + div_by(dt * (kv[0] + 2. * kv[1] + 2. * kv[2] + kv[3]), 6., K.i_six);
+    o.w = wn + div_by(dt * (kw[0] + 2. * kw[1] + 2. * kw[2] + kw[3]), 6., K.i_six);
+    o.aux_v = kv[3] + pg_v; o.aux_w = kw[3] + pg_w;
+    return o;
+}
+
+// M_* bits from the flags of the centre and its four neighbours; the +-2 bits start set
+__device__ __forceinline__ unsigned land_mask(uint8_t fc, int hyd, uint8_t tp, uint8_t tm, uint8_t pp, uint8_t pm) {
+    const bool L = (fc & FL_LAND) != 0;
+    const bool fluid_c = hyd ? ((fc & FL_HZERO) != 0) : !L;
+    return (L ? M_L : 0u) | (fluid_c ? M_FLUID_C : 0u) | ((tp & FL_LAND) ? M_TP : 0u) | ((tm & FL_LAND) ? M_TM : 0u)
+           | ((pp & FL_LAND) ? M_PP : 0u) | ((pm & FL_LAND) ? M_PM : 0u) | M_PP2 | M_PM2;
+}
+
+__device__ __forceinline__ RowGeo row_geometry(const Rk2dArgs& a, int j) {
+    const double rm = a.rm, rm2 = rm * rm;
+    const double sinthe = a.sinthe[j], sinthe2 = sinthe * sinthe, costhe = a.costhe[j];
+    RowGeo g;
+    g.costhe = costhe;
+    g.rmsin = rm * sinthe; g.rm2sin = rm2 * sinthe; g.rm2sin2 = rm2 * sinthe2;
+    g.i_rmsin = 1. / g.rmsin; g.i_rm2sin = 1. / g.rm2sin; g.i_rm2sin2 = 1. / g.rm2sin2;
+    g.coef = 1. + costhe * costhe / sinthe2;
+    return g;
+}
+
+// Fallback for grids with more interior rows than one workgroup has threads: the fields stay in their
+// row-major layout, a thread takes whatever rows of the diagonal fall to it, and every neighbour goes
+// through global memory (the barrier orders the writes of diagonal d before the reads of d + 1).
 __global__ __launch_bounds__(256) void k_rk2d(Rk2dArgs a, DevConst K) {
     extern __shared__ RowGeo geo[];  // [jm]
     const int jm = K.jm, km = K.km;
-    const double dt = K.dt;
-    const double rm = a.rm, rm2 = rm * rm;
-    {
-        for (int j = threadIdx.x; j < jm; j += blockDim.x) {
-            const double sinthe = a.sinthe[j], sinthe2 = sinthe * sinthe, costhe = a.costhe[j];
-            RowGeo g;
-            g.costhe = costhe;
-            g.rmsin = rm * sinthe; g.rm2sin = rm2 * sinthe; g.rm2sin2 = rm2 * sinthe2;
-            g.i_rmsin = 1. / g.rmsin; g.i_rm2sin = 1. / g.rm2sin; g.i_rm2sin2 = 1. / g.rm2sin2;
-            g.coef = 1. + costhe * costhe / sinthe2;
-            geo[j] = g;
-        }
-        __syncthreads();
-    }
+    for (int j = threadIdx.x; j < jm; j += blockDim.x) geo[j] = row_geometry(a, j);
+    __syncthreads();
     const long R = km;
     const int dmax = (jm - 2) + (km - 2);
     for (int d = 2; d <= dmax; d++) {
@@ -74,85 +169,126 @@ __global__ __launch_bounds__(256) void k_rk2d(Rk2dArgs a, DevConst K) {
             const int k = d - j;
             const size_t q = (size_t)j * km + k;
             const bool win_j = (j >= 2) && (j < jm - 3), win_k = (k >= 2) && (k < km - 3);
-            // ---- neighbourhood, read once: updated values on the side already swept, old ones ahead ----
-            const double v_tp = a.v[q + R], v_tm = a.v[q - R], v_pp = a.v[q + 1], v_pm = a.v[q - 1];
-            const double w_tp = a.w[q + R], w_tm = a.w[q - R], w_pp = a.w[q + 1], w_pm = a.w[q - 1];
-            const double p_tp = a.p[q + R], p_tm = a.p[q - R], p_pp = a.p[q + 1], p_pm = a.p[q - 1], p_c = a.p[q];
-            const uint8_t fc = a.fl[q];
-            const bool L = (fc & FL_LAND) != 0;
-            const bool fluid_c = a.hyd ? ((fc & FL_HZERO) != 0) : !L;
-            const bool l_tp = (a.fl[q + R] & FL_LAND) != 0, l_tm = (a.fl[q - R] & FL_LAND) != 0;
-            const bool l_pp = (a.fl[q + 1] & FL_LAND) != 0, l_pm = (a.fl[q - 1] & FL_LAND) != 0;
-            bool l_pp2 = true, l_pm2 = true;
-            if (win_k) { l_pp2 = (a.fl[q + 2] & FL_LAND) != 0; l_pm2 = (a.fl[q - 2] & FL_LAND) != 0; }
-            const double vn = a.vn[q], wn = a.wn[q];
-            double vc = a.v[q], wc = a.w[q];
-            const RowGeo G = geo[j];
-
-            double h_0_j, h_d_j, h_0_k, h_d_k;
-            if (fluid_c && (l_tp || l_tm)) { h_0_j = 1.; h_d_j = 0.; } else { h_0_j = 0.; h_d_j = 1.; }
-            if (fluid_c && (l_pp || l_pm)) { h_0_k = 1.; h_d_k = 0.; } else { h_0_k = 0.; h_d_k = 1.; }
-
-            // ---- the surviving variant of every difference ----
-            Diff T1 = { 0., 1., -1., h_d_j, K.two_dthe, K.i_two_dthe };  // central
-            if (win_j && L && !l_tp) T1 = { -1., 1., 0., h_d_j, K.dthe, K.i_dthe };   // forward two-point
-            if (win_j && L && !l_tm) T1 = { 1., 0., -1., h_d_j, K.dthe, K.i_dthe };   // backward two-point (wins)
-            Diff P1 = { 0., 1., -1., h_d_k, K.two_dphi, a.i_two_dphi };
+            PointIn in;
+            in.v_tp = a.v[q + R]; in.v_tm = a.v[q - R]; in.v_pp = a.v[q + 1]; in.v_pm = a.v[q - 1];
+            in.w_tp = a.w[q + R]; in.w_tm = a.w[q - R]; in.w_pp = a.w[q + 1]; in.w_pm = a.w[q - 1];
+            in.p_tp = a.p[q + R]; in.p_tm = a.p[q - R]; in.p_pp = a.p[q + 1]; in.p_pm = a.p[q - 1]; in.p_c = a.p[q];
+            in.m = land_mask(a.fl[q], a.hyd, a.fl[q + R], a.fl[q - R], a.fl[q + 1], a.fl[q - 1]);
+            in.v_pp2 = in.v_pm2 = in.w_pp2 = in.w_pm2 = 0.;
             if (win_k) {
-                if (L && !l_pp) P1 = { -1., 1., 0., h_d_k, K.dphi, a.i_dphi };
-                if (L && !l_pm) P1 = { 1., 0., -1., h_d_k, K.dphi, a.i_dphi };
-            } else {
-                if (L && !l_pp) P1 = { -1., 1., 0., h_d_k, K.dphi, a.i_dphi };
-                if (fluid_c && l_pm) P1 = { 1., 0., -1., h_d_k, K.dphi, a.i_dphi };
+                if (!(a.fl[q + 2] & FL_LAND)) in.m &= ~M_PP2;
+                if (!(a.fl[q - 2] & FL_LAND)) in.m &= ~M_PM2;
+                in.v_pp2 = a.v[q + 2]; in.v_pm2 = a.v[q - 2]; in.w_pp2 = a.w[q + 2]; in.w_pm2 = a.w[q - 2];
             }
-            // theta second derivative and its two neighbour operands (theta neighbours, or phi neighbours in the one-sided form)
-            Diff T2 = { 0., 0., 0., h_d_j, K.dthe2, K.i_dthe2 };  // zero
-            double v2A = v_tp, v2B = v_tm, w2A = w_tp, w2B = w_tm;
-            if (!win_j) T2 = { -2., 1., 1., h_d_j, K.dthe2, K.i_dthe2 };  // central
-            if (win_k) {
-                if (L && !l_pp && !l_pp2) {
-                    T2 = { 2., -2., 1., h_d_k, K.dphi2, K.i_dphi2 };
-                    v2A = v_pp; v2B = a.v[q + 2]; w2A = w_pp; w2B = a.w[q + 2];
-                }
-                if (L && !l_pm && !l_pm2) {
-                    T2 = { 2., -2., 1., h_d_k, K.dphi2, K.i_dphi2 };
-                    v2A = v_pm; v2B = a.v[q - 2]; w2A = w_pm; w2B = a.w[q - 2];
-                }
-            } else {
-                T2 = { 0., 0., 0., h_d_j, K.dthe2, K.i_dthe2 };
-            }
-            // pressure gradient terms do not change during the stages
-            const double dpdthe = diff(T1, p_c, p_tp, p_tm), dpdphi = diff(P1, p_c, p_pp, p_pm);
-            const double pg_v = div_by(div_by(h_d_j * dpdthe, rm, a.i_rm), a.rho, a.i_rho);         // h_d_j * dpdthe / rm / rho
-            const double pg_w = div_by(div_by(h_d_k * dpdphi, G.rmsin, G.i_rmsin), a.rho, a.i_rho);
-
-            double kv[4], kw[4];
-#pragma unroll
-            for (int s = 0; s < 4; s++) {
-                const double dvdthe = diff(T1, vc, v_tp, v_tm), dwdthe = diff(T1, wc, w_tp, w_tm);
-                const double dvdphi = diff(P1, vc, v_pp, v_pm), dwdphi = diff(P1, wc, w_pp, w_pm);
-                const double d2vdthe2 = diff(T2, vc, v2A, v2B), d2wdthe2 = diff(T2, wc, w2A, w2B);
-                // RHS_Atm.cpp:664-677 / RHS_Hyd.cpp:632-645 (k_Force = 1; the phi second derivatives are zero)
-                kv[s] = -(div_by(vc * dvdthe, rm, a.i_rm) + div_by(wc * dvdphi, G.rmsin, G.i_rmsin))
-                        + -pg_v
-                        - div_by(div_by(d2vdthe2, rm2, a.i_rm2) + div_by(dvdthe, G.rm2sin, G.i_rm2sin) * G.costhe
-                                 - G.coef * h_d_j * vc
-                                 - div_by(dwdphi * 2. * G.costhe, G.rm2sin2, G.i_rm2sin2), K.re, K.i_re)
-                        - div_by(h_0_j * vc, K.dthe2, K.i_dthe2);
-                kw[s] = -(div_by(vc * dwdthe, rm, a.i_rm) + div_by(wc * dwdphi, G.rmsin, G.i_rmsin))
-                        + -pg_w
-                        + div_by(div_by(d2wdthe2, rm2, a.i_rm2) + div_by(dwdthe, G.rm2sin, G.i_rm2sin) * G.costhe
-                                 - G.coef * h_d_k * wc
-                                 + div_by(dvdphi * 2. * G.costhe, G.rm2sin2, G.i_rm2sin2), K.re, K.i_re)
-                        - div_by(h_0_k * wc, K.dphi2, K.i_dphi2);
-                if (s < 2) { vc = vn + kv[s] * .5 * dt; wc = wn + kw[s] * .5 * dt; }
-                else if (s == 2) { vc = vn + kv[s] * dt; wc = wn + kw[s] * dt; }
-            }
-            a.v[q] = vn + div_by(dt * (kv[0] + 2. * kv[1] + 2. * kv[2] + kv[3]), 6., K.i_six);
-            a.w[q] = wn + div_by(dt * (kw[0] + 2. * kw[1] + 2. * kw[2] + kw[3]), 6., K.i_six);
-            a.aux_v[q] = kv[3] + pg_v; a.aux_w[q] = kw[3] + pg_w;
+            in.vn = a.vn[q]; in.wn = a.wn[q];
+            in.vc = a.v[q]; in.wc = a.w[q];
+            const PointOut o = rk_point(in, geo[j], win_j, win_k, a, K);
+            a.v[q] = o.v; a.w[q] = o.w; a.aux_v[q] = o.aux_v; a.aux_w[q] = o.aux_w;
         }
-        __syncthreads();  // orders the global writes of diagonal d before the reads of d+1 within this workgroup
+        __syncthreads();
+    }
+}
+
+// ---- the same sweep with one thread per row ----
+// Surface fields in a skewed copy: point (j, k) lives at [j + k][j] (pitch P), so the points of one anti-
+// diagonal, and each of their neighbour sets, are contiguous across the rows = across the lanes of a wave.
+struct Skewed {
+    double *v, *w, *p, *vn, *wn, *aux_v, *aux_w;
+    uint8_t* fl;
+    int P;
+};
+
+__global__ void k_skew(Rk2dArgs a, Skewed s, int jm, int km) {
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= jm * km) return;
+    const int j = id / km, k = id - j * km;
+    const size_t o = (size_t)(j + k) * s.P + j;
+    s.v[o] = a.v[id]; s.w[o] = a.w[id]; s.p[o] = a.p[id]; s.vn[o] = a.vn[id]; s.wn[o] = a.wn[id]; s.fl[o] = a.fl[id];
+}
+
+__global__ void k_unskew(Rk2dArgs a, Skewed s, int jm, int km) {
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= jm * km) return;
+    const int j = id / km, k = id - j * km;
+    if (j < 1 || j > jm - 2 || k < 1 || k > km - 2) return;  // the sweep writes interior points only
+    const size_t o = (size_t)(j + k) * s.P + j;
+    a.v[id] = s.v[o]; a.w[id] = s.w[o]; a.aux_v[id] = s.aux_v[o]; a.aux_w[id] = s.aux_w[o];
+}
+
+// What a thread reads from memory for its point on a diagonal; fetched one diagonal ahead.
+struct Fetched {
+    PointIn in;          // without v_tm, w_tm, v_pm, w_pm, v_pm2, w_pm2 (results of this sweep)
+    double v_b, w_b;     // (j, 0): the phi-boundary values, wanted when k == 1
+    double v_t0, w_t0;   // (0, k): the theta-boundary row, wanted by row 1
+    bool active;
+};
+
+// Thread t owns row j = t + 1 and walks it with the diagonals (k = d - j).  Of the values the sweep itself
+// produces, (j, k-1) and (j, k-2) are the thread's own last two results (registers) and (j-1, k) is the
+// neighbour thread's result of the previous diagonal (LDS, double-buffered); everything else is old or
+// static data, fetched from the skewed copy one diagonal ahead.  So no global memory access sits on the
+// chain of 538 dependent diagonals (1-degree grid), only an LDS exchange and one barrier per diagonal.
+template <int MAX_THREADS>
+__global__ __launch_bounds__(MAX_THREADS) void k_rk2d_rows(Rk2dArgs a, Skewed s, DevConst K) {
+    extern __shared__ double ex[];  // [2][P][2]: new (v, w) of row j on the last two diagonals
+    const int jm = K.jm, km = K.km, P = s.P;
+    const int j = (int)threadIdx.x + 1;
+    const bool row = j <= jm - 2;
+    const bool win_j = (j >= 2) && (j < jm - 3);
+    RowGeo G = row_geometry(a, row ? j : 1);
+    const int dmax = (jm - 2) + (km - 2);
+
+    auto fetch = [&](int d) {
+        Fetched f;
+        const int k = d - j;
+        f.active = row && k >= 1 && k <= km - 2;
+        f.v_b = f.w_b = f.v_t0 = f.w_t0 = 0.;
+        PointIn& in = f.in;
+        in.vc = in.wc = in.vn = in.wn = in.v_tp = in.v_tm = in.v_pp = in.v_pm = in.w_tp = in.w_tm = in.w_pp = in.w_pm = 0.;
+        in.v_pp2 = in.v_pm2 = in.w_pp2 = in.w_pm2 = in.p_c = in.p_tp = in.p_tm = in.p_pp = in.p_pm = 0.;
+        in.m = 0;
+        if (f.active) {
+            const size_t o = (size_t)d * P + j;           // (j, k)
+            const size_t o_tp = o + P + 1, o_tm = o - P - 1, o_pp = o + P, o_pm = o - P;
+            in.vc = s.v[o]; in.wc = s.w[o]; in.vn = s.vn[o]; in.wn = s.wn[o];
+            in.v_tp = s.v[o_tp]; in.w_tp = s.w[o_tp]; in.v_pp = s.v[o_pp]; in.w_pp = s.w[o_pp];
+            in.p_c = s.p[o]; in.p_tp = s.p[o_tp]; in.p_tm = s.p[o_tm]; in.p_pp = s.p[o_pp]; in.p_pm = s.p[o_pm];
+            in.m = land_mask(s.fl[o], a.hyd, s.fl[o_tp], s.fl[o_tm], s.fl[o_pp], s.fl[o_pm]);
+            if ((k >= 2) && (k < km - 3)) {
+                if (!(s.fl[o_pp + P] & FL_LAND)) in.m &= ~M_PP2;
+                if (!(s.fl[o_pm - P] & FL_LAND)) in.m &= ~M_PM2;
+                in.v_pp2 = s.v[o_pp + P]; in.w_pp2 = s.w[o_pp + P];
+            }
+            if (k == 1) { f.v_b = s.v[o_pm]; f.w_b = s.w[o_pm]; }
+            if (j == 1) { f.v_t0 = s.v[o_tm]; f.w_t0 = s.w[o_tm]; }
+        }
+        return f;
+    };
+
+    double v_m1 = 0., w_m1 = 0., v_m2 = 0., w_m2 = 0.;  // own results at k-1, k-2
+    Fetched nx = fetch(2);
+    for (int d = 2; d <= dmax; d++) {
+        const Fetched cur = nx;
+        nx = fetch(d + 1);
+        if (cur.active) {
+            const int k = d - j;
+            if (k == 1) { v_m1 = cur.v_b; w_m1 = cur.w_b; }
+            PointIn in = cur.in;
+            if (j == 1) { in.v_tm = cur.v_t0; in.w_tm = cur.w_t0; }
+            else {
+                const double* e = ex + ((size_t)((d - 1) & 1) * P + (j - 1)) * 2;
+                in.v_tm = e[0]; in.w_tm = e[1];
+            }
+            in.v_pm = v_m1; in.w_pm = w_m1; in.v_pm2 = v_m2; in.w_pm2 = w_m2;
+            const bool win_k = (k >= 2) && (k < km - 3);
+            const PointOut o = rk_point(in, G, win_j, win_k, a, K);
+            const size_t q = (size_t)d * P + j;
+            s.v[q] = o.v; s.w[q] = o.w; s.aux_v[q] = o.aux_v; s.aux_w[q] = o.aux_w;
+            double* e = ex + ((size_t)(d & 1) * P + j) * 2;
+            e[0] = o.v; e[1] = o.w;
+            v_m2 = v_m1; w_m2 = w_m1; v_m1 = o.v; w_m1 = o.w;
+        }
+        lds_barrier();
     }
 }
 
@@ -173,8 +309,36 @@ int rk2d(atomdev* h, bool hyd) {
     a.hyd = hyd ? 1 : 0;
     a.i_rm = 1. / a.rm; a.i_rm2 = 1. / (a.rm * a.rm); a.i_rho = 1. / a.rho;
     a.i_two_dphi = 1. / h->k.two_dphi; a.i_dphi = 1. / h->k.dphi;
-    hipLaunchKernelGGL(k_rk2d, dim3(1), dim3(256), (size_t)h->jm * sizeof(RowGeo), h->stream, a, h->k);
-    return atomdev_check(hipGetLastError(), "k_rk2d");
+    const int rows = h->jm - 2, threads = (rows + 63) / 64 * 64;
+    if (threads > 1024 || h->rk_variant == 1) {
+        hipLaunchKernelGGL(k_rk2d, dim3(1), dim3(256), (size_t)h->jm * sizeof(RowGeo), h->stream, a, h->k);
+        return atomdev_check(hipGetLastError(), "k_rk2d");
+    }
+    // skewed copy of the surface: 7 fp64 arrays and the flags, jm + km + 2 diagonals of pitch P
+    const int P = (h->jm + 15) & ~15;
+    const size_t ndiag = (size_t)h->jm + h->km + 2, cells = ndiag * P;
+    if (!h->surf) {
+        ATOMDEV_TRY(hipMalloc(&h->surf, cells * (7 * sizeof(double) + 1)));
+        ATOMDEV_TRY(hipMemsetAsync(h->surf, 0, cells * (7 * sizeof(double) + 1), h->stream));
+    }
+    Skewed s;
+    double* base = (double*)h->surf;
+    s.v = base; s.w = base + cells; s.p = base + 2 * cells; s.vn = base + 3 * cells; s.wn = base + 4 * cells;
+    s.aux_v = base + 5 * cells; s.aux_w = base + 6 * cells; s.fl = (uint8_t*)(base + 7 * cells);
+    s.P = P;
+    const unsigned nb = (unsigned)((h->n2 + 255) / 256);
+    hipLaunchKernelGGL(k_skew, dim3(nb), dim3(256), 0, h->stream, a, s, h->jm, h->km);
+    ATOMDEV_TRY(hipGetLastError());
+    const size_t lds = (size_t)2 * P * 2 * sizeof(double);
+    if (threads <= 256)
+        hipLaunchKernelGGL(k_rk2d_rows<256>, dim3(1), dim3(threads), lds, h->stream, a, s, h->k);
+    else if (threads <= 768)  // three waves per SIMD: the register allocation still fits without spills
+        hipLaunchKernelGGL(k_rk2d_rows<768>, dim3(1), dim3(threads), lds, h->stream, a, s, h->k);
+    else
+        hipLaunchKernelGGL(k_rk2d_rows<1024>, dim3(1), dim3(threads), lds, h->stream, a, s, h->k);
+    ATOMDEV_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_unskew, dim3(nb), dim3(256), 0, h->stream, a, s, h->jm, h->km);
+    return atomdev_check(hipGetLastError(), "k_unskew");
 }
 
 }  // namespace

@@ -96,6 +96,19 @@ def test_atm_everything_but_rk3d_bitexact():
     _run_sequence(H.ATM, (9, 23, 67), 31, "blobs", seq)
 
 
+@pytest.mark.parametrize("jm", [301, 801, 1101])
+def test_atm_surface_sweep_many_rows_bitexact(jm):
+    """The surface sweep runs one thread per row: 256-, 768- and 1024-thread forms, and beyond 1024 rows the
+    form that loops over the rows of a diagonal; the 1-degree grid only reaches the first."""
+    seq = ["atm_rk2d", "move2d", "atm_rk2d"]
+    _run_sequence(H.ATM, (5, jm, 11), 40 + jm, "blobs", seq)
+    o, d, names = _pair(H.ATM, (5, 45, 37), 47, "blobs")
+    d.set_rk_variant(1)  # the looping form on a small grid as well
+    H.run_op(o, "atm_rk2d"); _dev_op(d, "atm_rk2d")
+    _compare(o, d, names, "atm_rk2d", exact=True)
+    d.close()
+
+
 def test_golden_small_hyd_bitexact():
     """HIP path against the compiled reference's own outputs (tests/golden/hyd_small.npz)."""
     z = np.load(os.path.join(GOLD, "hyd_small.npz"))
