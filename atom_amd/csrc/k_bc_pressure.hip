@@ -293,6 +293,14 @@ int pressure2d(atomdev* h, bool hyd) {
 
 }  // namespace
 
+// Neumann fill of rows j = 0, jm-1 (every i, k) / averaged-seam fill of columns k = 0, km-1 (every i,
+// j in [j0, j1)) of one field, for operators in other translation units.
+int atomdev_fill_theta_neumann(atomdev* h, int field) {
+    const int mode = FILL_NEUMANN;
+    return fill_theta(h, &field, &mode, 1, 0, h->im);
+}
+int atomdev_fill_phi_seam(atomdev* h, int field, int j0, int j1) { return fill_phi(h, &field, 1, 0, h->im, j0, j1); }
+
 extern "C" int atomdev_atm_bc_radius(atomdev_t* h) {
     ATOMDEV_REQUIRE(h && h->model == ATOMDEV_ATM, "atomdev_atm_bc_radius: not an atmosphere handle");
     ATOMDEV_TRY(hipSetDevice(h->device));

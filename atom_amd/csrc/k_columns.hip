@@ -55,7 +55,149 @@ __global__ void k_hyd_pressure_density(const double* __restrict__ t, const doubl
     }
 }
 
+// Results_MSL_Atm::run_MSL_data (atmosphere/Results_Atm.cpp:139-353) without its printout.
+struct MslArgs {
+    const double *t, *v, *w, *q_latent, *q_sensible, *radiation_3d, *co2;
+    double *c, *cloud, *ice, *p_rain, *p_snow, *p_stat;
+    double *q_radiation, *precipitable_water, *evaporation_penman, *evaporation_dalton, *q_evaporation, *q_latent_2d,
+           *q_sensible_2d, *q_bottom, *co2_total, *precipitation;
+    const uint8_t* flags;
+    int im, radiation_model;
+    size_t n2;
+    double r_air, R_Air, t_0, g, L_atm, ep, hp, cp_l, lv, u_0, R_WaterVapour;
+};
+
+// Results_MSL_Atm::C_Dalton (Results_Atm.cpp:685-692)
+__device__ __forceinline__ double c_dalton(double u_0, double v, double w) {
+    const double C_max = -.053, v_max = 10.;
+    const double vel_magnitude = sqrt(v * v + w * w) * u_0;
+    return sqrt(C_max * C_max / v_max * vel_magnitude);
+}
+
+__device__ __forceinline__ void clamp_at_zero(double* p) {
+    const double x = *p;
+    if (x < 0.) *p = 0.;
+}
+
+// One thread per column.  First walk (:149-243): the surface branches, evaluated at every top of the
+// topography (land cell with air above; the last one met wins the 2-D fields) and on the sea surface;
+// second walk (:280-353): the zero clamps and the precipitable-water sum, which reads the p_stat and c
+// values the first walk and the clamps left behind.  The reference's test of the cell above level
+// im-1 (one level outside the array) counts as "not air".
+__global__ void k_atm_msl_columns(MslArgs a) {
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= a.n2) return;
+    const size_t n2 = a.n2;
+    const int im = a.im;
+    const double f_Penman = 2.;
+    const double step = a.L_atm / (double)(im - 1);
+    double q_rad = a.q_radiation[q];
+    if (a.radiation_model >= 1) { q_rad = a.radiation_3d[q]; a.q_radiation[q] = q_rad; }
+    double ev_penman = 0., ev_dalton = 0.;
+    double ps0 = a.p_stat[q];
+    bool land = (a.flags[q] & FL_LAND) != 0;
+    for (int i = 0; i < im; i++) {
+        const size_t id = (size_t)i * n2 + q;
+        const bool land_above = (i + 1 < im) ? (a.flags[id + n2] & FL_LAND) != 0 : true;
+        const bool summit = land && !land_above, sea = (i == 0) && !land;
+        if (summit || sea) {
+            const double t = a.t[id], cc = a.c[id];
+            double ps;
+            if (i == 0) { ps = (a.r_air * a.R_Air * t * a.t_0) * .01; ps0 = ps; }
+            else ps = exp(-a.g * (double)i * step / (a.R_Air * t * a.t_0)) * ps0;
+            a.p_stat[id] = ps;
+            const double t_Celsius = t * a.t_0 - a.t_0;
+            const double e = cc * ps / a.ep;
+            const double t_denom = t_Celsius + 234.175;
+            const double E = a.hp * exp(17.0809 * t_Celsius / t_denom);
+            const double Delta = 4000. * E / (t_denom * t_denom);
+            const double sat_deficit = (E - e);
+            const double gamma = ps0 * a.cp_l / (a.ep * a.lv);
+            const double v1 = a.v[id + n2], w1 = a.w[id + n2];  // level i + 1 exists in both branches
+            const double E_a = .35 * (1. + .15 * sqrt((v1 * v1 + w1 * w1) / 2.) * a.u_0 * 3.6) * sat_deficit;
+            double q_evap;
+            if (summit) q_evap = 2300.;
+            else if (t_Celsius >= -2.) q_evap = (2500.8 - 2.372 * (t * a.t_0 - a.t_0));
+            else q_evap = (2500.8 - 2.372 * (t * a.t_0 - a.t_0)) + 300.;
+            a.q_evaporation[q] = q_evap;
+            const double q_lat = a.q_latent[id], q_sen = a.q_sensible[id];
+            const double q_bot = -(q_rad - q_lat - q_sen);
+            a.q_latent_2d[q] = q_lat; a.q_sensible_2d[q] = q_sen; a.q_bottom[q] = q_bot;
+            double ed = c_dalton(a.u_0, a.v[id], a.w[id]) * sat_deficit * 24.;
+            if (ed <= 0.) ed = 0.;
+            double epm = f_Penman * .0346 * ((q_rad + q_bot) * Delta + gamma * E_a) / (Delta + gamma);
+            if (epm <= 0.) epm = 0.;
+            ev_penman = epm;
+            ev_dalton = summit ? .5 * epm : ed;
+        }
+        land = land_above;
+    }
+    a.evaporation_penman[q] = ev_penman;
+    a.evaporation_dalton[q] = ev_dalton;
+    a.co2_total[q] = a.co2[q];
+
+    double pw = 0.;
+    for (int i = 0; i < im; i++) {
+        const size_t id = (size_t)i * n2 + q;
+        double cc = a.c[id];
+        if (cc < 0.) { cc = 0.; a.c[id] = 0.; }
+        clamp_at_zero(a.cloud + id); clamp_at_zero(a.ice + id);
+        clamp_at_zero(a.p_rain + id); clamp_at_zero(a.p_snow + id);
+        const double e = 100. * cc * a.p_stat[id] / a.ep;
+        const double ah = e / (a.R_WaterVapour * a.t[id] * a.t_0);
+        pw = pw + ah * a.L_atm / (double)(im - 1);
+    }
+    a.precipitable_water[q] = pw;
+    double pr = 86400. * (a.p_rain[q] + a.p_snow[q]);
+    if (pr >= 25.) pr = 25.;
+    if (pr <= 0) pr = 0.;
+    a.precipitation[q] = pr;
+}
+
+// BuoyancyForce on the bottom and top levels (Results_Atm.cpp:248-256): interior (j, k) only
+__global__ void k_buoyancy_fill_r(double* b, const uint8_t* flags, int im, int jm, int km) {
+    const size_t n2 = (size_t)jm * km;
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n2) return;
+    const int j = (int)(q / km), k = (int)(q - (size_t)j * km);
+    if (j < 1 || j > jm - 2 || k < 1 || k > km - 2) return;
+    const double c43 = 4. / 3., c13 = 1. / 3.;
+    const size_t top = (size_t)(im - 1) * n2 + q;
+    b[q] = (flags[q] & FL_LAND) ? 0. : c43 * b[n2 + q] - c13 * b[2 * n2 + q];
+    b[top] = c43 * b[top - n2] - c13 * b[top - 2 * n2];
+}
+
 }  // namespace
+
+extern "C" int atomdev_atm_msl_data(atomdev_t* h, int RadiationModel) {
+    ATOMDEV_REQUIRE(h && h->model == ATOMDEV_ATM, "atomdev_atm_msl_data: not an atmosphere handle");
+    ATOMDEV_TRY(hipSetDevice(h->device));
+    if (int rc = atomdev_refresh_flags(h)) return rc;
+    const atomdev_params& P = h->p;
+    MslArgs a;
+    a.t = h->f[ATOMDEV_T]; a.v = h->f[ATOMDEV_V]; a.w = h->f[ATOMDEV_W];
+    a.q_latent = h->f[ATOMDEV_Q_LATENT]; a.q_sensible = h->f[ATOMDEV_Q_SENSIBLE]; a.radiation_3d = h->f[ATOMDEV_RADIATION_3D];
+    a.co2 = h->f[ATOMDEV_CO2];
+    a.c = h->f[ATOMDEV_C]; a.cloud = h->f[ATOMDEV_CLOUD]; a.ice = h->f[ATOMDEV_ICE];
+    a.p_rain = h->f[ATOMDEV_P_RAIN]; a.p_snow = h->f[ATOMDEV_P_SNOW]; a.p_stat = h->f[ATOMDEV_P_STAT];
+    a.q_radiation = h->g[ATOMDEV_Q_RADIATION]; a.precipitable_water = h->g[ATOMDEV_PRECIPITABLE_WATER];
+    a.evaporation_penman = h->g[ATOMDEV_EVAPORATION_PENMAN]; a.evaporation_dalton = h->g[ATOMDEV_EVAPORATION_DALTON];
+    a.q_evaporation = h->g[ATOMDEV_Q_EVAPORATION]; a.q_latent_2d = h->g[ATOMDEV_Q_LATENT_2D];
+    a.q_sensible_2d = h->g[ATOMDEV_Q_SENSIBLE_2D]; a.q_bottom = h->g[ATOMDEV_Q_BOTTOM];
+    a.co2_total = h->g[ATOMDEV_CO2_TOTAL]; a.precipitation = h->g[ATOMDEV_PRECIPITATION];
+    a.flags = h->flags; a.im = h->im; a.radiation_model = RadiationModel; a.n2 = h->n2;
+    a.r_air = P.r_air; a.R_Air = P.R_Air; a.t_0 = P.t_0; a.g = P.g; a.L_atm = P.L_atm; a.ep = P.ep; a.hp = P.hp;
+    a.cp_l = P.cp_l; a.lv = P.lv; a.u_0 = P.u_0; a.R_WaterVapour = P.R_WaterVapour;
+    const unsigned nb = (unsigned)((h->n2 + TPB - 1) / TPB);
+    hipLaunchKernelGGL(k_atm_msl_columns, dim3(nb), dim3(TPB), 0, h->stream, a);
+    ATOMDEV_TRY(hipGetLastError());
+    // boundary values of BuoyancyForce, r then theta then phi as in the reference (:248-278)
+    hipLaunchKernelGGL(k_buoyancy_fill_r, dim3(nb), dim3(TPB), 0, h->stream, h->f[ATOMDEV_BUOYANCY], h->flags, h->im, h->jm,
+                       h->km);
+    ATOMDEV_TRY(hipGetLastError());
+    if (int rc = atomdev_fill_theta_neumann(h, ATOMDEV_BUOYANCY)) return rc;
+    return atomdev_fill_phi_seam(h, ATOMDEV_BUOYANCY, 1, h->jm - 1);
+}
 
 extern "C" int atomdev_hyd_pressure_density(atomdev_t* h) {
     ATOMDEV_REQUIRE(h && h->model == ATOMDEV_HYD, "atomdev_hyd_pressure_density: not a hydrosphere handle");

@@ -18,8 +18,9 @@ F3 = dict(T=0, U=1, V=2, W=3, P_DYN=4, C=5, CLOUD=6, ICE=7, CO2=8,
           H=18, AUX_U=19, AUX_V=20, AUX_W=21, BUOYANCY=22,
           S_V=23, S_C=24, S_I=25, S_R=26, S_S=27,
           SALT_BALANCE=28, SALT_FINGER=29, SALT_DIFFUSION=30, R_WATER=31, R_SALT_WATER=32,
-          RESIDUUM=33, P_STAT=34)
-F2 = dict(TOPOGRAPHY=0, EVAPORATION_DALTON=1, PRECIPITATION=2)
+          RESIDUUM=33, P_STAT=34, Q_LATENT=35, Q_SENSIBLE=36, RADIATION_3D=37, P_RAIN=38, P_SNOW=39)
+F2 = dict(TOPOGRAPHY=0, EVAPORATION_DALTON=1, PRECIPITATION=2, Q_RADIATION=3, PRECIPITABLE_WATER=4,
+          EVAPORATION_PENMAN=5, Q_EVAPORATION=6, Q_LATENT_2D=7, Q_SENSIBLE_2D=8, Q_BOTTOM=9, CO2_TOTAL=10)
 
 
 class Params(C.Structure):
@@ -28,7 +29,7 @@ class Params(C.Structure):
         "dt", "dr", "dthe", "dphi", "r0", "the0", "phi0",
         "re", "pr", "g", "Buoyancy", "u_0", "t_0", "c_0",
         "sc_WaterVapour", "sc_CO2", "gam", "r_air", "R_Air", "R_WaterVapour", "L_atm", "cp_l", "t_tropopause",
-        "sc", "L_hyd", "r_0_water", "ta", "pa", "ca", "p_0")]
+        "sc", "L_hyd", "r_0_water", "ta", "pa", "ca", "p_0", "ep", "hp", "lv", "ls")]
 
 
 class AtomDevError(RuntimeError):
@@ -73,6 +74,7 @@ def load_library():
     lib.atomdev_fill.argtypes = [vp, C.c_int, C.c_double]
     lib.atomdev_sync.argtypes = [vp]
     lib.atomdev_move_data_to_new_arrays.argtypes = [vp, C.c_int]
+    lib.atomdev_atm_msl_data.argtypes = [vp, C.c_int]
     for op in _OPS:
         getattr(lib, "atomdev_" + op).argtypes = [vp]
     for name in ("atomdev_atm_residuum3d", "atomdev_atm_residuum2d", "atomdev_hyd_residuum3d"):
@@ -180,6 +182,10 @@ class DeviceModel:
     def op(self, name):
         """One reference operator, e.g. 'atm_rk3d', 'hyd_pressure3d'."""
         self._check(getattr(self.lib, "atomdev_" + name)(self._h))
+
+    def msl_data(self, radiation_model=1):
+        """Results_MSL_Atm::run_MSL_data, the part that changes model fields."""
+        self._check(self.lib.atomdev_atm_msl_data(self._h, radiation_model))
 
     def move_data_to_new_arrays(self, level=-1):
         self._check(self.lib.atomdev_move_data_to_new_arrays(self._h, level))

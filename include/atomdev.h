@@ -45,7 +45,9 @@ enum atomdev_field3d {
     ATOMDEV_R_WATER, ATOMDEV_R_SALT_WATER,                         /* hyd only */
     ATOMDEV_RESIDUUM = 33,       /* continuity residuum written by *_residuum3d/2d */
     ATOMDEV_P_STAT = 34,         /* hydrostatic pressure: bar in the hydrosphere, hPa in the atmosphere */
-    ATOMDEV_N3D = 35
+    ATOMDEV_Q_LATENT = 35, ATOMDEV_Q_SENSIBLE, ATOMDEV_RADIATION_3D,
+    ATOMDEV_P_RAIN, ATOMDEV_P_SNOW,                                /* atm only: inputs of run_MSL_data */
+    ATOMDEV_N3D = 40
 };
 
 /* 2-D fields (jm*km doubles each, index j*km + k). */
@@ -53,7 +55,10 @@ enum atomdev_field2d {
     ATOMDEV_TOPOGRAPHY = 0,        /* Topography (atm) / Bathymetry (hyd), metres */
     ATOMDEV_EVAPORATION_DALTON = 1,
     ATOMDEV_PRECIPITATION = 2,
-    ATOMDEV_N2D = 3
+    /* atmosphere surface diagnostics written by run_MSL_data (atmosphere/cAtmosphereModel.h:206-227) */
+    ATOMDEV_Q_RADIATION = 3, ATOMDEV_PRECIPITABLE_WATER, ATOMDEV_EVAPORATION_PENMAN, ATOMDEV_Q_EVAPORATION,
+    ATOMDEV_Q_LATENT_2D, ATOMDEV_Q_SENSIBLE_2D, ATOMDEV_Q_BOTTOM, ATOMDEV_CO2_TOTAL,
+    ATOMDEV_N2D = 11
 };
 
 /* Scalars the hot path reads.  Names and meaning are those of the reference's
@@ -71,6 +76,9 @@ typedef struct atomdev_params {
     double sc, L_hyd, r_0_water, ta, pa, ca;
     /* both models */
     double p_0;                 /* reference pressure in hPa */
+    /* atmosphere, surface fluxes (Results_MSL_Atm): gas-constant ratio, vapour pressure at 0 C in hPa,
+       latent heats of evaporation and sublimation in J/kg */
+    double ep, hp, lv, ls;
 } atomdev_params;
 
 /* Fills *p with the reference defaults for `model` on the 1-degree grid. */
@@ -136,6 +144,15 @@ int atomdev_atm_residuum2d(atomdev_t* h, double* min, int loc[3]);
 int atomdev_atm_steady3d(atomdev_t* h, double out[9], int loc[27]);
 /* Accuracy_Atm::steadyQuery_2D (:118-177) on level 0: order v w p_dyn. */
 int atomdev_atm_steady2d(atomdev_t* h, double out[3], int loc[9]);
+
+/* Results_MSL_Atm::run_MSL_data (atmosphere/Results_Atm.cpp:118-353), the part that changes model
+ * fields (the printed averages that follow it are not produced): surface pressure, evaporation after
+ * Dalton and Penman and the heat fluxes at the top of the topography and on the sea surface of every
+ * column (writes p_stat there, the 2-D fields Q_radiation [if RadiationModel >= 1], Q_Evaporation,
+ * Q_latent, Q_sensible, Q_bottom, Evaporation_Dalton, Evaporation_Penman); boundary values of
+ * BuoyancyForce; c, cloud, ice, P_rain, P_snow clamped at zero; co2_total, precipitable_water and
+ * Precipitation.  Reads t, c, v, w, Q_Latent, Q_Sensible, radiation_3D, co2, h. */
+int atomdev_atm_msl_data(atomdev_t* h, int RadiationModel);
 
 /* ---- hydrosphere ---- */
 /* BC_Hydrosphere::RB_radius / RB_theta / RB_phi (hydrosphere/BC_Hyd.cpp:38-158) */

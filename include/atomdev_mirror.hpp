@@ -82,6 +82,10 @@ public:
         for (int j = 0; j < jm_; j++) std::memcpy(&stage_[(size_t)j * km_], a.y[j], sizeof(double) * km_);
         if (atomdev_upload2d(h, field, stage_.data())) die("atomdev_upload2d");
     }
+    void pull2d(int field, Array_2D& a) {
+        if (atomdev_download2d(handle(), field, stage_.data())) die("atomdev_download2d");
+        for (int j = 0; j < jm_; j++) std::memcpy(a.y[j], &stage_[(size_t)j * km_], sizeof(double) * km_);
+    }
     void run(int rc, const char* what) { if (rc) die(what); }
     static void die(const char* where) {
         std::cerr << "ERROR: " << where << ": " << atomdev_last_error() << std::endl;
@@ -238,6 +242,51 @@ public:
     ATOMDEV_MIRROR_ATM_BC(BC_theta, atomdev_atm_bc_theta)    // atmosphere/BC_Atm.cpp:80-107
     ATOMDEV_MIRROR_ATM_BC(BC_phi, atomdev_atm_bc_phi)        // atmosphere/BC_Atm.cpp:115-150
 #undef ATOMDEV_MIRROR_ATM_BC
+
+private:
+    int im_, jm_, km_;
+};
+
+// atmosphere/Results_Atm.h.  run_MSL_data without its printout (Results_Atm.cpp:355-625 prints averages and
+// values at three fixed 1-degree locations; nothing of that is fed back into the model).
+class Results_MSL_Atm {
+public:
+    Results_MSL_Atm(int im, int jm, int km, int, double g, double ep, double hp, double u_0, double p_0, double t_0, double,
+                    double, double, double, double lv, double ls, double cp_l, double L_atm, double, double, double, double,
+                    double r_air, double R_Air, double, double R_WaterVapour, double, double, double, double, double, double,
+                    double)
+        : im_(im), jm_(jm), km_(km) {
+        atomdev_params& p = Device::of(ATOMDEV_ATM).params();
+        p.g = g; p.ep = ep; p.hp = hp; p.u_0 = u_0; p.p_0 = p_0; p.t_0 = t_0; p.lv = lv; p.ls = ls; p.cp_l = cp_l;
+        p.L_atm = L_atm; p.r_air = r_air; p.R_Air = R_Air; p.R_WaterVapour = R_WaterVapour;
+    }
+    // atmosphere/Results_Atm.cpp:118-353
+    void run_MSL_data(int, int, int RadiationModel, double&, Array_1D&, Array_1D&, Array_1D&, Array& h, Array& c, Array&,
+                      Array& co2, Array&, Array& t, Array&, Array&, Array& p_stat, Array& BuoyancyForce, Array&, Array& v,
+                      Array& w, Array& Q_Latent, Array& Q_Sensible, Array& radiation_3D, Array& cloud, Array&, Array& ice,
+                      Array&, Array& P_rain, Array& P_snow, Array&, Array&, Array&, Array_2D&, Array_2D&,
+                      Array_2D& precipitable_water, Array_2D& Q_radiation, Array_2D& Q_Evaporation, Array_2D& Q_latent,
+                      Array_2D& Q_sensible, Array_2D& Q_bottom, Array_2D& Evaporation_Penman, Array_2D& Evaporation_Dalton,
+                      Array_2D&, Array_2D&, Array_2D& co2_total, Array_2D& Precipitation, Array&, Array&, Array&, Array&,
+                      Array&, Array&) {
+        Device& d = Device::of(ATOMDEV_ATM);
+        d.grid(im_, jm_, km_);
+        push_all(d, { { ATOMDEV_H, &h }, { ATOMDEV_T, &t }, { ATOMDEV_C, &c }, { ATOMDEV_V, &v }, { ATOMDEV_W, &w },
+                      { ATOMDEV_CO2, &co2 }, { ATOMDEV_CLOUD, &cloud }, { ATOMDEV_ICE, &ice }, { ATOMDEV_P_STAT, &p_stat },
+                      { ATOMDEV_BUOYANCY, &BuoyancyForce }, { ATOMDEV_Q_LATENT, &Q_Latent }, { ATOMDEV_Q_SENSIBLE, &Q_Sensible },
+                      { ATOMDEV_RADIATION_3D, &radiation_3D }, { ATOMDEV_P_RAIN, &P_rain }, { ATOMDEV_P_SNOW, &P_snow } });
+        // columns without a sea surface or a summit keep what these held
+        d.push2d(ATOMDEV_Q_RADIATION, Q_radiation); d.push2d(ATOMDEV_Q_EVAPORATION, Q_Evaporation);
+        d.push2d(ATOMDEV_Q_LATENT_2D, Q_latent); d.push2d(ATOMDEV_Q_SENSIBLE_2D, Q_sensible); d.push2d(ATOMDEV_Q_BOTTOM, Q_bottom);
+        d.run(atomdev_atm_msl_data(d.handle(), RadiationModel), "atomdev_atm_msl_data");
+        pull_all(d, { { ATOMDEV_C, &c }, { ATOMDEV_CLOUD, &cloud }, { ATOMDEV_ICE, &ice }, { ATOMDEV_P_STAT, &p_stat },
+                      { ATOMDEV_BUOYANCY, &BuoyancyForce }, { ATOMDEV_P_RAIN, &P_rain }, { ATOMDEV_P_SNOW, &P_snow } });
+        d.pull2d(ATOMDEV_Q_RADIATION, Q_radiation); d.pull2d(ATOMDEV_Q_EVAPORATION, Q_Evaporation);
+        d.pull2d(ATOMDEV_Q_LATENT_2D, Q_latent); d.pull2d(ATOMDEV_Q_SENSIBLE_2D, Q_sensible); d.pull2d(ATOMDEV_Q_BOTTOM, Q_bottom);
+        d.pull2d(ATOMDEV_PRECIPITABLE_WATER, precipitable_water); d.pull2d(ATOMDEV_EVAPORATION_PENMAN, Evaporation_Penman);
+        d.pull2d(ATOMDEV_EVAPORATION_DALTON, Evaporation_Dalton); d.pull2d(ATOMDEV_CO2_TOTAL, co2_total);
+        d.pull2d(ATOMDEV_PRECIPITATION, Precipitation);
+    }
 
 private:
     int im_, jm_, km_;

@@ -878,6 +878,143 @@ void oracle_hyd_value_limitation(oracle_ctx* c) {
             }
 }
 
+/* Results_MSL_Atm::C_Dalton, atmosphere/Results_Atm.cpp:685-692 */
+static double C_Dalton(double u_0, double v, double w) {
+    double C_max = -.053, v_max = 10.;
+    double vel_magnitude = sqrt(v * v + w * w) * u_0;
+    return sqrt(C_max * C_max / v_max * vel_magnitude);
+}
+
+/* Results_MSL_Atm::run_MSL_data, atmosphere/Results_Atm.cpp:118-353: everything that changes model
+ * fields; the averages and the printout that follow (:355-625) are not restated.  The reference tests
+ * is_air(h, i+1, j, k) for i = im-1 as well, one level above the array, when the top cell is land;
+ * here that cell counts as not air. */
+void oracle_atm_msl_data(oracle_ctx* c, int RadiationModel) {
+    const atomdev_params* P = &c->p;
+    const int im = c->im, jm = c->jm, km = c->km;
+    const double r_air = P->r_air, R_Air = P->R_Air, t_0 = P->t_0, g = P->g, L_atm = P->L_atm, ep = P->ep, hp = P->hp;
+    const double cp_l = P->cp_l, lv = P->lv, u_0 = P->u_0, R_WaterVapour = P->R_WaterVapour;
+    const double f_Penman = 2., c43 = 4. / 3., c13 = 1. / 3.;
+#define T_(i) A3(c, ATOMDEV_T, i, j, k)
+#define PS_(i) A3(c, ATOMDEV_P_STAT, i, j, k)
+#define C_(i) A3(c, ATOMDEV_C, i, j, k)
+#define V_(i) A3(c, ATOMDEV_V, i, j, k)
+#define W_(i) A3(c, ATOMDEV_W, i, j, k)
+    for (int k = 0; k < km; k++)
+        for (int j = 0; j < jm; j++) {
+            if (RadiationModel >= 1) A2(c, ATOMDEV_Q_RADIATION, j, k) = A3(c, ATOMDEV_RADIATION_3D, 0, j, k);
+            A2(c, ATOMDEV_PRECIPITABLE_WATER, j, k) = 0.;
+            A2(c, ATOMDEV_EVAPORATION_PENMAN, j, k) = 0.;
+            A2(c, ATOMDEV_EVAPORATION_DALTON, j, k) = 0.;
+        }
+    for (int k = 0; k < km; k++)
+        for (int j = 0; j < jm; j++)
+            for (int i = 0; i < im; i++) {
+                double t_Celsius, r_dry, r_humid, e, t_denom, E, Delta, sat_deficit, gamma, E_a;
+                /* top of the topography (:153-201) */
+                if (is_land(c, i, j, k) && (i + 1 < im) && is_fluid(c, i + 1, j, k)) {
+                    if (i == 0) PS_(0) = (r_air * R_Air * T_(0) * t_0) * .01;
+                    else PS_(i) = exp(-g * (double)i * (L_atm / (double)(im - 1)) / (R_Air * T_(i) * t_0)) * PS_(0);
+                    t_Celsius = T_(i) * t_0 - t_0;
+                    r_dry = 100. * PS_(i) / (R_Air * T_(i) * t_0);
+                    r_humid = r_dry / (1. + (R_WaterVapour / R_Air - 1.) * C_(i));
+                    e = C_(i) * PS_(i) / ep;
+                    t_denom = t_Celsius + 234.175;
+                    E = hp * exp(17.0809 * t_Celsius / t_denom);
+                    Delta = 4000. * E / (t_denom * t_denom);
+                    sat_deficit = (E - e);
+                    gamma = PS_(0) * cp_l / (ep * lv);
+                    E_a = .35 * (1. + .15 * sqrt((V_(i + 1) * V_(i + 1) + W_(i + 1) * W_(i + 1)) / 2.) * u_0 * 3.6) * sat_deficit;
+                    A2(c, ATOMDEV_Q_EVAPORATION, j, k) = 2300.;
+                    A2(c, ATOMDEV_Q_LATENT_2D, j, k) = A3(c, ATOMDEV_Q_LATENT, i, j, k);
+                    A2(c, ATOMDEV_Q_SENSIBLE_2D, j, k) = A3(c, ATOMDEV_Q_SENSIBLE, i, j, k);
+                    A2(c, ATOMDEV_Q_BOTTOM, j, k) = -(A2(c, ATOMDEV_Q_RADIATION, j, k) - A2(c, ATOMDEV_Q_LATENT_2D, j, k)
+                                                      - A2(c, ATOMDEV_Q_SENSIBLE_2D, j, k));
+                    double ed = C_Dalton(u_0, V_(i), W_(i)) * sat_deficit * 24.;
+                    if (ed <= 0.) ed = 0.;
+                    double epm = f_Penman * .0346 * ((A2(c, ATOMDEV_Q_RADIATION, j, k) + A2(c, ATOMDEV_Q_BOTTOM, j, k)) * Delta
+                                                     + gamma * E_a) / (Delta + gamma);
+                    if (epm <= 0.) epm = 0.;
+                    A2(c, ATOMDEV_EVAPORATION_PENMAN, j, k) = epm;
+                    A2(c, ATOMDEV_EVAPORATION_DALTON, j, k) = .5 * epm; /* the centre is land (:200) */
+                    (void)ed; (void)r_humid;
+                }
+                /* sea surface (:204-240) */
+                if ((i == 0) && is_fluid(c, 0, j, k)) {
+                    PS_(0) = (r_air * R_Air * T_(0) * t_0) * .01;
+                    t_Celsius = T_(0) * t_0 - t_0;
+                    r_dry = 100. * PS_(0) / (R_Air * T_(0) * t_0);
+                    r_humid = r_dry / (1. + (R_WaterVapour / R_Air - 1.) * C_(i));
+                    e = C_(i) * PS_(i) / ep;
+                    t_denom = t_Celsius + 234.175;
+                    E = hp * exp(17.0809 * t_Celsius / t_denom);
+                    Delta = 4000. * E / (t_denom * t_denom);
+                    sat_deficit = (E - e);
+                    gamma = PS_(0) * cp_l / (ep * lv);
+                    E_a = .35 * (1. + .15 * sqrt((V_(1) * V_(1) + W_(1) * W_(1)) / 2.) * u_0 * 3.6) * sat_deficit;
+                    if (t_Celsius >= -2.) A2(c, ATOMDEV_Q_EVAPORATION, j, k) = (2500.8 - 2.372 * (T_(0) * t_0 - t_0));
+                    else A2(c, ATOMDEV_Q_EVAPORATION, j, k) = (2500.8 - 2.372 * (T_(0) * t_0 - t_0)) + 300.;
+                    A2(c, ATOMDEV_Q_LATENT_2D, j, k) = A3(c, ATOMDEV_Q_LATENT, 0, j, k);
+                    A2(c, ATOMDEV_Q_SENSIBLE_2D, j, k) = A3(c, ATOMDEV_Q_SENSIBLE, 0, j, k);
+                    A2(c, ATOMDEV_Q_BOTTOM, j, k) = -(A2(c, ATOMDEV_Q_RADIATION, j, k) - A2(c, ATOMDEV_Q_LATENT_2D, j, k)
+                                                      - A2(c, ATOMDEV_Q_SENSIBLE_2D, j, k));
+                    double ed = C_Dalton(u_0, V_(0), W_(0)) * sat_deficit * 24.;
+                    if (ed <= 0.) ed = 0.;
+                    A2(c, ATOMDEV_EVAPORATION_DALTON, j, k) = ed;
+                    double epm = f_Penman * .0346 * ((A2(c, ATOMDEV_Q_RADIATION, j, k) + A2(c, ATOMDEV_Q_BOTTOM, j, k)) * Delta
+                                                     + gamma * E_a) / (Delta + gamma);
+                    if (epm <= 0.) epm = 0.;
+                    A2(c, ATOMDEV_EVAPORATION_PENMAN, j, k) = epm;
+                    (void)r_humid;
+                }
+            }
+    /* boundary values of BuoyancyForce (:248-278), r then theta then phi */
+#define B_(i, j, k) A3(c, ATOMDEV_BUOYANCY, i, j, k)
+    for (int k = 1; k < km - 1; k++)
+        for (int j = 1; j < jm - 1; j++) {
+            B_(0, j, k) = c43 * B_(1, j, k) - c13 * B_(2, j, k);
+            B_(im - 1, j, k) = c43 * B_(im - 2, j, k) - c13 * B_(im - 3, j, k);
+            if (is_land(c, 0, j, k)) B_(0, j, k) = 0.;
+        }
+    for (int k = 0; k < km; k++)
+        for (int i = 0; i < im; i++) {
+            B_(i, 0, k) = c43 * B_(i, 1, k) - c13 * B_(i, 2, k);
+            B_(i, jm - 1, k) = c43 * B_(i, jm - 2, k) - c13 * B_(i, jm - 3, k);
+        }
+    for (int i = 0; i < im; i++)
+        for (int j = 1; j < jm - 1; j++) {
+            B_(i, j, 0) = c43 * B_(i, j, 1) - c13 * B_(i, j, 2);
+            B_(i, j, km - 1) = c43 * B_(i, j, km - 2) - c13 * B_(i, j, km - 3);
+            B_(i, j, 0) = B_(i, j, km - 1) = (B_(i, j, 0) + B_(i, j, km - 1)) / 2.;
+        }
+#undef B_
+    /* :280-290 */
+    static const int CL[5] = { ATOMDEV_C, ATOMDEV_CLOUD, ATOMDEV_ICE, ATOMDEV_P_RAIN, ATOMDEV_P_SNOW };
+    for (int n = 0; n < 5; n++) {
+        double* x = c->f[CL[n]];
+        for (size_t q = 0; q < (size_t)im * jm * km; q++) if (x[q] < 0.) x[q] = 0.;
+    }
+    /* :328-353 */
+    for (int j = 0; j < jm; j++)
+        for (int k = 0; k < km; k++) {
+            A2(c, ATOMDEV_CO2_TOTAL, j, k) = A3(c, ATOMDEV_CO2, 0, j, k);
+            for (int i = 0; i < im; i++) {
+                double e = 100. * C_(i) * PS_(i) / ep;
+                double a = e / (R_WaterVapour * T_(i) * t_0);
+                A2(c, ATOMDEV_PRECIPITABLE_WATER, j, k) += a * L_atm / (double)(im - 1);
+            }
+            double pr = 86400. * (A3(c, ATOMDEV_P_RAIN, 0, j, k) + A3(c, ATOMDEV_P_SNOW, 0, j, k));
+            if (pr >= 25.) pr = 25.;
+            if (pr <= 0) pr = 0.;
+            A2(c, ATOMDEV_PRECIPITATION, j, k) = pr;
+        }
+#undef T_
+#undef PS_
+#undef C_
+#undef V_
+#undef W_
+}
+
 /* BC_Thermohalin::BC_Pressure_Density, hydrosphere/BC_Thermohalin.cpp:518-583.  The local
  * r_air / R_Air of the reference function (:533-534) shadow the model parameters. */
 void oracle_hyd_pressure_density(oracle_ctx* c) {
@@ -1167,6 +1304,7 @@ void oracle_default_params(int model, atomdev_params* p) {
     p->dt = 0.00001; p->dr = 0.025; p->dthe = 1. / pi180; p->dphi = 1. / pi180;
     p->r0 = 1.; p->the0 = 0.; p->phi0 = 0.;
     p->g = 9.8066; p->Buoyancy = 1.0; p->t_0 = 273.15; p->p_0 = 1013.25; /* param.py:92,151 */
+    p->ep = .623; p->hp = 6.1078; p->lv = 2.52e6; p->ls = 2.83e6; /* param.py:77-85 */
     if (model == ATOMDEV_ATM) {
         p->re = 1000.; p->pr = .7179; p->u_0 = 8.; p->c_0 = .035;
     } else {

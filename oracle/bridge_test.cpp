@@ -28,6 +28,7 @@
 #include "RungeKutta_Atm.h"
 #include "Pressure_Atm.h"
 #include "BC_Atm.h"
+#include "Results_Atm.h"
 #undef _PRESSURE_
 #include "RHS_Hyd.h"
 #include "RungeKutta_Hyd.h"
@@ -41,12 +42,14 @@ namespace {
 
 struct RefClasses {
     typedef ::RHS_Atmosphere RHS_A; typedef ::RungeKutta_Atmosphere RK_A; typedef ::Pressure_Atm P_A; typedef ::BC_Atmosphere BC_A;
+    typedef ::Results_MSL_Atm MSL_A;
     typedef ::RHS_Hydrosphere RHS_H; typedef ::RungeKutta_Hydrosphere RK_H; typedef ::Pressure_Hyd P_H; typedef ::BC_Hydrosphere BC_H;
     typedef ::BC_Thermohalin TH_H;
 };
 struct DevClasses {
     typedef atomdev_mirror::RHS_Atmosphere RHS_A; typedef atomdev_mirror::RungeKutta_Atmosphere RK_A;
     typedef atomdev_mirror::Pressure_Atm P_A; typedef atomdev_mirror::BC_Atmosphere BC_A;
+    typedef atomdev_mirror::Results_MSL_Atm MSL_A;
     typedef atomdev_mirror::RHS_Hydrosphere RHS_H; typedef atomdev_mirror::RungeKutta_Hydrosphere RK_H;
     typedef atomdev_mirror::Pressure_Hyd P_H; typedef atomdev_mirror::BC_Hydrosphere BC_H;
     typedef atomdev_mirror::BC_Thermohalin TH_H;
@@ -75,7 +78,14 @@ struct Fields {
         rad.initArray_1D(nrad, 0.); the.initArray_1D(jm, 0.); phi.initArray_1D(km, 0.);
         rad.Coordinates(nrad, 1., s.dr); the.Coordinates(jm, 0., s.dthe); phi.Coordinates(km, 0., s.dphi);
     }
-    ~Fields() { for (Array* a : arr) delete a; }
+    std::vector<std::string> names2;
+    std::vector<Array_2D*> arr2;
+    Array_2D& g(const char* n) {  // surface fields by name, created on first use
+        for (size_t i = 0; i < names2.size(); i++) if (names2[i] == n) return *arr2[i];
+        names2.push_back(n); arr2.push_back(new Array_2D(jm, km, 0.));
+        return *arr2.back();
+    }
+    ~Fields() { for (Array* a : arr) delete a; for (Array_2D* a : arr2) delete a; }
 };
 
 void fill(Array& a, int im, int jm, int km, std::mt19937_64& rng, double lo, double hi) {
@@ -156,6 +166,36 @@ void atmosphere_calls(Fields& F, const Scalars& s, bool with_rk3d) {
     startPressure.computePressure_2D(s.u_0, s.r_air, F.rad, F.the, F["p_dyn"], F["p_dynn"], F["h"], F["aux_v"], F["aux_w"]);
 }
 
+// ---- cAtmosphereModel.cpp:854-859 ----
+template <class NS>
+void msl_calls(Fields& F, const Scalars& s) {
+    typename NS::MSL_A calculate_MSL(F.im, F.jm, F.km, 0, s.g, 0.623, 6.1078, s.u_0, 1013.25, s.t_0, s.c_0, 280.0, 5.670280e-8,
+                                     0.15, 2.52e6, 2.83e6, s.cp_l, s.L_atm, s.dt, s.dr, s.dthe, s.dphi, s.r_air, s.R_Air, 0.0094,
+                                     s.R_WaterVapour, 3.0, 0., 3., s.gam, -4.0, 0., 15.0);
+    double t_cretaceous = 0.;
+    calculate_MSL.run_MSL_data(1, 2, 1, t_cretaceous, F.rad, F.the, F.phi, F["h"], F["c"], F["cn"], F["co2"], F["co2n"], F["t"],
+        F["tn"], F["p_dyn"], F["p_stat"], F["BuoyancyForce"], F["u"], F["v"], F["w"], F["Q_Latent"], F["Q_Sensible"],
+        F["radiation_3D"], F["cloud"], F["cloudn"], F["ice"], F["icen"], F["P_rain"], F["P_snow"], F["aux_u"], F["aux_v"],
+        F["aux_w"], F.g("temperature_NASA"), F.g("precipitation_NASA"), F.g("precipitable_water"), F.g("Q_radiation"),
+        F.g("Q_Evaporation"), F.g("Q_latent"), F.g("Q_sensible"), F.g("Q_bottom"), F.g("Evaporation_Penman"), F.evap,
+        F.g("Vegetation"), F.g("albedo"), F.g("co2_total"), F.precip, F["S_v"], F["S_c"], F["S_i"], F["S_r"], F["S_s"],
+        F["spare"]);
+}
+
+void init_msl(Fields& F, unsigned seed, const Scalars& s) {
+    init_atm(F, seed, s);
+    std::mt19937_64 rng(seed + 1000);
+    const int im = F.im, jm = F.jm, km = F.km;
+    fill(F["p_stat"], im, jm, km, rng, 200., 1013.); fill(F["Q_Latent"], im, jm, km, rng, -50., 150.);
+    fill(F["Q_Sensible"], im, jm, km, rng, -50., 50.); fill(F["radiation_3D"], im, jm, km, rng, 100., 400.);
+    fill(F["P_rain"], im, jm, km, rng, -1e-5, 4e-4); fill(F["P_snow"], im, jm, km, rng, -1e-5, 1e-4);
+    fill(F["BuoyancyForce"], im, jm, km, rng, -1., 1.); fill(F["cloud"], im, jm, km, rng, -1e-3, .01);
+    std::uniform_real_distribution<double> d(0., 5.);
+    for (const char* n : { "Q_radiation", "Q_Evaporation", "Q_latent", "Q_sensible", "Q_bottom" })
+        for (int j = 0; j < jm; j++) for (int k = 0; k < km; k++) F.g(n).y[j][k] = d(rng);
+    for (int j = 0; j < jm; j++) for (int k = 0; k < km; k++) F.g("temperature_NASA").y[j][k] = 1.;
+}
+
 // ---- cHydrosphereModel.cpp:437-610 ----
 template <class NS>
 void hydrosphere_calls(Fields& F, const Scalars& s) {
@@ -199,7 +239,23 @@ int compare(Fields& A, Fields& B, double tol, const char* what) {
         const bool ok = tol == 0. ? bits : rel <= tol;
         if (!ok) { bad++; std::printf("  %s %-16s MISMATCH rel %.3e bits %d\n", what, A.names[n].c_str(), rel, (int)bits); }
     }
-    std::printf("%s: %zu fields, %s (%s)\n", what, A.names.size(), bad ? "FAIL" : "ok", tol == 0. ? "bit-exact" : "<= 1e-10 relative");
+    B.g("evap") ; A.g("evap");  // compare the constructor-made surface fields as well
+    for (int j = 0; j < A.jm; j++) for (int k = 0; k < A.km; k++) { A.g("evap").y[j][k] = A.evap.y[j][k]; B.g("evap").y[j][k] = B.evap.y[j][k]; }
+    A.g("precip"); B.g("precip");
+    for (int j = 0; j < A.jm; j++) for (int k = 0; k < A.km; k++) { A.g("precip").y[j][k] = A.precip.y[j][k]; B.g("precip").y[j][k] = B.precip.y[j][k]; }
+    for (size_t n = 0; n < A.names2.size(); n++) {
+        Array_2D& a = *A.arr2[n]; Array_2D& b = B.g(A.names2[n].c_str());
+        double maxd = 0., maxa = 0.; bool bits = true;
+        for (int j = 0; j < A.jm; j++) for (int k = 0; k < A.km; k++) {
+            const double x = a.y[j][k], y = b.y[j][k];
+            if (std::memcmp(&x, &y, 8) != 0 && !(x == 0. && y == 0.)) bits = false;
+            maxd = std::fmax(maxd, std::fabs(x - y)); maxa = std::fmax(maxa, std::fabs(x));
+        }
+        const double rel = maxa > 0. ? maxd / maxa : maxd;
+        const bool ok = tol == 0. ? bits : rel <= tol;
+        if (!ok) { bad++; std::printf("  %s %-16s MISMATCH rel %.3e bits %d\n", what, A.names2[n].c_str(), rel, (int)bits); }
+    }
+    std::printf("%s: %zu + %zu fields, %s (%s)\n", what, A.names.size(), A.names2.size(), bad ? "FAIL" : "ok", tol == 0. ? "bit-exact" : "<= 1e-10 relative");
     return bad;
 }
 
@@ -227,6 +283,16 @@ int main() {
         { Quiet q; atmosphere_calls<RefClasses>(R2, s, true); }
         atmosphere_calls<DevClasses>(D2, s, true);
         bad += compare(R2, D2, 1e-10, "atmosphere, with the 3-D RK sweep");
+    }
+    {   // surface fluxes: run_MSL_data prints at fixed 1-degree locations, so the surface stays 181 x 361
+        Scalars s; s.re = 1000.; s.pr = .7179; s.u_0 = 8.; s.c_0 = .035;
+        const int im = 5, jm = 181, km = 361;
+        s.dr = 1. / (im - 1); s.dthe = M_PI / (jm - 1); s.dphi = s.dthe;
+        Fields R(im, jm, km, s), D(im, jm, km, s);
+        init_msl(R, 10, s); init_msl(D, 10, s);
+        { Quiet q; msl_calls<RefClasses>(R, s); }
+        msl_calls<DevClasses>(D, s);
+        bad += compare(R, D, 1e-10, "atmosphere, run_MSL_data");
     }
     {   // hydrosphere (the surface RHS hard-codes im = 41, RHS_Hyd.cpp:466)
         Scalars s; s.re = 10.; s.pr = 6.957; s.u_0 = .25; s.c_0 = 34.6;

@@ -113,6 +113,32 @@ def full_case(model, tag):
     print("full", tag, len(out))
 
 
+def msl_case():
+    """Results_MSL_Atm::run_MSL_data on the 1-degree surface with five levels (the function prints at fixed
+    1-degree locations): SHA-256 and statistics of every field it changed, plus sample slices."""
+    import ctypes as C
+    im, jm, km = 5, 181, 361
+    p = H.default_params(H.ATM, im, jm, km)
+    f, g = H.make_msl_inputs(im, jm, km, 51, p)
+    m = H.CpuModel("ref", H.ATM, im, jm, km, p, f, g)
+    m.op("atm_msl_data", C.c_int(1))
+    out = {"input_sha256": np.array(digest(f, sorted(f)) + digest(g, sorted(g)))}
+    for k in sorted(f):
+        if not np.array_equal(m.f[k], f[k]):
+            a = m.f[k]
+            out[k + "/sha256"] = np.array(hashlib.sha256(a.tobytes()).hexdigest())
+            out[k + "/stats"] = np.array([a.sum(), a.min(), a.max(), np.abs(a).max()])
+            out[k + "/j62"] = a[:, 62, :].copy()
+    for k in sorted(g):
+        if not np.array_equal(m.g[k], g[k]):
+            a = m.g[k]
+            out[k + "/sha256"] = np.array(hashlib.sha256(a.tobytes()).hexdigest())
+            out[k + "/stats"] = np.array([a.sum(), a.min(), a.max(), np.abs(a).max()])
+            out[k + "/s4"] = a[::4, ::4].copy()
+    np.savez_compressed(os.path.join(GOLD, "atm_msl_data.npz"), **out)
+    print("atm_msl_data.npz", len(out), "entries")
+
+
 if __name__ == "__main__":
     assert H.have_ref(), "build oracle/_ref first: make -C oracle ref"
     os.makedirs(GOLD, exist_ok=True)
@@ -123,3 +149,4 @@ if __name__ == "__main__":
     residuum_case()
     full_case(H.ATM, "atm")
     full_case(H.HYD, "hyd")
+    msl_case()

@@ -26,6 +26,7 @@
 #include "BC_Atm.h"
 #include "BC_Bath_Atm.h"
 #include "Accuracy_Atm.h"
+#include "Results_Atm.h"
 // the reference reuses these two include guards for the hydrosphere headers
 #undef _PRESSURE_
 #undef _ACCURACY_
@@ -78,6 +79,10 @@ void copy_out(RefCtx* c) {
             for (int i = 0; i < c->im; i++)
                 for (int j = 0; j < c->jm; j++)
                     std::memcpy(c->f[n] + ((size_t)i * c->jm + j) * c->km, c->a[n]->x[i][j], sizeof(double) * c->km);
+    for (int n = 0; n < ATOMDEV_N2D; n++)
+        if (c->g[n])
+            for (int j = 0; j < c->jm; j++)
+                std::memcpy(c->g[n] + (size_t)j * c->km, c->b[n]->y[j], sizeof(double) * c->km);
 }
 
 #define A(F) (*c->a[ATOMDEV_##F])
@@ -232,6 +237,29 @@ void ref_atm_residuum2d(void* v, double* min, int loc[3]) {
     if (c->f[ATOMDEV_RESIDUUM])
         for (int j = 0; j < c->jm; j++) for (int k = 0; k < c->km; k++)
             c->f[ATOMDEV_RESIDUUM][(size_t)j * c->km + k] = res(0, j, k);
+}
+
+/* Results_MSL_Atm::run_MSL_data prints values at (j, k) = (39, 346), (123, 151), (90, 180)
+ * (Results_Atm.cpp:319-326): the grid must contain them (jm > 123, km > 346). */
+int ref_atm_msl_data(void* v, int RadiationModel) {
+    RefCtx* c = (RefCtx*)v; CoutSilencer s;
+    if (c->jm <= 123 || c->km <= 346) return 1;
+    copy_in(c);
+    const atomdev_params& P = c->p;
+    Results_MSL_Atm calculate_MSL(c->im, c->jm, c->km, 0, P.g, P.ep, P.hp, P.u_0, P.p_0, P.t_0, P.c_0, 280.0, 5.670280e-8, 0.15,
+                                  P.lv, P.ls, P.cp_l, P.L_atm, P.dt, P.dr, P.dthe, P.dphi, P.r_air, P.R_Air, 0.0094,
+                                  P.R_WaterVapour, 3.0, 0., 3., P.gam, -4.0, 0., 15.0);
+    double t_cretaceous = 0.;
+    Array spare(c->im, c->jm, c->km, 0.);
+    Array_2D spare2(c->jm, c->km, 0.), nasa_t(c->jm, c->km, 1.), nasa_p(c->jm, c->km, 0.);
+    calculate_MSL.run_MSL_data(1, 2, RadiationModel, t_cretaceous, c->rad, c->the, c->phi, A(H), A(C), A(CN), A(CO2), A(CO2N),
+        A(T), A(TN), A(P_DYN), A(P_STAT), A(BUOYANCY), A(U), A(V), A(W), A(Q_LATENT), A(Q_SENSIBLE), A(RADIATION_3D),
+        A(CLOUD), A(CLOUDN), A(ICE), A(ICEN), A(P_RAIN), A(P_SNOW), A(AUX_U), A(AUX_V), A(AUX_W), nasa_t, nasa_p,
+        B(PRECIPITABLE_WATER), B(Q_RADIATION), B(Q_EVAPORATION), B(Q_LATENT_2D), B(Q_SENSIBLE_2D), B(Q_BOTTOM),
+        B(EVAPORATION_PENMAN), B(EVAPORATION_DALTON), spare2, spare2, B(CO2_TOTAL), B(PRECIPITATION),
+        A(S_V), A(S_C), A(S_I), A(S_R), A(S_S), spare);
+    copy_out(c);
+    return 0;
 }
 
 /* ---- hydrosphere ---- */

@@ -28,8 +28,9 @@ F3 = dict(T=0, U=1, V=2, W=3, P_DYN=4, C=5, CLOUD=6, ICE=7, CO2=8,
           H=18, AUX_U=19, AUX_V=20, AUX_W=21, BUOYANCY=22,
           S_V=23, S_C=24, S_I=25, S_R=26, S_S=27,
           SALT_BALANCE=28, SALT_FINGER=29, SALT_DIFFUSION=30, R_WATER=31, R_SALT_WATER=32,
-          RESIDUUM=33, P_STAT=34)
-F2 = dict(TOPOGRAPHY=0, EVAPORATION_DALTON=1, PRECIPITATION=2)
+          RESIDUUM=33, P_STAT=34, Q_LATENT=35, Q_SENSIBLE=36, RADIATION_3D=37, P_RAIN=38, P_SNOW=39)
+F2 = dict(TOPOGRAPHY=0, EVAPORATION_DALTON=1, PRECIPITATION=2, Q_RADIATION=3, PRECIPITABLE_WATER=4,
+          EVAPORATION_PENMAN=5, Q_EVAPORATION=6, Q_LATENT_2D=7, Q_SENSIBLE_2D=8, Q_BOTTOM=9, CO2_TOTAL=10)
 
 ATM_FIELDS = ["T", "U", "V", "W", "P_DYN", "C", "CLOUD", "ICE", "CO2",
               "TN", "UN", "VN", "WN", "P_DYNN", "CN", "CLOUDN", "ICEN", "CO2N",
@@ -45,7 +46,7 @@ class Params(C.Structure):
         "dt", "dr", "dthe", "dphi", "r0", "the0", "phi0",
         "re", "pr", "g", "Buoyancy", "u_0", "t_0", "c_0",
         "sc_WaterVapour", "sc_CO2", "gam", "r_air", "R_Air", "R_WaterVapour", "L_atm", "cp_l", "t_tropopause",
-        "sc", "L_hyd", "r_0_water", "ta", "pa", "ca", "p_0")]
+        "sc", "L_hyd", "r_0_water", "ta", "pa", "ca", "p_0", "ep", "hp", "lv", "ls")]
 
 
 def build_oracle():
@@ -220,6 +221,34 @@ def make_inputs(model, im, jm, km, seed=1234, mask="blobs", params=None):
     return f, g
 
 
+MSL_FIELDS3D = ["P_STAT", "Q_LATENT", "Q_SENSIBLE", "RADIATION_3D", "P_RAIN", "P_SNOW"]
+MSL_FIELDS2D = ["Q_RADIATION", "PRECIPITABLE_WATER", "EVAPORATION_PENMAN", "Q_EVAPORATION", "Q_LATENT_2D",
+                "Q_SENSIBLE_2D", "Q_BOTTOM", "CO2_TOTAL"]
+
+
+def make_msl_inputs(im, jm, km, seed, params):
+    """Atmosphere inputs plus what Results_MSL_Atm::run_MSL_data reads and writes: negative moisture and
+    precipitation values for its clamps, precipitation above its 25 mm/d cap, no land on the top level
+    (the reference reads one level above the array there)."""
+    f, g = make_inputs(ATM, im, jm, km, seed, "blobs", params)
+    f = {k: f[k] for k in ATM_FIELDS}
+    rng = np.random.default_rng(seed + 4242)
+    shp = (im, jm, km)
+    f["H"][im - 1] = 0.0
+    f["P_STAT"] = rng.uniform(200.0, 1013.0, shp)
+    f["Q_LATENT"] = rng.uniform(-50.0, 150.0, shp)
+    f["Q_SENSIBLE"] = rng.uniform(-50.0, 50.0, shp)
+    f["RADIATION_3D"] = rng.uniform(100.0, 400.0, shp)
+    f["P_RAIN"] = rng.uniform(-1e-5, 4e-4, shp)
+    f["P_SNOW"] = rng.uniform(-1e-5, 1e-4, shp)
+    f["BUOYANCY"] = rng.uniform(-1.0, 1.0, shp)
+    for k in ("C", "CLOUD", "ICE"):
+        f[k] = f[k] - 0.1 * np.abs(f[k]).max() * (rng.uniform(0, 1, shp) < 0.05)
+    for k in MSL_FIELDS2D:
+        g[k] = rng.uniform(0.0, 5.0, (jm, km))
+    return f, g
+
+
 def bits_equal(a, b):
     """Bitwise equality up to the sign of zero (NaN == NaN)."""
     a = np.asarray(a); b = np.asarray(b)
@@ -284,3 +313,25 @@ def load_mask_0Ma(model):
     n = 41 * 181 * 361
     h = np.unpackbits(z[tag + "_h_bits"])[:n].astype(np.float64).reshape(41, 181, 361)
     return np.ascontiguousarray(h), np.ascontiguousarray(z[tag + "_topo"], dtype=np.float64)
+
+
+def check_msl_golden(get3d, get2d, exact, tol=1e-10):
+    """Compares the fields of a model that ran atm_msl_data(1) on make_msl_inputs(5, 181, 361, 51) with
+    tests/golden/atm_msl_data.npz (outputs of the compiled reference).  exact: SHA-256 of every changed
+    field; otherwise the sample slices within tol (relative to the field's largest magnitude)."""
+    import hashlib
+    z = np.load(os.path.join(ROOT, "tests", "golden", "atm_msl_data.npz"))
+    n = 0
+    for key in z.files:
+        if not key.endswith("/sha256"):
+            continue
+        k = key.split("/")[0]
+        a = get2d(k) if k in F2 else get3d(k)
+        n += 1
+        if exact:
+            assert hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest() == str(z[key]), k
+        else:
+            sl, ref = (a[::4, ::4], z[k + "/s4"]) if k in F2 else (a[:, 62, :], z[k + "/j62"])
+            scale = z[k + "/stats"][3]
+            assert np.max(np.abs(sl - ref)) <= tol * scale, (k, np.max(np.abs(sl - ref)) / scale)
+    return n

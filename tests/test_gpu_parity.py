@@ -109,6 +109,46 @@ def test_atm_surface_sweep_many_rows_bitexact(jm):
     d.close()
 
 
+@pytest.mark.parametrize("dims,radiation_model,seed", [((5, 181, 361), 1, 51), ((7, 13, 17), 0, 53), ((9, 21, 70), 1, 54)])
+def test_atm_msl_data(dims, radiation_model, seed):
+    """Results_MSL_Atm::run_MSL_data on the device: exp() appears in the surface pressure and the saturation
+    pressure (last-place differences between glibc and the device), so those outputs are held to 1e-10;
+    everything without exp (clamps, buoyancy boundary values, precipitation, co2_total, heat fluxes) is bit-exact."""
+    import ctypes as C
+    im, jm, km = dims
+    p = H.default_params(H.ATM, im, jm, km)
+    f, g = H.make_msl_inputs(im, jm, km, seed, p)
+    o = H.CpuModel("oracle", H.ATM, im, jm, km, p, f, g)
+    d = atom_amd.DeviceModel(H.ATM, im, jm, km, atom_amd.Params.from_buffer_copy(bytes(p)))
+    d.upload_all(f, g)
+    o.op("atm_msl_data", C.c_int(radiation_model))
+    d.msl_data(radiation_model)
+    with_exp = {"P_STAT", "EVAPORATION_DALTON", "EVAPORATION_PENMAN", "PRECIPITABLE_WATER"}
+    worst = 0.0
+    for k in list(f) + list(g):
+        got, ref = d.download(k), (o.f[k] if k in f else o.g[k])
+        if k in with_exp:
+            e = H.max_rel_err(got, ref)
+            worst = max(worst, e)
+            assert e <= TOL, (k, e)
+        else:
+            assert H.bits_equal(got, ref), (k, H.max_rel_err(got, ref))
+    print("msl_data: max rel err of the exp-dependent fields %.3e" % worst)
+    d.close()
+
+
+def test_atm_msl_data_golden():
+    """HIP path against the compiled reference's own outputs (tests/golden/atm_msl_data.npz), 1e-10 on the slices kept."""
+    im, jm, km = 5, 181, 361
+    p = H.default_params(H.ATM, im, jm, km)
+    f, g = H.make_msl_inputs(im, jm, km, 51, p)
+    d = atom_amd.DeviceModel(H.ATM, im, jm, km, atom_amd.Params.from_buffer_copy(bytes(p)))
+    d.upload_all(f, g)
+    d.msl_data(1)
+    assert H.check_msl_golden(d.download, d.download, exact=False, tol=TOL) >= 14
+    d.close()
+
+
 def test_golden_small_hyd_bitexact():
     """HIP path against the compiled reference's own outputs (tests/golden/hyd_small.npz)."""
     z = np.load(os.path.join(GOLD, "hyd_small.npz"))

@@ -143,3 +143,16 @@ def test_steady_queries_against_numpy():
     mh = H.CpuModel("oracle", H.HYD, im, jm, km, ph, {k: fh[k] for k in H.HYD_FIELDS}, gh)
     out, loc = mh.steady("hyd_steady3d", 6)
     assert out[0] == 1.0 and tuple(loc[0]) == (5, 6, 7)
+
+
+def test_atm_msl_data_golden_bitexact():
+    """Results_MSL_Atm::run_MSL_data: the oracle against the compiled reference's outputs."""
+    import ctypes as C
+    im, jm, km = 5, 181, 361
+    p = H.default_params(H.ATM, im, jm, km)
+    f, g = H.make_msl_inputs(im, jm, km, 51, p)
+    z = np.load(os.path.join(GOLD, "atm_msl_data.npz"))
+    assert _digest(f, sorted(f)) + _digest(g, sorted(g)) == str(z["input_sha256"]), "input generator drifted"
+    m = H.CpuModel("oracle", H.ATM, im, jm, km, p, f, g)
+    m.op("atm_msl_data", C.c_int(1))
+    assert H.check_msl_golden(lambda k: m.f[k], lambda k: m.g[k], exact=True) >= 14

@@ -58,3 +58,24 @@ def test_residuum_queries():
     assert a.residuum("atm_residuum2d") == b.residuum("atm_residuum2d")
     a, b, _ = _pair(H.HYD, (9, 21, 31), 10, "blobs")
     assert a.residuum("hyd_residuum3d") == b.residuum("hyd_residuum3d")
+
+
+@pytest.mark.parametrize("radiation_model,seed", [(1, 51), (0, 52)])
+def test_atm_msl_data(radiation_model, seed):
+    """Results_MSL_Atm::run_MSL_data prints values at fixed 1-degree locations, so the grid keeps the
+    1-degree surface (181 x 361); five levels keep it cheap."""
+    import ctypes as C
+    im, jm, km = 5, 181, 361
+    p = H.default_params(H.ATM, im, jm, km)
+    f, g = H.make_msl_inputs(im, jm, km, seed, p)
+    a = H.CpuModel("oracle", H.ATM, im, jm, km, p, f, g)
+    b = H.CpuModel("ref", H.ATM, im, jm, km, p, f, g)
+    a.op("atm_msl_data", C.c_int(radiation_model)); b.op("atm_msl_data", C.c_int(radiation_model))
+    changed = 0
+    for k in f:
+        assert H.bits_equal(a.f[k], b.f[k]), k
+        changed += not np.array_equal(a.f[k], f[k])
+    for k in g:
+        assert H.bits_equal(a.g[k], b.g[k]), k
+        changed += not np.array_equal(a.g[k], g[k])
+    assert changed >= 14  # p_stat, buoyancy, 5 clamped fields, 7-8 surface fields, evaporation, precipitation

@@ -21,6 +21,7 @@ BYTES = {
     "atm_value_limitation": n3 * 152, "hyd_value_limitation": n3 * 88,
     "move3d(atm)": n3 * 16 * 9, "move3d(hyd)": n3 * 16 * 6,
     "hyd_pressure_density": n3 * 40,
+    "atm_msl_data": n3 * (7 * 8 + 1),  # second walk: c, cloud, ice, P_rain, P_snow, p_stat, t + the mask byte
 }
 print("| operator | ms per call | algorithmic GB/s | % of 8 TB/s |")
 print("|---|---|---|---|")
@@ -36,12 +37,16 @@ for model, pre in ((H.ATM, "atm"), (H.HYD, "hyd")):
                                     "pressure3d", "rk2d", "pressure2d")] + ["move3d(%s)" % pre, "residuum3d", "steady3d"]
     if model == H.HYD:
         ops.append("hyd_pressure_density")
+    else:
+        ops.append("atm_msl_data")
     for op in ops:
         def call():
             if op.startswith("move3d"):
                 d.move_data_to_new_arrays(-1)
             elif op == "residuum3d":
                 d.residuum(pre + "_residuum3d")
+            elif op == "atm_msl_data":
+                d.msl_data(1)
             elif op == "steady3d":
                 d.steady(pre + "_steady3d", 9 if model == H.ATM else 6)
             else:
