@@ -74,16 +74,13 @@ __device__ __forceinline__ double c_dalton(double u_0, double v, double w) {
     return sqrt(C_max * C_max / v_max * vel_magnitude);
 }
 
-__device__ __forceinline__ void clamp_at_zero(double* p) {
-    const double x = *p;
-    if (x < 0.) *p = 0.;
-}
-
-// One thread per column.  First walk (:149-243): the surface branches, evaluated at every top of the
-// topography (land cell with air above; the last one met wins the 2-D fields) and on the sea surface;
-// second walk (:280-353): the zero clamps and the precipitable-water sum, which reads the p_stat and c
-// values the first walk and the clamps left behind.  The reference's test of the cell above level
-// im-1 (one level outside the array) counts as "not air".
+// One thread per column.  The surface branches (:149-243) are evaluated at every top of the topography
+// (land cell with air above; the last one met wins the 2-D fields) and on the sea surface: the land bits of
+// the column are gathered first (loads only, so they overlap), then only the levels that qualify are
+// visited, in level order.  The precipitable-water sum (:328-338) follows in level order as well; it reads
+// the p_stat values just written and c as the zero clamp (:280-290, done by k_clamp_at_zero afterwards)
+// leaves it.  The reference's test of the cell above level im-1 (one level outside the array) counts as
+// "not air".
 __global__ void k_atm_msl_columns(MslArgs a) {
     const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= a.n2) return;
@@ -95,12 +92,24 @@ __global__ void k_atm_msl_columns(MslArgs a) {
     if (a.radiation_model >= 1) { q_rad = a.radiation_3d[q]; a.q_radiation[q] = q_rad; }
     double ev_penman = 0., ev_dalton = 0.;
     double ps0 = a.p_stat[q];
-    bool land = (a.flags[q] & FL_LAND) != 0;
-    for (int i = 0; i < im; i++) {
-        const size_t id = (size_t)i * n2 + q;
-        const bool land_above = (i + 1 < im) ? (a.flags[id + n2] & FL_LAND) != 0 : true;
-        const bool summit = land && !land_above, sea = (i == 0) && !land;
-        if (summit || sea) {
+    // 64 levels per pass: bit l of `land` = level base + l is land; level base + 64 (or im) closes the window
+    for (int base = 0; base < im; base += 64) {
+        const int n = min(64, im - base);
+        unsigned long long land = 0ull;
+#pragma unroll 8
+        for (int l = 0; l < n; l++)
+            land |= (unsigned long long)(a.flags[(size_t)(base + l) * n2 + q] & FL_LAND) << l;
+        const bool land_next = (base + n < im) ? (a.flags[(size_t)(base + n) * n2 + q] & FL_LAND) != 0 : true;
+        const unsigned long long above = (land >> 1) | ((unsigned long long)land_next << (n - 1));
+        unsigned long long visit = land & ~above;                 // summits
+        if (base == 0 && !(land & 1ull)) visit |= 1ull;           // sea surface
+        if (n < 64) visit &= (1ull << n) - 1ull;
+        while (visit) {
+            const int l = __ffsll((long long)visit) - 1;
+            visit &= visit - 1ull;
+            const int i = base + l;
+            const bool summit = (land >> l) & 1ull;
+            const size_t id = (size_t)i * n2 + q;
             const double t = a.t[id], cc = a.c[id];
             double ps;
             if (i == 0) { ps = (a.r_air * a.R_Air * t * a.t_0) * .01; ps0 = ps; }
@@ -130,28 +139,38 @@ __global__ void k_atm_msl_columns(MslArgs a) {
             ev_penman = epm;
             ev_dalton = summit ? .5 * epm : ed;
         }
-        land = land_above;
     }
     a.evaporation_penman[q] = ev_penman;
     a.evaporation_dalton[q] = ev_dalton;
     a.co2_total[q] = a.co2[q];
 
     double pw = 0.;
+#pragma unroll 8
     for (int i = 0; i < im; i++) {
         const size_t id = (size_t)i * n2 + q;
         double cc = a.c[id];
-        if (cc < 0.) { cc = 0.; a.c[id] = 0.; }
-        clamp_at_zero(a.cloud + id); clamp_at_zero(a.ice + id);
-        clamp_at_zero(a.p_rain + id); clamp_at_zero(a.p_snow + id);
+        if (cc < 0.) cc = 0.;
         const double e = 100. * cc * a.p_stat[id] / a.ep;
         const double ah = e / (a.R_WaterVapour * a.t[id] * a.t_0);
         pw = pw + ah * a.L_atm / (double)(im - 1);
     }
     a.precipitable_water[q] = pw;
-    double pr = 86400. * (a.p_rain[q] + a.p_snow[q]);
+    double rain = a.p_rain[q], snow = a.p_snow[q];
+    if (rain < 0.) rain = 0.;
+    if (snow < 0.) snow = 0.;
+    double pr = 86400. * (rain + snow);
     if (pr >= 25.) pr = 25.;
     if (pr <= 0) pr = 0.;
     a.precipitation[q] = pr;
+}
+
+// c, cloud, ice, P_rain, P_snow: negative values to zero (Results_Atm.cpp:280-290); blockIdx.y = field
+struct Clamp5 { double* p[5]; };
+__global__ void k_clamp_at_zero(Clamp5 f, size_t n) {
+    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n) return;
+    double* x = f.p[blockIdx.y];
+    if (x[id] < 0.) x[id] = 0.;
 }
 
 // BuoyancyForce on the bottom and top levels (Results_Atm.cpp:248-256): interior (j, k) only
@@ -190,6 +209,9 @@ extern "C" int atomdev_atm_msl_data(atomdev_t* h, int RadiationModel) {
     a.cp_l = P.cp_l; a.lv = P.lv; a.u_0 = P.u_0; a.R_WaterVapour = P.R_WaterVapour;
     const unsigned nb = (unsigned)((h->n2 + TPB - 1) / TPB);
     hipLaunchKernelGGL(k_atm_msl_columns, dim3(nb), dim3(TPB), 0, h->stream, a);
+    ATOMDEV_TRY(hipGetLastError());
+    Clamp5 cl = { { a.c, a.cloud, a.ice, a.p_rain, a.p_snow } };
+    hipLaunchKernelGGL(k_clamp_at_zero, dim3((unsigned)((h->n3 + TPB - 1) / TPB), 5), dim3(TPB), 0, h->stream, cl, h->n3);
     ATOMDEV_TRY(hipGetLastError());
     // boundary values of BuoyancyForce, r then theta then phi as in the reference (:248-278)
     hipLaunchKernelGGL(k_buoyancy_fill_r, dim3(nb), dim3(TPB), 0, h->stream, h->f[ATOMDEV_BUOYANCY], h->flags, h->im, h->jm,

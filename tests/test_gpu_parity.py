@@ -109,7 +109,8 @@ def test_atm_surface_sweep_many_rows_bitexact(jm):
     d.close()
 
 
-@pytest.mark.parametrize("dims,radiation_model,seed", [((5, 181, 361), 1, 51), ((7, 13, 17), 0, 53), ((9, 21, 70), 1, 54)])
+@pytest.mark.parametrize("dims,radiation_model,seed", [((5, 181, 361), 1, 51), ((7, 13, 17), 0, 53), ((9, 21, 70), 1, 54),
+                                                       ((70, 9, 13), 1, 55), ((129, 8, 9), 1, 56)])
 def test_atm_msl_data(dims, radiation_model, seed):
     """Results_MSL_Atm::run_MSL_data on the device: exp() appears in the surface pressure and the saturation
     pressure (last-place differences between glibc and the device), so those outputs are held to 1e-10;
