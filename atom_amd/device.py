@@ -75,6 +75,9 @@ def load_library():
     lib.atomdev_sync.argtypes = [vp]
     lib.atomdev_move_data_to_new_arrays.argtypes = [vp, C.c_int]
     lib.atomdev_atm_msl_data.argtypes = [vp, C.c_int]
+    lib.atomdev_transfer_atm_to_hyd.argtypes = [vp, vp]
+    lib.atomdev_atm_write_transfer_file.argtypes = [vp, C.c_char_p]
+    lib.atomdev_hyd_read_transfer_file.argtypes = [vp, C.c_char_p]
     for op in _OPS:
         getattr(lib, "atomdev_" + op).argtypes = [vp]
     for name in ("atomdev_atm_residuum3d", "atomdev_atm_residuum2d", "atomdev_hyd_residuum3d"):
@@ -186,6 +189,17 @@ class DeviceModel:
     def msl_data(self, radiation_model=1):
         """Results_MSL_Atm::run_MSL_data, the part that changes model fields."""
         self._check(self.lib.atomdev_atm_msl_data(self._h, radiation_model))
+
+    def transfer_to_hyd(self, hyd):
+        """Surface velocities, temperature, evaporation and precipitation of this atmosphere into the top level of
+        a hydrosphere model, rounded as the reference's 4-decimal transfer file rounds them."""
+        self._check(self.lib.atomdev_transfer_atm_to_hyd(self._h, hyd._h))
+
+    def write_transfer_file(self, path):
+        self._check(self.lib.atomdev_atm_write_transfer_file(self._h, os.fsencode(path)))
+
+    def read_transfer_file(self, path):
+        self._check(self.lib.atomdev_hyd_read_transfer_file(self._h, os.fsencode(path)))
 
     def move_data_to_new_arrays(self, level=-1):
         self._check(self.lib.atomdev_move_data_to_new_arrays(self._h, level))

@@ -183,6 +183,18 @@ int atomdev_hyd_residuum3d(atomdev_t* h, double* min, int loc[3]);
  * (last location of the maximum); loc = 6 x {i,j,k}. */
 int atomdev_hyd_steady3d(atomdev_t* h, double out[6], int loc[18]);
 
+/* ---- atmosphere -> hydrosphere coupling ---- */
+/* PostProcess_Atmosphere::Atmosphere_v_w_Transfer (atmosphere/PostProcess_Atm.cpp:98-118) followed by
+ * PostProcess_Hydrosphere::Atmosphere_TransferFile_read (hydrosphere/PostProcess_Hyd.cpp:642-668), without the
+ * text file between them: level 0 of v * u_0, w * u_0, t of the atmosphere and its Evaporation_Dalton and
+ * Precipitation arrive in level im-1 of v, w, t and the two 2-D fields of the hydrosphere, each value as the
+ * file's fixed notation with 4 decimals would have carried it; p_dyn of that level is set to 0.  The handles
+ * may live on different GPUs; both streams are waited for. */
+int atomdev_transfer_atm_to_hyd(atomdev_t* atm, atomdev_t* hyd);
+/* The two halves with the file: the same bytes the reference writes, the same values it reads. */
+int atomdev_atm_write_transfer_file(atomdev_t* atm, const char* path);
+int atomdev_hyd_read_transfer_file(atomdev_t* hyd, const char* path);
+
 /* HIP-event timing on the handle's stream (for benchmarks): everything enqueued
  * between start and stop is measured; stop waits for it. */
 int atomdev_timer_start(atomdev_t* h);

@@ -292,6 +292,27 @@ private:
     int im_, jm_, km_;
 };
 
+// atmosphere/PostProcess_Atm.h: the transfer file of the coupling; the plot and VTK writers stay on the host.
+class PostProcess_Atmosphere {
+public:
+    PostProcess_Atmosphere(int im, int jm, int km, std::string& output_path) : im_(im), jm_(jm), km_(km), out_(output_path) {}
+    // atmosphere/PostProcess_Atm.cpp:98-118
+    void Atmosphere_v_w_Transfer(std::string& Name_Bathymetry_File, double u_0, Array& v, Array& w, Array& t, Array& p_dyn,
+                                 Array_2D& Evaporation_Dalton, Array_2D& Precipitation) {
+        Device& d = Device::of(ATOMDEV_ATM);
+        d.grid(im_, jm_, km_);
+        d.params().u_0 = u_0;
+        push_all(d, { { ATOMDEV_V, &v }, { ATOMDEV_W, &w }, { ATOMDEV_T, &t }, { ATOMDEV_P_DYN, &p_dyn } });
+        d.push2d(ATOMDEV_EVAPORATION_DALTON, Evaporation_Dalton); d.push2d(ATOMDEV_PRECIPITATION, Precipitation);
+        const std::string path = out_ + "/[" + Name_Bathymetry_File + "]_Transfer_Atm.vw";
+        d.run(atomdev_atm_write_transfer_file(d.handle(), path.c_str()), "atomdev_atm_write_transfer_file");
+    }
+
+private:
+    int im_, jm_, km_;
+    std::string out_;
+};
+
 // ---------------------------------------------------------------------------------------------
 // hydrosphere
 // ---------------------------------------------------------------------------------------------
@@ -465,6 +486,27 @@ public:
 
 private:
     int im_, jm_, km_;
+};
+
+// hydrosphere/PostProcess_Hyd.h: the reading half of the coupling.
+class PostProcess_Hydrosphere {
+public:
+    PostProcess_Hydrosphere(int im, int jm, int km, const std::string& output_path) : im_(im), jm_(jm), km_(km), out_(output_path) {}
+    // hydrosphere/PostProcess_Hyd.cpp:642-668: only level im-1 of v, w, t, p and the two 2-D fields change
+    void Atmosphere_TransferFile_read(const std::string& Name_Bathymetry_File, Array& v, Array& w, Array& t, Array& p,
+                                      Array_2D& Evaporation_Dalton, Array_2D& Precipitation) {
+        Device& d = Device::of(ATOMDEV_HYD);
+        d.grid(im_, jm_, km_);
+        push_all(d, { { ATOMDEV_V, &v }, { ATOMDEV_W, &w }, { ATOMDEV_T, &t }, { ATOMDEV_P_DYN, &p } });
+        const std::string path = out_ + "/[" + Name_Bathymetry_File + "]_Transfer_Atm.vw";
+        d.run(atomdev_hyd_read_transfer_file(d.handle(), path.c_str()), "atomdev_hyd_read_transfer_file");
+        pull_all(d, { { ATOMDEV_V, &v }, { ATOMDEV_W, &w }, { ATOMDEV_T, &t }, { ATOMDEV_P_DYN, &p } });
+        d.pull2d(ATOMDEV_EVAPORATION_DALTON, Evaporation_Dalton); d.pull2d(ATOMDEV_PRECIPITATION, Precipitation);
+    }
+
+private:
+    int im_, jm_, km_;
+    std::string out_;
 };
 
 }  // namespace atomdev_mirror

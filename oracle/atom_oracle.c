@@ -18,6 +18,7 @@
  */
 #include <float.h>
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -1013,6 +1014,27 @@ void oracle_atm_msl_data(oracle_ctx* c, int RadiationModel) {
 #undef C_
 #undef V_
 #undef W_
+}
+
+/* PostProcess_Atmosphere::Atmosphere_v_w_Transfer (atmosphere/PostProcess_Atm.cpp:98-118) followed by
+ * PostProcess_Hydrosphere::Atmosphere_TransferFile_read (hydrosphere/PostProcess_Hyd.cpp:642-668): every value
+ * goes through fixed notation with 4 decimals, as the file between the two models would carry it. */
+static double through_text(double x) {
+    char buf[400];
+    snprintf(buf, sizeof buf, "%.4f", x);
+    return strtod(buf, NULL);
+}
+void oracle_transfer_atm_to_hyd(oracle_ctx* a, oracle_ctx* h) {
+    const int jm = a->jm, km = a->km, top = h->im - 1;
+    for (int j = 0; j < jm; j++)
+        for (int k = 0; k < km; k++) {
+            A3(h, ATOMDEV_V, top, j, k) = through_text(A3(a, ATOMDEV_V, 0, j, k) * a->p.u_0);
+            A3(h, ATOMDEV_W, top, j, k) = through_text(A3(a, ATOMDEV_W, 0, j, k) * a->p.u_0);
+            A3(h, ATOMDEV_T, top, j, k) = through_text(A3(a, ATOMDEV_T, 0, j, k));
+            A3(h, ATOMDEV_P_DYN, top, j, k) = 0.;
+            A2(h, ATOMDEV_EVAPORATION_DALTON, j, k) = through_text(A2(a, ATOMDEV_EVAPORATION_DALTON, j, k));
+            A2(h, ATOMDEV_PRECIPITATION, j, k) = through_text(A2(a, ATOMDEV_PRECIPITATION, j, k));
+        }
 }
 
 /* BC_Thermohalin::BC_Pressure_Density, hydrosphere/BC_Thermohalin.cpp:518-583.  The local

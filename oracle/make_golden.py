@@ -139,6 +139,25 @@ def msl_case():
     print("atm_msl_data.npz", len(out), "entries")
 
 
+def transfer_case():
+    """Atmosphere -> hydrosphere transfer through the reference's own writer and reader: what arrives in the
+    hydrosphere, and the SHA-256 of the file the reference wrote."""
+    import tempfile
+    (pa, fa, ga), (ph, fh, gh) = H.make_transfer_inputs((5, 13, 17), (6, 13, 17), 61)
+    ra, rb = H.CpuModel("ref", H.ATM, 5, 13, 17, pa, fa, ga), H.CpuModel("ref", H.HYD, 6, 13, 17, ph, fh, gh)
+    with tempfile.TemporaryDirectory() as d:
+        ra.lib.ref_transfer_atm_to_hyd(ra.ctx, rb.ctx, d.encode())
+        text = open(os.path.join(d, "[bridge]_Transfer_Atm.vw"), "rb").read()
+    out = {"input_sha256": np.array(digest(fa, sorted(fa)) + digest(ga, sorted(ga)) + digest(fh, sorted(fh)) + digest(gh, sorted(gh))),
+           "file_sha256": np.array(hashlib.sha256(text).hexdigest()), "file_head": np.array(text[:600].decode())}
+    for k in ("V", "W", "T", "P_DYN"):
+        out[k] = rb.f[k][5].copy()
+    for k in ("EVAPORATION_DALTON", "PRECIPITATION"):
+        out[k] = rb.g[k].copy()
+    np.savez_compressed(os.path.join(GOLD, "transfer_small.npz"), **out)
+    print("transfer_small.npz", len(out), "entries")
+
+
 if __name__ == "__main__":
     assert H.have_ref(), "build oracle/_ref first: make -C oracle ref"
     os.makedirs(GOLD, exist_ok=True)
@@ -150,3 +169,4 @@ if __name__ == "__main__":
     full_case(H.ATM, "atm")
     full_case(H.HYD, "hyd")
     msl_case()
+    transfer_case()

@@ -27,6 +27,7 @@
 #include "BC_Bath_Atm.h"
 #include "Accuracy_Atm.h"
 #include "Results_Atm.h"
+#include "PostProcess_Atm.h"
 // the reference reuses these two include guards for the hydrosphere headers
 #undef _PRESSURE_
 #undef _ACCURACY_
@@ -37,6 +38,7 @@
 #include "BC_Bath_Hyd.h"
 #include "BC_Thermohalin.h"
 #include "Accuracy_Hyd.h"
+#include "PostProcess_Hyd.h"
 
 #include "../include/atomdev.h"
 
@@ -349,6 +351,21 @@ void ref_hyd_residuum3d(void* v, double* min, int loc[3]) {
     Accuracy_Hyd acc(c->im, c->jm, c->km, c->p.dr, c->p.dthe, c->p.dphi);
     acc.residuumQuery_3D(c->rad, c->the, A(U), A(V), A(W));
     *min = acc.out_min(); loc[0] = acc.out_i_res(); loc[1] = acc.out_j_res(); loc[2] = acc.out_k_res();
+}
+
+/* The reference's own writer and reader around the file dir/[name]_Transfer_Atm.vw */
+int ref_transfer_atm_to_hyd(void* va, void* vh, const char* dir) {
+    RefCtx* c = (RefCtx*)va; CoutSilencer s;
+    copy_in(c);
+    std::string out(dir), name("bridge");
+    PostProcess_Atmosphere ppa(c->im, c->jm, c->km, out);
+    ppa.Atmosphere_v_w_Transfer(name, c->p.u_0, A(V), A(W), A(T), A(P_DYN), B(EVAPORATION_DALTON), B(PRECIPITATION));
+    c = (RefCtx*)vh;
+    copy_in(c);
+    PostProcess_Hydrosphere read_Transfer(c->im, c->jm, c->km, out);
+    read_Transfer.Atmosphere_TransferFile_read(name, A(V), A(W), A(T), A(P_DYN), B(EVAPORATION_DALTON), B(PRECIPITATION));
+    copy_out(c);
+    return 0;
 }
 
 }  // extern "C"

@@ -335,3 +335,26 @@ def check_msl_golden(get3d, get2d, exact, tol=1e-10):
             scale = z[k + "/stats"][3]
             assert np.max(np.abs(sl - ref)) <= tol * scale, (k, np.max(np.abs(sl - ref)) / scale)
     return n
+
+
+def make_transfer_inputs(dims_atm, dims_hyd, seed):
+    """Atmosphere and hydrosphere inputs for the surface transfer; the atmosphere's surface values include the
+    hard cases of a 4-decimal round trip: exact ties (k + 1/2) / 10^4 that are representable (odd multiples of
+    1/32 ...), values one ulp either side of a tie, negative values that print as -0.0000, zeros of both signs."""
+    ia, jm, km = dims_atm
+    ih = dims_hyd[0]
+    pa, ph = default_params(ATM, ia, jm, km), default_params(HYD, ih, jm, km)
+    fa, ga = make_inputs(ATM, ia, jm, km, seed, "blobs", pa)
+    fh, gh = make_inputs(HYD, ih, jm, km, seed + 1, "blobs", ph)
+    fa = {k: fa[k] for k in ATM_FIELDS}
+    fh = {k: fh[k] for k in HYD_FIELDS}
+    ties = np.array([0.03125, -0.03125, 0.09375, 2.15625, -7.28125, 0.00005, 1.5, 1e-5, -1e-5, -4e-5, 6e-5, 0.0, -0.0,
+                     0.00015, 0.00025, 123.45675, 1000.00005, 0.99995, -0.99995, 5e-324, 24.99995])
+    hard = np.concatenate([ties, np.nextafter(ties, np.inf), np.nextafter(ties, -np.inf)])
+    n = min(hard.size, km * (jm - 1))
+    for name, arr in (("T", fa["T"][0]), ("P_DYN", fa["P_DYN"][0]), ("E", ga["EVAPORATION_DALTON"]), ("P", ga["PRECIPITATION"])):
+        arr.reshape(-1)[:n] = hard[:n]
+    # v and w are multiplied by u_0 = 8 before they are written: put the hard cases in the product
+    fa["V"][0].reshape(-1)[:n] = hard[:n] / 8.0
+    fa["W"][0].reshape(-1)[km:km + n] = hard[:n] / 8.0
+    return (pa, fa, ga), (ph, fh, gh)

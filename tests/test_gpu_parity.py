@@ -150,6 +150,72 @@ def test_atm_msl_data_golden():
     d.close()
 
 
+def test_transfer_atm_to_hyd_bitexact(tmp_path):
+    """The coupling without the text file: bit-exact (sign of zero included) against the oracle's print-and-parse
+    and against what the reference's writer + reader delivered (tests/golden/transfer_small.npz); the file written
+    by the library has the reference file's bytes, and reading it back gives the same fields again."""
+    import hashlib
+    z = np.load(os.path.join(GOLD, "transfer_small.npz"))
+    (pa, fa, ga), (ph, fh, gh) = H.make_transfer_inputs((5, 13, 17), (6, 13, 17), 61)
+    oa, ob = H.CpuModel("oracle", H.ATM, 5, 13, 17, pa, fa, ga), H.CpuModel("oracle", H.HYD, 6, 13, 17, ph, fh, gh)
+    oa.lib.oracle_transfer_atm_to_hyd(oa.ctx, ob.ctx)
+    da = atom_amd.DeviceModel(H.ATM, 5, 13, 17, atom_amd.Params.from_buffer_copy(bytes(pa)))
+    da.upload_all(fa, ga)
+
+    def same(a, b):
+        return np.array_equal(a, b) and np.array_equal(np.signbit(a), np.signbit(b))
+
+    def check(dh, what):
+        for k in fh:
+            assert same(dh.download(k), ob.f[k]), (what, k)
+        for k in gh:
+            assert same(dh.download(k), ob.g[k]), (what, k)
+        for k in ("V", "W", "T", "P_DYN"):
+            assert same(dh.download(k)[5], z[k]), (what, k)
+        for k in ("EVAPORATION_DALTON", "PRECIPITATION"):
+            assert same(dh.download(k), z[k]), (what, k)
+
+    dh = atom_amd.DeviceModel(H.HYD, 6, 13, 17, atom_amd.Params.from_buffer_copy(bytes(ph)))
+    dh.upload_all(fh, gh)
+    da.transfer_to_hyd(dh)
+    check(dh, "device to device")
+    path = str(tmp_path / "t.vw")
+    da.write_transfer_file(path)
+    assert hashlib.sha256(open(path, "rb").read()).hexdigest() == str(z["file_sha256"])
+    dh2 = atom_amd.DeviceModel(H.HYD, 6, 13, 17, atom_amd.Params.from_buffer_copy(bytes(ph)))
+    dh2.upload_all(fh, gh)
+    dh2.read_transfer_file(path)
+    check(dh2, "through the file")
+    with pytest.raises(atom_amd.AtomDevError):
+        dh2.read_transfer_file(str(tmp_path / "missing.vw"))
+    with pytest.raises(atom_amd.AtomDevError):
+        dh.transfer_to_hyd(da)
+    for m in (da, dh, dh2):
+        m.close()
+
+
+def test_transfer_wide_range_values_bitexact():
+    """390 000 surface values over twelve decades of magnitude, both signs, through the device's decimal
+    rounding and through the oracle's print-and-parse: identical bits."""
+    im_a, im_h, jm, km = 5, 6, 181, 361
+    (pa, fa, ga), (ph, fh, gh) = H.make_transfer_inputs((im_a, jm, km), (im_h, jm, km), 62)
+    rng = np.random.default_rng(63)
+    wide = lambda: rng.choice([-1.0, 1.0], (jm, km)) * 10.0 ** rng.uniform(-8, 4, (jm, km))
+    fa["V"][0], fa["W"][0], fa["T"][0] = wide() / 8.0, wide() / 8.0, wide()
+    ga["EVAPORATION_DALTON"], ga["PRECIPITATION"] = wide(), wide()
+    oa = H.CpuModel("oracle", H.ATM, im_a, jm, km, pa, fa, ga)
+    ob = H.CpuModel("oracle", H.HYD, im_h, jm, km, ph, fh, gh)
+    oa.lib.oracle_transfer_atm_to_hyd(oa.ctx, ob.ctx)
+    da = atom_amd.DeviceModel(H.ATM, im_a, jm, km, atom_amd.Params.from_buffer_copy(bytes(pa)))
+    dh = atom_amd.DeviceModel(H.HYD, im_h, jm, km, atom_amd.Params.from_buffer_copy(bytes(ph)))
+    da.upload_all(fa, ga); dh.upload_all(fh, gh)
+    da.transfer_to_hyd(dh)
+    for k in ("V", "W", "T", "P_DYN", "EVAPORATION_DALTON", "PRECIPITATION"):
+        got, ref = dh.download(k), (ob.f[k] if k in ob.f else ob.g[k])
+        assert np.array_equal(got, ref) and np.array_equal(np.signbit(got), np.signbit(ref)), k
+    da.close(); dh.close()
+
+
 def test_golden_small_hyd_bitexact():
     """HIP path against the compiled reference's own outputs (tests/golden/hyd_small.npz)."""
     z = np.load(os.path.join(GOLD, "hyd_small.npz"))

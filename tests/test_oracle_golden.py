@@ -156,3 +156,21 @@ def test_atm_msl_data_golden_bitexact():
     m = H.CpuModel("oracle", H.ATM, im, jm, km, p, f, g)
     m.op("atm_msl_data", C.c_int(1))
     assert H.check_msl_golden(lambda k: m.f[k], lambda k: m.g[k], exact=True) >= 14
+
+
+def _same_with_sign(a, b):
+    return np.array_equal(a, b) and np.array_equal(np.signbit(a), np.signbit(b))
+
+
+def test_transfer_golden_bitexact():
+    """Atmosphere -> hydrosphere transfer: the oracle against what the reference's writer + reader delivered."""
+    z = np.load(os.path.join(GOLD, "transfer_small.npz"))
+    (pa, fa, ga), (ph, fh, gh) = H.make_transfer_inputs((5, 13, 17), (6, 13, 17), 61)
+    assert (_digest(fa, sorted(fa)) + _digest(ga, sorted(ga)) + _digest(fh, sorted(fh)) + _digest(gh, sorted(gh))
+            == str(z["input_sha256"])), "input generator drifted"
+    oa, ob = H.CpuModel("oracle", H.ATM, 5, 13, 17, pa, fa, ga), H.CpuModel("oracle", H.HYD, 6, 13, 17, ph, fh, gh)
+    oa.lib.oracle_transfer_atm_to_hyd(oa.ctx, ob.ctx)
+    for k in ("V", "W", "T", "P_DYN"):
+        assert _same_with_sign(ob.f[k][5], z[k]), k
+    for k in ("EVAPORATION_DALTON", "PRECIPITATION"):
+        assert _same_with_sign(ob.g[k], z[k]), k

@@ -79,3 +79,18 @@ def test_atm_msl_data(radiation_model, seed):
         assert H.bits_equal(a.g[k], b.g[k]), k
         changed += not np.array_equal(a.g[k], g[k])
     assert changed >= 14  # p_stat, buoyancy, 5 clamped fields, 7-8 surface fields, evaporation, precipitation
+
+
+def test_transfer_atm_to_hyd(tmp_path):
+    """The decimal round trip of the atmosphere -> hydrosphere transfer file, through the reference's own
+    writer and reader, against the oracle's print-and-parse restatement."""
+    (pa, fa, ga), (ph, fh, gh) = H.make_transfer_inputs((5, 13, 17), (6, 13, 17), 61)
+    oa, ob = H.CpuModel("oracle", H.ATM, 5, 13, 17, pa, fa, ga), H.CpuModel("oracle", H.HYD, 6, 13, 17, ph, fh, gh)
+    ra, rb = H.CpuModel("ref", H.ATM, 5, 13, 17, pa, fa, ga), H.CpuModel("ref", H.HYD, 6, 13, 17, ph, fh, gh)
+    oa.lib.oracle_transfer_atm_to_hyd(oa.ctx, ob.ctx)
+    ra.lib.ref_transfer_atm_to_hyd(ra.ctx, rb.ctx, str(tmp_path).encode())
+    for k in fh:
+        assert np.array_equal(ob.f[k], rb.f[k]) and np.array_equal(np.signbit(ob.f[k]), np.signbit(rb.f[k])), k
+    for k in gh:
+        assert np.array_equal(ob.g[k], rb.g[k]) and np.array_equal(np.signbit(ob.g[k]), np.signbit(rb.g[k])), k
+    assert not np.array_equal(ob.f["V"][5], fh["V"][5])
