@@ -36,7 +36,7 @@ HBM_PEAK_GBS = 8000.0
 
 ATM_STEP = ["atm_bc_radius", "atm_bc_theta", "atm_bc_phi", "atm_value_limitation", "atm_solid_ground",
             "atm_rk3d", "atm_value_limitation", "move3d"]
-HYD_STEP = ["hyd_bc_radius", "hyd_bc_theta", "hyd_bc_phi", "hyd_value_limitation", "hyd_rk3d",
+HYD_STEP = ["hyd_bc_radius", "hyd_bc_theta", "hyd_bc_phi", "hyd_pressure_density", "hyd_value_limitation", "hyd_rk3d",
             "hyd_solid_ground", "move3d"]
 
 

@@ -358,3 +358,53 @@ def make_transfer_inputs(dims_atm, dims_hyd, seed):
     fa["V"][0].reshape(-1)[:n] = hard[:n] / 8.0
     fa["W"][0].reshape(-1)[km:km + n] = hard[:n] / 8.0
     return (pa, fa, ga), (ph, fh, gh)
+
+
+# --------------------------------------------------------------------------
+# the reference's 3-D iteration loops, operator by operator
+# --------------------------------------------------------------------------
+
+def _move3d(m):
+    if hasattr(m, "move_data_to_new_arrays"):
+        m.move_data_to_new_arrays(-1)
+    else:
+        m.op("move_data_to_new_arrays", C.c_int(-1))
+
+
+def hyd_3d_loop(m, pressure_iters=2, velocity_iters=2):
+    """cHydrosphereModel.cpp:420-610 without its printing: returns the queries' results in call order."""
+    log = []
+    for _ in range(pressure_iters):
+        for _ in range(velocity_iters):
+            log.append(m.residuum("hyd_residuum3d"))
+            for op in ("hyd_bc_radius", "hyd_bc_theta", "hyd_bc_phi", "hyd_pressure_density", "hyd_value_limitation",
+                       "hyd_rk3d", "hyd_solid_ground"):
+                m.op(op)
+            log.append(m.residuum("hyd_residuum3d"))
+            log.append(m.steady("hyd_steady3d", 6))
+            _move3d(m)
+        m.op("hyd_pressure3d")
+    return log
+
+
+def atm_3d_loop(m, pressure_iters=2, velocity_iters=2):
+    """cAtmosphereModel.cpp:756-874 with the operators of this library (the BC_Thermo column physics between them
+    is host code of the caller and left out here): returns the queries' results in call order."""
+    log = []
+    _move3d(m)
+    for _ in range(pressure_iters):
+        for _ in range(velocity_iters):
+            mn, loc = m.residuum("atm_residuum3d")
+            log.append((mn, loc))
+            for op in ("atm_bc_radius", "atm_bc_theta", "atm_bc_phi", "atm_value_limitation", "atm_solid_ground",
+                       "atm_rk3d", "atm_value_limitation"):
+                m.op(op)
+            log.append(m.residuum("atm_residuum3d", mn, loc))  # same Accuracy_Atm object: state carried
+            log.append(m.steady("atm_steady3d", 9))
+            if hasattr(m, "msl_data"):
+                m.msl_data(1)
+            else:
+                m.op("atm_msl_data", C.c_int(1))
+            _move3d(m)
+        m.op("atm_pressure3d")
+    return log
