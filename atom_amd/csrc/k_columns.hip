@@ -186,7 +186,28 @@ __global__ void k_buoyancy_fill_r(double* b, const uint8_t* flags, int im, int j
     b[top] = c43 * b[top - n2] - c13 * b[top - 2 * n2];
 }
 
+// BC_Bathymetry_Atmosphere::vegetationDistribution (atmosphere/BC_Bath_Atm.cpp:129-142)
+__global__ void k_vegetation(const double* __restrict__ precipitation, const double* __restrict__ t,
+                             const uint8_t* __restrict__ flags, double max_precipitation, size_t n2,
+                             double* __restrict__ vegetation) {
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n2) return;
+    const bool grows = max_precipitation > 0 && (flags[q] & FL_LAND) && !(t[q] < 1.);
+    vegetation[q] = grows ? precipitation[q] / max_precipitation : 0.;
+}
+
 }  // namespace
+
+extern "C" int atomdev_atm_vegetation_distribution(atomdev_t* h, double max_Precipitation) {
+    ATOMDEV_REQUIRE(h && h->model == ATOMDEV_ATM, "atomdev_atm_vegetation_distribution: not an atmosphere handle");
+    ATOMDEV_TRY(hipSetDevice(h->device));
+    if (int rc = atomdev_refresh_flags(h)) return rc;
+    hipLaunchKernelGGL(k_vegetation, dim3((unsigned)((h->n2 + TPB - 1) / TPB)), dim3(TPB), 0, h->stream,
+                       h->g[ATOMDEV_PRECIPITATION], h->f[ATOMDEV_T], h->flags, max_Precipitation, h->n2,
+                       h->g[ATOMDEV_VEGETATION]);
+    ATOMDEV_TRY(hipGetLastError());
+    return 0;
+}
 
 extern "C" int atomdev_atm_msl_data(atomdev_t* h, int RadiationModel) {
     ATOMDEV_REQUIRE(h && h->model == ATOMDEV_ATM, "atomdev_atm_msl_data: not an atmosphere handle");

@@ -20,7 +20,7 @@ F3 = dict(T=0, U=1, V=2, W=3, P_DYN=4, C=5, CLOUD=6, ICE=7, CO2=8,
           SALT_BALANCE=28, SALT_FINGER=29, SALT_DIFFUSION=30, R_WATER=31, R_SALT_WATER=32,
           RESIDUUM=33, P_STAT=34, Q_LATENT=35, Q_SENSIBLE=36, RADIATION_3D=37, P_RAIN=38, P_SNOW=39)
 F2 = dict(TOPOGRAPHY=0, EVAPORATION_DALTON=1, PRECIPITATION=2, Q_RADIATION=3, PRECIPITABLE_WATER=4,
-          EVAPORATION_PENMAN=5, Q_EVAPORATION=6, Q_LATENT_2D=7, Q_SENSIBLE_2D=8, Q_BOTTOM=9, CO2_TOTAL=10)
+          EVAPORATION_PENMAN=5, Q_EVAPORATION=6, Q_LATENT_2D=7, Q_SENSIBLE_2D=8, Q_BOTTOM=9, CO2_TOTAL=10, VEGETATION=11)
 
 
 class Params(C.Structure):
@@ -75,6 +75,7 @@ def load_library():
     lib.atomdev_sync.argtypes = [vp]
     lib.atomdev_move_data_to_new_arrays.argtypes = [vp, C.c_int]
     lib.atomdev_atm_msl_data.argtypes = [vp, C.c_int]
+    lib.atomdev_atm_vegetation_distribution.argtypes = [vp, C.c_double]
     lib.atomdev_transfer_atm_to_hyd.argtypes = [vp, vp]
     lib.atomdev_atm_write_transfer_file.argtypes = [vp, C.c_char_p]
     lib.atomdev_hyd_read_transfer_file.argtypes = [vp, C.c_char_p]
@@ -189,6 +190,9 @@ class DeviceModel:
     def msl_data(self, radiation_model=1):
         """Results_MSL_Atm::run_MSL_data, the part that changes model fields."""
         self._check(self.lib.atomdev_atm_msl_data(self._h, radiation_model))
+
+    def vegetation_distribution(self, max_precipitation):
+        self._check(self.lib.atomdev_atm_vegetation_distribution(self._h, float(max_precipitation)))
 
     def transfer_to_hyd(self, hyd):
         """Surface velocities, temperature, evaporation and precipitation of this atmosphere into the top level of

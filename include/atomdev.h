@@ -58,7 +58,8 @@ enum atomdev_field2d {
     /* atmosphere surface diagnostics written by run_MSL_data (atmosphere/cAtmosphereModel.h:206-227) */
     ATOMDEV_Q_RADIATION = 3, ATOMDEV_PRECIPITABLE_WATER, ATOMDEV_EVAPORATION_PENMAN, ATOMDEV_Q_EVAPORATION,
     ATOMDEV_Q_LATENT_2D, ATOMDEV_Q_SENSIBLE_2D, ATOMDEV_Q_BOTTOM, ATOMDEV_CO2_TOTAL,
-    ATOMDEV_N2D = 11
+    ATOMDEV_VEGETATION = 11,
+    ATOMDEV_N2D = 12
 };
 
 /* Scalars the hot path reads.  Names and meaning are those of the reference's
@@ -153,6 +154,9 @@ int atomdev_atm_steady2d(atomdev_t* h, double out[3], int loc[9]);
  * BuoyancyForce; c, cloud, ice, P_rain, P_snow clamped at zero; co2_total, precipitable_water and
  * Precipitation.  Reads t, c, v, w, Q_Latent, Q_Sensible, radiation_3D, co2, h. */
 int atomdev_atm_msl_data(atomdev_t* h, int RadiationModel);
+/* BC_Bathymetry_Atmosphere::vegetationDistribution (atmosphere/BC_Bath_Atm.cpp:129-142): Vegetation =
+ * Precipitation / max_Precipitation on land surface cells that are not colder than t = 1, else 0. */
+int atomdev_atm_vegetation_distribution(atomdev_t* h, double max_Precipitation);
 
 /* ---- hydrosphere ---- */
 /* BC_Hydrosphere::RB_radius / RB_theta / RB_phi (hydrosphere/BC_Hyd.cpp:38-158) */

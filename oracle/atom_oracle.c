@@ -1016,6 +1016,17 @@ void oracle_atm_msl_data(oracle_ctx* c, int RadiationModel) {
 #undef W_
 }
 
+/* BC_Bathymetry_Atmosphere::vegetationDistribution, atmosphere/BC_Bath_Atm.cpp:129-142 */
+void oracle_atm_vegetation_distribution(oracle_ctx* c, double max_Precipitation) {
+    for (int j = 0; j < c->jm; j++)
+        for (int k = 0; k < c->km; k++) {
+            if (max_Precipitation > 0 && is_land(c, 0, j, k) && !(A3(c, ATOMDEV_T, 0, j, k) < 1.))
+                A2(c, ATOMDEV_VEGETATION, j, k) = A2(c, ATOMDEV_PRECIPITATION, j, k) / max_Precipitation;
+            else
+                A2(c, ATOMDEV_VEGETATION, j, k) = 0.;
+        }
+}
+
 /* PostProcess_Atmosphere::Atmosphere_v_w_Transfer (atmosphere/PostProcess_Atm.cpp:98-118) followed by
  * PostProcess_Hydrosphere::Atmosphere_TransferFile_read (hydrosphere/PostProcess_Hyd.cpp:642-668): every value
  * goes through fixed notation with 4 decimals, as the file between the two models would carry it. */

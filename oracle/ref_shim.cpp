@@ -264,6 +264,13 @@ int ref_atm_msl_data(void* v, int RadiationModel) {
     return 0;
 }
 
+void ref_atm_vegetation_distribution(void* v, double max_Precipitation) {
+    RefCtx* c = (RefCtx*)v; CoutSilencer s; copy_in(c);
+    BC_Bathymetry_Atmosphere LandArea(1, c->im, c->jm, c->km, 3.0, 0., 0.);
+    LandArea.vegetationDistribution(max_Precipitation, B(PRECIPITATION), B(VEGETATION), A(T), A(H));
+    copy_out(c);
+}
+
 /* ---- hydrosphere ---- */
 
 void ref_hyd_rk3d(void* v) {

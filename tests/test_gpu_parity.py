@@ -216,6 +216,20 @@ def test_transfer_wide_range_values_bitexact():
     da.close(); dh.close()
 
 
+@pytest.mark.parametrize("max_precipitation", [7.5, 0.0])
+def test_atm_vegetation_distribution_bitexact(max_precipitation):
+    import ctypes as C
+    o, d, _ = _pair(H.ATM, (7, 13, 17), 81, "blobs")
+    o.f["T"][0, ::2, :] = 1.0
+    d.upload("T", o.f["T"])
+    o.g["VEGETATION"] = np.full((13, 17), -1.0)
+    getattr(o.lib, o.pre + "bind2d")(o.ctx, H.F2["VEGETATION"], o.g["VEGETATION"].ctypes.data_as(C.c_void_p))
+    o.op("atm_vegetation_distribution", C.c_double(max_precipitation))
+    d.vegetation_distribution(max_precipitation)
+    assert H.bits_equal(d.download("VEGETATION"), o.g["VEGETATION"])
+    d.close()
+
+
 def test_golden_small_hyd_bitexact():
     """HIP path against the compiled reference's own outputs (tests/golden/hyd_small.npz)."""
     z = np.load(os.path.join(GOLD, "hyd_small.npz"))

@@ -94,3 +94,16 @@ def test_transfer_atm_to_hyd(tmp_path):
     for k in gh:
         assert np.array_equal(ob.g[k], rb.g[k]) and np.array_equal(np.signbit(ob.g[k]), np.signbit(rb.g[k])), k
     assert not np.array_equal(ob.f["V"][5], fh["V"][5])
+
+
+@pytest.mark.parametrize("max_precipitation", [7.5, 0.0])
+def test_atm_vegetation_distribution(max_precipitation):
+    import ctypes as C
+    a, b, _ = _pair(H.ATM, (7, 13, 17), 81, "blobs")
+    for m in (a, b):
+        m.f["T"][0, ::2, :] = 1.0          # exactly the threshold: counts as warm enough
+        m.g["VEGETATION"] = np.full((13, 17), -1.0)
+        getattr(m.lib, m.pre + "bind2d")(m.ctx, H.F2["VEGETATION"], m.g["VEGETATION"].ctypes.data_as(C.c_void_p))
+        m.op("atm_vegetation_distribution", C.c_double(max_precipitation))
+    assert H.bits_equal(a.g["VEGETATION"], b.g["VEGETATION"])
+    assert (a.g["VEGETATION"] > 0).any() == (max_precipitation > 0)
