@@ -283,7 +283,105 @@ int steady(atomdev* h, const int* ids, int nf, size_t off, size_t n, bool last, 
     return 0;
 }
 
+// ---- extreme values and where the reference's scans find them ----
+// MinMax_Atm::searchMinMax_3D / _2D (atmosphere/MinMax_Atm.cpp:74-196) and MinMax_Hyd::searchMinMax_3D / _2D
+// (hydrosphere/MinMax_Hyd.cpp:51-260) walk the field in (j, k, i) order with strict comparisons, so each result
+// is the largest / smallest value at its first position in that order; what differs between the four is the
+// seed of the scan, applied on the host afterwards.  key = rank of a point in the (j, k, i) walk.
+struct Ext { double vmax; long long kmax; double vmin; long long kmin; };
+
+__device__ __forceinline__ void ext_take(Ext& a, double vmax, long long kmax, double vmin, long long kmin) {
+    if (vmax > a.vmax || (vmax == a.vmax && kmax < a.kmax)) { a.vmax = vmax; a.kmax = kmax; }
+    if (vmin < a.vmin || (vmin == a.vmin && kmin < a.kmin)) { a.vmin = vmin; a.kmin = kmin; }
+}
+
+__device__ __forceinline__ void ext_block_reduce(Ext& b, Ext* sh) {
+    sh[threadIdx.x] = b;
+    __syncthreads();
+    for (int st = TPB / 2; st > 0; st >>= 1) {
+        if (threadIdx.x < st) {
+            const Ext o = sh[threadIdx.x + st];
+            ext_take(sh[threadIdx.x], o.vmax, o.kmax, o.vmin, o.kmin);
+        }
+        __syncthreads();
+    }
+    b = sh[0];
+}
+
+// two_d: interior points of a jm x km surface (im = 1); skip_zero_min: zeros do not count for the minimum
+__global__ void k_minmax_partial(const double* __restrict__ x, int im, int jm, int km, int two_d, int skip_zero_min,
+                                 Ext* __restrict__ part) {
+    __shared__ Ext sh[TPB];
+    const long long none = 1LL << 62;
+    Ext b = { -INFINITY, none, INFINITY, none };
+    const size_t n = (size_t)im * jm * km;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(q % km), j = (int)((q / km) % jm), i = (int)(q / ((size_t)km * jm));
+        if (two_d && (j < 1 || j > jm - 2 || k < 1 || k > km - 2)) continue;
+        const long long key = ((long long)j * km + k) * im + i;
+        const double v = x[q];
+        if (v > b.vmax || (v == b.vmax && key < b.kmax)) { b.vmax = v; b.kmax = key; }
+        if (!(skip_zero_min && v == 0.) && (v < b.vmin || (v == b.vmin && key < b.kmin))) { b.vmin = v; b.kmin = key; }
+    }
+    ext_block_reduce(b, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = b;
+}
+
+__global__ void k_minmax_final(const Ext* __restrict__ part, int nblocks, const double* __restrict__ x, Ext* __restrict__ out,
+                               double* __restrict__ first_value) {
+    __shared__ Ext sh[TPB];
+    const long long none = 1LL << 62;
+    Ext b = { -INFINITY, none, INFINITY, none };
+    for (int i = threadIdx.x; i < nblocks; i += blockDim.x) ext_take(b, part[i].vmax, part[i].kmax, part[i].vmin, part[i].kmin);
+    ext_block_reduce(b, sh);
+    if (threadIdx.x == 0) { *out = b; *first_value = x[0]; }
+}
+
+int minmax(atomdev* h, const double* x, bool two_d, double out[2], int loc[6]) {
+    const bool hyd = h->model == ATOMDEV_HYD;
+    const int nblocks = 512;
+    Ext* part = (Ext*)h->red;
+    Ext* fin = part + nblocks;
+    double* first = (double*)(fin + 1);
+    if ((size_t)((char*)(first + 1) - (char*)h->red) > h->red_bytes) { atomdev_set_error("minmax: scratch too small"); return 1; }
+    const int im = two_d ? 1 : h->im;
+    hipLaunchKernelGGL(k_minmax_partial, dim3(nblocks), dim3(TPB), 0, h->stream, x, im, h->jm, h->km, two_d ? 1 : 0,
+                       (hyd && two_d) ? 1 : 0, part);
+    hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(TPB), 0, h->stream, part, nblocks, x, fin, first);
+    ATOMDEV_TRY(hipGetLastError());
+    struct { Ext e; double first; } r;
+    ATOMDEV_TRY(hipMemcpyAsync(&r, fin, sizeof(r), hipMemcpyDeviceToHost, h->stream));
+    ATOMDEV_TRY(hipStreamSynchronize(h->stream));
+    const long long none = 1LL << 62;
+    // seeds: MinMax_Atm starts both scans from the first element (which the 2-D scan, interior only, never visits);
+    // MinMax_Hyd starts the maximum from 0 and the minimum from the maximum it found
+    double vmax = hyd ? 0. : r.first, vmin;
+    long long kmax = 0, kmin = 0;
+    if (r.e.kmax != none && r.e.vmax > vmax) { vmax = r.e.vmax; kmax = r.e.kmax; }
+    vmin = hyd ? vmax : r.first;
+    if (r.e.kmin != none && r.e.vmin < vmin) { vmin = r.e.vmin; kmin = r.e.kmin; }
+    if (hyd && two_d && vmin < 0.) vmin = 0.;  // MinMax_Hyd.cpp:258
+    out[0] = vmax; out[1] = vmin;
+    const long long keys[2] = { kmax, kmin };
+    for (int n = 0; n < 2; n++) {
+        const long long key = keys[n];
+        loc[3 * n] = (int)(key % im); loc[3 * n + 1] = (int)(key / ((long long)h->km * im)); loc[3 * n + 2] = (int)((key / im) % h->km);
+    }
+    return 0;
+}
+
 }  // namespace
+
+extern "C" int atomdev_minmax3d(atomdev_t* h, int field3d, double out[2], int loc[6]) {
+    ATOMDEV_REQUIRE(h && out && loc && field3d >= 0 && field3d < ATOMDEV_N3D && h->f[field3d], "atomdev_minmax3d: bad argument");
+    ATOMDEV_TRY(hipSetDevice(h->device));
+    return minmax(h, h->f[field3d], false, out, loc);
+}
+extern "C" int atomdev_minmax2d(atomdev_t* h, int field2d, double out[2], int loc[6]) {
+    ATOMDEV_REQUIRE(h && out && loc && field2d >= 0 && field2d < ATOMDEV_N2D, "atomdev_minmax2d: bad argument");
+    ATOMDEV_TRY(hipSetDevice(h->device));
+    return minmax(h, h->g[field2d], true, out, loc);
+}
 
 extern "C" int atomdev_atm_residuum3d(atomdev_t* h, double* min, int loc[3]) {
     ATOMDEV_REQUIRE(h && h->model == ATOMDEV_ATM && min && loc, "atomdev_atm_residuum3d: bad argument");

@@ -85,6 +85,8 @@ def load_library():
         getattr(lib, name).argtypes = [vp, dp, ip]
     for name in ("atomdev_atm_steady3d", "atomdev_atm_steady2d", "atomdev_hyd_steady3d"):
         getattr(lib, name).argtypes = [vp, dp, ip]
+    for name in ("atomdev_minmax3d", "atomdev_minmax2d"):
+        getattr(lib, name).argtypes = [vp, C.c_int, dp, ip]
     lib.atomdev_timer_start.argtypes = [vp]
     lib.atomdev_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
     lib.atomdev_profile_rk.argtypes = [vp, C.c_int]
@@ -219,6 +221,16 @@ class DeviceModel:
         loc = (C.c_int * (3 * n))()
         self._check(getattr(self.lib, "atomdev_" + name)(self._h, out, loc))
         return np.array(out), np.array(loc).reshape(n, 3)
+
+    def minmax(self, name):
+        """((max, (i, j, k)), (min, (i, j, k))) of a field as MinMax_Atm / MinMax_Hyd search it."""
+        out = (C.c_double * 2)()
+        loc = (C.c_int * 6)()
+        if name in F2:
+            self._check(self.lib.atomdev_minmax2d(self._h, F2[name], out, loc))
+        else:
+            self._check(self.lib.atomdev_minmax3d(self._h, F3[name], out, loc))
+        return (out[0], tuple(loc[0:3])), (out[1], tuple(loc[3:6]))
 
     def timer_start(self):
         self._check(self.lib.atomdev_timer_start(self._h))

@@ -187,6 +187,18 @@ int atomdev_hyd_residuum3d(atomdev_t* h, double* min, int loc[3]);
  * (last location of the maximum); loc = 6 x {i,j,k}. */
 int atomdev_hyd_steady3d(atomdev_t* h, double out[6], int loc[18]);
 
+/* ---- extreme values (both models) ---- */
+/* MinMax_Atm::searchMinMax_3D / _2D (atmosphere/MinMax_Atm.cpp:74-196) on an atmosphere handle,
+ * MinMax_Hyd::searchMinMax_3D / _2D (hydrosphere/MinMax_Hyd.cpp:51-260) on a hydrosphere handle: the search
+ * itself, without the unit conversion and the printout that follow it.  out = {maxValue, minValue},
+ * loc = {imax, jmax, kmax, imin, jmin, kmin}, found as the reference's (j, k, i) scans with strict comparisons
+ * find them: MinMax_Atm seeds both from the first element (the 2-D scan covers interior points only),
+ * MinMax_Hyd seeds the maximum with 0 and the minimum with the maximum, and its 2-D minimum skips zeros and
+ * is raised to 0 if negative.  The atmosphere's max_Precipitation (cAtmosphereModel.cpp:555) is
+ * atomdev_minmax2d(h, ATOMDEV_PRECIPITATION, ...)'s out[0]. */
+int atomdev_minmax3d(atomdev_t* h, int field3d, double out[2], int loc[6]);
+int atomdev_minmax2d(atomdev_t* h, int field2d, double out[2], int loc[6]);
+
 /* ---- atmosphere -> hydrosphere coupling ---- */
 /* PostProcess_Atmosphere::Atmosphere_v_w_Transfer (atmosphere/PostProcess_Atm.cpp:98-118) followed by
  * PostProcess_Hydrosphere::Atmosphere_TransferFile_read (hydrosphere/PostProcess_Hyd.cpp:642-668), without the

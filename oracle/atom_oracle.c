@@ -1016,6 +1016,61 @@ void oracle_atm_msl_data(oracle_ctx* c, int RadiationModel) {
 #undef W_
 }
 
+/* MinMax_Atm::searchMinMax_3D / _2D (atmosphere/MinMax_Atm.cpp:74-196), MinMax_Hyd::searchMinMax_3D / _2D
+ * (hydrosphere/MinMax_Hyd.cpp:51-260): the scans, without unit conversion and printout.  The model of the
+ * context selects the class.  out = {max, min}; loc = {imax, jmax, kmax, imin, jmin, kmin}. */
+void oracle_minmax3d(oracle_ctx* c, int field, double out[2], int loc[6]) {
+    const int im = c->im, jm = c->jm, km = c->km;
+    double maxValue, minValue;
+    for (int n = 0; n < 6; n++) loc[n] = 0;
+    if (c->model == ATOMDEV_ATM) {
+        minValue = maxValue = A3(c, field, 0, 0, 0);
+        for (int j = 0; j < jm; j++) for (int k = 0; k < km; k++) for (int i = 0; i < im; i++) {
+            double v = A3(c, field, i, j, k);
+            if (v > maxValue) { maxValue = v; loc[0] = i; loc[1] = j; loc[2] = k; }
+            else if (v < minValue) { minValue = v; loc[3] = i; loc[4] = j; loc[5] = k; }
+        }
+    } else {
+        maxValue = 0.;
+        for (int j = 0; j < jm; j++) for (int k = 0; k < km; k++) for (int i = 0; i < im; i++) {
+            double v = A3(c, field, i, j, k);
+            if (v > maxValue) { maxValue = v; loc[0] = i; loc[1] = j; loc[2] = k; }
+        }
+        minValue = maxValue;
+        for (int j = 0; j < jm; j++) for (int k = 0; k < km; k++) for (int i = 0; i < im; i++) {
+            double v = A3(c, field, i, j, k);
+            if (v < minValue) { minValue = v; loc[3] = i; loc[4] = j; loc[5] = k; }
+        }
+    }
+    out[0] = maxValue; out[1] = minValue;
+}
+void oracle_minmax2d(oracle_ctx* c, int field, double out[2], int loc[6]) {
+    const int jm = c->jm, km = c->km;
+    double maxValue, minValue;
+    for (int n = 0; n < 6; n++) loc[n] = 0;
+    if (c->model == ATOMDEV_ATM) {
+        minValue = maxValue = A2(c, field, 0, 0);
+        for (int j = 1; j < jm - 1; j++) for (int k = 1; k < km - 1; k++) {
+            double v = A2(c, field, j, k);
+            if (v > maxValue) { maxValue = v; loc[1] = j; loc[2] = k; }
+            else if (v < minValue) { minValue = v; loc[4] = j; loc[5] = k; }
+        }
+    } else {
+        maxValue = 0.;
+        for (int j = 1; j < jm - 1; j++) for (int k = 1; k < km - 1; k++) {
+            double v = A2(c, field, j, k);
+            if (v > maxValue) { maxValue = v; loc[1] = j; loc[2] = k; }
+        }
+        minValue = maxValue;
+        for (int j = 1; j < jm - 1; j++) for (int k = 1; k < km - 1; k++) {
+            double v = A2(c, field, j, k);
+            if ((v < minValue) && (v != 0.)) { minValue = v; loc[4] = j; loc[5] = k; }
+        }
+        if (minValue < 0.) minValue = 0.;
+    }
+    out[0] = maxValue; out[1] = minValue;
+}
+
 /* BC_Bathymetry_Atmosphere::vegetationDistribution, atmosphere/BC_Bath_Atm.cpp:129-142 */
 void oracle_atm_vegetation_distribution(oracle_ctx* c, double max_Precipitation) {
     for (int j = 0; j < c->jm; j++)

@@ -28,9 +28,11 @@
 #include "Accuracy_Atm.h"
 #include "Results_Atm.h"
 #include "PostProcess_Atm.h"
-// the reference reuses these two include guards for the hydrosphere headers
+#include "MinMax_Atm.h"
+// the reference reuses these include guards for the hydrosphere headers
 #undef _PRESSURE_
 #undef _ACCURACY_
+#undef _MINMAX_
 #include "RHS_Hyd.h"
 #include "RungeKutta_Hyd.h"
 #include "Pressure_Hyd.h"
@@ -39,6 +41,7 @@
 #include "BC_Thermohalin.h"
 #include "Accuracy_Hyd.h"
 #include "PostProcess_Hyd.h"
+#include "MinMax_Hyd.h"
 
 #include "../include/atomdev.h"
 
@@ -358,6 +361,24 @@ void ref_hyd_residuum3d(void* v, double* min, int loc[3]) {
     Accuracy_Hyd acc(c->im, c->jm, c->km, c->p.dr, c->p.dthe, c->p.dphi);
     acc.residuumQuery_3D(c->rad, c->the, A(U), A(V), A(W));
     *min = acc.out_min(); loc[0] = acc.out_i_res(); loc[1] = acc.out_j_res(); loc[2] = acc.out_k_res();
+}
+
+/* MinMax_*::searchMinMax_*: the classes expose the two values only (the locations are printed);
+ * names that trigger no unit conversion (MinMax_Hyd.cpp:168-205). */
+void ref_minmax(void* v, int field, int two_d, double out[2]) {
+    RefCtx* c = (RefCtx*)v; CoutSilencer s; copy_in(c);
+    std::string a(" max x "), b(" min x "), u("-");
+    if (c->model == ATOMDEV_ATM) {
+        MinMax_Atm m(c->im, c->jm, c->km);
+        if (two_d) m.searchMinMax_2D(a, b, u, *c->b[field], A(H));
+        else m.searchMinMax_3D(a, b, u, *c->a[field], A(H));
+        out[0] = m.out_maxValue(); out[1] = m.out_minValue();
+    } else {
+        MinMax_Hyd m(c->im, c->jm, c->km, c->p.u_0, c->p.c_0, c->p.L_hyd);
+        if (two_d) m.searchMinMax_2D(a, b, u, *c->b[field], A(H));
+        else m.searchMinMax_3D(a, b, u, *c->a[field], A(H));
+        out[0] = m.out_maxValue(); out[1] = m.out_minValue();
+    }
 }
 
 /* The reference's own writer and reader around the file dir/[name]_Transfer_Atm.vw */

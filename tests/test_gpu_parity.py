@@ -230,6 +230,28 @@ def test_atm_vegetation_distribution_bitexact(max_precipitation):
     d.close()
 
 
+@pytest.mark.parametrize("model", [H.ATM, H.HYD])
+def test_minmax_searches(model):
+    """Values and locations of the MinMax_* scans (the reference exposes the values only; the locations follow the
+    oracle's literal restatement of the loops): ties, all-negative fields, zeros, a seed element that wins."""
+    import ctypes as C
+    from test_oracle_vs_reference import minmax_cases
+    o, d, _ = _pair(model, (7, 13, 17), 91, "blobs")
+    cases3, cases2 = minmax_cases(o.f, o.g)
+    for k, v in cases3.items():
+        o.f[k][...] = v; d.upload(k, v)
+    for k, v in cases2.items():
+        o.g[k][...] = v; d.upload(k, v)
+    for k in list(cases3) + list(cases2):
+        two_d = k in cases2
+        out = (C.c_double * 2)(); loc = (C.c_int * 6)()
+        getattr(o.lib, "oracle_minmax2d" if two_d else "oracle_minmax3d")(o.ctx, (H.F2 if two_d else H.F3)[k], out, loc)
+        (vmax, lmax), (vmin, lmin) = d.minmax(k)
+        assert (vmax, vmin) == (out[0], out[1]), (k, vmax, vmin, out[0], out[1])
+        assert lmax + lmin == tuple(loc), (k, lmax, lmin, tuple(loc))
+    d.close()
+
+
 def test_golden_small_hyd_bitexact():
     """HIP path against the compiled reference's own outputs (tests/golden/hyd_small.npz)."""
     z = np.load(os.path.join(GOLD, "hyd_small.npz"))

@@ -107,3 +107,44 @@ def test_atm_vegetation_distribution(max_precipitation):
         m.op("atm_vegetation_distribution", C.c_double(max_precipitation))
     assert H.bits_equal(a.g["VEGETATION"], b.g["VEGETATION"])
     assert (a.g["VEGETATION"] > 0).any() == (max_precipitation > 0)
+
+
+def _minmax(m, name, two_d):
+    import ctypes as C
+    out = (C.c_double * 2)(); loc = (C.c_int * 6)()
+    fid = H.F2[name] if two_d else H.F3[name]
+    if m.kind == "oracle":
+        getattr(m.lib, "oracle_minmax2d" if two_d else "oracle_minmax3d")(m.ctx, fid, out, loc)
+        return (out[0], out[1]), tuple(loc)
+    m.lib.ref_minmax(m.ctx, fid, 1 if two_d else 0, out)
+    return (out[0], out[1]), None
+
+
+def minmax_cases(f, g):
+    """Field variants that reach every seed rule of the four scans."""
+    shp, shp2 = f["T"].shape, g["PRECIPITATION"].shape
+    rng = np.random.default_rng(5)
+    cases3 = {"T": f["T"].copy(), "U": -np.abs(f["U"]) - 0.01,           # all negative: the hydrosphere maximum stays 0
+              "V": np.where(rng.uniform(0, 1, shp) < 0.5, 0.25, -0.5),   # ties everywhere
+              "W": np.zeros(shp)}
+    cases3["C"] = f["C"].copy(); cases3["C"][0, 0, 0] = 9.0               # the seed element is the maximum
+    e = rng.uniform(-1.0, 2.0, shp2); e[rng.uniform(0, 1, shp2) < 0.3] = 0.0
+    cases2 = {"PRECIPITATION": rng.uniform(0.0, 25.0, shp2), "EVAPORATION_DALTON": e,
+              "TOPOGRAPHY": -rng.uniform(0.5, 1.0, shp2)}
+    cases2["PRECIPITATION"][0, 0] = 99.0                                   # larger than every interior value
+    return cases3, cases2
+
+
+@pytest.mark.parametrize("model", [H.ATM, H.HYD])
+def test_minmax_values(model):
+    a, b, _ = _pair(model, (7, 13, 17), 91, "blobs")
+    cases3, cases2 = minmax_cases(a.f, a.g)
+    for m in (a, b):
+        for k, v in cases3.items():
+            m.f[k][...] = v
+        for k, v in cases2.items():
+            m.g[k][...] = v
+    for k in cases3:
+        assert _minmax(a, k, False)[0] == _minmax(b, k, False)[0], k
+    for k in cases2:
+        assert _minmax(a, k, True)[0] == _minmax(b, k, True)[0], k
