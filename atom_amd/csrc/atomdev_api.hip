@@ -149,7 +149,7 @@ extern "C" int atomdev_create(int model, int im, int jm, int km, const atomdev_p
     h->profile_rk = false; h->prof_used = 0;
     h->scr[0] = h->scr[1] = nullptr; h->tab_rm2sin = h->tab_irm2sin = h->tab_coefv = nullptr;
     h->rk_variant = 0;
-    h->ws_params = nullptr; h->surf = nullptr; h->xfer = nullptr;
+    h->ws_params = nullptr; h->surf = nullptr; h->xfer = nullptr; h->batch = nullptr; h->batch_bytes = 0;
     if (const char* e = getenv("ATOMDEV_RK_VARIANT")) h->rk_variant = atoi(e);
     h->rad = h->sinthe = h->costhe = h->plane = nullptr; h->red = nullptr;
     fill_constants(h);
@@ -217,6 +217,7 @@ extern "C" int atomdev_destroy(atomdev_t* h) {
     if (h->ws_params) (void)hipFree(h->ws_params);
     if (h->surf) (void)hipFree(h->surf);
     if (h->xfer) (void)hipFree(h->xfer);
+    if (h->batch) (void)hipFree(h->batch);
     for (int n = 0; n < 2; n++) if (h->scr[n]) (void)hipFree(h->scr[n]);
     for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
     if (h->ev0) (void)hipEventDestroy(h->ev0);

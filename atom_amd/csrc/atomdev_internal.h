@@ -57,6 +57,8 @@ struct atomdev {
     size_t red_bytes;
     double* scr[2];                 // 3-D scratch written by the RK prep kernels
     double *tab_rm2sin, *tab_irm2sin, *tab_coefv;  // [i*jm + j]: rm^2 sin(the), its reciprocal, viscous v coefficient
+    void* batch;                    // device copy of the item list of a batched surface sweep (lazy)
+    size_t batch_bytes;
     double* xfer;                   // six surface planes of the atmosphere -> hydrosphere transfer (lazy)
     void* surf;                     // skewed copy of the surface fields for the 2-D sweep (lazy)
     void* ws_params;                // device copy of the wave-specialised sweep's argument block(s) (lazy)

@@ -10,6 +10,8 @@
 // processed in increasing d.  One workgroup walks the diagonals with a barrier
 // between them (65 k points on the 1-degree grid: latency-bound, not worth more
 // than one CU).
+#include <vector>
+
 #include "atomdev_internal.h"
 
 namespace {
@@ -198,7 +200,12 @@ struct Skewed {
     int P;
 };
 
-__global__ void k_skew(Rk2dArgs a, Skewed s, int jm, int km) {
+// One surface of a batched launch (several independent models in one grid: blockIdx.y of the copy kernels,
+// blockIdx.x of the sweep selects the model).  A launch for a single model passes its arguments by value.
+struct BatchItem { Rk2dArgs a; Skewed s; DevConst K; };
+
+__global__ void k_skew(Rk2dArgs a, Skewed s, int jm, int km, const BatchItem* __restrict__ items) {
+    if (items) { a = items[blockIdx.y].a; s = items[blockIdx.y].s; }
     const int id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= jm * km) return;
     const int j = id / km, k = id - j * km;
@@ -206,7 +213,8 @@ __global__ void k_skew(Rk2dArgs a, Skewed s, int jm, int km) {
     s.v[o] = a.v[id]; s.w[o] = a.w[id]; s.p[o] = a.p[id]; s.vn[o] = a.vn[id]; s.wn[o] = a.wn[id]; s.fl[o] = a.fl[id];
 }
 
-__global__ void k_unskew(Rk2dArgs a, Skewed s, int jm, int km) {
+__global__ void k_unskew(Rk2dArgs a, Skewed s, int jm, int km, const BatchItem* __restrict__ items) {
+    if (items) { a = items[blockIdx.y].a; s = items[blockIdx.y].s; }
     const int id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= jm * km) return;
     const int j = id / km, k = id - j * km;
@@ -229,7 +237,9 @@ struct Fetched {
 // static data, fetched from the skewed copy one diagonal ahead.  So no global memory access sits on the
 // chain of 538 dependent diagonals (1-degree grid), only an LDS exchange and one barrier per diagonal.
 template <int MAX_THREADS>
-__global__ __launch_bounds__(MAX_THREADS) void k_rk2d_rows(Rk2dArgs a, Skewed s, DevConst K) {
+__global__ __launch_bounds__(MAX_THREADS) void k_rk2d_rows(Rk2dArgs a, Skewed s, DevConst K,
+                                                           const BatchItem* __restrict__ items) {
+    if (items) { a = items[blockIdx.x].a; s = items[blockIdx.x].s; K = items[blockIdx.x].K; }
     extern __shared__ double ex[];  // [2][P][2]: new (v, w) of row j on the last two diagonals
     const int jm = K.jm, km = K.km, P = s.P;
     const int j = (int)threadIdx.x + 1;
@@ -292,11 +302,13 @@ __global__ __launch_bounds__(MAX_THREADS) void k_rk2d_rows(Rk2dArgs a, Skewed s,
     }
 }
 
-int rk2d(atomdev* h, bool hyd) {
+// arguments of one model's surface sweep; allocates the skewed copy on first use
+int rk2d_item(atomdev* h, BatchItem& it) {
     if (int rc = atomdev_refresh_flags(h)) return rc;
+    const bool hyd = h->model == ATOMDEV_HYD;
     const int L = hyd ? h->im - 1 : 0;
     const size_t off = (size_t)L * h->n2;
-    Rk2dArgs a;
+    Rk2dArgs& a = it.a;
     a.v = h->f[ATOMDEV_V] + off; a.w = h->f[ATOMDEV_W] + off;
     a.vn = h->f[ATOMDEV_VN] + off; a.wn = h->f[ATOMDEV_WN] + off; a.p = h->f[ATOMDEV_P_DYN] + off;
     a.aux_v = h->f[ATOMDEV_AUX_V] + off; a.aux_w = h->f[ATOMDEV_AUX_W] + off;
@@ -309,11 +321,7 @@ int rk2d(atomdev* h, bool hyd) {
     a.hyd = hyd ? 1 : 0;
     a.i_rm = 1. / a.rm; a.i_rm2 = 1. / (a.rm * a.rm); a.i_rho = 1. / a.rho;
     a.i_two_dphi = 1. / h->k.two_dphi; a.i_dphi = 1. / h->k.dphi;
-    const int rows = h->jm - 2, threads = (rows + 63) / 64 * 64;
-    if (threads > 1024 || h->rk_variant == 1) {
-        hipLaunchKernelGGL(k_rk2d, dim3(1), dim3(256), (size_t)h->jm * sizeof(RowGeo), h->stream, a, h->k);
-        return atomdev_check(hipGetLastError(), "k_rk2d");
-    }
+    it.K = h->k;
     // skewed copy of the surface: 7 fp64 arrays and the flags, jm + km + 2 diagonals of pitch P
     const int P = (h->jm + 15) & ~15;
     const size_t ndiag = (size_t)h->jm + h->km + 2, cells = ndiag * P;
@@ -321,27 +329,91 @@ int rk2d(atomdev* h, bool hyd) {
         ATOMDEV_TRY(hipMalloc(&h->surf, cells * (7 * sizeof(double) + 1)));
         ATOMDEV_TRY(hipMemsetAsync(h->surf, 0, cells * (7 * sizeof(double) + 1), h->stream));
     }
-    Skewed s;
+    Skewed& s = it.s;
     double* base = (double*)h->surf;
     s.v = base; s.w = base + cells; s.p = base + 2 * cells; s.vn = base + 3 * cells; s.wn = base + 4 * cells;
     s.aux_v = base + 5 * cells; s.aux_w = base + 6 * cells; s.fl = (uint8_t*)(base + 7 * cells);
     s.P = P;
-    const unsigned nb = (unsigned)((h->n2 + 255) / 256);
-    hipLaunchKernelGGL(k_skew, dim3(nb), dim3(256), 0, h->stream, a, s, h->jm, h->km);
+    return 0;
+}
+
+// skew, sweep, unskew for n models (items == nullptr: one model, arguments of `one` by value) on `stream`
+int rk2d_launch(const BatchItem& one, const BatchItem* items, int n, int jm, int km, hipStream_t stream) {
+    const int rows = jm - 2, threads = (rows + 63) / 64 * 64;
+    const int P = one.s.P;
+    const unsigned nb = (unsigned)(((size_t)jm * km + 255) / 256);
+    hipLaunchKernelGGL(k_skew, dim3(nb, n), dim3(256), 0, stream, one.a, one.s, jm, km, items);
     ATOMDEV_TRY(hipGetLastError());
     const size_t lds = (size_t)2 * P * 2 * sizeof(double);
     if (threads <= 256)
-        hipLaunchKernelGGL(k_rk2d_rows<256>, dim3(1), dim3(threads), lds, h->stream, a, s, h->k);
+        hipLaunchKernelGGL(k_rk2d_rows<256>, dim3(n), dim3(threads), lds, stream, one.a, one.s, one.K, items);
     else if (threads <= 768)  // three waves per SIMD: the register allocation still fits without spills
-        hipLaunchKernelGGL(k_rk2d_rows<768>, dim3(1), dim3(threads), lds, h->stream, a, s, h->k);
+        hipLaunchKernelGGL(k_rk2d_rows<768>, dim3(n), dim3(threads), lds, stream, one.a, one.s, one.K, items);
     else
-        hipLaunchKernelGGL(k_rk2d_rows<1024>, dim3(1), dim3(threads), lds, h->stream, a, s, h->k);
+        hipLaunchKernelGGL(k_rk2d_rows<1024>, dim3(n), dim3(threads), lds, stream, one.a, one.s, one.K, items);
     ATOMDEV_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_unskew, dim3(nb), dim3(256), 0, h->stream, a, s, h->jm, h->km);
+    hipLaunchKernelGGL(k_unskew, dim3(nb, n), dim3(256), 0, stream, one.a, one.s, jm, km, items);
     return atomdev_check(hipGetLastError(), "k_unskew");
 }
 
+int rk2d(atomdev* h, bool hyd) {
+    (void)hyd;
+    BatchItem it;
+    const int rows = h->jm - 2, threads = (rows + 63) / 64 * 64;
+    if (threads > 1024 || h->rk_variant == 1) {
+        if (int rc = rk2d_item(h, it)) return rc;
+        hipLaunchKernelGGL(k_rk2d, dim3(1), dim3(256), (size_t)h->jm * sizeof(RowGeo), h->stream, it.a, h->k);
+        return atomdev_check(hipGetLastError(), "k_rk2d");
+    }
+    if (int rc = rk2d_item(h, it)) return rc;
+    return rk2d_launch(it, nullptr, 1, h->jm, h->km, h->stream);
+}
+
 }  // namespace
+
+// The surface sweep is a chain of dependent anti-diagonals that occupies one workgroup, so one model leaves 255
+// of 256 compute units idle: the sweeps of independent models (the time slices of a paleo series, each with its
+// own handle) go into one launch, one workgroup each.  Work already enqueued on the handles' streams is waited
+// for through events, and each stream in turn waits for the batch, so the ordering rules of single calls hold.
+extern "C" int atomdev_rk2d_batch(atomdev_t* const* handles, int n) {
+    ATOMDEV_REQUIRE(handles && n >= 1, "atomdev_rk2d_batch: bad argument");
+    atomdev* h0 = handles[0];
+    ATOMDEV_REQUIRE(h0 != nullptr, "atomdev_rk2d_batch: null handle");
+    const int rows = h0->jm - 2, threads = (rows + 63) / 64 * 64;
+    ATOMDEV_REQUIRE(threads <= 1024, "atomdev_rk2d_batch: more than 1024 interior rows");
+    for (int m = 0; m < n; m++) {
+        atomdev* h = handles[m];
+        ATOMDEV_REQUIRE(h != nullptr, "atomdev_rk2d_batch: null handle");
+        ATOMDEV_REQUIRE(h->device == h0->device, "atomdev_rk2d_batch: handles on different devices");
+        ATOMDEV_REQUIRE(h->jm == h0->jm && h->km == h0->km, "atomdev_rk2d_batch: surfaces of different size");
+        ATOMDEV_REQUIRE(h->model != ATOMDEV_HYD || h->im == 41,
+                        "atomdev_rk2d_batch: the reference hard-codes im = 41 for the hydrosphere surface sweep");
+        for (int q = 0; q < m; q++) ATOMDEV_REQUIRE(handles[q] != h, "atomdev_rk2d_batch: a handle appears twice");
+    }
+    ATOMDEV_TRY(hipSetDevice(h0->device));
+    std::vector<BatchItem> items(n);
+    for (int m = 0; m < n; m++)
+        if (int rc = rk2d_item(handles[m], items[m])) return rc;
+    const size_t bytes = (size_t)n * sizeof(BatchItem);
+    if (h0->batch_bytes < bytes) {
+        ATOMDEV_TRY(hipStreamSynchronize(h0->stream));
+        if (h0->batch) ATOMDEV_TRY(hipFree(h0->batch));
+        h0->batch = nullptr; h0->batch_bytes = 0;
+        ATOMDEV_TRY(hipMalloc(&h0->batch, bytes));
+        h0->batch_bytes = bytes;
+    }
+    // the first handle's stream carries the batch
+    for (int m = 1; m < n; m++) {
+        ATOMDEV_TRY(hipEventRecord(handles[m]->ev1, handles[m]->stream));
+        ATOMDEV_TRY(hipStreamWaitEvent(h0->stream, handles[m]->ev1, 0));
+    }
+    ATOMDEV_TRY(hipMemcpyAsync(h0->batch, items.data(), bytes, hipMemcpyHostToDevice, h0->stream));
+    ATOMDEV_TRY(hipStreamSynchronize(h0->stream));  // `items` is host memory that goes out of scope
+    if (int rc = rk2d_launch(items[0], (const BatchItem*)h0->batch, n, h0->jm, h0->km, h0->stream)) return rc;
+    ATOMDEV_TRY(hipEventRecord(h0->ev1, h0->stream));
+    for (int m = 1; m < n; m++) ATOMDEV_TRY(hipStreamWaitEvent(handles[m]->stream, h0->ev1, 0));
+    return 0;
+}
 
 extern "C" int atomdev_atm_rk2d(atomdev_t* h) {
     ATOMDEV_REQUIRE(h && h->model == ATOMDEV_ATM, "atomdev_atm_rk2d: not an atmosphere handle");

@@ -76,6 +76,7 @@ def load_library():
     lib.atomdev_move_data_to_new_arrays.argtypes = [vp, C.c_int]
     lib.atomdev_atm_msl_data.argtypes = [vp, C.c_int]
     lib.atomdev_atm_vegetation_distribution.argtypes = [vp, C.c_double]
+    lib.atomdev_rk2d_batch.argtypes = [C.POINTER(vp), C.c_int]
     lib.atomdev_transfer_atm_to_hyd.argtypes = [vp, vp]
     lib.atomdev_atm_write_transfer_file.argtypes = [vp, C.c_char_p]
     lib.atomdev_hyd_read_transfer_file.argtypes = [vp, C.c_char_p]
@@ -105,6 +106,14 @@ def default_params(model, im=41, jm=181, km=361):
         p.dthe = np.pi / (jm - 1)
         p.dphi = p.dthe
     return p
+
+
+def rk2d_batch(models):
+    """The surface sweeps (atm_rk2d / hyd_rk2d) of several models on one GPU in one launch."""
+    lib = load_library()
+    arr = (C.c_void_p * len(models))(*[m._h for m in models])
+    if lib.atomdev_rk2d_batch(arr, len(models)) != 0:
+        raise AtomDevError(lib.atomdev_last_error().decode())
 
 
 class DeviceModel:

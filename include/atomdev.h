@@ -177,6 +177,11 @@ int atomdev_hyd_rk3d(atomdev_t* h);
 /* solveRungeKutta_2D_Hydrosphere + RK_RHS_2D_Hydrosphere
  * (hydrosphere/RungeKutta_Hyd.cpp:130-186, RHS_Hyd.cpp:453-653) */
 int atomdev_hyd_rk2d(atomdev_t* h);
+/* atomdev_atm_rk2d / atomdev_hyd_rk2d for several independent models (handles on one GPU with the same jm, km;
+ * atmosphere and hydrosphere may be mixed) in one launch.  No counterpart in the reference, which computes one
+ * time slice at a time: the surface sweep is a chain of dependent anti-diagonals that keeps a single workgroup
+ * busy, so the sweeps of the slices of a paleo series run side by side instead of one after the other. */
+int atomdev_rk2d_batch(atomdev_t* const* handles, int n);
 /* Pressure_Hyd::computePressure_3D / _2D (hydrosphere/Pressure_Hyd.cpp:42-317) */
 int atomdev_hyd_pressure3d(atomdev_t* h);
 int atomdev_hyd_pressure2d(atomdev_t* h);

@@ -252,6 +252,40 @@ def test_minmax_searches(model):
     d.close()
 
 
+def test_rk2d_batch_same_bits():
+    """Surface sweeps of five independent models (three atmospheres, two hydrospheres) in one launch: each gets
+    the bits of its own single-model sweep; work enqueued before and after the batch keeps its order."""
+    dims = (41, 43, 19)
+    singles, batched, oracles = [], [], []
+    for n, model in enumerate([H.ATM, H.HYD, H.ATM, H.ATM, H.HYD]):
+        o, d1, names = _pair(model, dims, 100 + n, "blobs")
+        d2 = atom_amd.DeviceModel(model, *dims, atom_amd.Params.from_buffer_copy(bytes(o.params)))
+        d2.upload_all(o.f, o.g)
+        singles.append(d1); batched.append(d2); oracles.append((o, names))
+    pre = lambda m: "atm" if m.model == atom_amd.ATM else "hyd"
+    for rep in range(2):
+        for d in singles:
+            d.op(pre(d) + "_bc_theta"); d.op(pre(d) + "_rk2d"); d.op(pre(d) + "_pressure2d")
+        for d in batched:
+            d.op(pre(d) + "_bc_theta")
+        atom_amd.rk2d_batch(batched)
+        for d in batched:
+            d.op(pre(d) + "_pressure2d")
+    for d1, d2, (o, names) in zip(singles, batched, oracles):
+        for rep in range(2):
+            for op in ("_bc_theta", "_rk2d", "_pressure2d"):
+                H.run_op(o, pre(d1) + op)
+        for k in names:
+            if k != "RESIDUUM":
+                a, b = d1.download(k), d2.download(k)
+                assert H.bits_equal(a, b), k
+                assert H.bits_equal(a, o.f[k]), k
+    with pytest.raises(atom_amd.AtomDevError):
+        atom_amd.rk2d_batch([batched[0], batched[0]])
+    for d in singles + batched:
+        d.close()
+
+
 def test_golden_small_hyd_bitexact():
     """HIP path against the compiled reference's own outputs (tests/golden/hyd_small.npz)."""
     z = np.load(os.path.join(GOLD, "hyd_small.npz"))
