@@ -10,7 +10,7 @@
  * (same association order, same dead terms, same in-place lexicographic sweep
  * order, same quirks).  Each function cites the reference lines it follows.
  * Pinned bit-for-bit against the compiled reference (oracle/_ref) by
- * tests/test_oracle_vs_reference.py and against tests/golden/*.npz, which
+ * tests/test_oracle_vs_reference.py and against the .npz files of tests/golden, which
  * oracle/make_golden.py generated from that compiled reference.
  *
  * Build: gcc -O2 -ffp-contract=off -fPIC -shared (x86-64 baseline: no FMA, like
