@@ -186,6 +186,44 @@ __global__ void k_buoyancy_fill_r(double* b, const uint8_t* flags, int im, int j
     b[top] = c43 * b[top - n2] - c13 * b[top - 2 * n2];
 }
 
+// BC_Thermo::Latent_Heat (atmosphere/BC_Thermo.cpp:2418-2502), one thread per column.  i_topography as
+// BC_Thermo's constructor builds it (:128-139): the highest land level at or below im-2, else 0.  The bottom
+// formula (:2447-2462, one-sided over i_mount .. i_mount+2) divides by R_WaterVapour, the column formula
+// (:2481-2499, central, i_mount+1 .. im-3) by r_water_vapour; the saturation pressures evaluated next to them are
+// never used.  A column whose topography reaches level im-2 would read level im and gets no bottom value.
+__global__ void k_atm_latent_heat(const double* __restrict__ t, const double* __restrict__ c, const double* __restrict__ ice,
+                                  const double* __restrict__ p_stat, const uint8_t* __restrict__ flags,
+                                  double* __restrict__ q_latent, double* __restrict__ q_sensible, int im, size_t n2,
+                                  double L_atm, double dr, double ep, double t_0, double lv, double ls, double cp_l,
+                                  double r_air, double R_WaterVapour, double r_water_vapour) {
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n2) return;
+    const double step = L_atm / (double)(im - 1);
+    const double coeff_Lv = lv / step, coeff_Ls = ls / step, coeff_Q = cp_l * r_air * t_0 / step;
+    const double coeff_lat = .079, coeff_sen = .15;
+    int i_mount = 0;
+    for (int i = im - 2; i >= 0; i--)
+        if (flags[(size_t)i * n2 + q] & FL_LAND) { i_mount = i; break; }
+    if (i_mount + 2 <= im - 1) {
+        const size_t id = (size_t)i_mount * n2 + q;
+        const double e = .01 * c[id] * p_stat[id] / ep;
+        const double a = e / (R_WaterVapour * t[id] * t_0);
+        const double ql = -coeff_Lv * a * (-3. * c[id] + 4. * c[id + n2] - c[id + 2 * n2]) / (2. * dr);
+        const double qi = -coeff_Ls * a * (-3. * ice[id] + 4. * ice[id + n2] - ice[id + 2 * n2]) / (2. * dr);
+        q_latent[id] = coeff_lat * (ql + qi);
+        q_sensible[id] = -coeff_sen * coeff_Q * (-3. * t[id] + 4. * t[id + n2] - t[id + 2 * n2]) / (2. * dr);
+    }
+    for (int i = i_mount + 1; i < im - 2; i++) {
+        const size_t id = (size_t)i * n2 + q;
+        const double e = .01 * c[id] * p_stat[id] / ep;
+        const double a = e / (r_water_vapour * t[id] * t_0);
+        const double ql = -coeff_Lv * a * (c[id + n2] - c[id - n2]) / (2. * dr);
+        const double qi = -coeff_Ls * a * (ice[id + n2] - ice[id - n2]) / (2. * dr);
+        q_latent[id] = coeff_lat * (ql + qi);
+        q_sensible[id] = -coeff_sen * coeff_Q * (t[id + n2] - t[id - n2]) / (2. * dr);
+    }
+}
+
 // BC_Bathymetry_Atmosphere::vegetationDistribution (atmosphere/BC_Bath_Atm.cpp:129-142)
 __global__ void k_vegetation(const double* __restrict__ precipitation, const double* __restrict__ t,
                              const uint8_t* __restrict__ flags, double max_precipitation, size_t n2,
@@ -197,6 +235,19 @@ __global__ void k_vegetation(const double* __restrict__ precipitation, const dou
 }
 
 }  // namespace
+
+extern "C" int atomdev_atm_latent_heat(atomdev_t* h) {
+    ATOMDEV_REQUIRE(h && h->model == ATOMDEV_ATM, "atomdev_atm_latent_heat: not an atmosphere handle");
+    ATOMDEV_TRY(hipSetDevice(h->device));
+    if (int rc = atomdev_refresh_flags(h)) return rc;
+    const atomdev_params& P = h->p;
+    hipLaunchKernelGGL(k_atm_latent_heat, dim3((unsigned)((h->n2 + TPB - 1) / TPB)), dim3(TPB), 0, h->stream, h->f[ATOMDEV_T],
+                       h->f[ATOMDEV_C], h->f[ATOMDEV_ICE], h->f[ATOMDEV_P_STAT], h->flags, h->f[ATOMDEV_Q_LATENT],
+                       h->f[ATOMDEV_Q_SENSIBLE], h->im, h->n2, P.L_atm, P.dr, P.ep, P.t_0, P.lv, P.ls, P.cp_l, P.r_air,
+                       P.R_WaterVapour, P.r_water_vapour);
+    ATOMDEV_TRY(hipGetLastError());
+    return 0;
+}
 
 extern "C" int atomdev_atm_vegetation_distribution(atomdev_t* h, double max_Precipitation) {
     ATOMDEV_REQUIRE(h && h->model == ATOMDEV_ATM, "atomdev_atm_vegetation_distribution: not an atmosphere handle");

@@ -29,7 +29,7 @@ class Params(C.Structure):
         "dt", "dr", "dthe", "dphi", "r0", "the0", "phi0",
         "re", "pr", "g", "Buoyancy", "u_0", "t_0", "c_0",
         "sc_WaterVapour", "sc_CO2", "gam", "r_air", "R_Air", "R_WaterVapour", "L_atm", "cp_l", "t_tropopause",
-        "sc", "L_hyd", "r_0_water", "ta", "pa", "ca", "p_0", "ep", "hp", "lv", "ls")]
+        "sc", "L_hyd", "r_0_water", "ta", "pa", "ca", "p_0", "ep", "hp", "lv", "ls", "r_water_vapour")]
 
 
 class AtomDevError(RuntimeError):
@@ -39,7 +39,7 @@ class AtomDevError(RuntimeError):
 _OPS = ["atm_bc_radius", "atm_bc_theta", "atm_bc_phi", "atm_value_limitation", "atm_solid_ground",
         "atm_rk3d", "atm_rk2d", "atm_pressure3d", "atm_pressure2d",
         "hyd_bc_radius", "hyd_bc_theta", "hyd_bc_phi", "hyd_value_limitation", "hyd_solid_ground",
-        "hyd_rk3d", "hyd_rk2d", "hyd_pressure3d", "hyd_pressure2d", "hyd_pressure_density"]
+        "hyd_rk3d", "hyd_rk2d", "hyd_pressure3d", "hyd_pressure2d", "hyd_pressure_density", "atm_latent_heat"]
 
 _lib = None
 

@@ -80,6 +80,7 @@ typedef struct atomdev_params {
     /* atmosphere, surface fluxes (Results_MSL_Atm): gas-constant ratio, vapour pressure at 0 C in hPa,
        latent heats of evaporation and sublimation in J/kg */
     double ep, hp, lv, ls;
+    double r_water_vapour;      /* density of saturated water vapour in kg/m3 (param.py:82) */
 } atomdev_params;
 
 /* Fills *p with the reference defaults for `model` on the 1-degree grid. */
@@ -154,6 +155,11 @@ int atomdev_atm_steady2d(atomdev_t* h, double out[3], int loc[9]);
  * BuoyancyForce; c, cloud, ice, P_rain, P_snow clamped at zero; co2_total, precipitable_water and
  * Precipitation.  Reads t, c, v, w, Q_Latent, Q_Sensible, radiation_3D, co2, h. */
 int atomdev_atm_msl_data(atomdev_t* h, int RadiationModel);
+/* BC_Thermo::Latent_Heat (atmosphere/BC_Thermo.cpp:2418-2502): Q_Latent and Q_Sensible from the radial
+ * gradients of c, ice and t, one-sided at the top of the topography (i_topography, :128-139), central above it
+ * up to level im-3.  Reads t, c, ice, p_stat, h.  BC_Thermo.cpp cannot be compiled outside the reference's own
+ * build (generated headers), so this operator is checked against a restatement only: parity unpinned. */
+int atomdev_atm_latent_heat(atomdev_t* h);
 /* BC_Bathymetry_Atmosphere::vegetationDistribution (atmosphere/BC_Bath_Atm.cpp:129-142): Vegetation =
  * Precipitation / max_Precipitation on land surface cells that are not colder than t = 1, else 0. */
 int atomdev_atm_vegetation_distribution(atomdev_t* h, double max_Precipitation);

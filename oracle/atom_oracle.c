@@ -1016,6 +1016,52 @@ void oracle_atm_msl_data(oracle_ctx* c, int RadiationModel) {
 #undef W_
 }
 
+/* BC_Thermo::Latent_Heat, atmosphere/BC_Thermo.cpp:2418-2502, with i_topography as the constructor builds it
+ * (:128-139: the highest land level at or below im-2, else 0).  PARITY UNPINNED: BC_Thermo.cpp needs the
+ * reference's generated headers and cannot be compiled here, so this follows the source text only.  The
+ * saturation pressures the function evaluates (:2450-2453, :2488-2491) are never used and are left out; the
+ * bottom formula divides by R_WaterVapour (:2455), the column formula by r_water_vapour (:2493).  A column
+ * whose topography reaches level im-2 would read level im (outside the array) and is skipped. */
+void oracle_atm_latent_heat(oracle_ctx* c) {
+    const atomdev_params* P = &c->p;
+    const int im = c->im, jm = c->jm, km = c->km;
+    const double step = P->L_atm / (double)(im - 1), dr = P->dr, ep = P->ep, t_0 = P->t_0;
+    const double coeff_Lv = P->lv / step, coeff_Ls = P->ls / step, coeff_Q = P->cp_l * P->r_air * t_0 / step;
+    const double coeff_lat = .079, coeff_sen = .15;
+    for (int j = 0; j < jm; j++)
+        for (int k = 0; k < km; k++) {
+            int i_mount = 0;
+            for (int i = im - 2; i >= 0; i--) if (is_land(c, i, j, k)) { i_mount = i; break; }
+            if (i_mount + 2 > im - 1) continue;
+            {
+                const int i = i_mount;
+                double e = .01 * A3(c, ATOMDEV_C, i, j, k) * A3(c, ATOMDEV_P_STAT, i, j, k) / ep;
+                double a = e / (P->R_WaterVapour * A3(c, ATOMDEV_T, i, j, k) * t_0);
+                double ql = -coeff_Lv * a * (-3. * A3(c, ATOMDEV_C, i, j, k) + 4. * A3(c, ATOMDEV_C, i + 1, j, k)
+                                             - A3(c, ATOMDEV_C, i + 2, j, k)) / (2. * dr);
+                double qi = -coeff_Ls * a * (-3. * A3(c, ATOMDEV_ICE, i, j, k) + 4. * A3(c, ATOMDEV_ICE, i + 1, j, k)
+                                             - A3(c, ATOMDEV_ICE, i + 2, j, k)) / (2. * dr);
+                A3(c, ATOMDEV_Q_LATENT, i, j, k) = coeff_lat * (ql + qi);
+                A3(c, ATOMDEV_Q_SENSIBLE, i, j, k) = -coeff_sen * coeff_Q * (-3. * A3(c, ATOMDEV_T, i, j, k)
+                    + 4. * A3(c, ATOMDEV_T, i + 1, j, k) - A3(c, ATOMDEV_T, i + 2, j, k)) / (2. * dr);
+            }
+        }
+    for (int j = 0; j < jm; j++)
+        for (int k = 0; k < km; k++) {
+            int i_mount = 0;
+            for (int i = im - 2; i >= 0; i--) if (is_land(c, i, j, k)) { i_mount = i; break; }
+            for (int i = i_mount + 1; i < im - 2; i++) {
+                double e = .01 * A3(c, ATOMDEV_C, i, j, k) * A3(c, ATOMDEV_P_STAT, i, j, k) / ep;
+                double a = e / (P->r_water_vapour * A3(c, ATOMDEV_T, i, j, k) * t_0);
+                double ql = -coeff_Lv * a * (A3(c, ATOMDEV_C, i + 1, j, k) - A3(c, ATOMDEV_C, i - 1, j, k)) / (2. * dr);
+                double qi = -coeff_Ls * a * (A3(c, ATOMDEV_ICE, i + 1, j, k) - A3(c, ATOMDEV_ICE, i - 1, j, k)) / (2. * dr);
+                A3(c, ATOMDEV_Q_LATENT, i, j, k) = coeff_lat * (ql + qi);
+                A3(c, ATOMDEV_Q_SENSIBLE, i, j, k) = -coeff_sen * coeff_Q * (A3(c, ATOMDEV_T, i + 1, j, k)
+                    - A3(c, ATOMDEV_T, i - 1, j, k)) / (2. * dr);
+            }
+        }
+}
+
 /* MinMax_Atm::searchMinMax_3D / _2D (atmosphere/MinMax_Atm.cpp:74-196), MinMax_Hyd::searchMinMax_3D / _2D
  * (hydrosphere/MinMax_Hyd.cpp:51-260): the scans, without unit conversion and printout.  The model of the
  * context selects the class.  out = {max, min}; loc = {imax, jmax, kmax, imin, jmin, kmin}. */
@@ -1392,7 +1438,7 @@ void oracle_default_params(int model, atomdev_params* p) {
     p->dt = 0.00001; p->dr = 0.025; p->dthe = 1. / pi180; p->dphi = 1. / pi180;
     p->r0 = 1.; p->the0 = 0.; p->phi0 = 0.;
     p->g = 9.8066; p->Buoyancy = 1.0; p->t_0 = 273.15; p->p_0 = 1013.25; /* param.py:92,151 */
-    p->ep = .623; p->hp = 6.1078; p->lv = 2.52e6; p->ls = 2.83e6; /* param.py:77-85 */
+    p->ep = .623; p->hp = 6.1078; p->lv = 2.52e6; p->ls = 2.83e6; p->r_water_vapour = .0094; /* param.py:77-85 */
     if (model == ATOMDEV_ATM) {
         p->re = 1000.; p->pr = .7179; p->u_0 = 8.; p->c_0 = .035;
     } else {

@@ -46,7 +46,7 @@ class Params(C.Structure):
         "dt", "dr", "dthe", "dphi", "r0", "the0", "phi0",
         "re", "pr", "g", "Buoyancy", "u_0", "t_0", "c_0",
         "sc_WaterVapour", "sc_CO2", "gam", "r_air", "R_Air", "R_WaterVapour", "L_atm", "cp_l", "t_tropopause",
-        "sc", "L_hyd", "r_0_water", "ta", "pa", "ca", "p_0", "ep", "hp", "lv", "ls")]
+        "sc", "L_hyd", "r_0_water", "ta", "pa", "ca", "p_0", "ep", "hp", "lv", "ls", "r_water_vapour")]
 
 
 def build_oracle():

@@ -286,6 +286,24 @@ def test_rk2d_batch_same_bits():
         d.close()
 
 
+@pytest.mark.parametrize("dims,seed", [((9, 21, 70), 57), ((7, 13, 17), 58)])
+def test_atm_latent_heat_bitexact(dims, seed):
+    """BC_Thermo::Latent_Heat: +, -, *, / only, so bit-exact against the oracle's restatement - which itself is
+    PARITY UNPINNED (BC_Thermo.cpp cannot be compiled outside the reference's own build; no fixture exists)."""
+    im, jm, km = dims
+    p = H.default_params(H.ATM, im, jm, km)
+    f, g = H.make_msl_inputs(im, jm, km, seed, p)
+    f["H"][im - 2, ::3, ::4] = 1.0   # topography up to level im-2: the bottom formula is skipped there
+    o = H.CpuModel("oracle", H.ATM, im, jm, km, p, f, g)
+    d = atom_amd.DeviceModel(H.ATM, im, jm, km, atom_amd.Params.from_buffer_copy(bytes(p)))
+    d.upload_all(f, g)
+    o.op("atm_latent_heat"); d.op("atm_latent_heat")
+    for k in ("Q_LATENT", "Q_SENSIBLE"):
+        assert H.bits_equal(d.download(k), o.f[k]), k
+        assert not np.array_equal(o.f[k], f[k])
+    d.close()
+
+
 def test_golden_small_hyd_bitexact():
     """HIP path against the compiled reference's own outputs (tests/golden/hyd_small.npz)."""
     z = np.load(os.path.join(GOLD, "hyd_small.npz"))
