@@ -98,14 +98,15 @@ __device__ __forceinline__ void dtheta(int mode, double hdj, double xm2, double 
 // flags, the level above and the role's extras, row j+2 of the own variable) is issued at the
 // top, the stores of row j-1's results in stage 2; nothing loaded in a step is used before the
 // next one, and the end-of-step wait leaves only the stores outstanding.
-template <int ROLE>
+template <int ROLE, bool STORE = true>
 __device__ __forceinline__ void sweep_role(const HydWsArgs& a, const DevConst& K, Shared& sh, const double* tab,
                                            int bx, int i, int lag, int extra, double (*cfin)[64],
                                            const double* __restrict__ X, double* __restrict__ XO,
                                            const double* __restrict__ XN) {
-    // lag: steps this wave runs behind the workgroup's clock (1 for the waves of level im-2 in a paired
-    // workgroup); extra: additional clock ticks of the workgroup (1 when paired); cfin: the paired
-    // levels' hand-over buffer for the new salinity row, or null.
+    // lag: steps this wave runs behind the workgroup's clock (1 for the waves of level im-2, whose workgroup
+    // also carries shadow waves of level im-3); extra: additional clock ticks of the workgroup (1 there);
+    // cfin: that workgroup's hand-over buffer for the new salinity row, or null.  STORE = false: a shadow
+    // wave, which computes its variable like the wave that owns the level but writes nothing to memory.
     constexpr bool isT = ROLE == R_T, isU = ROLE == R_U, isV = ROLE == R_V, isW = ROLE == R_W, isC = ROLE == R_C;
     constexpr bool hasH0I = isT || isU || isC;
     constexpr int NST = isU ? 7 : (isV || isW || isC) ? 2 : 1;  // stores per step
@@ -272,7 +273,7 @@ __device__ __forceinline__ void sweep_role(const HydWsArgs& a, const DevConst& K
 #pragma unroll
         for (int s = 0; s < 4; s++) {
             const int rb = s & 1, wb = rb ^ 1;
-            if (s == 1 && j > 1) {  // results of the previous row
+            if (STORE && s == 1 && j > 1) {  // results of the previous row
                 stg(XO, o0 - rowB, xm1);
                 if constexpr (isU) {
                     stg(O1, o0 - rowB, so1); stg(O2, o0 - rowB, so2); stg(O3, o0 - rowB, so3);
@@ -374,14 +375,15 @@ __device__ __forceinline__ void sweep_role(const HydWsArgs& a, const DevConst& K
         if constexpr (isC) so1 = land ? 1007. : rw_cur;
         // Vector-memory operations complete in issue order: waiting until only this step's stores may
         // be outstanding completes its loads without waiting for the write acknowledgements.
-        if (j > 1) __builtin_amdgcn_s_waitcnt(0x0F70 | NST);  // vmcnt(NST)
-        else __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0): the first step stores nothing
+        if (STORE && j > 1) __builtin_amdgcn_s_waitcnt(0x0F70 | NST);  // vmcnt(NST)
+        else __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the first step (and a shadow wave) stores nothing
         xm2 = xm1; xm1 = st; x0 = xp1; xp1 = xp2;
         if constexpr (isV) { ym2 = ym1; ym1 = y0; y0 = yp1; yp1 = yp2; um2 = um1; up1 = up2; }
         if constexpr (isC) { rw_cur = rw_nxt; rw_nxt = n_rw2; }
         o0 += rowB; o1 += rowB; o2 += rowB; q1 += rowB;
     }
     // row jm-2
+    if constexpr (!STORE) return;
     stg(XO, o0 - rowB, xm1);
     if constexpr (isU) {
         stg(O1, o0 - rowB, so1); stg(O2, o0 - rowB, so2); stg(O3, o0 - rowB, so3);
@@ -390,7 +392,14 @@ __device__ __forceinline__ void sweep_role(const HydWsArgs& a, const DevConst& K
     if constexpr (isV || isW || isC) stg(O1, o0 - rowB, so1);
 }
 
-__global__ __launch_bounds__(640) void k_hyd_rk3d_ws(const HydWsParams* __restrict__ P, int nlev) {
+// Levels 1 .. im-2, one workgroup of five waves (one variable each) per 64 lines.  Level im-2 reads the NEW
+// salinity of level im-3 (RHS_Hyd.cpp:356-357), row by row as that level's sweep produces it.  Its workgroups
+// therefore carry three more waves that sweep level im-3's coupled variables (v, u, c - t and w do not feed back
+// into them) one step ahead in the same barrier rhythm, as shadows of the workgroup that owns level im-3: same
+// inputs (the sweep is out of place), same bits, no stores; the salinity row goes from the shadow c wave to the
+// c wave of level im-2 through LDS.  (As waves of level im-3's own workgroup - ten waves on four SIMDs - the
+// pair set the pace of the whole launch; as a launch of its own, level im-2 cost a second full sweep time.)
+__global__ __launch_bounds__(512) void k_hyd_rk3d_ws(const HydWsParams* __restrict__ P, int nlev) {
     const HydWsArgs& a = P->a;
     const DevConst& K = P->K;
     __shared__ Shared sh2[2];
@@ -401,21 +410,21 @@ __global__ __launch_bounds__(640) void k_hyd_rk3d_ws(const HydWsParams* __restri
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     const int lev = xcd + 8 * (idx / gx), bx = idx % gx;
     if (lev >= nlev) return;
-    // Levels 1 .. im-3 have a workgroup each; the one of level im-3 also sweeps level im-2 with waves 5-9.
     const int wave = threadIdx.x >> 6;
-    const int grp = wave >= 5 ? 1 : 0;
-#ifdef ATOMDEV_EXP_NOPAIR  // timing experiment only: level im-2 is not swept
-    const bool paired = false;
+    const int grp = wave >= 5 ? 1 : 0;  // 1: shadow waves
+#ifdef ATOMDEV_EXP_NOPAIR  // timing experiment only: level im-2 takes a stale salinity row
+    const bool top = false;
 #else
-    const bool paired = (1 + lev == K.im - 3);
+    const bool top = (1 + lev == K.im - 2);
 #endif
-    if (grp == 1 && !paired) return;  // before any barrier: a barrier only counts the waves still running
-    const int i = 1 + lev + grp;
+    if (grp == 1 && !top) return;  // before any barrier: a barrier only counts the waves still running
+    const int i = 1 + lev - grp;
     const int jm = K.jm;
     double* tab = tab2 + grp * 4 * jm;
     {
         const double rm = a.rad[i], rm2 = rm * rm;
-        for (int j = threadIdx.x - grp * 320; j < jm; j += 320) {
+        const int first = grp ? 320 : 0, stride = grp ? 192 : 320;
+        for (int j = threadIdx.x - first; j < jm; j += stride) {
             const double sinthe = a.sinthe[j], costhe = a.costhe[j];
             const double rm2sinthe = rm2 * sinthe;
             tab[4 * j + 0] = costhe;
@@ -426,14 +435,25 @@ __global__ __launch_bounds__(640) void k_hyd_rk3d_ws(const HydWsParams* __restri
         __syncthreads();
     }
     Shared& sh = sh2[grp];
-    double (*cf)[64] = paired ? cfin : nullptr;
-    const int lag = grp, extra = paired ? 1 : 0;
-    switch (wave - 5 * grp) {
-        case R_T: sweep_role<R_T>(a, K, sh, tab, bx, i, lag, extra, cf, a.t, a.to, a.tn); break;
-        case R_V: sweep_role<R_V>(a, K, sh, tab, bx, i, lag, extra, cf, a.v, a.vo, a.vn); break;
-        case R_U: sweep_role<R_U>(a, K, sh, tab, bx, i, lag, extra, cf, a.u, a.uo, a.un); break;
-        case R_C: sweep_role<R_C>(a, K, sh, tab, bx, i, lag, extra, cf, a.c, a.co, a.cn); break;
-        default: sweep_role<R_W>(a, K, sh, tab, bx, i, lag, extra, cf, a.w, a.wo, a.wn); break;
+    double (*cf)[64] = top ? cfin : nullptr;
+    const int lag = top ? 1 - grp : 0, extra = top ? 1 : 0;
+    if (grp == 0) {
+        // In the workgroups of level im-2 the heavier variables get a SIMD's first slot (waves w and w + 4 share a
+        // SIMD) so that each SIMD ends up with about the same work once the shadow waves are added.
+        const int role = top ? (wave == 0 ? R_C : wave == 1 ? R_V : wave == 2 ? R_U : wave == 3 ? R_T : R_W) : wave;
+        switch (role) {
+            case R_T: sweep_role<R_T>(a, K, sh, tab, bx, i, lag, extra, cf, a.t, a.to, a.tn); break;
+            case R_V: sweep_role<R_V>(a, K, sh, tab, bx, i, lag, extra, cf, a.v, a.vo, a.vn); break;
+            case R_U: sweep_role<R_U>(a, K, sh, tab, bx, i, lag, extra, cf, a.u, a.uo, a.un); break;
+            case R_C: sweep_role<R_C>(a, K, sh, tab, bx, i, lag, extra, cf, a.c, a.co, a.cn); break;
+            default: sweep_role<R_W>(a, K, sh, tab, bx, i, lag, extra, cf, a.w, a.wo, a.wn); break;
+        }
+    } else {
+        switch (wave) {  // shadows of level im-3: u beside v, v beside u, c beside t
+            case 5: sweep_role<R_U, false>(a, K, sh, tab, bx, i, lag, extra, cf, a.u, a.uo, a.un); break;
+            case 6: sweep_role<R_V, false>(a, K, sh, tab, bx, i, lag, extra, cf, a.v, a.vo, a.vn); break;
+            default: sweep_role<R_C, false>(a, K, sh, tab, bx, i, lag, extra, cf, a.c, a.co, a.cn); break;
+        }
     }
 }
 
@@ -502,8 +522,8 @@ int atomdev_hyd_rk3d_ws(atomdev* h) {
     const unsigned gx = (h->km - 2 + 63) / 64;
     const size_t lds = (size_t)h->jm * 8 * sizeof(double);
     ATOMDEV_REQUIRE(h->im >= 5, "hyd_rk3d: the grid needs at least 5 levels");
-    // levels 1 .. im-3, one workgroup per 64 lines; the workgroups of level im-3 sweep level im-2 as well
-    hipLaunchKernelGGL(k_hyd_rk3d_ws, dim3(8 * ((h->im - 3 + 7) / 8) * gx), dim3(640), lds, h->stream, P, h->im - 3);
+    // levels 1 .. im-2, one workgroup per 64 lines (waves 5-7 stay only in the workgroups of level im-2)
+    hipLaunchKernelGGL(k_hyd_rk3d_ws, dim3(8 * ((h->im - 2 + 7) / 8) * gx), dim3(512), lds, h->stream, P, h->im - 2);
     ATOMDEV_TRY(hipGetLastError());
     if (int rc = atomdev_prof_end(h)) return rc;
     for (int n = 0; n < 5; n++) { double* t = h->f[X[n]]; h->f[X[n]] = h->alt[X[n]]; h->alt[X[n]] = t; }
