@@ -224,6 +224,128 @@ __global__ void k_atm_latent_heat(const double* __restrict__ t, const double* __
     }
 }
 
+// BC_Thermo::BC_Radiation_multi_layer (atmosphere/BC_Thermo.cpp:166-424), one thread per column; the column's
+// levels of epsilon_3D, radiation_3D and t are the working arrays, as in the reference, and alfa / beta of the
+// Thomas recurrence live in two scratch fields.  The reference's transmission matrix CC is built by a
+// recurrence whose first element is never set (:341-344), so every entry is 0 and so are the sums CCC and DDD
+// taken from it (:357-362); they appear here as the zeros they are.
+struct RadArgs {
+    double *t, *c, *cloud, *ice, *epsilon_3d, *radiation_3d, *alfa, *beta;
+    const double* p_stat;
+    double *albedo, *epsilon, *radiation_surface;
+    const uint8_t* flags;
+    const int* i_trop;  // [jm]
+    int im, jm, km;
+    atomdev_radiation R;
+    double t_0, ep, t_tropopause;
+};
+
+__device__ __forceinline__ double parabola(double x) { return x * x - 2 * x; }  // lib/Utils.h:41-43
+
+__global__ void k_atm_radiation(RadArgs a) {
+    const size_t n2 = (size_t)a.jm * a.km;
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n2) return;
+    const int im = a.im, j = (int)(q / a.km);
+    const double sigma = a.R.sigma, t_0 = a.t_0;
+    const double j_max_half = (a.jm - 1) / 2;
+    const double par_j = parabola(j / j_max_half);
+    const int i_trop = a.i_trop[j];
+#define AT(F, i) a.F[(size_t)(i) * n2 + q]
+    // albedo where the column has a sea or a land surface (:210-218); i_topography (:128-139)
+    bool surface = false;
+    int i_mount = 0;
+    {
+        bool land = (AT(flags, 0) & FL_LAND) != 0;
+        if (!land) surface = true;
+        for (int i = 0; i < im - 1; i++) {
+            const bool land_above = (AT(flags, i + 1) & FL_LAND) != 0;
+            if (land && !land_above) surface = true;
+            if (land) i_mount = i;  // the last land level at or below im-2
+            land = land_above;
+        }
+    }
+    if (surface) a.albedo[q] = (a.R.albedo_pole - a.R.albedo_equator) * par_j + a.R.albedo_pole;
+    const double epsilon_eff_max = (a.R.epsilon_pole - a.R.epsilon_equator) * par_j + a.R.epsilon_pole;
+    const double radiation_surface = (a.R.rad_pole - a.R.rad_equator) * par_j + a.R.rad_pole;
+    a.radiation_surface[q] = radiation_surface;
+    for (int i = 0; i <= i_trop; i++) {  // :238-266
+        double cc = AT(c, i), cl = AT(cloud, i), ic = AT(ice, i);
+        if (cc < 0.) { cc = 0.; AT(c, i) = 0.; }
+        if (cl < 0.) { cl = 0.; AT(cloud, i) = 0.; }
+        if (ic < 0.) { ic = 0.; AT(ice, i) = 0.; }
+        const double e = (cc + cl + ic) * AT(p_stat, i) / a.ep;
+        const double epsilon_eff = epsilon_eff_max - (a.R.epsilon_tropopause - epsilon_eff_max) * parabola((double)i / (im - 1));
+        double eps;
+        if (i >= i_mount) {
+            eps = a.R.co2_coeff * epsilon_eff + .0416 * sqrt(e);
+            AT(radiation_3d, i) = (1. - eps) * sigma * pow(AT(t, i) * t_0, 4.);
+        } else {
+            eps = AT(epsilon_3d, i);
+        }
+        if (eps > 1.) eps = 1.;
+        AT(epsilon_3d, i) = eps;
+    }
+    const double eps_trop = AT(epsilon_3d, i_trop);
+    a.epsilon[q] = eps_trop;
+    for (int i = i_mount - 1; i >= 0; i--) { AT(epsilon_3d, i) = AT(epsilon_3d, i_mount); AT(radiation_3d, i) = AT(radiation_3d, i_mount); }
+    const double eps_above = AT(epsilon_3d, i_trop);  // read again: a mountain above the tropopause has just overwritten it
+    const double rad_above = (1. - eps_above) * sigma * pow(a.t_tropopause * t_0, 4.);
+    for (int i = i_trop; i < im; i++) { AT(epsilon_3d, i) = eps_above; AT(t, i) = a.t_tropopause; AT(radiation_3d, i) = rad_above; }
+
+    for (int iter_rad = 1; iter_rad <= 4; iter_rad++) {  // :293-399
+        const double e_trop = AT(epsilon_3d, i_trop);
+        const double rad_trop = (1. - e_trop) * sigma * pow(AT(t, i_trop) * t_0, 4.);
+        AT(radiation_3d, i_trop) = rad_trop;
+        const double radiation_back = AT(epsilon_3d, i_mount + 1) * sigma * pow(AT(t, i_mount + 1) * t_0, 4.);
+        const double atmospheric_window = .1007 * radiation_surface;
+        double rad_surf_diff = radiation_back + radiation_surface - atmospheric_window;
+        const double fac_rad = (double)i_mount * .07 + 1.;
+        rad_surf_diff = fac_rad * rad_surf_diff;
+        // the column's AA: only AA[i - 1] and AA[i] are ever read together (:336, :353, :366)
+        double AA_i = rad_surf_diff / AT(radiation_3d, i_trop);
+        AT(radiation_3d, i_mount) = (1. - AT(epsilon_3d, i_mount)) * sigma * pow(AT(t, i_mount) * t_0, 4.) / AT(radiation_3d, i_trop);
+        // AA[i] for i_mount < i <= i_trop goes to the beta scratch until the Thomas loop has used it
+        AT(beta, i_mount) = AA_i;
+        for (int i = i_mount + 1; i <= i_trop; i++) {
+            const double eps = AT(epsilon_3d, i);
+            AA_i = AA_i * (1. - eps);
+            AT(beta, i) = AA_i;
+            const double tmp = sigma * pow(AT(t, i) * t_0, 4.) / AT(radiation_3d, i_trop);
+            AT(radiation_3d, i) = (1. - eps) * tmp;
+        }
+        const double CCC = 0., DDD = 0.;
+        double alfa_prev = 0., beta_prev = 0., AA_prev = 0.;
+        for (int i = i_mount; i < i_trop; i++) {
+            const double AA_cur = AT(beta, i);
+            double al, be;
+            if (i == i_mount) {
+                const double bb = -AT(radiation_3d, i), cc = AT(radiation_3d, i + 1), dd = -AA_cur;
+                al = cc / bb; be = dd / bb;
+            } else {
+                const double aa = AT(radiation_3d, i - 1), bb = -2. * AT(radiation_3d, i), cc = AT(radiation_3d, i + 1);
+                const double dd = -AA_prev + AA_cur + CCC - DDD;
+                al = cc / (bb - aa * alfa_prev);
+                be = (dd - aa * beta_prev) / (bb - aa * alfa_prev);
+            }
+            AT(alfa, i) = al; AT(beta, i) = be;
+            alfa_prev = al; beta_prev = be; AA_prev = AA_cur;
+        }
+        AT(t, i_trop) = a.t_tropopause;
+        double rad_next = (1. - AT(epsilon_3d, i_trop)) * sigma * pow(a.t_tropopause * t_0, 4.);
+        AT(radiation_3d, i_trop) = rad_next;
+        for (int i = i_trop - 1; i >= i_mount; i--) {
+            const double rad = -AT(alfa, i) * rad_next + AT(beta, i);
+            AT(radiation_3d, i) = rad;
+            AT(t, i) = .5 * (AT(t, i) + pow(rad / sigma, (1. / 4.)) / t_0);
+            rad_next = rad;
+        }
+        const double rad_top = (1. - AT(epsilon_3d, i_trop)) * sigma * pow(a.t_tropopause * t_0, 4.);
+        for (int i = i_trop; i < im; i++) { AT(t, i) = a.t_tropopause; AT(radiation_3d, i) = rad_top; }
+    }
+#undef AT
+}
+
 // BC_Bathymetry_Atmosphere::vegetationDistribution (atmosphere/BC_Bath_Atm.cpp:129-142)
 __global__ void k_vegetation(const double* __restrict__ precipitation, const double* __restrict__ t,
                              const uint8_t* __restrict__ flags, double max_precipitation, size_t n2,
@@ -235,6 +357,36 @@ __global__ void k_vegetation(const double* __restrict__ precipitation, const dou
 }
 
 }  // namespace
+
+extern "C" void atomdev_default_radiation(atomdev_radiation* r) {  // param.py:60-70, 123-130
+    r->albedo_pole = .7; r->albedo_equator = .15; r->epsilon_pole = .59; r->epsilon_equator = .594; r->epsilon_tropopause = .001;
+    r->rad_pole = 40.; r->rad_equator = 230.; r->co2_coeff = .98 * (330. / 320.); r->sigma = 5.670280e-8;
+}
+
+extern "C" int atomdev_atm_radiation_multi_layer(atomdev_t* h, const atomdev_radiation* r, const int* i_trop) {
+    ATOMDEV_REQUIRE(h && h->model == ATOMDEV_ATM && r && i_trop, "atomdev_atm_radiation_multi_layer: bad argument");
+    for (int j = 0; j < h->jm; j++)
+        ATOMDEV_REQUIRE(i_trop[j] >= 0 && i_trop[j] <= h->im - 1, "atomdev_atm_radiation_multi_layer: tropopause level outside the grid");
+    ATOMDEV_TRY(hipSetDevice(h->device));
+    if (int rc = atomdev_refresh_flags(h)) return rc;
+    const size_t need = (size_t)h->jm * sizeof(int);
+    ATOMDEV_REQUIRE(need <= h->red_bytes, "atomdev_atm_radiation_multi_layer: scratch too small");
+    ATOMDEV_TRY(hipMemcpyAsync(h->red, i_trop, need, hipMemcpyHostToDevice, h->stream));
+    ATOMDEV_TRY(hipStreamSynchronize(h->stream));  // the caller's array may change after the call
+    RadArgs a;
+    a.t = h->f[ATOMDEV_T]; a.c = h->f[ATOMDEV_C]; a.cloud = h->f[ATOMDEV_CLOUD]; a.ice = h->f[ATOMDEV_ICE];
+    a.epsilon_3d = h->f[ATOMDEV_EPSILON_3D]; a.radiation_3d = h->f[ATOMDEV_RADIATION_3D];
+    a.alfa = h->scr[0]; a.beta = h->scr[1];
+    h->h0i_valid = false;  // scr[1] held the sweep's cached damping coefficients
+    a.p_stat = h->f[ATOMDEV_P_STAT];
+    a.albedo = h->g[ATOMDEV_ALBEDO]; a.epsilon = h->g[ATOMDEV_EPSILON]; a.radiation_surface = h->g[ATOMDEV_RADIATION_SURFACE];
+    a.flags = h->flags; a.i_trop = (const int*)h->red;
+    a.im = h->im; a.jm = h->jm; a.km = h->km;
+    a.R = *r; a.t_0 = h->p.t_0; a.ep = h->p.ep; a.t_tropopause = h->p.t_tropopause;
+    hipLaunchKernelGGL(k_atm_radiation, dim3((unsigned)((h->n2 + 127) / 128)), dim3(128), 0, h->stream, a);
+    ATOMDEV_TRY(hipGetLastError());
+    return 0;
+}
 
 extern "C" int atomdev_atm_latent_heat(atomdev_t* h) {
     ATOMDEV_REQUIRE(h && h->model == ATOMDEV_ATM, "atomdev_atm_latent_heat: not an atmosphere handle");

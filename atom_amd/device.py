@@ -18,9 +18,16 @@ F3 = dict(T=0, U=1, V=2, W=3, P_DYN=4, C=5, CLOUD=6, ICE=7, CO2=8,
           H=18, AUX_U=19, AUX_V=20, AUX_W=21, BUOYANCY=22,
           S_V=23, S_C=24, S_I=25, S_R=26, S_S=27,
           SALT_BALANCE=28, SALT_FINGER=29, SALT_DIFFUSION=30, R_WATER=31, R_SALT_WATER=32,
-          RESIDUUM=33, P_STAT=34, Q_LATENT=35, Q_SENSIBLE=36, RADIATION_3D=37, P_RAIN=38, P_SNOW=39)
+          RESIDUUM=33, P_STAT=34, Q_LATENT=35, Q_SENSIBLE=36, RADIATION_3D=37, P_RAIN=38, P_SNOW=39, EPSILON_3D=40)
 F2 = dict(TOPOGRAPHY=0, EVAPORATION_DALTON=1, PRECIPITATION=2, Q_RADIATION=3, PRECIPITABLE_WATER=4,
-          EVAPORATION_PENMAN=5, Q_EVAPORATION=6, Q_LATENT_2D=7, Q_SENSIBLE_2D=8, Q_BOTTOM=9, CO2_TOTAL=10, VEGETATION=11)
+          EVAPORATION_PENMAN=5, Q_EVAPORATION=6, Q_LATENT_2D=7, Q_SENSIBLE_2D=8, Q_BOTTOM=9, CO2_TOTAL=10, VEGETATION=11,
+          ALBEDO=12, EPSILON=13, RADIATION_SURFACE=14)
+
+
+class Radiation(C.Structure):
+    """struct atomdev_radiation"""
+    _fields_ = [(n, C.c_double) for n in ("albedo_pole", "albedo_equator", "epsilon_pole", "epsilon_equator",
+                                          "epsilon_tropopause", "rad_pole", "rad_equator", "co2_coeff", "sigma")]
 
 
 class Params(C.Structure):
@@ -76,6 +83,9 @@ def load_library():
     lib.atomdev_move_data_to_new_arrays.argtypes = [vp, C.c_int]
     lib.atomdev_atm_msl_data.argtypes = [vp, C.c_int]
     lib.atomdev_atm_vegetation_distribution.argtypes = [vp, C.c_double]
+    lib.atomdev_default_radiation.argtypes = [C.POINTER(Radiation)]
+    lib.atomdev_default_radiation.restype = None
+    lib.atomdev_atm_radiation_multi_layer.argtypes = [vp, C.POINTER(Radiation), ip]
     lib.atomdev_rk2d_batch.argtypes = [C.POINTER(vp), C.c_int]
     lib.atomdev_transfer_atm_to_hyd.argtypes = [vp, vp]
     lib.atomdev_atm_write_transfer_file.argtypes = [vp, C.c_char_p]
@@ -201,6 +211,16 @@ class DeviceModel:
     def msl_data(self, radiation_model=1):
         """Results_MSL_Atm::run_MSL_data, the part that changes model fields."""
         self._check(self.lib.atomdev_atm_msl_data(self._h, radiation_model))
+
+    def radiation_multi_layer(self, i_trop, radiation=None):
+        """BC_Thermo::BC_Radiation_multi_layer; i_trop: tropopause level of every row (jm ints)."""
+        if radiation is None:
+            radiation = Radiation()
+            self.lib.atomdev_default_radiation(C.byref(radiation))
+        it = np.ascontiguousarray(i_trop, dtype=np.int32)
+        if it.shape != (self.jm,):
+            raise AtomDevError("i_trop must have jm entries")
+        self._check(self.lib.atomdev_atm_radiation_multi_layer(self._h, C.byref(radiation), it.ctypes.data_as(C.POINTER(C.c_int))))
 
     def vegetation_distribution(self, max_precipitation):
         self._check(self.lib.atomdev_atm_vegetation_distribution(self._h, float(max_precipitation)))

@@ -47,7 +47,8 @@ enum atomdev_field3d {
     ATOMDEV_P_STAT = 34,         /* hydrostatic pressure: bar in the hydrosphere, hPa in the atmosphere */
     ATOMDEV_Q_LATENT = 35, ATOMDEV_Q_SENSIBLE, ATOMDEV_RADIATION_3D,
     ATOMDEV_P_RAIN, ATOMDEV_P_SNOW,                                /* atm only: inputs of run_MSL_data */
-    ATOMDEV_N3D = 40
+    ATOMDEV_EPSILON_3D = 40,                                       /* atm only: emissivity of the radiation model */
+    ATOMDEV_N3D = 41
 };
 
 /* 2-D fields (jm*km doubles each, index j*km + k). */
@@ -59,7 +60,8 @@ enum atomdev_field2d {
     ATOMDEV_Q_RADIATION = 3, ATOMDEV_PRECIPITABLE_WATER, ATOMDEV_EVAPORATION_PENMAN, ATOMDEV_Q_EVAPORATION,
     ATOMDEV_Q_LATENT_2D, ATOMDEV_Q_SENSIBLE_2D, ATOMDEV_Q_BOTTOM, ATOMDEV_CO2_TOTAL,
     ATOMDEV_VEGETATION = 11,
-    ATOMDEV_N2D = 12
+    ATOMDEV_ALBEDO = 12, ATOMDEV_EPSILON, ATOMDEV_RADIATION_SURFACE,   /* written by the radiation model */
+    ATOMDEV_N2D = 15
 };
 
 /* Scalars the hot path reads.  Names and meaning are those of the reference's
@@ -155,6 +157,21 @@ int atomdev_atm_steady2d(atomdev_t* h, double out[3], int loc[9]);
  * BuoyancyForce; c, cloud, ice, P_rain, P_snow clamped at zero; co2_total, precipitable_water and
  * Precipitation.  Reads t, c, v, w, Q_Latent, Q_Sensible, radiation_3D, co2, h. */
 int atomdev_atm_msl_data(atomdev_t* h, int RadiationModel);
+/* Scalars of BC_Thermo::BC_Radiation_multi_layer; names as in param.py:60-70.  co2_coeff is what the
+ * function derives from the model's CO2 switch (BC_Thermo.cpp:252-257): co2_factor * (co2_equator /
+ * co2_tropopause) if CO2 == 1, else 1. */
+typedef struct atomdev_radiation {
+    double albedo_pole, albedo_equator, epsilon_pole, epsilon_equator, epsilon_tropopause, rad_pole, rad_equator;
+    double co2_coeff, sigma;
+} atomdev_radiation;
+void atomdev_default_radiation(atomdev_radiation* r);
+/* BC_Thermo::BC_Radiation_multi_layer (atmosphere/BC_Thermo.cpp:166-424): albedo, emissivity and long-wave
+ * radiation of every column and four rounds of the multi-layer balance that relaxes t between the top of the
+ * topography and the tropopause.  i_trop[j] (jm entries, host memory) is the tropopause level of row j as the
+ * function computes it: im_tropopause[j] + GetTropopauseHightAdd(t_cretaceous / t_0) (:226, :3299-3303).
+ * Reads p_stat, h; changes t, c, cloud, ice (zero clamps below the tropopause), epsilon_3D, radiation_3D and
+ * the 2-D fields albedo, epsilon, radiation_surface.  Parity unpinned, like atomdev_atm_latent_heat. */
+int atomdev_atm_radiation_multi_layer(atomdev_t* h, const atomdev_radiation* r, const int* i_trop);
 /* BC_Thermo::Latent_Heat (atmosphere/BC_Thermo.cpp:2418-2502): Q_Latent and Q_Sensible from the radial
  * gradients of c, ice and t, one-sided at the top of the topography (i_topography, :128-139), central above it
  * up to level im-3.  Reads t, c, ice, p_stat, h.  BC_Thermo.cpp cannot be compiled outside the reference's own

@@ -1062,6 +1062,116 @@ void oracle_atm_latent_heat(oracle_ctx* c) {
         }
 }
 
+/* BC_Thermo::BC_Radiation_multi_layer, atmosphere/BC_Thermo.cpp:166-424.  PARITY UNPINNED (BC_Thermo.cpp cannot
+ * be compiled here): a statement-by-statement restatement of the source text, including the transmission
+ * matrix CC whose recurrence starts from an element that is never set (so all of it stays 0, :341-344) and the
+ * sums CCC / DDD that are not reset inside the level loop (:312, :357-362). */
+static double parabola(double x) { return x * x - 2 * x; } /* lib/Utils.h:41-43 */
+void oracle_atm_radiation_multi_layer(oracle_ctx* c, const atomdev_radiation* R, const int* i_trop_of_row) {
+    const atomdev_params* P = &c->p;
+    const int im = c->im, jm = c->jm, km = c->km;
+    const double t_0 = P->t_0, ep = P->ep, sigma = R->sigma, t_tropopause = P->t_tropopause;
+    const double rad_eff = R->rad_pole - R->rad_equator, albedo_co2_eff = R->albedo_pole - R->albedo_equator;
+    double j_max_half = (jm - 1) / 2;
+#define T_(i) A3(c, ATOMDEV_T, i, j, k)
+#define EPS_(i) A3(c, ATOMDEV_EPSILON_3D, i, j, k)
+#define RAD_(i) A3(c, ATOMDEV_RADIATION_3D, i, j, k)
+    for (int j = 0; j < jm; j++)
+        for (int k = 0; k < km; k++)
+            for (int i = 0; i < im - 1; i++)
+                if ((i == 0 && !is_land(c, i, j, k)) || (is_land(c, i, j, k) && !is_land(c, i + 1, j, k)))
+                    A2(c, ATOMDEV_ALBEDO, j, k) = albedo_co2_eff * parabola(j / j_max_half) + R->albedo_pole;
+    double epsilon_eff_max;
+    const double epsilon_eff_2D = R->epsilon_pole - R->epsilon_equator;
+    for (int j = 0; j < jm; j++) {
+        const int i_trop = i_trop_of_row[j];
+        epsilon_eff_max = epsilon_eff_2D * parabola(j / j_max_half) + R->epsilon_pole;
+        for (int k = 0; k < km; k++) {
+            int i_mount = 0;
+            for (int i = im - 2; i >= 0; i--) if (is_land(c, i, j, k)) { i_mount = i; break; }
+            A2(c, ATOMDEV_RADIATION_SURFACE, j, k) = rad_eff * parabola(j / j_max_half) + R->rad_pole;
+            for (int i = 0; i <= i_trop; i++) {
+                if (A3(c, ATOMDEV_C, i, j, k) < 0.) A3(c, ATOMDEV_C, i, j, k) = 0.;
+                if (A3(c, ATOMDEV_CLOUD, i, j, k) < 0.) A3(c, ATOMDEV_CLOUD, i, j, k) = 0.;
+                if (A3(c, ATOMDEV_ICE, i, j, k) < 0.) A3(c, ATOMDEV_ICE, i, j, k) = 0.;
+                double e = (A3(c, ATOMDEV_C, i, j, k) + A3(c, ATOMDEV_CLOUD, i, j, k) + A3(c, ATOMDEV_ICE, i, j, k))
+                           * A3(c, ATOMDEV_P_STAT, i, j, k) / ep;
+                double epsilon_eff = epsilon_eff_max - (R->epsilon_tropopause - epsilon_eff_max) * parabola((double)i / (im - 1));
+                if (i >= i_mount) {
+                    EPS_(i) = R->co2_coeff * epsilon_eff + .0416 * sqrt(e);
+                    RAD_(i) = (1. - EPS_(i)) * sigma * pow(T_(i) * t_0, 4.);
+                }
+                if (EPS_(i) > 1.) EPS_(i) = 1.;
+            }
+            A2(c, ATOMDEV_EPSILON, j, k) = EPS_(i_trop);
+            for (int i = i_mount - 1; i >= 0; i--) { EPS_(i) = EPS_(i_mount); RAD_(i) = RAD_(i_mount); }
+            for (int i = i_trop; i < im; i++) {
+                EPS_(i) = EPS_(i_trop);
+                T_(i) = t_tropopause;
+                RAD_(i) = (1. - EPS_(i)) * sigma * pow(T_(i) * t_0, 4.);
+            }
+        }
+    }
+    double* alfa = (double*)malloc(sizeof(double) * im); double* beta = (double*)malloc(sizeof(double) * im);
+    double* AA = (double*)malloc(sizeof(double) * im); double* CC = (double*)malloc(sizeof(double) * im * im);
+#define CC_(a, b) CC[(size_t)(a) * im + (b)]
+    for (int iter_rad = 1; iter_rad <= 4; iter_rad++)
+        for (int j = 0; j < jm; j++) {
+            const int i_trop = i_trop_of_row[j];
+            for (int k = 0; k < km; k++) {
+                int i_mount = 0;
+                for (int i = im - 2; i >= 0; i--) if (is_land(c, i, j, k)) { i_mount = i; break; }
+                for (int i = 0; i < im; i++) { alfa[i] = beta[i] = AA[i] = 0.; }
+                for (int i = 0; i < im * im; i++) CC[i] = 0.;
+                double CCC = 0, DDD = 0, aa, bb, cc, dd;
+                RAD_(i_trop) = (1. - EPS_(i_trop)) * sigma * pow(T_(i_trop) * t_0, 4.);
+                double radiation_back = EPS_(i_mount + 1) * sigma * pow(T_(i_mount + 1) * t_0, 4.);
+                double atmospheric_window = .1007 * A2(c, ATOMDEV_RADIATION_SURFACE, j, k);
+                double rad_surf_diff = radiation_back + A2(c, ATOMDEV_RADIATION_SURFACE, j, k) - atmospheric_window;
+                double fac_rad = (double)i_mount * .07 + 1.;
+                rad_surf_diff = fac_rad * rad_surf_diff;
+                AA[i_mount] = rad_surf_diff / RAD_(i_trop);
+                CC_(i_mount, i_mount) = 0.;
+                RAD_(i_mount) = (1. - EPS_(i_mount)) * sigma * pow(T_(i_mount) * t_0, 4.) / RAD_(i_trop);
+                for (int i = i_mount + 1; i <= i_trop; i++) {
+                    AA[i] = AA[i - 1] * (1. - EPS_(i));
+                    double tmp = sigma * pow(T_(i) * t_0, 4.) / RAD_(i_trop);
+                    CC_(i, i) = EPS_(i) * tmp;
+                    RAD_(i) = (1. - EPS_(i)) * tmp;
+                    for (int l = i_mount + 1; l <= i_trop; l++) CC_(i, l) = CC_(i, l - 1) * (1. - EPS_(l));
+                }
+                for (int i = i_mount; i < i_trop; i++) {
+                    if (i == i_mount) {
+                        bb = -RAD_(i); cc = RAD_(i + 1); dd = -AA[i];
+                        alfa[i] = cc / bb; beta[i] = dd / bb;
+                    } else {
+                        for (int l = i_mount + 1; l <= i - 1; l++) CCC = CCC + CC_(l, i);
+                        for (int l = i_mount + 1; l <= i - 2; l++) DDD = DDD + CC_(l, i - 1);
+                        aa = RAD_(i - 1); bb = -2. * RAD_(i); cc = RAD_(i + 1);
+                        dd = -AA[i - 1] + AA[i] + CCC - DDD;
+                        alfa[i] = cc / (bb - aa * alfa[i - 1]);
+                        beta[i] = (dd - aa * beta[i - 1]) / (bb - aa * alfa[i - 1]);
+                    }
+                }
+                T_(i_trop) = t_tropopause;
+                RAD_(i_trop) = (1. - EPS_(i_trop)) * sigma * pow(T_(i_trop) * t_0, 4.);
+                for (int i = i_trop - 1; i >= i_mount; i--) {
+                    RAD_(i) = -alfa[i] * RAD_(i + 1) + beta[i];
+                    T_(i) = .5 * (T_(i) + pow(RAD_(i) / sigma, (1. / 4.)) / t_0);
+                }
+                for (int i = i_trop; i < im; i++) {
+                    T_(i) = t_tropopause;
+                    RAD_(i) = (1. - EPS_(i_trop)) * sigma * pow(T_(i) * t_0, 4.);
+                }
+            }
+        }
+    free(alfa); free(beta); free(AA); free(CC);
+#undef CC_
+#undef T_
+#undef EPS_
+#undef RAD_
+}
+
 /* MinMax_Atm::searchMinMax_3D / _2D (atmosphere/MinMax_Atm.cpp:74-196), MinMax_Hyd::searchMinMax_3D / _2D
  * (hydrosphere/MinMax_Hyd.cpp:51-260): the scans, without unit conversion and printout.  The model of the
  * context selects the class.  out = {max, min}; loc = {imax, jmax, kmax, imin, jmin, kmin}. */

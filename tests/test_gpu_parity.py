@@ -304,6 +304,41 @@ def test_atm_latent_heat_bitexact(dims, seed):
     d.close()
 
 
+@pytest.mark.parametrize("dims,seed,trop", [((41, 19, 23), 59, 30), ((12, 13, 17), 60, 8), ((9, 21, 70), 61, 3)])
+def test_atm_radiation_multi_layer(dims, seed, trop):
+    """BC_Thermo::BC_Radiation_multi_layer against the oracle's statement-by-statement restatement (which builds
+    the reference's full transmission matrix): pow() and sqrt() on both sides, 1e-10 per field.  PARITY UNPINNED
+    against the reference itself (BC_Thermo.cpp cannot be compiled outside its own build).  trop = 3 puts
+    mountains above the tropopause."""
+    import ctypes as C
+    im, jm, km = dims
+    p = H.default_params(H.ATM, im, jm, km)
+    f, g = H.make_msl_inputs(im, jm, km, seed, p)
+    rng = np.random.default_rng(seed)
+    f["EPSILON_3D"] = rng.uniform(0.3, 1.3, (im, jm, km))
+    for k in ("ALBEDO", "EPSILON", "RADIATION_SURFACE"):
+        g[k] = rng.uniform(0.0, 1.0, (jm, km))
+    i_trop = np.full(jm, trop, dtype=np.int32)
+    i_trop[::5] -= 1
+    o = H.CpuModel("oracle", H.ATM, im, jm, km, p, f, g)
+    d = atom_amd.DeviceModel(H.ATM, im, jm, km, atom_amd.Params.from_buffer_copy(bytes(p)))
+    d.upload_all(f, g)
+    r = atom_amd.Radiation(); d.lib.atomdev_default_radiation(C.byref(r))
+    o.lib.oracle_atm_radiation_multi_layer(o.ctx, C.byref(r), i_trop.ctypes.data_as(C.POINTER(C.c_int)))
+    d.radiation_multi_layer(i_trop, r)
+    worst = 0.0
+    for k in list(f) + list(g):
+        ref = o.f[k] if k in f else o.g[k]
+        e = H.max_rel_err(d.download(k), ref)
+        worst = max(worst, e)
+        assert e <= TOL, (k, e)
+    for k in ("T", "RADIATION_3D", "EPSILON_3D", "ALBEDO", "EPSILON", "RADIATION_SURFACE"):
+        assert not np.array_equal(o.f[k] if k in f else o.g[k], f[k] if k in f else g[k]), k
+    assert np.isfinite(o.f["T"]).all()
+    print("radiation: max rel err %.3e" % worst)
+    d.close()
+
+
 def test_golden_small_hyd_bitexact():
     """HIP path against the compiled reference's own outputs (tests/golden/hyd_small.npz)."""
     z = np.load(os.path.join(GOLD, "hyd_small.npz"))
