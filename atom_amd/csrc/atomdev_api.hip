@@ -41,7 +41,7 @@ extern "C" void atomdev_default_params(int model, atomdev_params* p) {
 static bool field_used(int model, int f) {
     if (f < 0 || f >= ATOMDEV_N3D) return false;
     if (model == ATOMDEV_ATM) return !(f >= ATOMDEV_SALT_BALANCE && f <= ATOMDEV_R_SALT_WATER);
-    if (f >= ATOMDEV_Q_LATENT && f <= ATOMDEV_EPSILON_3D) return false;
+    if (f >= ATOMDEV_Q_LATENT && f <= ATOMDEV_S_C_C) return false;
     // hydrosphere: no cloud / ice / co2 / S_*
     if (f == ATOMDEV_CLOUD || f == ATOMDEV_ICE || f == ATOMDEV_CO2) return false;
     if (f == ATOMDEV_CLOUDN || f == ATOMDEV_ICEN || f == ATOMDEV_CO2N) return false;

@@ -1,0 +1,280 @@
+// BC_Thermo::Two_Category_Ice_Scheme (atmosphere/BC_Thermo.cpp:2803-3143) on the device.
+//
+// Every term of the scheme is local to a grid point except two: the column integrals of rain and snow (top
+// down, inside a column) and the class members S_nuc and S_i_dep, which the reference assigns only under
+// conditions (:2923-2931, :2995-3016) - where no condition holds, a grid point works with whatever the point
+// visited before it left behind (k outer, j, i from im-2 down; then the next pass; then the next call).  The
+// values that ARE assigned depend on local data only (t, c, ice; the scheme changes none of them), so the
+// inherited value of a point is simply the last assignment before it in the reference's visiting order, the
+// same in each of the five passes.  That order is restored in three steps: (1) every column finds its own last
+// assignments; (2) a scan over the columns in the reference's (k, j) order gives each column what it inherits
+// from the columns before it, and the last assignment of the whole grid, which is what the first columns
+// inherit from the previous pass; (3) every column runs the preparatory and the five full passes on its own.
+#include "atomdev_internal.h"
+
+namespace {
+
+constexpr int TPB = 128;
+
+struct IceArgs {
+    double *c, *cloud, *ice, *p_rain, *p_snow, *s_v, *s_c, *s_i, *s_r, *s_s, *s_c_c;
+    const double* t;
+    const uint8_t* flags;
+    int im, jm, km;
+    double t_0, g, gam, R_Air, r_air, R_WaterVapour, L_atm, hp, ep, dr;
+    // per column, indexed by its rank k * jm + j in the reference's visiting order
+    double *out_nuc, *out_dep, *in_nuc, *in_dep;
+    uint8_t *out_def, *in_def;   // bit 0: S_nuc, bit 1: S_i_dep
+    double* last;                // {def S_nuc, S_nuc, def S_i_dep, S_i_dep} of the whole grid
+    double state_nuc, state_dep; // the members as the call found them
+};
+
+// lib/Utils.h:79-81
+__device__ __forceinline__ double exp_func(double T_K, double co_1, double co_2) { return exp(co_1 * (T_K - 273.15) / (T_K - co_2)); }
+
+constexpr double N_i_0 = 1.e2, m_i_0 = 1.e-12, m_i_max = 1.e-9, m_s_0 = 3.e-9;
+constexpr double c_i_dep = 1.3e-5, c_c_au = 4.e-4, c_i_au = 1.e-3, c_ac = .24, c_rim = 18.6, c_agg = 10.3, c_i_cri = .24,
+                 c_r_cri = 3.2e-5, a_ev = 1.e-3, b_ev = 5.9, c_s_dep = 1.8e-2, b_s_dep = 12.3, c_s_melt = 8.43e-5,
+                 b_s_melt = 12.05, a_s_melt = 2.31e3, c_r_frz = 3.75e-2;
+constexpr double t_nuc = 267.15, t_d = 248.15, t_hn = 236.15, t_r_frz = 271.15;
+constexpr double dt_snow_dim = 417., dt_rain_dim = 250.;  // BC_Thermo.cpp:113-119
+
+// what a grid point's state (t, c, ice; clamped) fixes, whatever the pass
+struct Local {
+    double t_u, r_humid, q_Rain, q_Ice, N_i, m_i;
+    bool cold;              // t_u <= t_0
+    bool nuc_def, dep_def;  // the point assigns S_nuc / S_i_dep
+    double nuc_val, dep_val;
+};
+
+__device__ __forceinline__ Local local_terms(const IceArgs& a, int i, double t, double t_surface, double cc, double ic) {
+    Local L;
+    const double t_0 = a.t_0;
+    const double exp_pressure = a.g / (1.e-2 * a.gam * a.R_Air);
+    L.t_u = t * t_0;
+    const double p_SL = .01 * (a.r_air * a.R_Air * t_surface * t_0);
+    const double hight = (double)i * (a.L_atm / (double)(a.im - 1));
+    double p_h;
+    if (i != 0) p_h = pow(((L.t_u - a.gam * hight * 1.e-2) / (L.t_u)), exp_pressure) * p_SL;
+    else p_h = p_SL;
+    const double r_dry = 100. * p_h / (a.R_Air * L.t_u);
+    L.r_humid = r_dry * (1. + cc) / (1. + a.R_WaterVapour / a.R_Air * cc);
+    const double E_Rain = a.hp * exp_func(L.t_u, 17.2694, 35.86);
+    const double E_Ice = a.hp * exp_func(L.t_u, 21.8746, 7.66);
+    L.q_Rain = a.ep * E_Rain / (p_h - E_Rain);
+    L.q_Ice = a.ep * E_Ice / (p_h - E_Ice);
+    L.cold = L.t_u <= t_0;
+    L.N_i = 0.; L.m_i = m_i_max;
+    if (L.cold) {  // :2985-2992 (where t_u > t_0 neither is read)
+        L.N_i = N_i_0 * exp(.2 * (t_0 - L.t_u));
+        L.m_i = L.r_humid * ic / L.N_i;
+        if (L.m_i > m_i_max) L.m_i = m_i_max;
+        if (L.m_i < m_i_0) L.m_i = m_i_0;
+    }
+    // S_nuc, :2995-3002
+    L.nuc_def = false; L.nuc_val = 0.;
+    if (ic == 0.) {
+        if (((L.t_u < t_d) && (cc >= L.q_Ice)) || (((t_d <= L.t_u) && (L.t_u <= t_nuc)) && (cc >= L.q_Rain))) {
+            L.nuc_def = true; L.nuc_val = m_i_0 / (L.r_humid * dt_snow_dim) * L.N_i;
+        }
+    } else { L.nuc_def = true; L.nuc_val = 0.; }
+    // S_i_dep, :3008-3016 (t_Celsius = t_u - t_0 <= 0 exactly where t_u <= t_0)
+    L.dep_def = false; L.dep_val = 0.;
+    if (L.cold) {
+        if (cc > L.q_Ice) { L.dep_def = true; L.dep_val = c_i_dep * L.N_i * pow(L.m_i, (1. / 3.)) * (cc - L.q_Ice); }
+        if ((cc < L.q_Ice) && (-ic / dt_snow_dim > (cc - L.q_Ice) / dt_snow_dim)) { L.dep_def = true; L.dep_val = -ic / dt_snow_dim; }
+    } else { L.dep_def = true; L.dep_val = 0.; }
+    return L;
+}
+
+__device__ __forceinline__ double at_least_zero(double x) { return x < 0. ? 0. : x; }
+
+// step 1: clamp the column's c, cloud, ice, P_rain, P_snow (:2861-2871) and record its last assignments
+__global__ void k_ice_column_summary(IceArgs a) {
+    const size_t n2 = (size_t)a.jm * a.km;
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n2) return;
+    const int j = (int)(q / a.km), k = (int)(q - (size_t)j * a.km);
+    const size_t rank = (size_t)k * a.jm + j;
+    double* cl5[5] = { a.c, a.cloud, a.ice, a.p_rain, a.p_snow };
+    for (int i = 0; i < a.im; i++)
+        for (int n = 0; n < 5; n++) {
+            double* p = cl5[n] + (size_t)i * n2 + q;
+            if (*p < 0.) *p = 0.;
+        }
+    const double t_surface = a.t[q];
+    uint8_t def = 0; double nuc = 0., dep = 0.;
+    for (int i = a.im - 2; i >= 0; i--) {  // the later a point is visited, the later its assignment
+        const size_t id = (size_t)i * n2 + q;
+        const Local L = local_terms(a, i, a.t[id], t_surface, a.c[id], a.ice[id]);
+        if (L.nuc_def) { def |= 1; nuc = L.nuc_val; }
+        if (L.dep_def) { def |= 2; dep = L.dep_val; }
+    }
+    a.out_def[rank] = def; a.out_nuc[rank] = nuc; a.out_dep[rank] = dep;
+}
+
+// step 2: what every column inherits from the columns before it; one workgroup, each thread a run of columns
+__global__ __launch_bounds__(1024) void k_ice_inherit(IceArgs a) {
+    __shared__ uint8_t sdef[1024];
+    __shared__ double snuc[1024], sdep[1024];
+    const size_t n2 = (size_t)a.jm * a.km;
+    const size_t per = (n2 + blockDim.x - 1) / blockDim.x;
+    const size_t r0 = (size_t)threadIdx.x * per, r1 = r0 + per < n2 ? r0 + per : n2;
+    uint8_t def = 0; double nuc = 0., dep = 0.;
+    for (size_t r = r0; r < r1; r++) {
+        const uint8_t d = a.out_def[r];
+        if (d & 1) { def |= 1; nuc = a.out_nuc[r]; }
+        if (d & 2) { def |= 2; dep = a.out_dep[r]; }
+    }
+    sdef[threadIdx.x] = def; snuc[threadIdx.x] = nuc; sdep[threadIdx.x] = dep;
+    __syncthreads();
+    // last assignment in the runs before this one
+    def = 0; nuc = 0.; dep = 0.;
+    for (int t = (int)threadIdx.x - 1; t >= 0 && def != 3; t--) {
+        if (!(def & 1) && (sdef[t] & 1)) { def |= 1; nuc = snuc[t]; }
+        if (!(def & 2) && (sdef[t] & 2)) { def |= 2; dep = sdep[t]; }
+    }
+    for (size_t r = r0; r < r1; r++) {
+        a.in_def[r] = def; a.in_nuc[r] = nuc; a.in_dep[r] = dep;
+        const uint8_t d = a.out_def[r];
+        if (d & 1) { def |= 1; nuc = a.out_nuc[r]; }
+        if (d & 2) { def |= 2; dep = a.out_dep[r]; }
+    }
+    if (threadIdx.x == blockDim.x - 1) {  // its running value now covers the whole grid
+        a.last[0] = (def & 1) ? 1. : 0.; a.last[1] = nuc; a.last[2] = (def & 2) ? 1. : 0.; a.last[3] = dep;
+    }
+}
+
+// step 3: the preparatory pass (:2875-2954) and the five full passes (:2959-3135) of one column
+__global__ void k_ice_column_passes(IceArgs a) {
+    const size_t n2 = (size_t)a.jm * a.km;
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n2) return;
+    const int im = a.im;
+    const int j = (int)(q / a.km), k = (int)(q - (size_t)j * a.km);
+    const size_t rank = (size_t)k * a.jm + j;
+    const double t_0 = a.t_0, dr = a.dr;
+    const double exp_pressure = a.g / (1.e-2 * a.gam * a.R_Air);
+    const double t_surface = a.t[q];
+#define AT(F, i) a.F[(size_t)(i) * n2 + q]
+    // inherited members: from the columns before this one, else from the end of the previous pass, else from the caller
+    const uint8_t in_def = a.in_def[rank];
+    const bool grid_nuc = a.last[0] != 0., grid_dep = a.last[2] != 0.;
+    const double nuc_first = (in_def & 1) ? a.in_nuc[rank] : a.state_nuc;                                  // pass 1
+    const double nuc_later = (in_def & 1) ? a.in_nuc[rank] : (grid_nuc ? a.last[1] : a.state_nuc);        // passes 2-5
+    const double dep_in = (in_def & 2) ? a.in_dep[rank] : (grid_dep ? a.last[3] : a.state_dep);           // the preparatory pass assigns S_i_dep like the others
+
+    // preparatory pass
+    AT(p_rain, im - 1) = 0.; AT(p_snow, im - 1) = 0.; AT(s_r, im - 1) = 0.; AT(s_s, im - 1) = 0.;
+    {
+        double pr_above = 0., ps_above = 0., sr_above = 0., ss_above = 0.;
+        bool land_above = (AT(flags, im - 1) & FL_LAND) != 0;
+        for (int i = im - 2; i >= 0; i--) {
+            const double cc = AT(c, i), cl = AT(cloud, i), ic = AT(ice, i);
+            const Local L = local_terms(a, i, AT(t, i), t_surface, cc, ic);
+            double S_c_au = ((L.t_u >= t_0) && (c_c_au * cl > 0.)) ? c_c_au * cl : 0.;
+            double S_i_au = ((L.t_u < t_0) && (c_i_au * ic > 0.)) ? c_i_au * ic : 0.;
+            const bool land = (AT(flags, i) & FL_LAND) != 0;
+            double sr = S_c_au, ss = S_i_au;
+            if (land && land_above) { sr = 0.; ss = 0.; }
+            AT(s_r, i) = sr; AT(s_s, i) = ss;
+            const double pr = at_least_zero(pr_above + (sr + sr_above) * .5 * L.r_humid * dr * 200.);
+            const double ps = at_least_zero(ps_above + (ss + ss_above) * .5 * L.r_humid * dr * 200.);
+            AT(p_rain, i) = pr; AT(p_snow, i) = ps;
+            pr_above = pr; ps_above = ps; sr_above = sr; ss_above = ss; land_above = land;
+        }
+    }
+    // full passes
+    for (int iter_prec = 1; iter_prec <= 5; iter_prec++) {
+        double S_nuc = iter_prec == 1 ? nuc_first : nuc_later, S_i_dep = dep_in;
+        AT(p_rain, im - 1) = 0.; AT(p_snow, im - 1) = 0.;
+        double pr_above = 0., ps_above = 0., sr_above = AT(s_r, im - 1), ss_above = AT(s_s, im - 1);
+        bool land_above = (AT(flags, im - 1) & FL_LAND) != 0;
+        for (int i = im - 2; i >= 0; i--) {
+            const double cc = AT(c, i), cl = AT(cloud, i), ic = AT(ice, i), pr0 = AT(p_rain, i), ps0 = AT(p_snow, i);
+            const Local L = local_terms(a, i, AT(t, i), t_surface, cc, ic);
+            const double t_u = L.t_u;
+            if (L.nuc_def) S_nuc = L.nuc_val;
+            if (L.dep_def) S_i_dep = L.dep_val;
+            const double S_c_frz = ((t_u < t_hn) && (cl > 0.)) ? cl / dt_rain_dim : 0.;
+            const double S_c_au = ((t_u >= t_0) && (cl > 0.)) ? c_c_au * cl : 0.;
+            const double S_i_au = ((t_u <= t_0) && (ic > 0.)) ? c_i_au * ic : 0.;
+            const double S_d_au = (t_u <= t_0) ? S_i_dep / (1.5 * (pow((m_s_0 / L.m_i), (2. / 3.)) - 1.)) : 0.;
+            const double S_ac = (t_u > t_0) ? c_ac * cl * pow(pr0, (7. / 9.)) : 0.;
+            const double S_rim = (t_u < t_0) ? c_rim * cl * ps0 : 0.;
+            const double S_shed = (t_u >= t_0) ? c_rim * cl * ps0 : 0.;
+            double S_agg = 0., S_i_cri = 0., S_r_cri = 0.;
+            if (t_u <= t_0) {
+                S_agg = c_agg * ic * ps0;
+                S_i_cri = c_i_cri * ic * pow(pr0, (7. / 9.));
+                S_r_cri = c_r_cri * ic / L.m_i * pow(pr0, (13. / 9.));
+            }
+            const double S_ev = (t_u >= t_0) ? a_ev * (1. + b_ev * pow(pr0, (1. / 6.))) * (L.q_Rain - cc) * pow(pr0, (4. / 9.)) : 0.;
+            const double S_s_dep = (t_u < t_0) ? c_s_dep * (1. + b_s_dep * pow(ps0, (5. / 26.))) * (cc - L.q_Ice) * pow(ps0, (8. / 13.)) : 0.;
+            const double S_i_melt = ((t_u > t_0) && (ic > 0.)) ? ic / dt_snow_dim : 0.;
+            double S_s_melt = 0.;
+            if (t_u > t_0) {
+                const double p_SL = .01 * (a.r_air * a.R_Air * t_surface * t_0);
+                const double hight = (double)i * (a.L_atm / (double)(im - 1));
+                const double p_t_in = pow(((t_0 - a.gam * hight * 1.e-2) / t_0), exp_pressure) * p_SL;
+                double t0v = t_0;
+                const double E_Rain_t_in = a.hp * exp_func(t0v, 17.2694, 35.86);
+                const double q_Rain_t_in = a.ep * E_Rain_t_in / (p_t_in - E_Rain_t_in);
+                S_s_melt = c_s_melt * (1. + b_s_melt * pow(ps0, (5. / 26.))) * ((t_u - t_0) + a_s_melt * (cc - q_Rain_t_in))
+                           * pow(ps0, (8. / 13.));
+            }
+            const double S_r_frz = (t_r_frz - t_u > 0.) ? c_r_frz * pow((t_r_frz - t_u), (3. / 2.)) * pow(pr0, (3. / 2.)) : 0.;
+            const double scc = AT(s_c_c, i);
+            double sv = -scc + S_ev - S_i_dep - S_s_dep - S_nuc;
+            double sc = scc - S_c_au - S_ac - S_c_frz + S_i_melt - S_rim - S_shed;
+            double si = S_nuc + S_c_frz + S_i_dep - S_i_melt - S_i_au - S_d_au - S_agg - S_i_cri;
+            double sr = S_c_au + S_ac - S_ev + S_shed - S_r_cri - S_r_frz + S_s_melt;
+            double ss = S_d_au + S_s_dep + S_i_au + S_rim + S_agg + S_i_cri + S_r_cri + S_r_frz - S_s_melt;
+            const bool land = (AT(flags, i) & FL_LAND) != 0;
+            if (land && land_above) { AT(s_c_c, i) = 0.; sv = 0.; sc = 0.; si = 0.; sr = 0.; ss = 0.; }
+            AT(s_v, i) = sv; AT(s_c, i) = sc; AT(s_i, i) = si; AT(s_r, i) = sr; AT(s_s, i) = ss;
+            const double pr = at_least_zero(pr_above + (sr + sr_above) * .5 * L.r_humid * dr * 200.);
+            const double ps = at_least_zero(ps_above + (ss + ss_above) * .5 * L.r_humid * dr * 200.);
+            AT(p_rain, i) = pr; AT(p_snow, i) = ps;
+            pr_above = pr; ps_above = ps; sr_above = sr; ss_above = ss; land_above = land;
+        }
+    }
+#undef AT
+}
+
+}  // namespace
+
+extern "C" int atomdev_atm_two_category_ice_scheme(atomdev_t* h, double state[2]) {
+    ATOMDEV_REQUIRE(h && h->model == ATOMDEV_ATM && state, "atomdev_atm_two_category_ice_scheme: bad argument");
+    ATOMDEV_REQUIRE(h->im >= 8, "atomdev_atm_two_category_ice_scheme: needs at least 8 levels (scratch layout)");
+    ATOMDEV_TRY(hipSetDevice(h->device));
+    if (int rc = atomdev_refresh_flags(h)) return rc;
+    const atomdev_params& P = h->p;
+    IceArgs a;
+    a.c = h->f[ATOMDEV_C]; a.cloud = h->f[ATOMDEV_CLOUD]; a.ice = h->f[ATOMDEV_ICE];
+    a.p_rain = h->f[ATOMDEV_P_RAIN]; a.p_snow = h->f[ATOMDEV_P_SNOW];
+    a.s_v = h->f[ATOMDEV_S_V]; a.s_c = h->f[ATOMDEV_S_C]; a.s_i = h->f[ATOMDEV_S_I]; a.s_r = h->f[ATOMDEV_S_R];
+    a.s_s = h->f[ATOMDEV_S_S]; a.s_c_c = h->f[ATOMDEV_S_C_C];
+    a.t = h->f[ATOMDEV_T]; a.flags = h->flags;
+    a.im = h->im; a.jm = h->jm; a.km = h->km;
+    a.t_0 = P.t_0; a.g = P.g; a.gam = P.gam; a.R_Air = P.R_Air; a.r_air = P.r_air; a.R_WaterVapour = P.R_WaterVapour;
+    a.L_atm = P.L_atm; a.hp = P.hp; a.ep = P.ep; a.dr = P.dr;
+    // per-column scratch in the first volume scratch field (the sweep's prep kernel refills it on every call)
+    const size_t n2 = h->n2;
+    double* s = h->scr[0];
+    a.out_nuc = s; a.out_dep = s + n2; a.in_nuc = s + 2 * n2; a.in_dep = s + 3 * n2;
+    a.out_def = (uint8_t*)(s + 4 * n2); a.in_def = a.out_def + n2;
+    a.last = s + 6 * n2;
+    a.state_nuc = state[0]; a.state_dep = state[1];
+    const unsigned nb = (unsigned)((n2 + TPB - 1) / TPB);
+    hipLaunchKernelGGL(k_ice_column_summary, dim3(nb), dim3(TPB), 0, h->stream, a);
+    hipLaunchKernelGGL(k_ice_inherit, dim3(1), dim3(1024), 0, h->stream, a);
+    hipLaunchKernelGGL(k_ice_column_passes, dim3(nb), dim3(TPB), 0, h->stream, a);
+    ATOMDEV_TRY(hipGetLastError());
+    double last[4];
+    ATOMDEV_TRY(hipMemcpyAsync(last, a.last, sizeof(last), hipMemcpyDeviceToHost, h->stream));
+    ATOMDEV_TRY(hipStreamSynchronize(h->stream));
+    if (last[0] != 0.) state[0] = last[1];
+    if (last[2] != 0.) state[1] = last[3];
+    return 0;
+}

@@ -48,7 +48,8 @@ enum atomdev_field3d {
     ATOMDEV_Q_LATENT = 35, ATOMDEV_Q_SENSIBLE, ATOMDEV_RADIATION_3D,
     ATOMDEV_P_RAIN, ATOMDEV_P_SNOW,                                /* atm only: inputs of run_MSL_data */
     ATOMDEV_EPSILON_3D = 40,                                       /* atm only: emissivity of the radiation model */
-    ATOMDEV_N3D = 41
+    ATOMDEV_S_C_C = 41,                                            /* atm only: condensation rate (cloud physics) */
+    ATOMDEV_N3D = 42
 };
 
 /* 2-D fields (jm*km doubles each, index j*km + k). */
@@ -172,6 +173,14 @@ void atomdev_default_radiation(atomdev_radiation* r);
  * Reads p_stat, h; changes t, c, cloud, ice (zero clamps below the tropopause), epsilon_3D, radiation_3D and
  * the 2-D fields albedo, epsilon, radiation_surface.  Parity unpinned, like atomdev_atm_latent_heat. */
 int atomdev_atm_radiation_multi_layer(atomdev_t* h, const atomdev_radiation* r, const int* i_trop);
+/* BC_Thermo::Two_Category_Ice_Scheme (atmosphere/BC_Thermo.cpp:2803-3143): rain and snow by the two-category
+ * ice scheme - one preparatory and five full passes over the grid, each integrating P_rain and P_snow down
+ * every column from the sources S_r, S_s.  Reads t, h, S_c_c; writes S_v, S_c, S_i, S_r, S_s, P_rain, P_snow,
+ * clamps c, cloud, ice at zero and zeroes S_c_c inside the ground.  The reference keeps S_nuc and S_i_dep as
+ * class members that are assigned only under conditions, so a grid point may inherit them from the point
+ * visited before it (k outer, j, i downwards), from the previous pass or from the previous call:
+ * state = {S_nuc, S_i_dep} carries the two members in and out.  Parity unpinned, like atomdev_atm_latent_heat. */
+int atomdev_atm_two_category_ice_scheme(atomdev_t* h, double state[2]);
 /* BC_Thermo::Latent_Heat (atmosphere/BC_Thermo.cpp:2418-2502): Q_Latent and Q_Sensible from the radial
  * gradients of c, ice and t, one-sided at the top of the topography (i_topography, :128-139), central above it
  * up to level im-3.  Reads t, c, ice, p_stat, h.  BC_Thermo.cpp cannot be compiled outside the reference's own

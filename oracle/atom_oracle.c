@@ -1062,6 +1062,175 @@ void oracle_atm_latent_heat(oracle_ctx* c) {
         }
 }
 
+/* lib/Utils.h:79-81 */
+static double exp_func(double T_K, double co_1, double co_2) { return exp(co_1 * (T_K - 273.15) / (T_K - co_2)); }
+
+/* BC_Thermo::Two_Category_Ice_Scheme, atmosphere/BC_Thermo.cpp:2803-3143.  PARITY UNPINNED (BC_Thermo.cpp cannot be
+ * compiled here): a statement-by-statement restatement of the source text in the reference's traversal order.
+ * S_nuc and S_i_dep are class members there, assigned only under conditions (:2923-2931, :2995-3016), so their
+ * values travel from grid point to grid point, pass to pass and call to call: state[0], state[1].  N_i (member)
+ * and m_i (local) are carried too but are only read where they have just been assigned.  dt_snow_dim = 417,
+ * dt_rain_dim = 250 (:113-119). */
+void oracle_atm_two_category_ice_scheme(oracle_ctx* c, double state[2]) {
+    const atomdev_params* P = &c->p;
+    const int im = c->im, jm = c->jm, km = c->km;
+    const double N_i_0 = 1.e2, m_i_0 = 1.e-12, m_i_max = 1.e-9, m_s_0 = 3.e-9;
+    const double c_i_dep = 1.3e-5, c_c_au = 4.e-4, c_i_au = 1.e-3, c_ac = .24, c_rim = 18.6, c_agg = 10.3, c_i_cri = .24,
+                 c_r_cri = 3.2e-5, a_ev = 1.e-3, b_ev = 5.9, c_s_dep = 1.8e-2, b_s_dep = 12.3, c_s_melt = 8.43e-5,
+                 b_s_melt = 12.05, a_s_melt = 2.31e3, c_r_frz = 3.75e-2;
+    const double t_nuc = 267.15, t_d = 248.15, t_hn = 236.15, t_r_frz = 271.15;
+    const double dt_snow_dim = 417., dt_rain_dim = 250.;
+    const double t_0 = P->t_0, g = P->g, gam = P->gam, R_Air = P->R_Air, r_air = P->r_air, R_WaterVapour = P->R_WaterVapour,
+                 L_atm = P->L_atm, hp = P->hp, ep = P->ep, dr = P->dr;
+    const double exp_pressure = g / (1.e-2 * gam * R_Air);
+    double m_i = m_i_max, N_i = 0., S_nuc = state[0], S_i_dep = state[1];
+    double S_c_au, S_i_au, S_c_frz, S_d_au, S_ac, S_rim, S_shed, S_agg, S_i_cri, S_r_cri, S_ev, S_s_dep, S_i_melt, S_s_melt, S_r_frz;
+#define F_(N, i) A3(c, ATOMDEV_##N, i, j, k)
+    static const int CL[5] = { ATOMDEV_C, ATOMDEV_CLOUD, ATOMDEV_ICE, ATOMDEV_P_RAIN, ATOMDEV_P_SNOW };
+    for (int n = 0; n < 5; n++) {
+        double* x = c->f[CL[n]];
+        for (size_t q = 0; q < (size_t)im * jm * km; q++) if (x[q] < 0.) x[q] = 0.;
+    }
+    /* initial values for rain and snow (:2875-2954) */
+    for (int k = 0; k < km; k++)
+        for (int j = 0; j < jm; j++) {
+            F_(P_RAIN, im - 1) = 0.; F_(P_SNOW, im - 1) = 0.; F_(S_R, im - 1) = 0.; F_(S_S, im - 1) = 0.;
+            for (int i = im - 2; i >= 0; i--) {
+                if (F_(C, i) < 0.) F_(C, i) = 0.;
+                if (F_(CLOUD, i) < 0.) F_(CLOUD, i) = 0.;
+                if (F_(ICE, i) < 0.) F_(ICE, i) = 0.;
+                double t_Celsius = F_(T, i) * t_0 - t_0;
+                double t_u = F_(T, i) * t_0;
+                double p_SL = .01 * (r_air * R_Air * F_(T, 0) * t_0);
+                double hight = (double)i * (L_atm / (double)(im - 1));
+                double p_h;
+                if (i != 0) p_h = pow(((t_u - gam * hight * 1.e-2) / (t_u)), exp_pressure) * p_SL;
+                else p_h = p_SL;
+                double r_dry = 100. * p_h / (R_Air * t_u);
+                double r_humid = r_dry * (1. + F_(C, i)) / (1. + R_WaterVapour / R_Air * F_(C, i));
+                double E_Ice = hp * exp_func(t_u, 21.8746, 7.66);
+                double q_Ice = ep * E_Ice / (p_h - E_Ice);
+                if ((t_u >= t_0) && (c_c_au * F_(CLOUD, i) > 0.)) S_c_au = c_c_au * F_(CLOUD, i);
+                else S_c_au = 0.;
+                if ((t_u < t_0) && (c_i_au * F_(ICE, i) > 0.)) S_i_au = c_i_au * F_(ICE, i);
+                else S_i_au = 0.;
+                if (t_u <= t_0) N_i = N_i_0 * exp(.2 * (t_0 - t_u));
+                if (t_u <= t_0) {
+                    m_i = r_humid * F_(ICE, i) / N_i;
+                    if (m_i > m_i_max) { m_i = m_i_max; }
+                    else m_i = r_humid * F_(ICE, i) / N_i;
+                    if (m_i < m_i_0) { m_i = m_i_0; }
+                }
+                if (t_Celsius <= 0.) {
+                    if (F_(C, i) > q_Ice) S_i_dep = c_i_dep * N_i * pow(m_i, (1. / 3.)) * (F_(C, i) - q_Ice);
+                    if ((F_(C, i) < q_Ice) && (-F_(ICE, i) / dt_snow_dim > (F_(C, i) - q_Ice) / dt_snow_dim))
+                        S_i_dep = -F_(ICE, i) / dt_snow_dim;
+                } else S_i_dep = 0.;
+                F_(S_R, i) = S_c_au;
+                F_(S_S, i) = S_i_au;
+                if (is_land(c, i, j, k) && is_land(c, i + 1, j, k)) { F_(S_R, i) = 0.; F_(S_S, i) = 0.; }
+                if (F_(P_RAIN, i + 1) < 0.) F_(P_RAIN, i + 1) = 0.;
+                if (F_(P_SNOW, i + 1) < 0.) F_(P_SNOW, i + 1) = 0.;
+                F_(P_RAIN, i) = F_(P_RAIN, i + 1) + (F_(S_R, i) + F_(S_R, i + 1)) * .5 * r_humid * dr * 200.;
+                F_(P_SNOW, i) = F_(P_SNOW, i + 1) + (F_(S_S, i) + F_(S_S, i + 1)) * .5 * r_humid * dr * 200.;
+                if (F_(P_RAIN, i) < 0.) F_(P_RAIN, i) = 0.;
+                if (F_(P_SNOW, i) < 0.) F_(P_SNOW, i) = 0.;
+            }
+        }
+    /* main part (:2959-3135) */
+    for (int iter_prec = 1; iter_prec <= 5; iter_prec++)
+        for (int k = 0; k < km; k++)
+            for (int j = 0; j < jm; j++) {
+                F_(P_RAIN, im - 1) = 0.; F_(P_SNOW, im - 1) = 0.;
+                for (int i = im - 2; i >= 0; i--) {
+                    double t_u = F_(T, i) * t_0;
+                    double t_Celsius = t_u - t_0;
+                    double p_SL = .01 * (r_air * R_Air * F_(T, 0) * t_0);
+                    double hight = (double)i * (L_atm / (double)(im - 1));
+                    double p_h;
+                    if (i != 0) p_h = pow(((t_u - gam * hight * 1.e-2) / (t_u)), exp_pressure) * p_SL;
+                    else p_h = p_SL;
+                    double r_dry = 100. * p_h / (R_Air * t_u);
+                    double r_humid = r_dry * (1. + F_(C, i)) / (1. + R_WaterVapour / R_Air * F_(C, i));
+                    double E_Rain = hp * exp_func(t_u, 17.2694, 35.86);
+                    double E_Ice = hp * exp_func(t_u, 21.8746, 7.66);
+                    double q_Rain = ep * E_Rain / (p_h - E_Rain);
+                    double q_Ice = ep * E_Ice / (p_h - E_Ice);
+                    const double cc = F_(C, i), cl = F_(CLOUD, i), ic = F_(ICE, i), pr = F_(P_RAIN, i), ps = F_(P_SNOW, i);
+                    if (t_u <= t_0) N_i = N_i_0 * exp(.2 * (t_0 - t_u));
+                    if (t_u <= t_0) {
+                        m_i = r_humid * ic / N_i;
+                        if (m_i > m_i_max) { m_i = m_i_max; }
+                        else m_i = r_humid * ic / N_i;
+                        if (m_i < m_i_0) { m_i = m_i_0; }
+                    }
+                    if (ic == 0.) {
+                        if ((t_u < t_d) && (cc >= q_Ice)) S_nuc = m_i_0 / (r_humid * dt_snow_dim) * N_i;
+                        if (((t_d <= t_u) && (t_u <= t_nuc)) && (cc >= q_Rain)) S_nuc = m_i_0 / (r_humid * dt_snow_dim) * N_i;
+                    } else S_nuc = 0.;
+                    if ((t_u < t_hn) && (cl > 0.)) S_c_frz = cl / dt_rain_dim;
+                    else S_c_frz = 0.;
+                    if (t_Celsius <= 0.) {
+                        if (cc > q_Ice) S_i_dep = c_i_dep * N_i * pow(m_i, (1. / 3.)) * (cc - q_Ice);
+                        if ((cc < q_Ice) && (-ic / dt_snow_dim > (cc - q_Ice) / dt_snow_dim)) S_i_dep = -ic / dt_snow_dim;
+                    } else S_i_dep = 0.;
+                    if ((t_u >= t_0) && (cl > 0.)) S_c_au = c_c_au * cl;
+                    else S_c_au = 0.;
+                    if ((t_u <= t_0) && (ic > 0.)) S_i_au = c_i_au * ic;
+                    else S_i_au = 0.;
+                    if (t_u <= t_0) S_d_au = S_i_dep / (1.5 * (pow((m_s_0 / m_i), (2. / 3.)) - 1.));
+                    else S_d_au = 0.;
+                    if (t_u > t_0) S_ac = c_ac * cl * pow(pr, (7. / 9.));
+                    else S_ac = 0.;
+                    if (t_u < t_0) S_rim = c_rim * cl * ps;
+                    else S_rim = 0.;
+                    if (t_u >= t_0) S_shed = c_rim * cl * ps;
+                    else S_shed = 0.;
+                    if (t_u <= t_0) {
+                        S_agg = c_agg * ic * ps;
+                        S_i_cri = c_i_cri * ic * pow(pr, (7. / 9.));
+                        S_r_cri = c_r_cri * ic / m_i * pow(pr, (13. / 9.));
+                    } else { S_agg = 0.; S_i_cri = 0.; S_r_cri = 0.; }
+                    if (t_u >= t_0) S_ev = a_ev * (1. + b_ev * pow(pr, (1. / 6.))) * (q_Rain - cc) * pow(pr, (4. / 9.));
+                    else S_ev = 0.;
+                    if (t_u < t_0) S_s_dep = c_s_dep * (1. + b_s_dep * pow(ps, (5. / 26.))) * (cc - q_Ice) * pow(ps, (8. / 13.));
+                    else S_s_dep = 0.;
+                    if ((t_u > t_0) && (ic > 0.)) S_i_melt = ic / dt_snow_dim;
+                    else S_i_melt = 0.;
+                    if (t_u > t_0) {
+                        p_SL = .01 * (r_air * R_Air * F_(T, 0) * t_0);
+                        hight = (double)i * (L_atm / (double)(im - 1));
+                        double p_t_in = pow(((t_0 - gam * hight * 1.e-2) / t_0), exp_pressure) * p_SL;
+                        double E_Rain_t_in = hp * exp_func(t_0, 17.2694, 35.86);
+                        double q_Rain_t_in = ep * E_Rain_t_in / (p_t_in - E_Rain_t_in);
+                        S_s_melt = c_s_melt * (1. + b_s_melt * pow(ps, (5. / 26.))) * ((t_u - t_0) + a_s_melt * (cc - q_Rain_t_in))
+                                   * pow(ps, (8. / 13.));
+                    } else S_s_melt = 0.;
+                    if (t_r_frz - t_u > 0.) S_r_frz = c_r_frz * pow((t_r_frz - t_u), (3. / 2.)) * pow(pr, (3. / 2.));
+                    else S_r_frz = 0.;
+                    F_(S_V, i) = -F_(S_C_C, i) + S_ev - S_i_dep - S_s_dep - S_nuc;
+                    F_(S_C, i) = F_(S_C_C, i) - S_c_au - S_ac - S_c_frz + S_i_melt - S_rim - S_shed;
+                    F_(S_I, i) = S_nuc + S_c_frz + S_i_dep - S_i_melt - S_i_au - S_d_au - S_agg - S_i_cri;
+                    F_(S_R, i) = S_c_au + S_ac - S_ev + S_shed - S_r_cri - S_r_frz + S_s_melt;
+                    F_(S_S, i) = S_d_au + S_s_dep + S_i_au + S_rim + S_agg + S_i_cri + S_r_cri + S_r_frz - S_s_melt;
+                    if (is_land(c, i, j, k) && is_land(c, i + 1, j, k)) {
+                        F_(S_C_C, i) = 0.; F_(S_V, i) = 0.; F_(S_C, i) = 0.; F_(S_I, i) = 0.; F_(S_R, i) = 0.; F_(S_S, i) = 0.;
+                    }
+                    if (F_(P_RAIN, i + 1) < 0.) F_(P_RAIN, i + 1) = 0.;
+                    if (F_(P_SNOW, i + 1) < 0.) F_(P_SNOW, i + 1) = 0.;
+                    F_(P_RAIN, i) = F_(P_RAIN, i + 1) + (F_(S_R, i) + F_(S_R, i + 1)) * .5 * r_humid * dr * 200.;
+                    F_(P_SNOW, i) = F_(P_SNOW, i + 1) + (F_(S_S, i) + F_(S_S, i + 1)) * .5 * r_humid * dr * 200.;
+                    if (F_(P_RAIN, i) < 0.) F_(P_RAIN, i) = 0.;
+                    if (F_(P_SNOW, i) < 0.) F_(P_SNOW, i) = 0.;
+                    if (F_(C, i) < 0.) F_(C, i) = 0.;
+                    if (F_(CLOUD, i) < 0.) F_(CLOUD, i) = 0.;
+                    if (F_(ICE, i) < 0.) F_(ICE, i) = 0.;
+                }
+            }
+    state[0] = S_nuc; state[1] = S_i_dep;
+#undef F_
+}
+
 /* BC_Thermo::BC_Radiation_multi_layer, atmosphere/BC_Thermo.cpp:166-424.  PARITY UNPINNED (BC_Thermo.cpp cannot
  * be compiled here): a statement-by-statement restatement of the source text, including the transmission
  * matrix CC whose recurrence starts from an element that is never set (so all of it stays 0, :341-344) and the

@@ -28,7 +28,7 @@ F3 = dict(T=0, U=1, V=2, W=3, P_DYN=4, C=5, CLOUD=6, ICE=7, CO2=8,
           H=18, AUX_U=19, AUX_V=20, AUX_W=21, BUOYANCY=22,
           S_V=23, S_C=24, S_I=25, S_R=26, S_S=27,
           SALT_BALANCE=28, SALT_FINGER=29, SALT_DIFFUSION=30, R_WATER=31, R_SALT_WATER=32,
-          RESIDUUM=33, P_STAT=34, Q_LATENT=35, Q_SENSIBLE=36, RADIATION_3D=37, P_RAIN=38, P_SNOW=39, EPSILON_3D=40)
+          RESIDUUM=33, P_STAT=34, Q_LATENT=35, Q_SENSIBLE=36, RADIATION_3D=37, P_RAIN=38, P_SNOW=39, EPSILON_3D=40, S_C_C=41)
 F2 = dict(TOPOGRAPHY=0, EVAPORATION_DALTON=1, PRECIPITATION=2, Q_RADIATION=3, PRECIPITABLE_WATER=4,
           EVAPORATION_PENMAN=5, Q_EVAPORATION=6, Q_LATENT_2D=7, Q_SENSIBLE_2D=8, Q_BOTTOM=9, CO2_TOTAL=10, VEGETATION=11,
           ALBEDO=12, EPSILON=13, RADIATION_SURFACE=14)

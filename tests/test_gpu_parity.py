@@ -339,6 +339,62 @@ def test_atm_radiation_multi_layer(dims, seed, trop):
     d.close()
 
 
+@pytest.mark.parametrize("dims,seed,first", [((41, 19, 23), 62, "warm"), ((12, 13, 17), 63, "icy"), ((9, 21, 70), 64, "warm")])
+def test_atm_two_category_ice_scheme(dims, seed, first):
+    """BC_Thermo::Two_Category_Ice_Scheme against the oracle's restatement in the reference's serial visiting
+    order (exp() and pow() on both sides, 1e-10 per field), PARITY UNPINNED against the reference itself
+    (BC_Thermo.cpp cannot be compiled outside its own build).  S_nuc and S_i_dep are assigned only under
+    conditions and otherwise keep the value of the grid point visited before - across columns, passes and calls:
+    the first columns of the visiting order are built so that they assign nothing ("warm": S_nuc, "icy":
+    S_i_dep), which makes them work with the caller's state in the first pass and with the grid's last
+    assignment afterwards; two calls in a row hand the state on."""
+    import ctypes as C
+    im, jm, km = dims
+    p = H.default_params(H.ATM, im, jm, km)
+    f, g = H.make_msl_inputs(im, jm, km, seed, p)
+    rng = np.random.default_rng(seed)
+    shp = (im, jm, km)
+    lev = np.arange(im).reshape(im, 1, 1) / (im - 1)
+    f["T"] = 1.07 - 0.25 * lev + rng.uniform(-0.03, 0.03, shp)          # 295 K at the ground to 224 K at the top
+    f["C"] = rng.uniform(-1e-4, 2e-2, shp) * (1.0 - 0.95 * lev)
+    f["CLOUD"] = np.where(rng.random(shp) < 0.5, 0.0, rng.uniform(-1e-5, 1e-3, shp))
+    f["ICE"] = np.where(rng.random(shp) < 0.5, 0.0, rng.uniform(-1e-5, 2e-3, shp))
+    f["S_C_C"] = rng.uniform(-1e-7, 1e-7, shp)
+    f["H"][im - 2, ::3, ::4] = 1.0
+    f["H"][im - 3, ::3, ::4] = 1.0
+    if first == "warm":   # no ice, above t_nuc: S_nuc is not assigned
+        f["T"][:, :4, 0] = 1.05; f["ICE"][:, :4, 0] = 0.0
+    else:                 # cold, dry, more ice than the deficit: S_i_dep is not assigned
+        f["T"][:, :4, 0] = 0.9; f["C"][:, :4, 0] = 0.0; f["ICE"][:, :4, 0] = 0.01
+    f["T"][:, 5:8, 2:4] = 1.05; f["ICE"][:, 5:8, 2:4] = 0.0               # more columns without an S_nuc of their own
+    o = H.CpuModel("oracle", H.ATM, im, jm, km, p, f, g)
+    d = atom_amd.DeviceModel(H.ATM, im, jm, km, atom_amd.Params.from_buffer_copy(bytes(p)))
+    d.upload_all(f, g)
+    o.lib.oracle_atm_two_category_ice_scheme.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    o.lib.oracle_atm_two_category_ice_scheme.restype = None
+    st_o = (C.c_double * 2)(3.0e-7, -2.0e-7)
+    st_d = (3.0e-7, -2.0e-7)
+    worst = 0.0
+    for call in range(2):
+        o.lib.oracle_atm_two_category_ice_scheme(o.ctx, st_o)
+        st_d = d.two_category_ice_scheme(st_d)
+        for n in range(2):
+            assert abs(st_d[n] - st_o[n]) <= TOL * max(abs(st_o[n]), 1e-300), (call, n, st_d[n], st_o[n])
+        for k in list(f):
+            e = H.max_rel_err(d.download(k), o.f[k])
+            worst = max(worst, e)
+            assert e <= TOL, (call, k, e)
+        if call == 0:   # between the calls the model moves on: new moisture, same geometry
+            for k in ("C", "ICE"):
+                x = o.f[k] * rng.uniform(0.5, 1.5, shp)
+                o.f[k][...] = x; d.upload(k, x)
+    for k in ("S_V", "S_C", "S_I", "S_R", "S_S", "P_RAIN", "P_SNOW", "C", "ICE", "CLOUD"):
+        assert not np.array_equal(o.f[k], f[k]), k
+    assert (o.f["P_RAIN"] > 0).any() and (o.f["P_SNOW"] > 0).any()
+    print("two-category ice scheme: max rel err %.3e, state %s" % (worst, st_d))
+    d.close()
+
+
 def test_golden_small_hyd_bitexact():
     """HIP path against the compiled reference's own outputs (tests/golden/hyd_small.npz)."""
     z = np.load(os.path.join(GOLD, "hyd_small.npz"))
