@@ -242,6 +242,206 @@ __global__ void k_ice_column_passes(IceArgs a) {
 #undef AT
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// BC_Thermo::Ice_Water_Saturation_Adjustment (atmosphere/BC_Thermo.cpp:2509-2796)
+//
+// Local to a grid point but for (1) the column's sea-level pressure, which uses t(0) as the column's first
+// point has just left it, and (2) the class member q_v_hyp: a cold point assigns it before its iteration only
+// if its cloud water and cloud ice come in non-negative (:2658-2661); a point whose input is negative starts
+// from what the cold point visited before it (k outer, j, i upwards) left behind.  Every cold point assigns it
+// inside its iteration, so only a column whose FIRST cold point has negative input depends on the columns
+// before it.  Such columns are rare (extrapolated boundary values); they are left untouched by the column
+// kernel and done in visiting order by the scan kernel, which also hands the member on from column to column.
+struct AdjArgs {
+    double *c, *cn, *cloud, *cloudn, *ice, *icen, *t, *s_c_c;
+    const uint8_t* flags;
+    int im, jm, km;
+    double t_0, g, gam, R_Air, r_air, R_WaterVapour, L_atm, hp, ep, lv, ls, cp_l, dt_dim;
+    double* out;      // per column rank: q_v_hyp after the column
+    uint8_t* kind;    // per column rank: 0 no cold point, 1 out[] valid, 2 depends on the columns before it
+    double* last;     // q_v_hyp after the whole grid
+    double state;     // q_v_hyp as the call found it
+};
+
+constexpr double t_00 = 236.15;
+
+// does the member get a value before the iteration? (:2658-2661)
+__device__ __forceinline__ bool hyp_assigned(double q_c_b, double q_i_b) {
+    return ((q_c_b > 0.) && (q_i_b > 0.)) || ((q_c_b >= 0.) && (q_i_b == 0.)) || ((q_c_b == 0.) && (q_i_b > 0.));
+}
+
+__device__ __forceinline__ double hyp_value(double q_c_b, double q_i_b, double q_Rain, double q_Ice, double q_v_hyp) {
+    if ((q_c_b > 0.) && (q_i_b > 0.)) q_v_hyp = (q_c_b * q_Rain + q_i_b * q_Ice) / (q_c_b + q_i_b);
+    if ((q_c_b >= 0.) && (q_i_b == 0.)) q_v_hyp = q_Rain;
+    if ((q_c_b == 0.) && (q_i_b > 0.)) q_v_hyp = q_Ice;
+    return q_v_hyp;
+}
+
+// 0: no cold point; 1: the first cold point assigns q_v_hyp itself; 2: it needs the inherited value
+__device__ int adj_column_kind(const AdjArgs& a, size_t q) {
+    const size_t n2 = (size_t)a.jm * a.km;
+    for (int i = 0; i < a.im; i++) {
+        const size_t id = (size_t)i * n2 + q;
+        const double t_Celsius = a.t[id] * a.t_0 - a.t_0;
+        if (t_Celsius < 0.) {
+            const double q_c_b = (t_Celsius < t_00 - a.t_0) ? 0. : a.cloud[id];
+            return hyp_assigned(q_c_b, a.ice[id]) ? 1 : 2;
+        }
+    }
+    return 0;
+}
+
+// one column, bottom to top; returns q_v_hyp as the column leaves it
+__device__ double adj_column(const AdjArgs& a, size_t q, double q_v_hyp) {
+    const size_t n2 = (size_t)a.jm * a.km;
+    const double t_0 = a.t_0, lv = a.lv, ls = a.ls, cp_l = a.cp_l;
+    const double t_Celsius_2 = t_00 - t_0;
+    const double exp_pressure = a.g / (1.e-2 * a.gam * a.R_Air);
+    double t_ground = a.t[q];
+    for (int i = 0; i < a.im; i++) {
+        const size_t id = (size_t)i * n2 + q;
+        const double t_in = a.t[id];
+        double t_u = t_in * t_0;
+        const double t_Celsius = t_u - t_0;
+        double p_SL = .01 * (a.r_air * a.R_Air * t_ground * t_0);
+        const double hight = (double)i * (a.L_atm / (double)(a.im - 1));
+        double p_h;
+        if (i != 0) p_h = pow(((t_in * t_0 - a.gam * hight * 1.e-2) / (t_in * t_0)), exp_pressure) * p_SL;
+        else p_h = p_SL;
+        double cc = a.c[id], cl = a.cloud[id], ic = a.ice[id], t_out;
+        double cn_out, cloudn_out, icen_out;
+        if (t_Celsius >= 0.) {  // warm cloud phase, :2566-2629
+            double q_T = cc + cl;
+            double E_Rain = a.hp * exp_func(t_u, 17.2694, 35.86);
+            double q_Rain = a.ep * E_Rain / (p_h - E_Rain);
+            double q_Rain_n = q_Rain, T_it;
+            if (q_T <= q_Rain) {
+                cc = q_T; cl = 0.; ic = 0.;
+                T_it = t_u;
+            } else {
+                T_it = t_u;
+                for (int iter_prec = 1; iter_prec <= 20; iter_prec++) {
+                    T_it = (t_u + lv / cp_l * cc - lv / cp_l * q_Rain);
+                    E_Rain = a.hp * exp_func(T_it, 17.2694, 35.86);
+                    q_Rain = a.ep * E_Rain / (p_h - E_Rain);
+                    q_Rain = .5 * (q_Rain_n + q_Rain);
+                    cc = q_Rain;
+                    cl = q_T - cc;
+                    ic = 0.;
+                    q_T = cc + cl;
+                    if (cc < 0.) cc = 0.;
+                    if (cl < 0.) cl = 0.;
+                    if ((q_Rain_n) > 2.220446049250313e-16 && fabs(q_Rain / q_Rain_n - 1.) <= 1.e-5) break;
+                    q_Rain_n = q_Rain;
+                }
+            }
+            cn_out = cc; cloudn_out = cl; icen_out = ic;
+            t_out = T_it / t_0;
+        } else if (t_Celsius < 0.) {  // mixed cloud phase, :2637-2765
+            if (t_Celsius < t_Celsius_2) cl = 0.;
+            double q_v_b = cc, q_c_b = cl, q_i_b = ic;
+            double T = t_u;
+            double E_Rain = a.hp * exp_func(T, 17.2694, 35.86);
+            double E_Ice = a.hp * exp_func(T, 21.8746, 7.66);
+            double q_Rain = a.ep * E_Rain / (p_h - E_Rain);
+            double q_Ice = a.ep * E_Ice / (p_h - E_Ice);
+            q_v_hyp = hyp_value(q_c_b, q_i_b, q_Rain, q_Ice, q_v_hyp);
+            for (int iter_prec = 1; iter_prec <= 20; iter_prec++) {
+                double CND = (T - t_00) / (t_0 - t_00);
+                if (T < t_00) CND = 0.;
+                double DEP = (t_0 - T) / (t_0 - t_00);
+                if (T > t_0) DEP = 0.;
+                const double d_q_v = q_v_hyp - q_v_b;
+                const double d_q_c = -d_q_v * CND;
+                const double d_q_i = -d_q_v * DEP;
+                const double d_t = (lv * d_q_c + ls * d_q_i) / cp_l;
+                T = T + d_t;
+                q_v_b = cc + d_q_v;
+                q_c_b = cl + d_q_c;
+                q_i_b = ic + d_q_i;
+                if (q_v_b < 0.) q_v_b = 0.;
+                if (q_c_b < 0.) q_c_b = 0.;
+                if (q_i_b < 0.) q_i_b = 0.;
+                if (i != 0) {
+                    if (T > a.gam * hight * 1.e-2) p_h = pow(((T - a.gam * hight * 1.e-2) / (T)), exp_pressure) * p_SL;
+                    else p_h = p_SL;  // the reference logs a warning here
+                } else p_h = p_SL;
+                E_Rain = a.hp * exp_func(T, 17.2694, 35.86);
+                E_Ice = a.hp * exp_func(T, 21.8746, 7.66);
+                q_Rain = a.ep * E_Rain / (p_h - E_Rain);
+                q_Ice = a.ep * E_Ice / (p_h - E_Ice);
+                q_v_hyp = hyp_value(q_c_b, q_i_b, q_Rain, q_Ice, q_v_hyp);
+                if (iter_prec >= 3 && (q_v_hyp) > 2.220446049250313e-16 && fabs(q_v_b / q_v_hyp - 1.) <= 1.e-5) break;
+                q_v_b = .5 * (q_v_hyp + q_v_b);
+            }
+            // S_c_c from the point's incoming cn and c (:2732; c is overwritten only after the iteration)
+            a.s_c_c[id] = (a.flags[id] & FL_LAND) ? 0. : .5 * (a.cn[id] - cc) / a.dt_dim;
+            cc = q_v_b; cl = q_c_b; ic = q_i_b;
+            if (t_Celsius < t_Celsius_2) cl = 0.;
+            cn_out = cc; cloudn_out = cl; icen_out = ic;
+            t_out = T / t_0;
+        } else {  // t is not a number: neither branch is taken, the closing clamp still is
+            a.c[id] = at_least_zero(cc); a.cloud[id] = at_least_zero(cl); a.ice[id] = at_least_zero(ic);
+            continue;
+        }
+        a.cn[id] = cn_out; a.cloudn[id] = cloudn_out; a.icen[id] = icen_out;
+        // the closing clamp of c, cloud and ice (:2770-2778) touches the old-level arrays only
+        a.c[id] = at_least_zero(cc); a.cloud[id] = at_least_zero(cl); a.ice[id] = at_least_zero(ic);
+        a.t[id] = t_out;
+        if (i == 0) t_ground = t_out;
+    }
+    return q_v_hyp;
+}
+
+__global__ void k_adj_columns(AdjArgs a) {
+    const size_t n2 = (size_t)a.jm * a.km;
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n2) return;
+    const int j = (int)(q / a.km), k = (int)(q - (size_t)j * a.km);
+    const size_t rank = (size_t)k * a.jm + j;
+    const int kind = adj_column_kind(a, q);
+    a.kind[rank] = (uint8_t)kind;
+    if (kind == 2) return;  // left for the scan kernel
+    const double out = adj_column(a, q, 0.);  // the start value is never read: the first cold point assigns it
+    a.out[rank] = out;
+}
+
+// one workgroup; each thread owns a run of consecutive columns and takes its turn in visiting order
+__global__ __launch_bounds__(1024) void k_adj_inherit(AdjArgs a) {
+    __shared__ double carry;
+    const size_t n2 = (size_t)a.jm * a.km;
+    const size_t per = (n2 + blockDim.x - 1) / blockDim.x;
+    const size_t r0 = (size_t)threadIdx.x * per, r1 = r0 + per < n2 ? r0 + per : n2;
+    // a run without dependent columns is summarised ahead of its turn
+    bool has_dep = false, def = false; double out = 0.;
+    for (size_t r = r0; r < r1; r++) {
+        const uint8_t kd = a.kind[r];
+        if (kd == 2) has_dep = true;
+        if (kd == 1) { def = true; out = a.out[r]; }
+    }
+    if (threadIdx.x == 0) carry = a.state;
+    __syncthreads();
+    for (unsigned turn = 0; turn < blockDim.x; turn++) {  // every thread runs all turns: the barrier is uniform
+        if (turn == threadIdx.x) {
+            if (!has_dep) { if (def) carry = out; }
+            else {
+                double v = carry;
+                for (size_t r = r0; r < r1; r++) {
+                    const uint8_t kd = a.kind[r];
+                    if (kd == 1) v = a.out[r];
+                    else if (kd == 2) {
+                        const size_t k = r / a.jm, j = r - k * a.jm;
+                        v = adj_column(a, j * a.km + k, v);
+                    }
+                }
+                carry = v;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) a.last[0] = carry;
+}
+
 }  // namespace
 
 extern "C" int atomdev_atm_two_category_ice_scheme(atomdev_t* h, double state[2]) {
@@ -276,5 +476,32 @@ extern "C" int atomdev_atm_two_category_ice_scheme(atomdev_t* h, double state[2]
     ATOMDEV_TRY(hipStreamSynchronize(h->stream));
     if (last[0] != 0.) state[0] = last[1];
     if (last[2] != 0.) state[1] = last[3];
+    return 0;
+}
+
+extern "C" int atomdev_atm_ice_water_saturation_adjustment(atomdev_t* h, double* q_v_hyp) {
+    ATOMDEV_REQUIRE(h && h->model == ATOMDEV_ATM && q_v_hyp, "atomdev_atm_ice_water_saturation_adjustment: bad argument");
+    ATOMDEV_REQUIRE(h->im >= 4, "atomdev_atm_ice_water_saturation_adjustment: needs at least 4 levels (scratch layout)");
+    ATOMDEV_TRY(hipSetDevice(h->device));
+    if (int rc = atomdev_refresh_flags(h)) return rc;
+    const atomdev_params& P = h->p;
+    AdjArgs a;
+    a.c = h->f[ATOMDEV_C]; a.cn = h->f[ATOMDEV_CN]; a.cloud = h->f[ATOMDEV_CLOUD]; a.cloudn = h->f[ATOMDEV_CLOUDN];
+    a.ice = h->f[ATOMDEV_ICE]; a.icen = h->f[ATOMDEV_ICEN]; a.t = h->f[ATOMDEV_T]; a.s_c_c = h->f[ATOMDEV_S_C_C];
+    a.flags = h->flags;
+    a.im = h->im; a.jm = h->jm; a.km = h->km;
+    a.t_0 = P.t_0; a.g = P.g; a.gam = P.gam; a.R_Air = P.R_Air; a.r_air = P.r_air; a.R_WaterVapour = P.R_WaterVapour;
+    a.L_atm = P.L_atm; a.hp = P.hp; a.ep = P.ep; a.lv = P.lv; a.ls = P.ls; a.cp_l = P.cp_l;
+    a.dt_dim = P.L_atm / P.u_0 * P.dt;  // BC_Thermo.cpp:121
+    const size_t n2 = h->n2;
+    double* s = h->scr[0];
+    a.out = s; a.kind = (uint8_t*)(s + n2); a.last = s + 2 * n2;
+    a.state = *q_v_hyp;
+    const unsigned nb = (unsigned)((n2 + TPB - 1) / TPB);
+    hipLaunchKernelGGL(k_adj_columns, dim3(nb), dim3(TPB), 0, h->stream, a);
+    hipLaunchKernelGGL(k_adj_inherit, dim3(1), dim3(1024), 0, h->stream, a);
+    ATOMDEV_TRY(hipGetLastError());
+    ATOMDEV_TRY(hipMemcpyAsync(q_v_hyp, a.last, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    ATOMDEV_TRY(hipStreamSynchronize(h->stream));
     return 0;
 }

@@ -84,6 +84,7 @@ def load_library():
     lib.atomdev_atm_msl_data.argtypes = [vp, C.c_int]
     lib.atomdev_atm_vegetation_distribution.argtypes = [vp, C.c_double]
     lib.atomdev_atm_two_category_ice_scheme.argtypes = [vp, dp]
+    lib.atomdev_atm_ice_water_saturation_adjustment.argtypes = [vp, dp]
     lib.atomdev_default_radiation.argtypes = [C.POINTER(Radiation)]
     lib.atomdev_default_radiation.restype = None
     lib.atomdev_atm_radiation_multi_layer.argtypes = [vp, C.POINTER(Radiation), ip]
@@ -222,6 +223,12 @@ class DeviceModel:
         if it.shape != (self.jm,):
             raise AtomDevError("i_trop must have jm entries")
         self._check(self.lib.atomdev_atm_radiation_multi_layer(self._h, C.byref(radiation), it.ctypes.data_as(C.POINTER(C.c_int))))
+
+    def ice_water_saturation_adjustment(self, q_v_hyp=0.0):
+        """BC_Thermo::Ice_Water_Saturation_Adjustment; q_v_hyp as the previous call left it. Returns the new value."""
+        st = C.c_double(q_v_hyp)
+        self._check(self.lib.atomdev_atm_ice_water_saturation_adjustment(self._h, C.byref(st)))
+        return st.value
 
     def two_category_ice_scheme(self, state=(0.0, 0.0)):
         """BC_Thermo::Two_Category_Ice_Scheme; state = (S_nuc, S_i_dep) as the previous call left them. Returns the new state."""

@@ -181,6 +181,13 @@ int atomdev_atm_radiation_multi_layer(atomdev_t* h, const atomdev_radiation* r, 
  * visited before it (k outer, j, i downwards), from the previous pass or from the previous call:
  * state = {S_nuc, S_i_dep} carries the two members in and out.  Parity unpinned, like atomdev_atm_latent_heat. */
 int atomdev_atm_two_category_ice_scheme(atomdev_t* h, double state[2]);
+
+/* BC_Thermo::Ice_Water_Saturation_Adjustment (atmosphere/BC_Thermo.cpp:2509-2796): water vapour, cloud water and
+ * cloud ice brought into saturation equilibrium at every grid point (up to 20 iterations each), t changed by the
+ * latent heat; writes c, cloud, ice, their new-level twins, t and S_c_c.  The class member q_v_hyp is assigned before
+ * a cold point's iteration only where its cloud water and cloud ice come in non-negative (:2658-2661) and otherwise
+ * keeps what the point visited before left behind: *q_v_hyp is the member, read on entry and written on return. */
+int atomdev_atm_ice_water_saturation_adjustment(atomdev_t* h, double* q_v_hyp);
 /* BC_Thermo::Latent_Heat (atmosphere/BC_Thermo.cpp:2418-2502): Q_Latent and Q_Sensible from the radial
  * gradients of c, ice and t, one-sided at the top of the topography (i_topography, :128-139), central above it
  * up to level im-3.  Reads t, c, ice, p_stat, h.  BC_Thermo.cpp cannot be compiled outside the reference's own

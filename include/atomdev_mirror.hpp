@@ -22,6 +22,7 @@
 #ifndef ATOMDEV_MIRROR_HPP_
 #define ATOMDEV_MIRROR_HPP_
 
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
@@ -290,6 +291,137 @@ public:
 
 private:
     int im_, jm_, km_;
+};
+
+// atmosphere/BC_Bath_Atm.h: the two members the iteration loop calls; the mask reader stays on the host.
+class BC_Bathymetry_Atmosphere {
+public:
+    BC_Bathymetry_Atmosphere(int, int im, int jm, int km, double, double, double) : im_(im), jm_(jm), km_(km) {}
+    // atmosphere/BC_Bath_Atm.cpp:94-119: only h and the seven reset fields are touched, most scalars are unused
+    void BC_SolidGround(int, int, double g, double, double, double r_air, double R_Air, double t_0, double c_0, double, double,
+                        double, double, double t_tropopause, double, double, double, double, double, double, double,
+                        double gam, double, Array& h, Array& u, Array& v, Array& w, Array& t, Array& p_dyn, Array& c,
+                        Array& cloud, Array& ice, Array& co2, Array&, Array_2D&) {
+        Device& d = Device::of(ATOMDEV_ATM);
+        d.grid(im_, jm_, km_);
+        atomdev_params& p = d.params();
+        p.g = g; p.r_air = r_air; p.R_Air = R_Air; p.t_0 = t_0; p.c_0 = c_0; p.t_tropopause = t_tropopause; p.gam = gam;
+        push_all(d, { { ATOMDEV_H, &h }, { ATOMDEV_U, &u }, { ATOMDEV_V, &v }, { ATOMDEV_W, &w }, { ATOMDEV_T, &t },
+                      { ATOMDEV_P_DYN, &p_dyn }, { ATOMDEV_C, &c }, { ATOMDEV_CLOUD, &cloud }, { ATOMDEV_ICE, &ice },
+                      { ATOMDEV_CO2, &co2 } });
+        d.run(atomdev_atm_solid_ground(d.handle()), "atomdev_atm_solid_ground");
+        pull_all(d, { { ATOMDEV_U, &u }, { ATOMDEV_V, &v }, { ATOMDEV_W, &w }, { ATOMDEV_T, &t }, { ATOMDEV_P_DYN, &p_dyn },
+                      { ATOMDEV_C, &c }, { ATOMDEV_CLOUD, &cloud }, { ATOMDEV_ICE, &ice }, { ATOMDEV_CO2, &co2 } });
+    }
+    // atmosphere/BC_Bath_Atm.cpp:129-142
+    void vegetationDistribution(double max_Precipitation, Array_2D& Precipitation, Array_2D& Vegetation, Array& t, Array& h) {
+        Device& d = Device::of(ATOMDEV_ATM);
+        d.grid(im_, jm_, km_);
+        push_all(d, { { ATOMDEV_H, &h }, { ATOMDEV_T, &t } });
+        d.push2d(ATOMDEV_PRECIPITATION, Precipitation); d.push2d(ATOMDEV_VEGETATION, Vegetation);
+        d.run(atomdev_atm_vegetation_distribution(d.handle(), max_Precipitation), "atomdev_atm_vegetation_distribution");
+        d.pull2d(ATOMDEV_VEGETATION, Vegetation);
+    }
+
+private:
+    int im_, jm_, km_;
+};
+
+// atmosphere/BC_Thermo.h: the members cAtmosphereModel::run_3D_loop calls (cAtmosphereModel.cpp:788-865); the
+// initial-condition members (BC_Temperature, BC_WaterVapour, IC_CellStructure, ...) run once per time slice and stay
+// on the host.  The constructor reads the same public members of the model object as BC_Thermo.cpp:30-94 does; it is a
+// template so that this header needs no model class of its own.
+class BC_Thermo {
+public:
+    template <class Model>
+    BC_Thermo(Model* model, int im, int jm, int km, Array& h) : im_(im), jm_(jm), km_(km), h_(&h) {
+        Device& d = Device::of(ATOMDEV_ATM);
+        d.grid(im, jm, km);
+        atomdev_params& p = d.params();
+        p.L_atm = model->L_atm; p.dt = model->dt; p.dr = model->dr; p.dthe = model->dthe; p.dphi = model->dphi;
+        p.g = model->g; p.ep = model->ep; p.hp = model->hp; p.u_0 = model->u_0; p.p_0 = model->p_0; p.t_0 = model->t_0;
+        p.gam = model->gam; p.lv = model->lv; p.ls = model->ls; p.cp_l = model->cp_l; p.r_air = model->r_air;
+        p.R_Air = model->R_Air; p.r_water_vapour = model->r_water_vapour; p.R_WaterVapour = model->R_WaterVapour;
+        p.t_tropopause = model->t_tropopause;
+        atomdev_default_radiation(&rad_);
+        rad_.sigma = model->sigma; rad_.albedo_equator = model->albedo_equator; rad_.albedo_pole = model->albedo_pole;
+        rad_.rad_equator = model->rad_equator; rad_.rad_pole = model->rad_pole; rad_.epsilon_pole = model->epsilon_pole;
+        rad_.epsilon_tropopause = model->epsilon_tropopause; rad_.epsilon_equator = model->epsilon_equator;
+        rad_.co2_coeff = std::fabs(model->CO2 - 1) < 2.220446049250313e-16   // BC_Thermo.cpp:252-257
+                             ? model->co2_factor * (model->co2_equator / model->co2_tropopause) : 1.;
+        im_tropopause_ = model->get_tropopause();
+        const int Ma = int(round(*model->get_current_time()));
+        t_cretaceous_ = model->get_mean_temperature_from_curve(Ma) - model->get_mean_temperature_from_curve(0);
+        t_0_ = model->t_0;
+    }
+    // atmosphere/BC_Thermo.cpp:3235-3275
+    void Value_Limitation_Atm(Array& h, Array& u, Array& v, Array& w, Array& p_dyn, Array& t, Array& c, Array& cloud,
+                              Array& ice, Array& co2) {
+        Device& d = start();
+        push_all(d, { { ATOMDEV_H, &h }, { ATOMDEV_U, &u }, { ATOMDEV_V, &v }, { ATOMDEV_W, &w }, { ATOMDEV_P_DYN, &p_dyn },
+                      { ATOMDEV_T, &t }, { ATOMDEV_C, &c }, { ATOMDEV_CLOUD, &cloud }, { ATOMDEV_ICE, &ice }, { ATOMDEV_CO2, &co2 } });
+        d.run(atomdev_atm_value_limitation(d.handle()), "atomdev_atm_value_limitation");
+        pull_all(d, { { ATOMDEV_U, &u }, { ATOMDEV_V, &v }, { ATOMDEV_W, &w }, { ATOMDEV_P_DYN, &p_dyn }, { ATOMDEV_T, &t },
+                      { ATOMDEV_C, &c }, { ATOMDEV_CLOUD, &cloud }, { ATOMDEV_ICE, &ice }, { ATOMDEV_CO2, &co2 } });
+    }
+    // atmosphere/BC_Thermo.cpp:166-424
+    void BC_Radiation_multi_layer(Array_2D& albedo, Array_2D& epsilon, Array_2D& radiation_surface, Array& p_stat, Array& t,
+                                  Array& c, Array& h, Array& epsilon_3D, Array& radiation_3D, Array& cloud, Array& ice, Array&) {
+        Device& d = start();
+        push_all(d, { { ATOMDEV_H, &h }, { ATOMDEV_P_STAT, &p_stat }, { ATOMDEV_T, &t }, { ATOMDEV_C, &c },
+                      { ATOMDEV_CLOUD, &cloud }, { ATOMDEV_ICE, &ice }, { ATOMDEV_EPSILON_3D, &epsilon_3D },
+                      { ATOMDEV_RADIATION_3D, &radiation_3D } });
+        d.push2d(ATOMDEV_ALBEDO, albedo); d.push2d(ATOMDEV_EPSILON, epsilon); d.push2d(ATOMDEV_RADIATION_SURFACE, radiation_surface);
+        std::vector<int> i_trop(jm_);
+        for (int j = 0; j < jm_; j++) i_trop[j] = im_tropopause_[j] + GetTropopauseHightAdd(t_cretaceous_ / t_0_);  // :226
+        d.run(atomdev_atm_radiation_multi_layer(d.handle(), &rad_, i_trop.data()), "atomdev_atm_radiation_multi_layer");
+        pull_all(d, { { ATOMDEV_T, &t }, { ATOMDEV_C, &c }, { ATOMDEV_CLOUD, &cloud }, { ATOMDEV_ICE, &ice },
+                      { ATOMDEV_EPSILON_3D, &epsilon_3D }, { ATOMDEV_RADIATION_3D, &radiation_3D } });
+        d.pull2d(ATOMDEV_ALBEDO, albedo); d.pull2d(ATOMDEV_EPSILON, epsilon); d.pull2d(ATOMDEV_RADIATION_SURFACE, radiation_surface);
+    }
+    // atmosphere/BC_Thermo.cpp:2509-2796; q_v_hyp is a member there too
+    void Ice_Water_Saturation_Adjustment(Array& h, Array& c, Array& cn, Array& cloud, Array& cloudn, Array& ice, Array& icen,
+                                         Array& t, Array&, Array& S_c_c) {
+        Device& d = start();
+        push_all(d, { { ATOMDEV_H, &h }, { ATOMDEV_C, &c }, { ATOMDEV_CN, &cn }, { ATOMDEV_CLOUD, &cloud },
+                      { ATOMDEV_CLOUDN, &cloudn }, { ATOMDEV_ICE, &ice }, { ATOMDEV_ICEN, &icen }, { ATOMDEV_T, &t },
+                      { ATOMDEV_S_C_C, &S_c_c } });
+        d.run(atomdev_atm_ice_water_saturation_adjustment(d.handle(), &q_v_hyp_), "atomdev_atm_ice_water_saturation_adjustment");
+        pull_all(d, { { ATOMDEV_C, &c }, { ATOMDEV_CN, &cn }, { ATOMDEV_CLOUD, &cloud }, { ATOMDEV_CLOUDN, &cloudn },
+                      { ATOMDEV_ICE, &ice }, { ATOMDEV_ICEN, &icen }, { ATOMDEV_T, &t }, { ATOMDEV_S_C_C, &S_c_c } });
+    }
+    // atmosphere/BC_Thermo.cpp:2803-3143; S_nuc and S_i_dep are members there too
+    void Two_Category_Ice_Scheme(Array& h, Array& c, Array& t, Array&, Array& cloud, Array& ice, Array& P_rain, Array& P_snow,
+                                 Array& S_v, Array& S_c, Array& S_i, Array& S_r, Array& S_s, Array& S_c_c) {
+        Device& d = start();
+        push_all(d, { { ATOMDEV_H, &h }, { ATOMDEV_C, &c }, { ATOMDEV_T, &t }, { ATOMDEV_CLOUD, &cloud }, { ATOMDEV_ICE, &ice },
+                      { ATOMDEV_P_RAIN, &P_rain }, { ATOMDEV_P_SNOW, &P_snow }, { ATOMDEV_S_V, &S_v }, { ATOMDEV_S_C, &S_c },
+                      { ATOMDEV_S_I, &S_i }, { ATOMDEV_S_R, &S_r }, { ATOMDEV_S_S, &S_s }, { ATOMDEV_S_C_C, &S_c_c } });
+        d.run(atomdev_atm_two_category_ice_scheme(d.handle(), ice_state_), "atomdev_atm_two_category_ice_scheme");
+        pull_all(d, { { ATOMDEV_C, &c }, { ATOMDEV_CLOUD, &cloud }, { ATOMDEV_ICE, &ice }, { ATOMDEV_P_RAIN, &P_rain },
+                      { ATOMDEV_P_SNOW, &P_snow }, { ATOMDEV_S_V, &S_v }, { ATOMDEV_S_C, &S_c }, { ATOMDEV_S_I, &S_i },
+                      { ATOMDEV_S_R, &S_r }, { ATOMDEV_S_S, &S_s }, { ATOMDEV_S_C_C, &S_c_c } });
+    }
+    // atmosphere/BC_Thermo.cpp:2418-2502
+    void Latent_Heat(Array_1D&, Array_1D&, Array_1D&, Array& h, Array& t, Array&, Array&, Array&, Array&, Array&, Array& p_stat,
+                     Array& c, Array& ice, Array& Q_Latent, Array& Q_Sensible, Array&, Array_2D&, Array_2D&, Array_2D&, Array_2D&) {
+        Device& d = start();
+        push_all(d, { { ATOMDEV_H, &h }, { ATOMDEV_T, &t }, { ATOMDEV_P_STAT, &p_stat }, { ATOMDEV_C, &c }, { ATOMDEV_ICE, &ice },
+                      { ATOMDEV_Q_LATENT, &Q_Latent }, { ATOMDEV_Q_SENSIBLE, &Q_Sensible } });
+        d.run(atomdev_atm_latent_heat(d.handle()), "atomdev_atm_latent_heat");
+        pull_all(d, { { ATOMDEV_Q_LATENT, &Q_Latent }, { ATOMDEV_Q_SENSIBLE, &Q_Sensible } });
+    }
+    // atmosphere/BC_Thermo.cpp:3299-3303
+    int GetTropopauseHightAdd(double t_cret) { return (int)round((t_cret * t_0_) / 2.6); }
+
+private:
+    Device& start() { Device& d = Device::of(ATOMDEV_ATM); d.grid(im_, jm_, km_); return d; }
+    int im_, jm_, km_;
+    Array* h_;
+    atomdev_radiation rad_;
+    int* im_tropopause_ = nullptr;
+    double t_cretaceous_ = 0., t_0_ = 273.15;
+    double q_v_hyp_ = 0., ice_state_[2] = { 0., 0. };
 };
 
 // atmosphere/PostProcess_Atm.h: the transfer file of the coupling; the plot and VTK writers stay on the host.

@@ -1231,6 +1231,126 @@ void oracle_atm_two_category_ice_scheme(oracle_ctx* c, double state[2]) {
 #undef F_
 }
 
+/* BC_Thermo::Ice_Water_Saturation_Adjustment, atmosphere/BC_Thermo.cpp:2509-2796.  PARITY UNPINNED (BC_Thermo.cpp
+ * cannot be compiled here): a statement-by-statement restatement of the source text in the reference's traversal
+ * order (k outer, j, i upwards; a column's sea-level pressure uses t(0), which the column's first point has just
+ * changed).  q_v_hyp is a class member assigned only under conditions (:2658-2661; none holds where cloud water or
+ * cloud ice comes in negative), so it travels from grid point to grid point and call to call: *q_v_hyp_state. */
+void oracle_atm_ice_water_saturation_adjustment(oracle_ctx* c, double* q_v_hyp_state) {
+    const atomdev_params* P = &c->p;
+    const int im = c->im, jm = c->jm, km = c->km;
+    const double t_0 = P->t_0, g = P->g, gam = P->gam, R_Air = P->R_Air, r_air = P->r_air, R_WaterVapour = P->R_WaterVapour,
+                 L_atm = P->L_atm, hp = P->hp, ep = P->ep, lv = P->lv, ls = P->ls, cp_l = P->cp_l;
+    const double dt_dim = L_atm / P->u_0 * P->dt; /* :121 */
+    const double t_00 = 236.15, t_Celsius_2 = t_00 - t_0;
+    const double exp_pressure = g / (1.e-2 * gam * R_Air);
+    double q_v_hyp = *q_v_hyp_state, T_it = 0.;
+#define F_(N) A3(c, ATOMDEV_##N, i, j, k)
+    for (int k = 0; k < km; k++)
+        for (int j = 0; j < jm; j++)
+            for (int i = 0; i < im; i++) {
+                double t_u = F_(T) * t_0;
+                double t_Celsius = t_u - t_0;
+                double p_SL = .01 * (r_air * R_Air * A3(c, ATOMDEV_T, 0, j, k) * t_0);
+                double hight = (double)i * (L_atm / (double)(im - 1));
+                double p_h;
+                if (i != 0) p_h = pow(((F_(T) * t_0 - gam * hight * 1.e-2) / (F_(T) * t_0)), exp_pressure) * p_SL;
+                else p_h = p_SL;
+                double E_Rain, E_Ice, q_Rain, q_Ice, q_T;
+                if (t_Celsius >= 0.) { /* warm cloud phase */
+                    q_T = F_(C) + F_(CLOUD);
+                    E_Rain = hp * exp_func(t_u, 17.2694, 35.86);
+                    q_Rain = ep * E_Rain / (p_h - E_Rain);
+                    double q_Rain_n = q_Rain;
+                    if (q_T <= q_Rain) {
+                        F_(C) = q_T; F_(CLOUD) = 0.; F_(ICE) = 0.;
+                        T_it = t_u;
+                    } else {
+                        for (int iter_prec = 1; iter_prec <= 20; iter_prec++) {
+                            T_it = (t_u + lv / cp_l * F_(C) - lv / cp_l * q_Rain);
+                            E_Rain = hp * exp_func(T_it, 17.2694, 35.86);
+                            q_Rain = ep * E_Rain / (p_h - E_Rain);
+                            q_Rain = .5 * (q_Rain_n + q_Rain);
+                            F_(C) = q_Rain;
+                            F_(CLOUD) = q_T - F_(C);
+                            F_(ICE) = 0.;
+                            q_T = F_(C) + F_(CLOUD);
+                            if (F_(C) < 0.) F_(C) = 0.;
+                            if (F_(CLOUD) < 0.) F_(CLOUD) = 0.;
+                            if ((q_Rain_n) > DBL_EPSILON && fabs(q_Rain / q_Rain_n - 1.) <= 1.e-5) break;
+                            q_Rain_n = q_Rain;
+                        }
+                    }
+                    F_(CN) = F_(C); F_(CLOUDN) = F_(CLOUD); F_(ICEN) = F_(ICE);
+                    F_(T) = T_it / t_0;
+                }
+                if (t_Celsius < 0.) { /* mixed cloud phase */
+                    if (t_Celsius < t_Celsius_2) F_(CLOUD) = 0.;
+                    if (t_Celsius > 0.) F_(ICE) = 0.;
+                    double q_v_b = F_(C), q_c_b = F_(CLOUD), q_i_b = F_(ICE);
+                    q_T = q_v_b + q_c_b + q_i_b;
+                    t_u = F_(T) * t_0;
+                    double T = t_u;
+                    E_Rain = hp * exp_func(T, 17.2694, 35.86);
+                    E_Ice = hp * exp_func(T, 21.8746, 7.66);
+                    q_Rain = ep * E_Rain / (p_h - E_Rain);
+                    q_Ice = ep * E_Ice / (p_h - E_Ice);
+                    if ((q_c_b > 0.) && (q_i_b > 0.)) q_v_hyp = (q_c_b * q_Rain + q_i_b * q_Ice) / (q_c_b + q_i_b);
+                    if ((q_c_b >= 0.) && (q_i_b == 0.)) q_v_hyp = q_Rain;
+                    if ((q_c_b == 0.) && (q_i_b > 0.)) q_v_hyp = q_Ice;
+                    for (int iter_prec = 1; iter_prec <= 20; iter_prec++) {
+                        double CND = (T - t_00) / (t_0 - t_00);
+                        if (T < t_00) CND = 0.;
+                        double DEP = (t_0 - T) / (t_0 - t_00);
+                        if (T > t_0) DEP = 0.;
+                        double d_q_v = q_v_hyp - q_v_b;
+                        double d_q_c = -d_q_v * CND;
+                        double d_q_i = -d_q_v * DEP;
+                        double d_t = (lv * d_q_c + ls * d_q_i) / cp_l;
+                        T = T + d_t;
+                        q_v_b = F_(C) + d_q_v;
+                        q_c_b = F_(CLOUD) + d_q_c;
+                        q_i_b = F_(ICE) + d_q_i;
+                        if (q_v_b < 0.) q_v_b = 0.;
+                        if (q_c_b < 0.) q_c_b = 0.;
+                        if (q_i_b < 0.) q_i_b = 0.;
+                        p_SL = .01 * (r_air * R_Air * A3(c, ATOMDEV_T, 0, j, k) * t_0);
+                        hight = (double)i * (L_atm / (double)(im - 1));
+                        if (i != 0) {
+                            if (T > gam * hight * 1.e-2) p_h = pow(((T - gam * hight * 1.e-2) / (T)), exp_pressure) * p_SL;
+                            else p_h = p_SL; /* the reference logs a warning here */
+                        } else p_h = p_SL;
+                        E_Rain = hp * exp_func(T, 17.2694, 35.86);
+                        E_Ice = hp * exp_func(T, 21.8746, 7.66);
+                        q_Rain = ep * E_Rain / (p_h - E_Rain);
+                        q_Ice = ep * E_Ice / (p_h - E_Ice);
+                        if ((q_c_b > 0.) && (q_i_b > 0.)) q_v_hyp = (q_c_b * q_Rain + q_i_b * q_Ice) / (q_c_b + q_i_b);
+                        if ((q_c_b >= 0.) && (q_i_b == 0.)) q_v_hyp = q_Rain;
+                        if ((q_c_b == 0.) && (q_i_b > 0.)) q_v_hyp = q_Ice;
+                        F_(S_C_C) = .5 * (F_(CN) - F_(C)) / dt_dim;
+                        if (is_land(c, i, j, k)) F_(S_C_C) = 0.;
+                        q_T = q_v_b + q_c_b + q_i_b;
+                        if (iter_prec >= 3 && (q_v_hyp) > DBL_EPSILON && fabs(q_v_b / q_v_hyp - 1.) <= 1.e-5) break;
+                        q_v_b = .5 * (q_v_hyp + q_v_b);
+                    }
+                    F_(CN) = F_(C) = q_v_b;
+                    F_(CLOUDN) = F_(CLOUD) = q_c_b;
+                    F_(ICEN) = F_(ICE) = q_i_b;
+                    if (t_Celsius < t_Celsius_2) F_(CLOUDN) = F_(CLOUD) = 0.;
+                    if (t_Celsius > 0.) F_(ICEN) = F_(ICE) = 0.;
+                    F_(T) = T / t_0;
+                }
+                (void)q_T;
+            }
+    static const int CL[3] = { ATOMDEV_C, ATOMDEV_CLOUD, ATOMDEV_ICE };
+    for (int n = 0; n < 3; n++) {
+        double* x = c->f[CL[n]];
+        for (size_t q = 0; q < (size_t)im * jm * km; q++) if (x[q] < 0.) x[q] = 0.;
+    }
+    *q_v_hyp_state = q_v_hyp;
+#undef F_
+}
+
 /* BC_Thermo::BC_Radiation_multi_layer, atmosphere/BC_Thermo.cpp:166-424.  PARITY UNPINNED (BC_Thermo.cpp cannot
  * be compiled here): a statement-by-statement restatement of the source text, including the transmission
  * matrix CC whose recurrence starts from an element that is never set (so all of it stays 0, :341-344) and the

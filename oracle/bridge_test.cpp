@@ -29,6 +29,7 @@
 #include "Pressure_Atm.h"
 #include "BC_Atm.h"
 #include "Results_Atm.h"
+#include "BC_Bath_Atm.h"
 #undef _PRESSURE_
 #include "RHS_Hyd.h"
 #include "RungeKutta_Hyd.h"
@@ -42,14 +43,14 @@ namespace {
 
 struct RefClasses {
     typedef ::RHS_Atmosphere RHS_A; typedef ::RungeKutta_Atmosphere RK_A; typedef ::Pressure_Atm P_A; typedef ::BC_Atmosphere BC_A;
-    typedef ::Results_MSL_Atm MSL_A;
+    typedef ::Results_MSL_Atm MSL_A; typedef ::BC_Bathymetry_Atmosphere BATH_A;
     typedef ::RHS_Hydrosphere RHS_H; typedef ::RungeKutta_Hydrosphere RK_H; typedef ::Pressure_Hyd P_H; typedef ::BC_Hydrosphere BC_H;
     typedef ::BC_Thermohalin TH_H;
 };
 struct DevClasses {
     typedef atomdev_mirror::RHS_Atmosphere RHS_A; typedef atomdev_mirror::RungeKutta_Atmosphere RK_A;
     typedef atomdev_mirror::Pressure_Atm P_A; typedef atomdev_mirror::BC_Atmosphere BC_A;
-    typedef atomdev_mirror::Results_MSL_Atm MSL_A;
+    typedef atomdev_mirror::Results_MSL_Atm MSL_A; typedef atomdev_mirror::BC_Bathymetry_Atmosphere BATH_A;
     typedef atomdev_mirror::RHS_Hydrosphere RHS_H; typedef atomdev_mirror::RungeKutta_Hydrosphere RK_H;
     typedef atomdev_mirror::Pressure_Hyd P_H; typedef atomdev_mirror::BC_Hydrosphere BC_H;
     typedef atomdev_mirror::BC_Thermohalin TH_H;
@@ -196,6 +197,111 @@ void init_msl(Fields& F, unsigned seed, const Scalars& s) {
     for (int j = 0; j < jm; j++) for (int k = 0; k < km; k++) F.g("temperature_NASA").y[j][k] = 1.;
 }
 
+// ---- cAtmosphereModel.cpp:793-796, 850 ----
+template <class NS>
+void land_calls(Fields& F, const Scalars& s) {
+    typename NS::BATH_A LandArea(1, F.im, F.jm, F.km, 3.0, 0., 0.);
+    LandArea.BC_SolidGround(1, 0, s.g, 6.1078, 0.623, s.r_air, s.R_Air, s.t_0, s.c_0, 0., 0., 1.0842, 0.945, s.t_tropopause,
+        0.64, 0.001, 280.0, 330.0, 320.0, 320.0, 0., s.gam, 5.670280e-8, F["h"], F["u"], F["v"], F["w"], F["t"], F["p_dyn"],
+        F["c"], F["cloud"], F["ice"], F["co2"], F["radiation_3D"], F.g("Vegetation"));
+    LandArea.vegetationDistribution(.8, F.precip, F.g("Vegetation"), F["t"], F["h"]);
+}
+
+// ---- the BC_Thermo members of the iteration loop (cAtmosphereModel.cpp:788-865) ----
+// BC_Thermo.cpp cannot be compiled outside the reference's own build, so the mirror class is checked for its
+// plumbing instead: the same calls through the C-ABI with all fields resident must give the same bits.
+struct LoopModel {  // the public members BC_Thermo's constructor reads (BC_Thermo.cpp:38-94)
+    double L_atm = 16000., dt = 0.00001, dr, dthe, dphi, g = 9.8066, ep = .623, hp = 6.1078, u_0 = 8., p_0 = 1013.25,
+           t_0 = 273.15, sigma = 5.670280e-8, albedo_equator = .15, albedo_pole = .7, gam = .65, lv = 2.52e6, ls = 2.83e6,
+           cp_l = 1005., r_air = 1.2041, R_Air = 287.1, r_water_vapour = .0094, R_WaterVapour = 461.6, co2_factor = .98,
+           rad_equator = 230., rad_pole = 40., epsilon_pole = .59, epsilon_tropopause = .001, epsilon_equator = .594,
+           co2_equator = 330., co2_tropopause = 320., t_tropopause = .798, CO2 = 1.;
+    std::vector<int> trop;
+    double now = 0.;
+    int* get_tropopause() { return trop.data(); }
+    double* get_current_time() { return &now; }
+    double get_mean_temperature_from_curve(int) const { return 0.; }
+};
+
+void init_thermo(Fields& F, unsigned seed, const Scalars& s) {
+    init_msl(F, seed, s);
+    std::mt19937_64 rng(seed + 2000);
+    const int im = F.im, jm = F.jm, km = F.km;
+    fill(F["cloud"], im, jm, km, rng, -1e-5, 1e-3); fill(F["ice"], im, jm, km, rng, -1e-5, 1e-3);
+    fill(F["c"], im, jm, km, rng, -1e-5, 4e-3); fill(F["cn"], im, jm, km, rng, 0., 4e-3);
+    fill(F["S_c_c"], im, jm, km, rng, -1e-7, 1e-7); fill(F["epsilon_3D"], im, jm, km, rng, .3, 1.2);
+    for (int i = 0; i < im; i++) for (int j = 0; j < jm; j++) for (int k = 0; k < km; k++)
+        F["t"].x[i][j][k] = 1.07 - .25 * i / (im - 1.) + .02 * std::sin(.37 * j + .11 * k);
+    for (int j = 0; j < jm; j++) for (int k = 0; k < km; k++) F["h"].x[im - 1][j][k] = 0.;
+    for (const char* n : { "albedo", "epsilon", "radiation_surface" }) (void)F.g(n);
+}
+
+void thermo_mirror_calls(Fields& F, LoopModel& m) {
+    atomdev_mirror::BC_Thermo circulation(&m, F.im, F.jm, F.km, F["h"]);
+    for (int velocity_iter = 1; velocity_iter <= 2; velocity_iter++) {  // two rounds: the carried members travel
+        circulation.Ice_Water_Saturation_Adjustment(F["h"], F["c"], F["cn"], F["cloud"], F["cloudn"], F["ice"], F["icen"], F["t"],
+            F["p_stat"], F["S_c_c"]);
+        circulation.Value_Limitation_Atm(F["h"], F["u"], F["v"], F["w"], F["p_dyn"], F["t"], F["c"], F["cloud"], F["ice"], F["co2"]);
+        circulation.BC_Radiation_multi_layer(F.g("albedo"), F.g("epsilon"), F.g("radiation_surface"), F["p_stat"], F["t"], F["c"],
+            F["h"], F["epsilon_3D"], F["radiation_3D"], F["cloud"], F["ice"], F["co2"]);
+        circulation.Latent_Heat(F.rad, F.the, F.phi, F["h"], F["t"], F["tn"], F["u"], F["v"], F["w"], F["p_dyn"], F["p_stat"], F["c"],
+            F["ice"], F["Q_Latent"], F["Q_Sensible"], F["radiation_3D"], F.g("Q_radiation"), F.g("Q_latent"), F.g("Q_sensible"),
+            F.g("Q_bottom"));
+        circulation.Two_Category_Ice_Scheme(F["h"], F["c"], F["t"], F["p_stat"], F["cloud"], F["ice"], F["P_rain"], F["P_snow"],
+            F["S_v"], F["S_c"], F["S_i"], F["S_r"], F["S_s"], F["S_c_c"]);
+    }
+}
+
+#define CHECK(call) do { if (call) { std::printf("  %s: %s\n", #call, atomdev_last_error()); std::abort(); } } while (0)
+void thermo_resident_calls(Fields& F, LoopModel& m, const Scalars& s) {
+    static const struct { const char* name; int id; } map3[] = {
+        { "h", ATOMDEV_H }, { "t", ATOMDEV_T }, { "u", ATOMDEV_U }, { "v", ATOMDEV_V }, { "w", ATOMDEV_W }, { "p_dyn", ATOMDEV_P_DYN },
+        { "c", ATOMDEV_C }, { "cloud", ATOMDEV_CLOUD }, { "ice", ATOMDEV_ICE }, { "co2", ATOMDEV_CO2 }, { "cn", ATOMDEV_CN },
+        { "cloudn", ATOMDEV_CLOUDN }, { "icen", ATOMDEV_ICEN }, { "p_stat", ATOMDEV_P_STAT }, { "S_c_c", ATOMDEV_S_C_C },
+        { "epsilon_3D", ATOMDEV_EPSILON_3D }, { "radiation_3D", ATOMDEV_RADIATION_3D }, { "Q_Latent", ATOMDEV_Q_LATENT },
+        { "Q_Sensible", ATOMDEV_Q_SENSIBLE }, { "P_rain", ATOMDEV_P_RAIN }, { "P_snow", ATOMDEV_P_SNOW }, { "S_v", ATOMDEV_S_V },
+        { "S_c", ATOMDEV_S_C }, { "S_i", ATOMDEV_S_I }, { "S_r", ATOMDEV_S_R }, { "S_s", ATOMDEV_S_S } };
+    static const struct { const char* name; int id; } map2[] = {
+        { "albedo", ATOMDEV_ALBEDO }, { "epsilon", ATOMDEV_EPSILON }, { "radiation_surface", ATOMDEV_RADIATION_SURFACE } };
+    const int im = F.im, jm = F.jm, km = F.km;
+    atomdev_params p; atomdev_default_params(ATOMDEV_ATM, &p);
+    p.dr = m.dr; p.dthe = m.dthe; p.dphi = m.dphi; p.dt = m.dt; p.u_0 = m.u_0; p.t_tropopause = m.t_tropopause;
+    p.r0 = F.rad.z[0]; p.the0 = F.the.z[0]; (void)s;
+    atomdev_t* h = nullptr;
+    CHECK(atomdev_create(ATOMDEV_ATM, im, jm, km, &p, -1, &h));
+    std::vector<double> buf((size_t)im * jm * km);
+    for (const auto& e : map3) {
+        Array& a = F[e.name];
+        for (int i = 0; i < im; i++) for (int j = 0; j < jm; j++) std::memcpy(&buf[((size_t)i * jm + j) * km], a.x[i][j], 8 * km);
+        CHECK(atomdev_upload(h, e.id, buf.data()));
+    }
+    for (const auto& e : map2) {
+        Array_2D& a = F.g(e.name);
+        for (int j = 0; j < jm; j++) std::memcpy(&buf[(size_t)j * km], a.y[j], 8 * km);
+        CHECK(atomdev_upload2d(h, e.id, buf.data()));
+    }
+    atomdev_radiation r; atomdev_default_radiation(&r);
+    double q_v_hyp = 0., ice_state[2] = { 0., 0. };
+    for (int velocity_iter = 1; velocity_iter <= 2; velocity_iter++) {
+        CHECK(atomdev_atm_ice_water_saturation_adjustment(h, &q_v_hyp));
+        CHECK(atomdev_atm_value_limitation(h));
+        CHECK(atomdev_atm_radiation_multi_layer(h, &r, m.trop.data()));
+        CHECK(atomdev_atm_latent_heat(h));
+        CHECK(atomdev_atm_two_category_ice_scheme(h, ice_state));
+    }
+    for (const auto& e : map3) {
+        Array& a = F[e.name];
+        CHECK(atomdev_download(h, e.id, buf.data()));
+        for (int i = 0; i < im; i++) for (int j = 0; j < jm; j++) std::memcpy(a.x[i][j], &buf[((size_t)i * jm + j) * km], 8 * km);
+    }
+    for (const auto& e : map2) {
+        Array_2D& a = F.g(e.name);
+        CHECK(atomdev_download2d(h, e.id, buf.data()));
+        for (int j = 0; j < jm; j++) std::memcpy(a.y[j], &buf[(size_t)j * km], 8 * km);
+    }
+    atomdev_destroy(h);
+}
+
 // ---- cHydrosphereModel.cpp:437-610 ----
 template <class NS>
 void hydrosphere_calls(Fields& F, const Scalars& s) {
@@ -293,6 +399,27 @@ int main() {
         { Quiet q; msl_calls<RefClasses>(R, s); }
         msl_calls<DevClasses>(D, s);
         bad += compare(R, D, 1e-10, "atmosphere, run_MSL_data");
+    }
+    {   // land reset and vegetation: the reference's class against the mirror, bit-exact
+        Scalars s; s.re = 1000.; s.pr = .7179; s.u_0 = 8.; s.c_0 = .035;
+        const int im = 9, jm = 21, km = 70;
+        s.dr = 1. / (im - 1); s.dthe = M_PI / (jm - 1); s.dphi = s.dthe;
+        Fields R(im, jm, km, s), D(im, jm, km, s);
+        init_msl(R, 11, s); init_msl(D, 11, s);
+        { Quiet q; land_calls<RefClasses>(R, s); }
+        land_calls<DevClasses>(D, s);
+        bad += compare(R, D, 0., "atmosphere, BC_SolidGround + vegetationDistribution");
+    }
+    {   // BC_Thermo's loop members: mirror class (fields travel with every call) against resident fields, bit-exact
+        Scalars s; s.re = 1000.; s.pr = .7179; s.u_0 = 8.; s.c_0 = .035;
+        const int im = 12, jm = 21, km = 34;
+        s.dr = 1. / (im - 1); s.dthe = M_PI / (jm - 1); s.dphi = s.dthe;
+        LoopModel m; m.dr = s.dr; m.dthe = s.dthe; m.dphi = s.dphi; m.trop.assign(jm, im - 3);
+        Fields A(im, jm, km, s), B(im, jm, km, s);
+        init_thermo(A, 12, s); init_thermo(B, 12, s);
+        thermo_mirror_calls(A, m);
+        thermo_resident_calls(B, m, s);
+        bad += compare(A, B, 0., "atmosphere, BC_Thermo loop members: mirror against resident C-ABI");
     }
     {   // hydrosphere (the surface RHS hard-codes im = 41, RHS_Hyd.cpp:466)
         Scalars s; s.re = 10.; s.pr = 6.957; s.u_0 = .25; s.c_0 = 34.6;

@@ -388,24 +388,97 @@ def hyd_3d_loop(m, pressure_iters=2, velocity_iters=2):
     return log
 
 
-def atm_3d_loop(m, pressure_iters=2, velocity_iters=2):
-    """cAtmosphereModel.cpp:756-874 with the operators of this library (the BC_Thermo column physics between them
-    is host code of the caller and left out here): returns the queries' results in call order."""
+def _is_device(m):
+    return not hasattr(m, "ctx")
+
+
+def _atm_physics(m):
+    """The BC_Thermo column physics and the two searches between them, the same calls for the oracle and the device."""
+    import atom_amd
+    dev = _is_device(m)
+    dp = C.POINTER(C.c_double)
+
+    def adjust(q):
+        if dev:
+            return m.ice_water_saturation_adjustment(q)
+        st = C.c_double(q)
+        fn = m.lib.oracle_atm_ice_water_saturation_adjustment; fn.argtypes = [C.c_void_p, dp]; fn.restype = None
+        fn(m.ctx, C.byref(st))
+        return st.value
+
+    def ice_scheme(state):
+        if dev:
+            return m.two_category_ice_scheme(state)
+        st = (C.c_double * 2)(*state)
+        fn = m.lib.oracle_atm_two_category_ice_scheme; fn.argtypes = [C.c_void_p, dp]; fn.restype = None
+        fn(m.ctx, st)
+        return (st[0], st[1])
+
+    def radiation(i_trop):
+        r = atom_amd.Radiation(albedo_pole=.7, albedo_equator=.15, epsilon_pole=.59, epsilon_equator=.594,
+                               epsilon_tropopause=.001, rad_pole=40., rad_equator=230., co2_coeff=.98 * (330. / 320.),
+                               sigma=5.670280e-8)   # param.py:60-70, 123-130
+        if dev:
+            m.radiation_multi_layer(i_trop, r)
+        else:
+            fn = m.lib.oracle_atm_radiation_multi_layer
+            fn.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]; fn.restype = None
+            fn(m.ctx, C.byref(r), i_trop.ctypes.data_as(C.POINTER(C.c_int)))
+
+    def max_precipitation():
+        if dev:
+            return m.minmax("PRECIPITATION")[0][0]
+        out = (C.c_double * 2)(); loc = (C.c_int * 6)()
+        m.lib.oracle_minmax2d.argtypes = [C.c_void_p, C.c_int, dp, C.POINTER(C.c_int)]
+        m.lib.oracle_minmax2d(m.ctx, F2["PRECIPITATION"], out, loc)
+        return out[0]
+
+    def vegetation(maxp):
+        if dev:
+            m.vegetation_distribution(maxp)
+        else:
+            m.op("atm_vegetation_distribution", C.c_double(maxp))
+
+    return adjust, ice_scheme, radiation, max_precipitation, vegetation
+
+
+def atm_3d_loop(m, pressure_iters=2, velocity_iters=2, physics=False, i_trop=None):
+    """cAtmosphereModel.cpp:756-874 with the operators of this library: returns the queries' results in call order.
+    physics=True adds the BC_Thermo column physics where the reference calls it (:787-789, :828-831, :844-866;
+    the saturation adjustment and the ice scheme on even velocity iterations) with the carried class members
+    kept across the iterations as the reference's circulation object keeps them."""
     log = []
+    if physics:
+        adjust, ice_scheme, radiation, max_precipitation, vegetation = _atm_physics(m)
+        q_v_hyp, ice_state = 0.0, (0.0, 0.0)
     _move3d(m)
     for _ in range(pressure_iters):
-        for _ in range(velocity_iters):
+        for velocity_iter in range(1, velocity_iters + 1):
             mn, loc = m.residuum("atm_residuum3d")
             log.append((mn, loc))
-            for op in ("atm_bc_radius", "atm_bc_theta", "atm_bc_phi", "atm_value_limitation", "atm_solid_ground",
-                       "atm_rk3d", "atm_value_limitation"):
+            for op in ("atm_bc_radius", "atm_bc_theta", "atm_bc_phi"):
                 m.op(op)
+            if physics and velocity_iter % 2 == 0:
+                q_v_hyp = adjust(q_v_hyp)
+            for op in ("atm_value_limitation", "atm_solid_ground", "atm_rk3d", "atm_value_limitation"):
+                m.op(op)
+            if physics:
+                radiation(i_trop)
             log.append(m.residuum("atm_residuum3d", mn, loc))  # same Accuracy_Atm object: state carried
             log.append(m.steady("atm_steady3d", 9))
+            if physics:
+                m.op("atm_latent_heat")
+                vegetation(max_precipitation())
             if hasattr(m, "msl_data"):
                 m.msl_data(1)
             else:
                 m.op("atm_msl_data", C.c_int(1))
+            if physics and velocity_iter % 2 == 0:
+                ice_state = ice_scheme(ice_state)
             _move3d(m)
         m.op("atm_pressure3d")
+    if physics:
+        log.append((q_v_hyp, (0, 0, 0)))
+        log.append((ice_state[0], (0, 0, 0)))
+        log.append((ice_state[1], (0, 0, 0)))
     return log

@@ -395,6 +395,71 @@ def test_atm_two_category_ice_scheme(dims, seed, first):
     d.close()
 
 
+@pytest.mark.parametrize("dims,seed", [((41, 19, 23), 65), ((12, 13, 17), 66), ((9, 21, 70), 67)])
+def test_atm_ice_water_saturation_adjustment(dims, seed):
+    """BC_Thermo::Ice_Water_Saturation_Adjustment against the oracle's restatement in the reference's serial
+    visiting order (exp() and pow() inside an iteration with a 1e-5 exit test; 1e-10 per field), PARITY UNPINNED
+    against the reference itself (BC_Thermo.cpp cannot be compiled outside its own build).  The member q_v_hyp
+    is inherited by cold points whose cloud water or ice comes in negative: the inputs hold such points, whole
+    columns that start with one (three of them in a row in visiting order, and the very first column, which
+    takes the caller's value), columns without a cold point, and warm points below, at and above saturation."""
+    import ctypes as C
+    im, jm, km = dims
+    p = H.default_params(H.ATM, im, jm, km)
+    f, g = H.make_msl_inputs(im, jm, km, seed, p)
+    rng = np.random.default_rng(seed)
+    shp = (im, jm, km)
+    lev = np.arange(im).reshape(im, 1, 1) / (im - 1)
+    f["T"] = 1.07 - 0.25 * lev + rng.uniform(-0.03, 0.03, shp)
+    f["T"][:, 7, 3] = 1.06                                   # a column without a cold point
+    f["T"][0, ::4, ::5] = 1.0                                # exactly 0 degrees Celsius counts as warm
+    cold_all = [(0, 0), (2, 1), (3, 1), (4, 1), (jm - 1, km - 1)]   # (j, k): columns cold from the ground up ...
+    for j, k in cold_all:
+        f["T"][:, j, k] = np.minimum(f["T"][:, j, k], 0.97)
+    # water vapour between 20 % and 115 % of saturation over water (far above it the reference's iteration diverges)
+    t_u = f["T"] * p.t_0
+    p_h = ((t_u - p.gam * lev * p.L_atm * 1e-2) / t_u) ** (p.g / (1e-2 * p.gam * p.R_Air)) * .01 * p.r_air * p.R_Air * t_u[0]
+    e_rain = p.hp * np.exp(17.2694 * (t_u - 273.15) / (t_u - 35.86))
+    f["C"] = p.ep * e_rain / (p_h - e_rain) * rng.uniform(0.2, 1.15, shp)
+    f["C"] = np.minimum(f["C"], 0.02)
+    f["C"][rng.random(shp) < 0.02] = -1e-5
+    f["CLOUD"] = np.where(rng.random(shp) < 0.4, 0.0, rng.uniform(-1e-4, 1e-3, shp))
+    f["ICE"] = np.where(rng.random(shp) < 0.4, 0.0, rng.uniform(-1e-4, 1e-3, shp))
+    f["CN"] = f["C"] + rng.uniform(-1e-5, 1e-5, shp)
+    f["S_C_C"] = rng.uniform(-1e-7, 1e-7, shp)
+    for j, k in cold_all:
+        f["ICE"][0, j, k] = -1e-4                            # ... whose first point cannot assign q_v_hyp itself
+    f["CLOUD"][0, 3, 1] = -2e-4; f["ICE"][0, 3, 1] = 3e-4
+    o = H.CpuModel("oracle", H.ATM, im, jm, km, p, f, g)
+    d = atom_amd.DeviceModel(H.ATM, im, jm, km, atom_amd.Params.from_buffer_copy(bytes(p)))
+    d.upload_all(f, g)
+    o.lib.oracle_atm_ice_water_saturation_adjustment.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    o.lib.oracle_atm_ice_water_saturation_adjustment.restype = None
+    st_o = C.c_double(4.0e-3)
+    st_d = 4.0e-3
+    worst = 0.0
+    for call in range(2):
+        o.lib.oracle_atm_ice_water_saturation_adjustment(o.ctx, C.byref(st_o))
+        st_d = d.ice_water_saturation_adjustment(st_d)
+        assert abs(st_d - st_o.value) <= TOL * abs(st_o.value), (call, st_d, st_o.value)
+        for k in list(f):
+            assert np.isfinite(o.f[k]).all(), k
+            e = H.max_rel_err(d.download(k), o.f[k])
+            worst = max(worst, e)
+            assert e <= TOL, (call, k, e)
+        if call == 0:   # the model moves on: moisture changes, some of it to negative values
+            for k, lo, hi in (("C", 0.7, 1.02), ("CLOUD", 0.5, 1.5), ("ICE", 0.5, 1.5)):
+                x = o.f[k] * rng.uniform(lo, hi, shp) - 2e-5
+                o.f[k][...] = x; d.upload(k, x)
+    for k in ("T", "C", "CLOUD", "ICE", "CN", "CLOUDN", "ICEN", "S_C_C"):
+        assert not np.array_equal(o.f[k], f[k]), k
+    for k in ("C", "CLOUD", "ICE"):
+        assert (o.f[k] >= 0).all()
+    assert o.f["T"].max() < 1.2 and o.f["CLOUD"].max() < 0.1          # the iterations stayed bounded
+    print("saturation adjustment: max rel err %.3e, q_v_hyp %r" % (worst, st_d))
+    d.close()
+
+
 def test_golden_small_hyd_bitexact():
     """HIP path against the compiled reference's own outputs (tests/golden/hyd_small.npz)."""
     z = np.load(os.path.join(GOLD, "hyd_small.npz"))
