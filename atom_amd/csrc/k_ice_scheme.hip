@@ -23,8 +23,11 @@ struct IceArgs {
     int im, jm, km;
     double t_0, g, gam, R_Air, r_air, R_WaterVapour, L_atm, hp, ep, dr;
     // per column, indexed by its rank k * jm + j in the reference's visiting order
-    double *out_nuc, *out_dep, *in_nuc, *in_dep;
+    double *out_nuc, *out_dep, *in_nuc, *in_dep;   // in_*: from the columns before it inside its chunk of CHUNK ranks
     uint8_t *out_def, *in_def;   // bit 0: S_nuc, bit 1: S_i_dep
+    double *chunk_nuc, *chunk_dep;                 // per chunk: its own last assignments, then (after the carry kernel)
+    uint8_t* chunk_def;                            // what the chunk inherits from the chunks before it
+    int nchunks;
     double* last;                // {def S_nuc, S_nuc, def S_i_dep, S_i_dep} of the whole grid
     double state_nuc, state_dep; // the members as the call found them
 };
@@ -113,36 +116,66 @@ __global__ void k_ice_column_summary(IceArgs a) {
     a.out_def[rank] = def; a.out_nuc[rank] = nuc; a.out_dep[rank] = dep;
 }
 
-// step 2: what every column inherits from the columns before it; one workgroup, each thread a run of columns
-__global__ __launch_bounds__(1024) void k_ice_inherit(IceArgs a) {
-    __shared__ uint8_t sdef[1024];
-    __shared__ double snuc[1024], sdep[1024];
+// step 2: what every column inherits from the columns before it.  "The last assignment so far" is an associative
+// operation without arithmetic (take the right operand where it is defined), so it is scanned in parallel: inside
+// chunks of CHUNK consecutive ranks by one workgroup each, then over the chunk totals by one thread.
+constexpr int CHUNK = 1024;
+
+__global__ __launch_bounds__(CHUNK) void k_ice_chunk_scan(IceArgs a) {
+    __shared__ uint8_t sd[2][CHUNK];
+    __shared__ double sn[2][CHUNK], sp[2][CHUNK];
     const size_t n2 = (size_t)a.jm * a.km;
-    const size_t per = (n2 + blockDim.x - 1) / blockDim.x;
-    const size_t r0 = (size_t)threadIdx.x * per, r1 = r0 + per < n2 ? r0 + per : n2;
+    const int t = threadIdx.x;
+    const size_t r = (size_t)blockIdx.x * CHUNK + t;
     uint8_t def = 0; double nuc = 0., dep = 0.;
-    for (size_t r = r0; r < r1; r++) {
-        const uint8_t d = a.out_def[r];
-        if (d & 1) { def |= 1; nuc = a.out_nuc[r]; }
-        if (d & 2) { def |= 2; dep = a.out_dep[r]; }
-    }
-    sdef[threadIdx.x] = def; snuc[threadIdx.x] = nuc; sdep[threadIdx.x] = dep;
+    if (r < n2) { def = a.out_def[r]; nuc = a.out_nuc[r]; dep = a.out_dep[r]; }
+    int cur = 0;
+    sd[0][t] = def; sn[0][t] = nuc; sp[0][t] = dep;
     __syncthreads();
-    // last assignment in the runs before this one
-    def = 0; nuc = 0.; dep = 0.;
-    for (int t = (int)threadIdx.x - 1; t >= 0 && def != 3; t--) {
-        if (!(def & 1) && (sdef[t] & 1)) { def |= 1; nuc = snuc[t]; }
-        if (!(def & 2) && (sdef[t] & 2)) { def |= 2; dep = sdep[t]; }
+    for (int off = 1; off < CHUNK; off <<= 1) {  // inclusive scan
+        if (t >= off) {
+            const uint8_t ld = sd[cur][t - off];
+            if (!(def & 1) && (ld & 1)) { def |= 1; nuc = sn[cur][t - off]; }
+            if (!(def & 2) && (ld & 2)) { def |= 2; dep = sp[cur][t - off]; }
+        }
+        cur ^= 1;
+        sd[cur][t] = def; sn[cur][t] = nuc; sp[cur][t] = dep;
+        __syncthreads();
     }
-    for (size_t r = r0; r < r1; r++) {
-        a.in_def[r] = def; a.in_nuc[r] = nuc; a.in_dep[r] = dep;
-        const uint8_t d = a.out_def[r];
-        if (d & 1) { def |= 1; nuc = a.out_nuc[r]; }
-        if (d & 2) { def |= 2; dep = a.out_dep[r]; }
+    if (r < n2) {  // exclusive: what the columns before this one in the chunk left
+        a.in_def[r] = t ? sd[cur][t - 1] : 0; a.in_nuc[r] = t ? sn[cur][t - 1] : 0.; a.in_dep[r] = t ? sp[cur][t - 1] : 0.;
     }
-    if (threadIdx.x == blockDim.x - 1) {  // its running value now covers the whole grid
-        a.last[0] = (def & 1) ? 1. : 0.; a.last[1] = nuc; a.last[2] = (def & 2) ? 1. : 0.; a.last[3] = dep;
+    if (t == CHUNK - 1) { a.chunk_def[blockIdx.x] = def; a.chunk_nuc[blockIdx.x] = nuc; a.chunk_dep[blockIdx.x] = dep; }
+}
+
+__global__ void k_ice_chunk_carry(IceArgs a) {
+    if (blockIdx.x || threadIdx.x) return;
+    uint8_t def = 0; double nuc = 0., dep = 0.;
+    for (int c = 0; c < a.nchunks; c++) {
+        const uint8_t d = a.chunk_def[c]; const double n = a.chunk_nuc[c], p = a.chunk_dep[c];
+        a.chunk_def[c] = def; a.chunk_nuc[c] = nuc; a.chunk_dep[c] = dep;  // the total becomes the inheritance
+        if (d & 1) { def |= 1; nuc = n; }
+        if (d & 2) { def |= 2; dep = p; }
     }
+    a.last[0] = (def & 1) ? 1. : 0.; a.last[1] = nuc; a.last[2] = (def & 2) ? 1. : 0.; a.last[3] = dep;
+}
+
+// the members as a point finds them when neither it nor the levels above it in its column assign them: from the
+// columns before it, else (first pass) the caller's value or (later passes) the grid's last assignment
+struct Inherited { double nuc_first, nuc_later, dep; };
+__device__ __forceinline__ Inherited inherited(const IceArgs& a, size_t rank, bool have_n, double vn, bool have_d, double vd) {
+    const uint8_t in_def = a.in_def[rank];
+    if (!have_n && (in_def & 1)) { have_n = true; vn = a.in_nuc[rank]; }
+    if (!have_d && (in_def & 2)) { have_d = true; vd = a.in_dep[rank]; }
+    const size_t c = rank / CHUNK;
+    const uint8_t ch_def = a.chunk_def[c];
+    if (!have_n && (ch_def & 1)) { have_n = true; vn = a.chunk_nuc[c]; }
+    if (!have_d && (ch_def & 2)) { have_d = true; vd = a.chunk_dep[c]; }
+    Inherited r;
+    r.nuc_first = have_n ? vn : a.state_nuc;
+    r.nuc_later = have_n ? vn : (a.last[0] != 0. ? a.last[1] : a.state_nuc);
+    r.dep = have_d ? vd : (a.last[2] != 0. ? a.last[3] : a.state_dep);  // the preparatory pass assigns S_i_dep like the others
+    return r;
 }
 
 // step 3: the preparatory pass (:2875-2954) and the five full passes (:2959-3135) of one column
@@ -157,12 +190,8 @@ __global__ void k_ice_column_passes(IceArgs a) {
     const double exp_pressure = a.g / (1.e-2 * a.gam * a.R_Air);
     const double t_surface = a.t[q];
 #define AT(F, i) a.F[(size_t)(i) * n2 + q]
-    // inherited members: from the columns before this one, else from the end of the previous pass, else from the caller
-    const uint8_t in_def = a.in_def[rank];
-    const bool grid_nuc = a.last[0] != 0., grid_dep = a.last[2] != 0.;
-    const double nuc_first = (in_def & 1) ? a.in_nuc[rank] : a.state_nuc;                                  // pass 1
-    const double nuc_later = (in_def & 1) ? a.in_nuc[rank] : (grid_nuc ? a.last[1] : a.state_nuc);        // passes 2-5
-    const double dep_in = (in_def & 2) ? a.in_dep[rank] : (grid_dep ? a.last[3] : a.state_dep);           // the preparatory pass assigns S_i_dep like the others
+    const Inherited inh = inherited(a, rank, false, 0., false, 0.);
+    const double nuc_first = inh.nuc_first, nuc_later = inh.nuc_later, dep_in = inh.dep;
 
     // preparatory pass
     AT(p_rain, im - 1) = 0.; AT(p_snow, im - 1) = 0.; AT(s_r, im - 1) = 0.; AT(s_s, im - 1) = 0.;
@@ -242,6 +271,179 @@ __global__ void k_ice_column_passes(IceArgs a) {
 #undef AT
 }
 
+// ---- the same scheme, one thread per grid point -----------------------------------------------------------
+// Inside a pass only the column integrals of rain and snow run along a column; the sources of a grid point use
+// the integrals of the pass BEFORE (a point reads P_rain(i), P_snow(i) before it overwrites them).  So a workgroup
+// takes COLS neighbouring columns with one thread per level: every thread keeps what its point fixes for all
+// passes (densities, saturation values, the inherited members) in registers, publishes S_r, S_s of the pass in
+// LDS, and 2 x COLS threads integrate rain and snow down their columns between two barriers.  Used while
+// COLS * im threads fit a workgroup; taller grids take the column kernels above.
+constexpr int COLS = 16;
+constexpr int MAX_LEVELS = 1024 / COLS;
+
+struct PointGeom {
+    size_t q, id, rank;
+    int i;
+    bool valid, physics;  // inside the grid; below the top level
+};
+
+__device__ __forceinline__ PointGeom point_geom(const IceArgs& a) {
+    PointGeom g;
+    const size_t n2 = (size_t)a.jm * a.km;
+    g.q = (size_t)blockIdx.x * COLS + threadIdx.x;
+    g.i = (int)threadIdx.y;
+    g.valid = g.q < n2;
+    if (!g.valid) g.q = n2 - 1;
+    g.id = (size_t)g.i * n2 + g.q;
+    const size_t j = g.q / a.km, k = g.q - j * a.km;
+    g.rank = k * a.jm + j;
+    g.physics = g.valid && g.i <= a.im - 2;
+    return g;
+}
+
+// step 1 of 3: clamps (:2861-2871) and the column's last assignments of S_nuc and S_i_dep
+__global__ __launch_bounds__(1024) void k_ice_points_summary(IceArgs a) {
+    extern __shared__ double lds[];  // [2][im][COLS] doubles, then [im][COLS] bytes
+    const int plane = a.im * COLS;
+    double *s_nuc = lds, *s_dep = lds + plane;
+    uint8_t* s_def = (uint8_t*)(lds + 2 * plane);
+    const PointGeom g = point_geom(a);
+    const int tx = threadIdx.x;
+    uint8_t def = 0; double nuc = 0., dep = 0.;
+    if (g.valid) {
+        double* cl5[5] = { a.c, a.cloud, a.ice, a.p_rain, a.p_snow };
+        double v[5];
+        for (int n = 0; n < 5; n++) { v[n] = cl5[n][g.id]; if (v[n] < 0.) { v[n] = 0.; cl5[n][g.id] = 0.; } }
+        if (g.physics) {
+            const Local L = local_terms(a, g.i, a.t[g.id], a.t[g.q], v[0], v[2]);
+            if (L.nuc_def) { def |= 1; nuc = L.nuc_val; }
+            if (L.dep_def) { def |= 2; dep = L.dep_val; }
+        }
+    }
+    s_def[(g.i) * COLS + tx] = def; s_nuc[(g.i) * COLS + tx] = nuc; s_dep[(g.i) * COLS + tx] = dep;
+    __syncthreads();
+    if (g.i == 0 && g.valid) {  // the lowest assigning level is the one visited last
+        uint8_t od = 0; double on = 0., odp = 0.;
+        for (int i = a.im - 2; i >= 0; i--) {
+            const uint8_t d = s_def[(i) * COLS + tx];
+            if (d & 1) { od |= 1; on = s_nuc[(i) * COLS + tx]; }
+            if (d & 2) { od |= 2; odp = s_dep[(i) * COLS + tx]; }
+        }
+        a.out_def[g.rank] = od; a.out_nuc[g.rank] = on; a.out_dep[g.rank] = odp;
+    }
+}
+
+// step 3 of 3: the preparatory pass and the five full passes, all levels of COLS columns at once
+__global__ __launch_bounds__(1024) void k_ice_points_passes(IceArgs a) {
+    extern __shared__ double lds[];  // [5][im][COLS] doubles, then [im][COLS] bytes
+    const int plane = a.im * COLS;
+    double *s_r = lds, *s_s = lds + plane, *s_rh = lds + 2 * plane, *s_pr = lds + 3 * plane, *s_ps = lds + 4 * plane;
+    double *s_nuc = s_pr, *s_dep = s_ps;  // the assignments are only needed before the first integration
+    uint8_t* s_def = (uint8_t*)(lds + 5 * plane);
+    const PointGeom g = point_geom(a);
+    const int tx = threadIdx.x, i = g.i, im = a.im;
+    const size_t n2 = (size_t)a.jm * a.km;
+    const double t_0 = a.t_0, dr = a.dr;
+    // what the point fixes for all passes
+    double cc = 0., cl = 0., ic = 0., scc = 0.;
+    Local L = {};
+    bool land_rule = false;
+    if (g.physics) {
+        cc = a.c[g.id]; cl = a.cloud[g.id]; ic = a.ice[g.id]; scc = a.s_c_c[g.id];
+        L = local_terms(a, i, a.t[g.id], a.t[g.q], cc, ic);
+        land_rule = (a.flags[g.id] & FL_LAND) && (a.flags[g.id + n2] & FL_LAND);
+    }
+    s_def[(i) * COLS + tx] = (uint8_t)((L.nuc_def ? 1 : 0) | (L.dep_def ? 2 : 0));
+    s_nuc[(i) * COLS + tx] = L.nuc_val; s_dep[(i) * COLS + tx] = L.dep_val;
+    s_rh[(i) * COLS + tx] = L.r_humid;
+    __syncthreads();
+    // the members as this point finds them: its own assignment, else the nearest one above it in the column, else
+    // what the column inherits, else (first pass) the caller's value or (later) the grid's last assignment
+    double S_nuc_first = 0., S_nuc_later = 0., S_i_dep = 0.;
+    if (g.physics) {
+        bool have_n = L.nuc_def, have_d = L.dep_def;
+        double vn = L.nuc_val, vd = L.dep_val;
+        for (int l = i + 1; l <= im - 2 && !(have_n && have_d); l++) {
+            const uint8_t d = s_def[(l) * COLS + tx];
+            if (!have_n && (d & 1)) { have_n = true; vn = s_nuc[(l) * COLS + tx]; }
+            if (!have_d && (d & 2)) { have_d = true; vd = s_dep[(l) * COLS + tx]; }
+        }
+        const Inherited inh = inherited(a, g.rank, have_n, vn, have_d, vd);
+        S_nuc_first = inh.nuc_first; S_nuc_later = inh.nuc_later; S_i_dep = inh.dep;
+    }
+    // sources that no pass changes
+    const double t_u = L.t_u;
+    double S_c_frz = 0., S_c_au = 0., S_i_au = 0., S_d_au = 0., S_i_melt = 0., melt = 0., frz = 0.;
+    double sr = 0., ss = 0.;
+    if (g.physics) {
+        S_c_frz = ((t_u < t_hn) && (cl > 0.)) ? cl / dt_rain_dim : 0.;
+        S_c_au = ((t_u >= t_0) && (cl > 0.)) ? c_c_au * cl : 0.;
+        S_i_au = ((t_u <= t_0) && (ic > 0.)) ? c_i_au * ic : 0.;
+        S_d_au = (t_u <= t_0) ? S_i_dep / (1.5 * (pow((m_s_0 / L.m_i), (2. / 3.)) - 1.)) : 0.;
+        S_i_melt = ((t_u > t_0) && (ic > 0.)) ? ic / dt_snow_dim : 0.;
+        if (t_u > t_0) {  // the bracket of S_s_melt, :3087-3096
+            const double exp_pressure = a.g / (1.e-2 * a.gam * a.R_Air);
+            const double p_SL = .01 * (a.r_air * a.R_Air * a.t[g.q] * t_0);
+            const double hight = (double)i * (a.L_atm / (double)(im - 1));
+            const double p_t_in = pow(((t_0 - a.gam * hight * 1.e-2) / t_0), exp_pressure) * p_SL;
+            const double E_Rain_t_in = a.hp * exp_func(t_0, 17.2694, 35.86);
+            const double q_Rain_t_in = a.ep * E_Rain_t_in / (p_t_in - E_Rain_t_in);
+            melt = ((t_u - t_0) + a_s_melt * (cc - q_Rain_t_in));
+        }
+        if (t_r_frz - t_u > 0.) frz = pow((t_r_frz - t_u), (3. / 2.));
+        // preparatory pass, :2875-2954
+        sr = ((t_u >= t_0) && (c_c_au * cl > 0.)) ? c_c_au * cl : 0.;
+        ss = ((t_u < t_0) && (c_i_au * ic > 0.)) ? c_i_au * ic : 0.;
+        if (land_rule) { sr = 0.; ss = 0.; }
+    }
+    double sv = 0., sc = 0., si = 0.;
+    for (int pass = 0; pass <= 5; pass++) {
+        if (pass > 0 && g.physics) {
+            const double pr0 = s_pr[(i) * COLS + tx], ps0 = s_ps[(i) * COLS + tx];
+            const double S_nuc = pass == 1 ? S_nuc_first : S_nuc_later;
+            const double S_ac = (t_u > t_0) ? c_ac * cl * pow(pr0, (7. / 9.)) : 0.;
+            const double S_rim = (t_u < t_0) ? c_rim * cl * ps0 : 0.;
+            const double S_shed = (t_u >= t_0) ? c_rim * cl * ps0 : 0.;
+            double S_agg = 0., S_i_cri = 0., S_r_cri = 0.;
+            if (t_u <= t_0) {
+                S_agg = c_agg * ic * ps0;
+                S_i_cri = c_i_cri * ic * pow(pr0, (7. / 9.));
+                S_r_cri = c_r_cri * ic / L.m_i * pow(pr0, (13. / 9.));
+            }
+            const double S_ev = (t_u >= t_0) ? a_ev * (1. + b_ev * pow(pr0, (1. / 6.))) * (L.q_Rain - cc) * pow(pr0, (4. / 9.)) : 0.;
+            const double S_s_dep = (t_u < t_0) ? c_s_dep * (1. + b_s_dep * pow(ps0, (5. / 26.))) * (cc - L.q_Ice) * pow(ps0, (8. / 13.)) : 0.;
+            const double S_s_melt = (t_u > t_0) ? c_s_melt * (1. + b_s_melt * pow(ps0, (5. / 26.))) * melt * pow(ps0, (8. / 13.)) : 0.;
+            const double S_r_frz = (t_r_frz - t_u > 0.) ? c_r_frz * frz * pow(pr0, (3. / 2.)) : 0.;
+            sv = -scc + S_ev - S_i_dep - S_s_dep - S_nuc;
+            sc = scc - S_c_au - S_ac - S_c_frz + S_i_melt - S_rim - S_shed;
+            si = S_nuc + S_c_frz + S_i_dep - S_i_melt - S_i_au - S_d_au - S_agg - S_i_cri;
+            sr = S_c_au + S_ac - S_ev + S_shed - S_r_cri - S_r_frz + S_s_melt;
+            ss = S_d_au + S_s_dep + S_i_au + S_rim + S_agg + S_i_cri + S_r_cri + S_r_frz - S_s_melt;
+            if (land_rule) { scc = 0.; sv = 0.; sc = 0.; si = 0.; sr = 0.; ss = 0.; }
+        }
+        s_r[(i) * COLS + tx] = sr; s_s[(i) * COLS + tx] = ss;  // the top level keeps its zeros (:2878-2881)
+        __syncthreads();
+        if (i < 2) {  // level 0's thread integrates rain, level 1's snow (:2946-2953, :3118-3125)
+            const double* src = i == 0 ? s_r : s_s;
+            double* dst = i == 0 ? s_pr : s_ps;
+            double p_above = 0.;
+            dst[(im - 1) * COLS + tx] = 0.;
+            for (int l = im - 2; l >= 0; l--) {
+                p_above = at_least_zero(p_above + (src[(l) * COLS + tx] + src[(l + 1) * COLS + tx]) * .5 * s_rh[(l) * COLS + tx] * dr * 200.);
+                dst[(l) * COLS + tx] = p_above;
+            }
+        }
+        __syncthreads();
+    }
+    if (!g.valid) return;
+    a.p_rain[g.id] = s_pr[(i) * COLS + tx]; a.p_snow[g.id] = s_ps[(i) * COLS + tx];
+    a.s_r[g.id] = sr; a.s_s[g.id] = ss;
+    if (g.physics) {
+        a.s_v[g.id] = sv; a.s_c[g.id] = sc; a.s_i[g.id] = si;
+        if (land_rule) a.s_c_c[g.id] = 0.;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // BC_Thermo::Ice_Water_Saturation_Adjustment (atmosphere/BC_Thermo.cpp:2509-2796)
 //
@@ -259,7 +461,10 @@ struct AdjArgs {
     double t_0, g, gam, R_Air, r_air, R_WaterVapour, L_atm, hp, ep, lv, ls, cp_l, dt_dim;
     double* out;      // per column rank: q_v_hyp after the column
     uint8_t* kind;    // per column rank: 0 no cold point, 1 out[] valid, 2 depends on the columns before it
-    double* last;     // q_v_hyp after the whole grid
+    double* last;     // [0] q_v_hyp after the whole grid, [1] != 0: columns were left for the serial kernel
+    double* chunk_out;   // per chunk of CHUNK ranks: out[] of its last column with a cold point
+    uint8_t* chunk_kind; // per chunk: bit 0 chunk_out valid, bit 1 a column of the chunk was left for the serial kernel
+    int nchunks;
     double state;     // q_v_hyp as the call found it
 };
 
@@ -406,7 +611,39 @@ __global__ void k_adj_columns(AdjArgs a) {
     a.out[rank] = out;
 }
 
-// one workgroup; each thread owns a run of consecutive columns and takes its turn in visiting order
+// No column left over (the usual case): the member ends as the last column with a cold point left it - the
+// highest such rank, found per chunk by a workgroup each and over the chunks by one thread.
+__global__ __launch_bounds__(CHUNK) void k_adj_chunk_last(AdjArgs a) {
+    __shared__ int s_last[CHUNK / 64];
+    const size_t n2 = (size_t)a.jm * a.km;
+    const int t = threadIdx.x;
+    const size_t r = (size_t)blockIdx.x * CHUNK + t;
+    const uint8_t kind = r < n2 ? a.kind[r] : 0;
+    const int left_over = __syncthreads_or(kind == 2);
+    const unsigned long long m = __ballot(kind == 1);  // highest lane of the wave whose column has a cold point
+    if ((t & 63) == 0) s_last[t >> 6] = m ? (t | (63 - __builtin_clzll(m))) : -1;
+    __syncthreads();
+    if (t == 0) {
+        int last = -1;
+        for (int w = 0; w < CHUNK / 64; w++) if (s_last[w] >= 0) last = s_last[w];
+        a.chunk_kind[blockIdx.x] = (uint8_t)((last >= 0 ? 1 : 0) | (left_over ? 2 : 0));
+        a.chunk_out[blockIdx.x] = last >= 0 ? a.out[(size_t)blockIdx.x * CHUNK + last] : 0.;
+    }
+}
+
+__global__ void k_adj_finish(AdjArgs a) {
+    if (blockIdx.x || threadIdx.x) return;
+    double v = a.state; bool left_over = false;
+    for (int c = 0; c < a.nchunks; c++) {
+        const uint8_t kd = a.chunk_kind[c];
+        if (kd & 1) v = a.chunk_out[c];
+        if (kd & 2) left_over = true;
+    }
+    a.last[0] = v; a.last[1] = left_over ? 1. : 0.;
+}
+
+// columns were left over: one workgroup; each thread owns a run of consecutive columns and takes its turn in
+// visiting order
 __global__ __launch_bounds__(1024) void k_adj_inherit(AdjArgs a) {
     __shared__ double carry;
     const size_t n2 = (size_t)a.jm * a.km;
@@ -465,11 +702,24 @@ extern "C" int atomdev_atm_two_category_ice_scheme(atomdev_t* h, double state[2]
     a.out_nuc = s; a.out_dep = s + n2; a.in_nuc = s + 2 * n2; a.in_dep = s + 3 * n2;
     a.out_def = (uint8_t*)(s + 4 * n2); a.in_def = a.out_def + n2;
     a.last = s + 6 * n2;
+    a.nchunks = (int)((n2 + CHUNK - 1) / CHUNK);
+    a.chunk_nuc = a.last + 8; a.chunk_dep = a.chunk_nuc + a.nchunks; a.chunk_def = (uint8_t*)(a.chunk_dep + a.nchunks);
+    ATOMDEV_REQUIRE(6 * n2 + 8 + 3 * (size_t)a.nchunks <= h->n3, "atomdev_atm_two_category_ice_scheme: grid too small for the scratch layout");
     a.state_nuc = state[0]; a.state_dep = state[1];
-    const unsigned nb = (unsigned)((n2 + TPB - 1) / TPB);
-    hipLaunchKernelGGL(k_ice_column_summary, dim3(nb), dim3(TPB), 0, h->stream, a);
-    hipLaunchKernelGGL(k_ice_inherit, dim3(1), dim3(1024), 0, h->stream, a);
-    hipLaunchKernelGGL(k_ice_column_passes, dim3(nb), dim3(TPB), 0, h->stream, a);
+    if (h->im <= MAX_LEVELS && h->im >= 2) {
+        const unsigned nb = (unsigned)((n2 + COLS - 1) / COLS);
+        const size_t plane = (size_t)h->im * COLS;
+        hipLaunchKernelGGL(k_ice_points_summary, dim3(nb), dim3(COLS, h->im), 2 * plane * sizeof(double) + plane, h->stream, a);
+        hipLaunchKernelGGL(k_ice_chunk_scan, dim3(a.nchunks), dim3(CHUNK), 0, h->stream, a);
+        hipLaunchKernelGGL(k_ice_chunk_carry, dim3(1), dim3(64), 0, h->stream, a);
+        hipLaunchKernelGGL(k_ice_points_passes, dim3(nb), dim3(COLS, h->im), 5 * plane * sizeof(double) + plane, h->stream, a);
+    } else {
+        const unsigned nb = (unsigned)((n2 + TPB - 1) / TPB);
+        hipLaunchKernelGGL(k_ice_column_summary, dim3(nb), dim3(TPB), 0, h->stream, a);
+        hipLaunchKernelGGL(k_ice_chunk_scan, dim3(a.nchunks), dim3(CHUNK), 0, h->stream, a);
+        hipLaunchKernelGGL(k_ice_chunk_carry, dim3(1), dim3(64), 0, h->stream, a);
+        hipLaunchKernelGGL(k_ice_column_passes, dim3(nb), dim3(TPB), 0, h->stream, a);
+    }
     ATOMDEV_TRY(hipGetLastError());
     double last[4];
     ATOMDEV_TRY(hipMemcpyAsync(last, a.last, sizeof(last), hipMemcpyDeviceToHost, h->stream));
@@ -496,12 +746,24 @@ extern "C" int atomdev_atm_ice_water_saturation_adjustment(atomdev_t* h, double*
     const size_t n2 = h->n2;
     double* s = h->scr[0];
     a.out = s; a.kind = (uint8_t*)(s + n2); a.last = s + 2 * n2;
+    a.nchunks = (int)((n2 + CHUNK - 1) / CHUNK);
+    a.chunk_out = a.last + 2; a.chunk_kind = (uint8_t*)(a.chunk_out + a.nchunks);
+    ATOMDEV_REQUIRE(2 * n2 + 2 + 2 * (size_t)a.nchunks <= h->n3, "atomdev_atm_ice_water_saturation_adjustment: grid too small for the scratch layout");
     a.state = *q_v_hyp;
     const unsigned nb = (unsigned)((n2 + TPB - 1) / TPB);
     hipLaunchKernelGGL(k_adj_columns, dim3(nb), dim3(TPB), 0, h->stream, a);
-    hipLaunchKernelGGL(k_adj_inherit, dim3(1), dim3(1024), 0, h->stream, a);
+    hipLaunchKernelGGL(k_adj_chunk_last, dim3(a.nchunks), dim3(CHUNK), 0, h->stream, a);
+    hipLaunchKernelGGL(k_adj_finish, dim3(1), dim3(64), 0, h->stream, a);
     ATOMDEV_TRY(hipGetLastError());
-    ATOMDEV_TRY(hipMemcpyAsync(q_v_hyp, a.last, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    double last[2];
+    ATOMDEV_TRY(hipMemcpyAsync(last, a.last, sizeof(last), hipMemcpyDeviceToHost, h->stream));
     ATOMDEV_TRY(hipStreamSynchronize(h->stream));
+    if (last[1] != 0.) {  // rare: columns whose first cold point inherits q_v_hyp, done in visiting order
+        hipLaunchKernelGGL(k_adj_inherit, dim3(1), dim3(1024), 0, h->stream, a);
+        ATOMDEV_TRY(hipGetLastError());
+        ATOMDEV_TRY(hipMemcpyAsync(last, a.last, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        ATOMDEV_TRY(hipStreamSynchronize(h->stream));
+    }
+    *q_v_hyp = last[0];
     return 0;
 }

@@ -339,7 +339,8 @@ def test_atm_radiation_multi_layer(dims, seed, trop):
     d.close()
 
 
-@pytest.mark.parametrize("dims,seed,first", [((41, 19, 23), 62, "warm"), ((12, 13, 17), 63, "icy"), ((9, 21, 70), 64, "warm")])
+@pytest.mark.parametrize("dims,seed,first", [((41, 19, 23), 62, "warm"), ((12, 13, 17), 63, "icy"), ((9, 21, 70), 64, "warm"),
+                                             ((41, 37, 45), 68, "icy"), ((70, 7, 9), 69, "warm")])   # 70 levels: the column kernels
 def test_atm_two_category_ice_scheme(dims, seed, first):
     """BC_Thermo::Two_Category_Ice_Scheme against the oracle's restatement in the reference's serial visiting
     order (exp() and pow() on both sides, 1e-10 per field), PARITY UNPINNED against the reference itself

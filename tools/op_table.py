@@ -22,10 +22,17 @@ BYTES = {
     "move3d(atm)": n3 * 16 * 9, "move3d(hyd)": n3 * 16 * 6,
     "hyd_pressure_density": n3 * 40,
     "atm_msl_data": n3 * (7 * 8 + 1),  # second walk: c, cloud, ice, P_rain, P_snow, p_stat, t + the mask byte
+    # column physics: every field the function reads plus every field it writes, once (the reference's own
+    # passes re-read them: five passes in the ice scheme, up to 20 iterations per point in the adjustment)
+    "atm_latent_heat": n3 * (5 * 8 + 1 + 2 * 8),
+    "atm_radiation_multi_layer": n3 * (6 * 8 + 1 + 6 * 8),
+    "atm_ice_water_saturation_adjustment": n3 * (5 * 8 + 1 + 8 * 8),
+    "atm_two_category_ice_scheme": n3 * (7 * 8 + 1 + 11 * 8),
 }
+only_physics = len(sys.argv) > 2 and sys.argv[2] == "physics"
 print("| operator | ms per call | algorithmic GB/s | % of 8 TB/s |")
 print("|---|---|---|---|")
-for model, pre in ((H.ATM, "atm"), (H.HYD, "hyd")):
+for model, pre in (() if only_physics else ((H.ATM, "atm"), (H.HYD, "hyd"))):
     p = H.default_params(model, im, jm, km)
     f, g = H.make_inputs(model, im, jm, km, 1234, "allfluid", p)
     names = H.ATM_FIELDS if model == H.ATM else H.HYD_FIELDS
@@ -64,3 +71,35 @@ for model, pre in ((H.ATM, "atm"), (H.HYD, "hyd")):
         else:
             print("| %s | %.4f | | |" % (name, ms))
     d.close()
+
+# the BC_Thermo column physics, on a state it keeps bounded (tests/test_loops.py); the state is restored before
+# every call because the iteration counts of the adjustment depend on it
+import numpy as np  # noqa: E402
+import test_loops as TL  # noqa: E402
+p, f, g, i_trop = TL.physics_loop_inputs(im, jm, km, 75)
+i_trop[:] = 30
+d = atom_amd.DeviceModel(H.ATM, im, jm, km, atom_amd.Params.from_buffer_copy(bytes(p)))
+d.upload_all(f, g)
+state = ("T", "C", "CLOUD", "ICE", "CN", "CLOUDN", "ICEN", "P_RAIN", "P_SNOW", "S_C_C")
+calls = {
+    "atm_latent_heat": lambda: d.op("atm_latent_heat"),
+    "atm_radiation_multi_layer": lambda: d.radiation_multi_layer(i_trop),
+    "atm_vegetation_distribution": lambda: d.vegetation_distribution(0.8),
+    "atm_ice_water_saturation_adjustment": lambda: d.ice_water_saturation_adjustment(0.0),
+    "atm_two_category_ice_scheme": lambda: d.two_category_ice_scheme((0.0, 0.0)),
+}
+for name, call in calls.items():
+    ms = []
+    for rep in range(min(reps, 5) + 1):
+        for k in state:
+            d.upload(k, f[k])
+        d.timer_start()
+        call()
+        ms.append(d.timer_stop())
+    ms = float(np.mean(ms[1:]))
+    b = BYTES.get(name)
+    if b:
+        print("| %s | %.4f | %.0f | %.1f |" % (name, ms, b / ms / 1e6, b / ms / 1e6 / 80.0))
+    else:
+        print("| %s | %.4f | | |" % (name, ms))
+d.close()
