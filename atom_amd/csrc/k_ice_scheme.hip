@@ -496,104 +496,116 @@ __device__ int adj_column_kind(const AdjArgs& a, size_t q) {
     return 0;
 }
 
-// one column, bottom to top; returns q_v_hyp as the column leaves it
-__device__ double adj_column(const AdjArgs& a, size_t q, double q_v_hyp) {
-    const size_t n2 = (size_t)a.jm * a.km;
+// What one grid point makes of its input.  branch: 0 neither (t is not a number), 1 warm, 2 cold.
+struct AdjOut { double c, cloud, ice, t, q_v_hyp; int branch; };
+
+__device__ AdjOut adj_point(const AdjArgs& a, int i, double t_in, double t_ground, double cc, double cl, double ic,
+                            double q_v_hyp) {
     const double t_0 = a.t_0, lv = a.lv, ls = a.ls, cp_l = a.cp_l;
     const double t_Celsius_2 = t_00 - t_0;
     const double exp_pressure = a.g / (1.e-2 * a.gam * a.R_Air);
+    AdjOut o;
+    const double t_u = t_in * t_0;
+    const double t_Celsius = t_u - t_0;
+    const double p_SL = .01 * (a.r_air * a.R_Air * t_ground * t_0);
+    const double hight = (double)i * (a.L_atm / (double)(a.im - 1));
+    double p_h;
+    if (i != 0) p_h = pow(((t_in * t_0 - a.gam * hight * 1.e-2) / (t_in * t_0)), exp_pressure) * p_SL;
+    else p_h = p_SL;
+    if (t_Celsius >= 0.) {  // warm cloud phase, :2566-2629
+        double q_T = cc + cl;
+        double E_Rain = a.hp * exp_func(t_u, 17.2694, 35.86);
+        double q_Rain = a.ep * E_Rain / (p_h - E_Rain);
+        double q_Rain_n = q_Rain, T_it = t_u;
+        if (q_T <= q_Rain) {
+            cc = q_T; cl = 0.; ic = 0.;
+        } else {
+            for (int iter_prec = 1; iter_prec <= 20; iter_prec++) {
+                T_it = (t_u + lv / cp_l * cc - lv / cp_l * q_Rain);
+                E_Rain = a.hp * exp_func(T_it, 17.2694, 35.86);
+                q_Rain = a.ep * E_Rain / (p_h - E_Rain);
+                q_Rain = .5 * (q_Rain_n + q_Rain);
+                cc = q_Rain;
+                cl = q_T - cc;
+                ic = 0.;
+                q_T = cc + cl;
+                if (cc < 0.) cc = 0.;
+                if (cl < 0.) cl = 0.;
+                if ((q_Rain_n) > 2.220446049250313e-16 && fabs(q_Rain / q_Rain_n - 1.) <= 1.e-5) break;
+                q_Rain_n = q_Rain;
+            }
+        }
+        o.t = T_it / t_0; o.branch = 1;
+    } else if (t_Celsius < 0.) {  // mixed cloud phase, :2637-2765
+        if (t_Celsius < t_Celsius_2) cl = 0.;
+        double q_v_b = cc, q_c_b = cl, q_i_b = ic;
+        double T = t_u;
+        double E_Rain = a.hp * exp_func(T, 17.2694, 35.86);
+        double E_Ice = a.hp * exp_func(T, 21.8746, 7.66);
+        double q_Rain = a.ep * E_Rain / (p_h - E_Rain);
+        double q_Ice = a.ep * E_Ice / (p_h - E_Ice);
+        q_v_hyp = hyp_value(q_c_b, q_i_b, q_Rain, q_Ice, q_v_hyp);
+        for (int iter_prec = 1; iter_prec <= 20; iter_prec++) {
+            double CND = (T - t_00) / (t_0 - t_00);
+            if (T < t_00) CND = 0.;
+            double DEP = (t_0 - T) / (t_0 - t_00);
+            if (T > t_0) DEP = 0.;
+            const double d_q_v = q_v_hyp - q_v_b;
+            const double d_q_c = -d_q_v * CND;
+            const double d_q_i = -d_q_v * DEP;
+            const double d_t = (lv * d_q_c + ls * d_q_i) / cp_l;
+            T = T + d_t;
+            q_v_b = cc + d_q_v;
+            q_c_b = cl + d_q_c;
+            q_i_b = ic + d_q_i;
+            if (q_v_b < 0.) q_v_b = 0.;
+            if (q_c_b < 0.) q_c_b = 0.;
+            if (q_i_b < 0.) q_i_b = 0.;
+            if (i != 0) {
+                if (T > a.gam * hight * 1.e-2) p_h = pow(((T - a.gam * hight * 1.e-2) / (T)), exp_pressure) * p_SL;
+                else p_h = p_SL;  // the reference logs a warning here
+            } else p_h = p_SL;
+            E_Rain = a.hp * exp_func(T, 17.2694, 35.86);
+            E_Ice = a.hp * exp_func(T, 21.8746, 7.66);
+            q_Rain = a.ep * E_Rain / (p_h - E_Rain);
+            q_Ice = a.ep * E_Ice / (p_h - E_Ice);
+            q_v_hyp = hyp_value(q_c_b, q_i_b, q_Rain, q_Ice, q_v_hyp);
+            if (iter_prec >= 3 && (q_v_hyp) > 2.220446049250313e-16 && fabs(q_v_b / q_v_hyp - 1.) <= 1.e-5) break;
+            q_v_b = .5 * (q_v_hyp + q_v_b);
+        }
+        cc = q_v_b; cl = q_c_b; ic = q_i_b;
+        if (t_Celsius < t_Celsius_2) cl = 0.;
+        o.t = T / t_0; o.branch = 2;
+    } else {
+        o.t = t_in; o.branch = 0;
+    }
+    o.c = cc; o.cloud = cl; o.ice = ic; o.q_v_hyp = q_v_hyp;
+    return o;
+}
+
+// a point's results into the fields; c_in: the point's water vapour as it came in
+__device__ __forceinline__ void adj_store(const AdjArgs& a, size_t id, const AdjOut& o, double c_in) {
+    if (o.branch) {
+        // S_c_c from the point's incoming cn and c (:2732; both are overwritten only after the iteration)
+        if (o.branch == 2) a.s_c_c[id] = (a.flags[id] & FL_LAND) ? 0. : .5 * (a.cn[id] - c_in) / a.dt_dim;
+        a.cn[id] = o.c; a.cloudn[id] = o.cloud; a.icen[id] = o.ice;
+        a.t[id] = o.t;
+    }
+    // the closing clamp of c, cloud and ice (:2770-2778) touches the old-level arrays only
+    a.c[id] = at_least_zero(o.c); a.cloud[id] = at_least_zero(o.cloud); a.ice[id] = at_least_zero(o.ice);
+}
+
+// one column, bottom to top; returns q_v_hyp as the column leaves it
+__device__ double adj_column(const AdjArgs& a, size_t q, double q_v_hyp) {
+    const size_t n2 = (size_t)a.jm * a.km;
     double t_ground = a.t[q];
     for (int i = 0; i < a.im; i++) {
         const size_t id = (size_t)i * n2 + q;
-        const double t_in = a.t[id];
-        double t_u = t_in * t_0;
-        const double t_Celsius = t_u - t_0;
-        double p_SL = .01 * (a.r_air * a.R_Air * t_ground * t_0);
-        const double hight = (double)i * (a.L_atm / (double)(a.im - 1));
-        double p_h;
-        if (i != 0) p_h = pow(((t_in * t_0 - a.gam * hight * 1.e-2) / (t_in * t_0)), exp_pressure) * p_SL;
-        else p_h = p_SL;
-        double cc = a.c[id], cl = a.cloud[id], ic = a.ice[id], t_out;
-        double cn_out, cloudn_out, icen_out;
-        if (t_Celsius >= 0.) {  // warm cloud phase, :2566-2629
-            double q_T = cc + cl;
-            double E_Rain = a.hp * exp_func(t_u, 17.2694, 35.86);
-            double q_Rain = a.ep * E_Rain / (p_h - E_Rain);
-            double q_Rain_n = q_Rain, T_it;
-            if (q_T <= q_Rain) {
-                cc = q_T; cl = 0.; ic = 0.;
-                T_it = t_u;
-            } else {
-                T_it = t_u;
-                for (int iter_prec = 1; iter_prec <= 20; iter_prec++) {
-                    T_it = (t_u + lv / cp_l * cc - lv / cp_l * q_Rain);
-                    E_Rain = a.hp * exp_func(T_it, 17.2694, 35.86);
-                    q_Rain = a.ep * E_Rain / (p_h - E_Rain);
-                    q_Rain = .5 * (q_Rain_n + q_Rain);
-                    cc = q_Rain;
-                    cl = q_T - cc;
-                    ic = 0.;
-                    q_T = cc + cl;
-                    if (cc < 0.) cc = 0.;
-                    if (cl < 0.) cl = 0.;
-                    if ((q_Rain_n) > 2.220446049250313e-16 && fabs(q_Rain / q_Rain_n - 1.) <= 1.e-5) break;
-                    q_Rain_n = q_Rain;
-                }
-            }
-            cn_out = cc; cloudn_out = cl; icen_out = ic;
-            t_out = T_it / t_0;
-        } else if (t_Celsius < 0.) {  // mixed cloud phase, :2637-2765
-            if (t_Celsius < t_Celsius_2) cl = 0.;
-            double q_v_b = cc, q_c_b = cl, q_i_b = ic;
-            double T = t_u;
-            double E_Rain = a.hp * exp_func(T, 17.2694, 35.86);
-            double E_Ice = a.hp * exp_func(T, 21.8746, 7.66);
-            double q_Rain = a.ep * E_Rain / (p_h - E_Rain);
-            double q_Ice = a.ep * E_Ice / (p_h - E_Ice);
-            q_v_hyp = hyp_value(q_c_b, q_i_b, q_Rain, q_Ice, q_v_hyp);
-            for (int iter_prec = 1; iter_prec <= 20; iter_prec++) {
-                double CND = (T - t_00) / (t_0 - t_00);
-                if (T < t_00) CND = 0.;
-                double DEP = (t_0 - T) / (t_0 - t_00);
-                if (T > t_0) DEP = 0.;
-                const double d_q_v = q_v_hyp - q_v_b;
-                const double d_q_c = -d_q_v * CND;
-                const double d_q_i = -d_q_v * DEP;
-                const double d_t = (lv * d_q_c + ls * d_q_i) / cp_l;
-                T = T + d_t;
-                q_v_b = cc + d_q_v;
-                q_c_b = cl + d_q_c;
-                q_i_b = ic + d_q_i;
-                if (q_v_b < 0.) q_v_b = 0.;
-                if (q_c_b < 0.) q_c_b = 0.;
-                if (q_i_b < 0.) q_i_b = 0.;
-                if (i != 0) {
-                    if (T > a.gam * hight * 1.e-2) p_h = pow(((T - a.gam * hight * 1.e-2) / (T)), exp_pressure) * p_SL;
-                    else p_h = p_SL;  // the reference logs a warning here
-                } else p_h = p_SL;
-                E_Rain = a.hp * exp_func(T, 17.2694, 35.86);
-                E_Ice = a.hp * exp_func(T, 21.8746, 7.66);
-                q_Rain = a.ep * E_Rain / (p_h - E_Rain);
-                q_Ice = a.ep * E_Ice / (p_h - E_Ice);
-                q_v_hyp = hyp_value(q_c_b, q_i_b, q_Rain, q_Ice, q_v_hyp);
-                if (iter_prec >= 3 && (q_v_hyp) > 2.220446049250313e-16 && fabs(q_v_b / q_v_hyp - 1.) <= 1.e-5) break;
-                q_v_b = .5 * (q_v_hyp + q_v_b);
-            }
-            // S_c_c from the point's incoming cn and c (:2732; c is overwritten only after the iteration)
-            a.s_c_c[id] = (a.flags[id] & FL_LAND) ? 0. : .5 * (a.cn[id] - cc) / a.dt_dim;
-            cc = q_v_b; cl = q_c_b; ic = q_i_b;
-            if (t_Celsius < t_Celsius_2) cl = 0.;
-            cn_out = cc; cloudn_out = cl; icen_out = ic;
-            t_out = T / t_0;
-        } else {  // t is not a number: neither branch is taken, the closing clamp still is
-            a.c[id] = at_least_zero(cc); a.cloud[id] = at_least_zero(cl); a.ice[id] = at_least_zero(ic);
-            continue;
-        }
-        a.cn[id] = cn_out; a.cloudn[id] = cloudn_out; a.icen[id] = icen_out;
-        // the closing clamp of c, cloud and ice (:2770-2778) touches the old-level arrays only
-        a.c[id] = at_least_zero(cc); a.cloud[id] = at_least_zero(cl); a.ice[id] = at_least_zero(ic);
-        a.t[id] = t_out;
-        if (i == 0) t_ground = t_out;
+        const double c_in = a.c[id];
+        const AdjOut o = adj_point(a, i, a.t[id], t_ground, c_in, a.cloud[id], a.ice[id], q_v_hyp);
+        adj_store(a, id, o, c_in);
+        q_v_hyp = o.q_v_hyp;
+        if (i == 0) t_ground = o.t;  // the levels above see the ground temperature as its own point left it
     }
     return q_v_hyp;
 }
@@ -606,9 +618,88 @@ __global__ void k_adj_columns(AdjArgs a) {
     const size_t rank = (size_t)k * a.jm + j;
     const int kind = adj_column_kind(a, q);
     a.kind[rank] = (uint8_t)kind;
-    if (kind == 2) return;  // left for the scan kernel
+    if (kind == 2) return;  // left for the serial kernel
     const double out = adj_column(a, q, 0.);  // the start value is never read: the first cold point assigns it
     a.out[rank] = out;
+}
+
+// The same with one thread per grid point: COLS neighbouring columns and all their levels per workgroup.  The ground
+// points go first (the levels above need their new t), then every point that assigns q_v_hyp itself, then - in as many
+// rounds as the longest run of them needs - the points that start from what the cold point below them left.
+__global__ __launch_bounds__(1024) void k_adj_points(AdjArgs a) {
+    extern __shared__ double lds[];  // [im][COLS] q_v_hyp as the points leave it, [COLS] ground t, then bytes
+    const int im = a.im, tx = threadIdx.x, i = threadIdx.y;
+    double* s_hyp = lds;
+    double* s_t0 = lds + (size_t)im * COLS;
+    uint8_t* s_flag = (uint8_t*)(s_t0 + COLS);   // [im][COLS]: 1 cold, 2 inherits q_v_hyp, 4 done
+    uint8_t* s_kind = s_flag + (size_t)im * COLS; // [COLS]
+    const size_t n2 = (size_t)a.jm * a.km;
+    size_t q = (size_t)blockIdx.x * COLS + tx;
+    const bool valid = q < n2;
+    if (!valid) q = n2 - 1;
+    const size_t id = (size_t)i * n2 + q;
+    const size_t jj = q / a.km, kk = q - jj * a.km;
+    const size_t rank = kk * a.jm + jj;
+    const double t_in = a.t[id], c_in = a.c[id], cl_in = a.cloud[id], ic_in = a.ice[id];
+    const double t_Celsius = t_in * a.t_0 - a.t_0;
+    const bool cold = t_Celsius < 0.;
+    const bool inherits = cold && !hyp_assigned((t_Celsius < t_00 - a.t_0) ? 0. : cl_in, ic_in);
+    s_flag[i * COLS + tx] = (uint8_t)((cold ? 1 : 0) | (inherits ? 2 : 0));
+    __syncthreads();
+    if (i == 0) {
+        int kind = 0;
+        for (int l = 0; l < im; l++) {
+            const uint8_t f = s_flag[l * COLS + tx];
+            if (f & 1) { kind = (f & 2) ? 2 : 1; break; }
+        }
+        s_kind[tx] = (uint8_t)kind;
+        if (valid) a.kind[rank] = (uint8_t)kind;
+    }
+    __syncthreads();
+    const bool mine = valid && s_kind[tx] != 2;  // columns of kind 2 are left for the serial kernel
+    if (i == 0) {
+        double t0 = t_in;
+        if (mine) {
+            const AdjOut o = adj_point(a, 0, t_in, t_in, c_in, cl_in, ic_in, 0.);
+            adj_store(a, id, o, c_in);
+            s_hyp[tx] = o.q_v_hyp; t0 = o.t;
+            s_flag[tx] |= 4;
+        }
+        s_t0[tx] = t0;
+    }
+    __syncthreads();
+    bool pending = mine && i > 0;
+    if (pending && !inherits) {
+        const AdjOut o = adj_point(a, i, t_in, s_t0[tx], c_in, cl_in, ic_in, 0.);
+        adj_store(a, id, o, c_in);
+        s_hyp[i * COLS + tx] = o.q_v_hyp;
+        pending = false;
+    }
+    __syncthreads();
+    if (!pending && mine && i > 0) s_flag[i * COLS + tx] |= 4;
+    __syncthreads();
+    // every round finishes at least the lowest pending point of every column, so im rounds always suffice
+    for (int round = 0; round < im && __syncthreads_or(pending); round++) {
+        bool ready = false; double hyp_in = 0.;
+        if (pending) {
+            for (int l = i - 1; l >= 0; l--) {
+                const uint8_t f = s_flag[l * COLS + tx];
+                if (f & 1) { ready = (f & 4) != 0; hyp_in = s_hyp[l * COLS + tx]; break; }
+            }
+        }
+        __syncthreads();
+        if (ready) {
+            const AdjOut o = adj_point(a, i, t_in, s_t0[tx], c_in, cl_in, ic_in, hyp_in);
+            adj_store(a, id, o, c_in);
+            s_hyp[i * COLS + tx] = o.q_v_hyp;
+            s_flag[i * COLS + tx] |= 4;
+            pending = false;
+        }
+    }
+    if (i == 0 && mine && s_kind[tx] == 1) {  // the highest cold level is the one visited last
+        for (int l = im - 1; l >= 0; l--)
+            if (s_flag[l * COLS + tx] & 1) { a.out[rank] = s_hyp[l * COLS + tx]; break; }
+    }
 }
 
 // No column left over (the usual case): the member ends as the last column with a cold point left it - the
@@ -750,8 +841,12 @@ extern "C" int atomdev_atm_ice_water_saturation_adjustment(atomdev_t* h, double*
     a.chunk_out = a.last + 2; a.chunk_kind = (uint8_t*)(a.chunk_out + a.nchunks);
     ATOMDEV_REQUIRE(2 * n2 + 2 + 2 * (size_t)a.nchunks <= h->n3, "atomdev_atm_ice_water_saturation_adjustment: grid too small for the scratch layout");
     a.state = *q_v_hyp;
-    const unsigned nb = (unsigned)((n2 + TPB - 1) / TPB);
-    hipLaunchKernelGGL(k_adj_columns, dim3(nb), dim3(TPB), 0, h->stream, a);
+    if (h->im <= MAX_LEVELS) {
+        const size_t lds = ((size_t)h->im * COLS + COLS) * sizeof(double) + (size_t)h->im * COLS + COLS;
+        hipLaunchKernelGGL(k_adj_points, dim3((unsigned)((n2 + COLS - 1) / COLS)), dim3(COLS, h->im), lds, h->stream, a);
+    } else {
+        hipLaunchKernelGGL(k_adj_columns, dim3((unsigned)((n2 + TPB - 1) / TPB)), dim3(TPB), 0, h->stream, a);
+    }
     hipLaunchKernelGGL(k_adj_chunk_last, dim3(a.nchunks), dim3(CHUNK), 0, h->stream, a);
     hipLaunchKernelGGL(k_adj_finish, dim3(1), dim3(64), 0, h->stream, a);
     ATOMDEV_TRY(hipGetLastError());
