@@ -274,12 +274,13 @@ __global__ void k_ice_column_passes(IceArgs a) {
 // ---- the same scheme, one thread per grid point -----------------------------------------------------------
 // Inside a pass only the column integrals of rain and snow run along a column; the sources of a grid point use
 // the integrals of the pass BEFORE (a point reads P_rain(i), P_snow(i) before it overwrites them).  So a workgroup
-// takes COLS neighbouring columns with one thread per level: every thread keeps what its point fixes for all
+// takes COLS (= blockDim.x) neighbouring columns with one thread per level: every thread keeps what its point fixes for all
 // passes (densities, saturation values, the inherited members) in registers, publishes S_r, S_s of the pass in
 // LDS, and 2 x COLS threads integrate rain and snow down their columns between two barriers.  Used while
 // COLS * im threads fit a workgroup; taller grids take the column kernels above.
-constexpr int COLS = 16;
-constexpr int MAX_LEVELS = 1024 / COLS;
+constexpr int MAX_LEVELS = 128;  // at least 8 columns per workgroup
+// columns per workgroup: as many as fit 1024 threads (one workgroup then fills a CU's 16 wave slots at 128 VGPRs)
+inline int cols_per_group(int im) { const int c = 1024 / im; return c > 32 ? 32 : c; }
 
 struct PointGeom {
     size_t q, id, rank;
@@ -290,7 +291,7 @@ struct PointGeom {
 __device__ __forceinline__ PointGeom point_geom(const IceArgs& a) {
     PointGeom g;
     const size_t n2 = (size_t)a.jm * a.km;
-    g.q = (size_t)blockIdx.x * COLS + threadIdx.x;
+    g.q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     g.i = (int)threadIdx.y;
     g.valid = g.q < n2;
     if (!g.valid) g.q = n2 - 1;
@@ -304,6 +305,7 @@ __device__ __forceinline__ PointGeom point_geom(const IceArgs& a) {
 // step 1 of 3: clamps (:2861-2871) and the column's last assignments of S_nuc and S_i_dep
 __global__ __launch_bounds__(1024) void k_ice_points_summary(IceArgs a) {
     extern __shared__ double lds[];  // [2][im][COLS] doubles, then [im][COLS] bytes
+    const int COLS = (int)blockDim.x;
     const int plane = a.im * COLS;
     double *s_nuc = lds, *s_dep = lds + plane;
     uint8_t* s_def = (uint8_t*)(lds + 2 * plane);
@@ -336,6 +338,7 @@ __global__ __launch_bounds__(1024) void k_ice_points_summary(IceArgs a) {
 // step 3 of 3: the preparatory pass and the five full passes, all levels of COLS columns at once
 __global__ __launch_bounds__(1024) void k_ice_points_passes(IceArgs a) {
     extern __shared__ double lds[];  // [5][im][COLS] doubles, then [im][COLS] bytes
+    const int COLS = (int)blockDim.x;
     const int plane = a.im * COLS;
     double *s_r = lds, *s_s = lds + plane, *s_rh = lds + 2 * plane, *s_pr = lds + 3 * plane, *s_ps = lds + 4 * plane;
     double *s_nuc = s_pr, *s_dep = s_ps;  // the assignments are only needed before the first integration
@@ -628,6 +631,7 @@ __global__ void k_adj_columns(AdjArgs a) {
 // rounds as the longest run of them needs - the points that start from what the cold point below them left.
 __global__ __launch_bounds__(1024) void k_adj_points(AdjArgs a) {
     extern __shared__ double lds[];  // [im][COLS] q_v_hyp as the points leave it, [COLS] ground t, then bytes
+    const int COLS = (int)blockDim.x;
     const int im = a.im, tx = threadIdx.x, i = threadIdx.y;
     double* s_hyp = lds;
     double* s_t0 = lds + (size_t)im * COLS;
@@ -798,6 +802,7 @@ extern "C" int atomdev_atm_two_category_ice_scheme(atomdev_t* h, double state[2]
     ATOMDEV_REQUIRE(6 * n2 + 8 + 3 * (size_t)a.nchunks <= h->n3, "atomdev_atm_two_category_ice_scheme: grid too small for the scratch layout");
     a.state_nuc = state[0]; a.state_dep = state[1];
     if (h->im <= MAX_LEVELS && h->im >= 2) {
+        const int COLS = cols_per_group(h->im);
         const unsigned nb = (unsigned)((n2 + COLS - 1) / COLS);
         const size_t plane = (size_t)h->im * COLS;
         hipLaunchKernelGGL(k_ice_points_summary, dim3(nb), dim3(COLS, h->im), 2 * plane * sizeof(double) + plane, h->stream, a);
@@ -842,6 +847,7 @@ extern "C" int atomdev_atm_ice_water_saturation_adjustment(atomdev_t* h, double*
     ATOMDEV_REQUIRE(2 * n2 + 2 + 2 * (size_t)a.nchunks <= h->n3, "atomdev_atm_ice_water_saturation_adjustment: grid too small for the scratch layout");
     a.state = *q_v_hyp;
     if (h->im <= MAX_LEVELS) {
+        const int COLS = cols_per_group(h->im);
         const size_t lds = ((size_t)h->im * COLS + COLS) * sizeof(double) + (size_t)h->im * COLS + COLS;
         hipLaunchKernelGGL(k_adj_points, dim3((unsigned)((n2 + COLS - 1) / COLS)), dim3(COLS, h->im), lds, h->stream, a);
     } else {

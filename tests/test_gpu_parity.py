@@ -340,7 +340,8 @@ def test_atm_radiation_multi_layer(dims, seed, trop):
 
 
 @pytest.mark.parametrize("dims,seed,first", [((41, 19, 23), 62, "warm"), ((12, 13, 17), 63, "icy"), ((9, 21, 70), 64, "warm"),
-                                             ((41, 37, 45), 68, "icy"), ((70, 7, 9), 69, "warm")])   # 70 levels: the column kernels
+                                             ((41, 37, 45), 68, "icy"), ((70, 7, 9), 69, "warm"),
+                                             ((130, 7, 9), 70, "icy")])   # 130 levels: the one-thread-per-column kernels
 def test_atm_two_category_ice_scheme(dims, seed, first):
     """BC_Thermo::Two_Category_Ice_Scheme against the oracle's restatement in the reference's serial visiting
     order (exp() and pow() on both sides, 1e-10 per field), PARITY UNPINNED against the reference itself
@@ -396,7 +397,8 @@ def test_atm_two_category_ice_scheme(dims, seed, first):
     d.close()
 
 
-@pytest.mark.parametrize("dims,seed", [((41, 19, 23), 65), ((12, 13, 17), 66), ((9, 21, 70), 67)])
+@pytest.mark.parametrize("dims,seed", [((41, 19, 23), 65), ((12, 13, 17), 66), ((9, 21, 70), 67),
+                                       ((130, 9, 9), 71)])   # 130 levels: the one-thread-per-column kernel
 def test_atm_ice_water_saturation_adjustment(dims, seed):
     """BC_Thermo::Ice_Water_Saturation_Adjustment against the oracle's restatement in the reference's serial
     visiting order (exp() and pow() inside an iteration with a 1e-5 exit test; 1e-10 per field), PARITY UNPINNED
