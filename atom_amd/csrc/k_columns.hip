@@ -241,6 +241,11 @@ struct RadArgs {
 };
 
 __device__ __forceinline__ double parabola(double x) { return x * x - 2 * x; }  // lib/Utils.h:41-43
+// The reference writes pow(x, 4.) and pow(y, 1. / 4.) (:262, :380, :387 ...).  Two squarings and two square roots
+// stay within 2 units in the last place of those (each step is correctly rounded), far inside the 1e-10 the
+// operator is held to, and cost a hundredth of the general pow().
+__device__ __forceinline__ double pow4(double x) { const double x2 = x * x; return x2 * x2; }
+__device__ __forceinline__ double root4(double y) { return sqrt(sqrt(y)); }
 
 __global__ void k_atm_radiation(RadArgs a) {
     const size_t n2 = (size_t)a.jm * a.km;
@@ -279,7 +284,7 @@ __global__ void k_atm_radiation(RadArgs a) {
         double eps;
         if (i >= i_mount) {
             eps = a.R.co2_coeff * epsilon_eff + .0416 * sqrt(e);
-            AT(radiation_3d, i) = (1. - eps) * sigma * pow(AT(t, i) * t_0, 4.);
+            AT(radiation_3d, i) = (1. - eps) * sigma * pow4(AT(t, i) * t_0);
         } else {
             eps = AT(epsilon_3d, i);
         }
@@ -290,28 +295,28 @@ __global__ void k_atm_radiation(RadArgs a) {
     a.epsilon[q] = eps_trop;
     for (int i = i_mount - 1; i >= 0; i--) { AT(epsilon_3d, i) = AT(epsilon_3d, i_mount); AT(radiation_3d, i) = AT(radiation_3d, i_mount); }
     const double eps_above = AT(epsilon_3d, i_trop);  // read again: a mountain above the tropopause has just overwritten it
-    const double rad_above = (1. - eps_above) * sigma * pow(a.t_tropopause * t_0, 4.);
+    const double rad_above = (1. - eps_above) * sigma * pow4(a.t_tropopause * t_0);
     for (int i = i_trop; i < im; i++) { AT(epsilon_3d, i) = eps_above; AT(t, i) = a.t_tropopause; AT(radiation_3d, i) = rad_above; }
 
     for (int iter_rad = 1; iter_rad <= 4; iter_rad++) {  // :293-399
         const double e_trop = AT(epsilon_3d, i_trop);
-        const double rad_trop = (1. - e_trop) * sigma * pow(AT(t, i_trop) * t_0, 4.);
+        const double rad_trop = (1. - e_trop) * sigma * pow4(AT(t, i_trop) * t_0);
         AT(radiation_3d, i_trop) = rad_trop;
-        const double radiation_back = AT(epsilon_3d, i_mount + 1) * sigma * pow(AT(t, i_mount + 1) * t_0, 4.);
+        const double radiation_back = AT(epsilon_3d, i_mount + 1) * sigma * pow4(AT(t, i_mount + 1) * t_0);
         const double atmospheric_window = .1007 * radiation_surface;
         double rad_surf_diff = radiation_back + radiation_surface - atmospheric_window;
         const double fac_rad = (double)i_mount * .07 + 1.;
         rad_surf_diff = fac_rad * rad_surf_diff;
         // the column's AA: only AA[i - 1] and AA[i] are ever read together (:336, :353, :366)
         double AA_i = rad_surf_diff / AT(radiation_3d, i_trop);
-        AT(radiation_3d, i_mount) = (1. - AT(epsilon_3d, i_mount)) * sigma * pow(AT(t, i_mount) * t_0, 4.) / AT(radiation_3d, i_trop);
+        AT(radiation_3d, i_mount) = (1. - AT(epsilon_3d, i_mount)) * sigma * pow4(AT(t, i_mount) * t_0) / AT(radiation_3d, i_trop);
         // AA[i] for i_mount < i <= i_trop goes to the beta scratch until the Thomas loop has used it
         AT(beta, i_mount) = AA_i;
         for (int i = i_mount + 1; i <= i_trop; i++) {
             const double eps = AT(epsilon_3d, i);
             AA_i = AA_i * (1. - eps);
             AT(beta, i) = AA_i;
-            const double tmp = sigma * pow(AT(t, i) * t_0, 4.) / AT(radiation_3d, i_trop);
+            const double tmp = sigma * pow4(AT(t, i) * t_0) / AT(radiation_3d, i_trop);
             AT(radiation_3d, i) = (1. - eps) * tmp;
         }
         const double CCC = 0., DDD = 0.;
@@ -332,17 +337,148 @@ __global__ void k_atm_radiation(RadArgs a) {
             alfa_prev = al; beta_prev = be; AA_prev = AA_cur;
         }
         AT(t, i_trop) = a.t_tropopause;
-        double rad_next = (1. - AT(epsilon_3d, i_trop)) * sigma * pow(a.t_tropopause * t_0, 4.);
+        double rad_next = (1. - AT(epsilon_3d, i_trop)) * sigma * pow4(a.t_tropopause * t_0);
         AT(radiation_3d, i_trop) = rad_next;
         for (int i = i_trop - 1; i >= i_mount; i--) {
             const double rad = -AT(alfa, i) * rad_next + AT(beta, i);
             AT(radiation_3d, i) = rad;
-            AT(t, i) = .5 * (AT(t, i) + pow(rad / sigma, (1. / 4.)) / t_0);
+            AT(t, i) = .5 * (AT(t, i) + root4(rad / sigma) / t_0);
             rad_next = rad;
         }
-        const double rad_top = (1. - AT(epsilon_3d, i_trop)) * sigma * pow(a.t_tropopause * t_0, 4.);
+        const double rad_top = (1. - AT(epsilon_3d, i_trop)) * sigma * pow4(a.t_tropopause * t_0);
         for (int i = i_trop; i < im; i++) { AT(t, i) = a.t_tropopause; AT(radiation_3d, i) = rad_top; }
     }
+#undef AT
+}
+
+// The same function with the levels of a column spread over threads: a workgroup takes blockDim.x neighbouring
+// columns, blockDim.y threads share a column's levels, and the column's t, epsilon_3D, radiation_3D, alfa and beta
+// live in LDS.  What costs time - pow() at every level, twice per round - runs on all threads; the recurrences
+// along the column (AA, the Thomas sweep and its back-substitution: a few multiplications and divisions per level)
+// are done by the column's first thread between two barriers.
+__global__ __launch_bounds__(1024) void k_atm_radiation_levels(RadArgs a) {
+    extern __shared__ double lds[];  // [5][im][COLS] doubles, [COLS] ints, [im][COLS] bytes
+    const int COLS = (int)blockDim.x, LT = (int)blockDim.y, tx = threadIdx.x, ty = threadIdx.y;
+    const int im = a.im;
+    const int plane = im * COLS;
+    double *s_t = lds, *s_eps = lds + plane, *s_rad = lds + 2 * plane, *s_al = lds + 3 * plane, *s_be = lds + 4 * plane;
+    int* s_mount = (int*)(lds + 5 * plane);
+    uint8_t* s_land = (uint8_t*)(s_mount + COLS);
+    const size_t n2 = (size_t)a.jm * a.km;
+    size_t q = (size_t)blockIdx.x * COLS + tx;
+    const bool valid = q < n2;
+    if (!valid) q = n2 - 1;
+    const int j = (int)(q / a.km);
+    const double sigma = a.R.sigma, t_0 = a.t_0;
+    const double j_max_half = (a.jm - 1) / 2;
+    const double par_j = parabola(j / j_max_half);
+    const int i_trop = a.i_trop[j];
+    const double epsilon_eff_max = (a.R.epsilon_pole - a.R.epsilon_equator) * par_j + a.R.epsilon_pole;
+    const double radiation_surface = (a.R.rad_pole - a.R.rad_equator) * par_j + a.R.rad_pole;
+#define AT(F, i) a.F[(size_t)(i) * n2 + q]
+#define S(P, i) P[(i) * COLS + tx]
+    for (int i = ty; i < im; i += LT) S(s_land, i) = (AT(flags, i) & FL_LAND) ? 1 : 0;
+    __syncthreads();
+    if (ty == 0) {  // albedo where the column has a sea or a land surface (:210-218); i_topography (:128-139)
+        bool surface = !S(s_land, 0);
+        int i_mount = 0;
+        for (int i = 0; i < im - 1; i++) {
+            if (S(s_land, i) && !S(s_land, i + 1)) surface = true;
+            if (S(s_land, i)) i_mount = i;
+        }
+        s_mount[tx] = i_mount;
+        if (valid) {
+            if (surface) a.albedo[q] = (a.R.albedo_pole - a.R.albedo_equator) * par_j + a.R.albedo_pole;
+            a.radiation_surface[q] = radiation_surface;
+        }
+    }
+    __syncthreads();
+    const int i_mount = s_mount[tx];
+    for (int i = ty; i < im; i += LT) {  // :238-266
+        double eps = AT(epsilon_3d, i), rad = AT(radiation_3d, i);
+        const double t = AT(t, i);
+        if (i <= i_trop) {
+            double cc = AT(c, i), cl = AT(cloud, i), ic = AT(ice, i);
+            if (cc < 0.) { cc = 0.; if (valid) AT(c, i) = 0.; }
+            if (cl < 0.) { cl = 0.; if (valid) AT(cloud, i) = 0.; }
+            if (ic < 0.) { ic = 0.; if (valid) AT(ice, i) = 0.; }
+            const double e = (cc + cl + ic) * AT(p_stat, i) / a.ep;
+            const double epsilon_eff = epsilon_eff_max - (a.R.epsilon_tropopause - epsilon_eff_max) * parabola((double)i / (im - 1));
+            if (i >= i_mount) {
+                eps = a.R.co2_coeff * epsilon_eff + .0416 * sqrt(e);
+                rad = (1. - eps) * sigma * pow4(t * t_0);
+            }
+            if (eps > 1.) eps = 1.;
+        }
+        S(s_t, i) = t; S(s_eps, i) = eps; S(s_rad, i) = rad;
+    }
+    __syncthreads();
+    if (ty == 0 && valid) a.epsilon[q] = S(s_eps, i_trop);
+    const double eps_mount = S(s_eps, i_mount), rad_mount = S(s_rad, i_mount);
+    __syncthreads();
+    for (int i = ty; i < i_mount; i += LT) { S(s_eps, i) = eps_mount; S(s_rad, i) = rad_mount; }
+    __syncthreads();
+    const double eps_above = S(s_eps, i_trop);  // read after the fill: a mountain above the tropopause has just overwritten it
+    const double rad_above = (1. - eps_above) * sigma * pow4(a.t_tropopause * t_0);
+    __syncthreads();
+    for (int i = ty; i < im; i += LT)
+        if (i >= i_trop) { S(s_eps, i) = eps_above; S(s_t, i) = a.t_tropopause; S(s_rad, i) = rad_above; }
+    __syncthreads();
+    for (int iter_rad = 1; iter_rad <= 4; iter_rad++) {  // :293-399
+        // t(i_trop) is t_tropopause and epsilon_3D(i_trop) is eps_above from here on, so radiation_3D(i_trop) as the
+        // round first sets it (:308) is rad_above, operation for operation
+        const double rad_trop = rad_above;
+        for (int i = ty; i < im; i += LT) {
+            const double eps = S(s_eps, i), t = S(s_t, i);
+            if (i == i_mount) S(s_rad, i) = (1. - eps) * sigma * pow4(t * t_0) / rad_trop;
+            else if (i > i_mount && i <= i_trop) {
+                const double tmp = sigma * pow4(t * t_0) / rad_trop;
+                S(s_rad, i) = (1. - eps) * tmp;
+            } else if (i == i_trop) S(s_rad, i) = rad_trop;
+        }
+        __syncthreads();
+        if (ty == 0) {
+            const double radiation_back = S(s_eps, i_mount + 1) * sigma * pow4(S(s_t, i_mount + 1) * t_0);
+            const double atmospheric_window = .1007 * radiation_surface;
+            double rad_surf_diff = radiation_back + radiation_surface - atmospheric_window;
+            const double fac_rad = (double)i_mount * .07 + 1.;
+            rad_surf_diff = fac_rad * rad_surf_diff;
+            double AA_cur = rad_surf_diff / rad_trop;
+            const double CCC = 0., DDD = 0.;
+            double alfa_prev = 0., beta_prev = 0., AA_prev = 0.;
+            for (int i = i_mount; i < i_trop; i++) {
+                if (i > i_mount) AA_cur = AA_prev * (1. - S(s_eps, i));
+                double al, be;
+                if (i == i_mount) {
+                    const double bb = -S(s_rad, i), cc = S(s_rad, i + 1), dd = -AA_cur;
+                    al = cc / bb; be = dd / bb;
+                } else {
+                    const double aa = S(s_rad, i - 1), bb = -2. * S(s_rad, i), cc = S(s_rad, i + 1);
+                    const double dd = -AA_prev + AA_cur + CCC - DDD;
+                    al = cc / (bb - aa * alfa_prev);
+                    be = (dd - aa * beta_prev) / (bb - aa * alfa_prev);
+                }
+                S(s_al, i) = al; S(s_be, i) = be;
+                alfa_prev = al; beta_prev = be; AA_prev = AA_cur;
+            }
+            double rad_next = rad_above;  // (1 - epsilon_3D(i_trop)) sigma (t_tropopause t_0)^4, :379-380
+            S(s_rad, i_trop) = rad_next;
+            for (int i = i_trop - 1; i >= i_mount; i--) {
+                const double rad = -S(s_al, i) * rad_next + S(s_be, i);
+                S(s_rad, i) = rad;
+                rad_next = rad;
+            }
+        }
+        __syncthreads();
+        for (int i = ty; i < im; i += LT) {
+            if (i >= i_mount && i < i_trop) S(s_t, i) = .5 * (S(s_t, i) + root4(S(s_rad, i) / sigma) / t_0);
+            else if (i >= i_trop) { S(s_t, i) = a.t_tropopause; S(s_rad, i) = rad_above; }
+        }
+        __syncthreads();
+    }
+    if (valid)
+        for (int i = ty; i < im; i += LT) { AT(t, i) = S(s_t, i); AT(epsilon_3d, i) = S(s_eps, i); AT(radiation_3d, i) = S(s_rad, i); }
+#undef S
 #undef AT
 }
 
@@ -383,7 +519,24 @@ extern "C" int atomdev_atm_radiation_multi_layer(atomdev_t* h, const atomdev_rad
     a.flags = h->flags; a.i_trop = (const int*)h->red;
     a.im = h->im; a.jm = h->jm; a.km = h->km;
     a.R = *r; a.t_0 = h->p.t_0; a.ep = h->p.ep; a.t_tropopause = h->p.t_tropopause;
-    hipLaunchKernelGGL(k_atm_radiation, dim3((unsigned)((h->n2 + 127) / 128)), dim3(128), 0, h->stream, a);
+    {
+#if defined(RAD_COLS) && defined(RAD_LT)
+        const int cols = RAD_COLS, lt = h->im < RAD_LT ? h->im : RAD_LT;
+#else
+        // 16 columns and about 11 threads per column: small workgroups, so that several share a CU and one's
+        // recurrences (16 lanes busy) overlap the others' level-parallel phases
+        const int cols = 16, passes = (h->im + 10) / 11, lt = (h->im + passes - 1) / passes;
+#endif
+        const size_t lds = (size_t)5 * h->im * cols * sizeof(double) + cols * sizeof(int) + (size_t)h->im * cols;
+#ifdef ATOMDEV_RAD_COLUMNS
+        if (false)
+#else
+        if (lds <= 64 * 1024)
+#endif
+            hipLaunchKernelGGL(k_atm_radiation_levels, dim3((unsigned)((h->n2 + cols - 1) / cols)), dim3(cols, lt), lds, h->stream, a);
+        else  // very tall grids: one thread per column, work arrays in global memory
+            hipLaunchKernelGGL(k_atm_radiation, dim3((unsigned)((h->n2 + 127) / 128)), dim3(128), 0, h->stream, a);
+    }
     ATOMDEV_TRY(hipGetLastError());
     return 0;
 }

@@ -304,7 +304,8 @@ def test_atm_latent_heat_bitexact(dims, seed):
     d.close()
 
 
-@pytest.mark.parametrize("dims,seed,trop", [((41, 19, 23), 59, 30), ((12, 13, 17), 60, 8), ((9, 21, 70), 61, 3)])
+@pytest.mark.parametrize("dims,seed,trop", [((41, 19, 23), 59, 30), ((12, 13, 17), 60, 8), ((9, 21, 70), 61, 3),
+                                            ((41, 37, 45), 76, 12), ((60, 9, 11), 77, 40)])   # 60 levels: one thread per column
 def test_atm_radiation_multi_layer(dims, seed, trop):
     """BC_Thermo::BC_Radiation_multi_layer against the oracle's statement-by-statement restatement (which builds
     the reference's full transmission matrix): pow() and sqrt() on both sides, 1e-10 per field.  PARITY UNPINNED
