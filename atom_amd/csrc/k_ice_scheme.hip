@@ -469,6 +469,14 @@ struct AdjArgs {
     uint8_t* chunk_kind; // per chunk: bit 0 chunk_out valid, bit 1 a column of the chunk was left for the serial kernel
     int nchunks;
     double state;     // q_v_hyp as the call found it
+    // the resumable point kernel (k_adj_pass) and its scan
+    double* hyp;          // per grid point: q_v_hyp as the finished cold point left it
+    uint8_t* status;      // per grid point: bit 0 finished, bit 1 it was a cold point
+    uint8_t* col_state;   // per column rank: 0 unfinished, 1 finished (out[] valid), 2 finished without a cold point
+    double* carry;        // per column rank: out[] of the nearest column before it that is not of state 2 ...
+    uint8_t* carry_state; // ... and that column's state: 1 the value is known, 0 not yet, 2 look in the chunk's entry
+    double* chunk_carry; uint8_t* chunk_carry_state;  // the same per chunk, from the chunks before it
+    int* chunk_unfinished;
 };
 
 constexpr double t_00 = 236.15;
@@ -626,17 +634,21 @@ __global__ void k_adj_columns(AdjArgs a) {
     a.out[rank] = out;
 }
 
-// The same with one thread per grid point: COLS neighbouring columns and all their levels per workgroup.  The ground
-// points go first (the levels above need their new t), then every point that assigns q_v_hyp itself, then - in as many
-// rounds as the longest run of them needs - the points that start from what the cold point below them left.
-__global__ __launch_bounds__(1024) void k_adj_points(AdjArgs a) {
-    extern __shared__ double lds[];  // [im][COLS] q_v_hyp as the points leave it, [COLS] ground t, then bytes
+// The same with one thread per grid point (COLS neighbouring columns and all their levels per workgroup), in passes.
+// A point can be finished when the ground point of its column is (the levels above need its new t) and, if it
+// inherits q_v_hyp, when the cold point it inherits from is: the nearest one below it in its column, or - for the
+// first cold point of a column - the last cold point of the nearest column before it that has one (carry).  A pass
+// finishes every point whose inputs are there and leaves the others untouched; the scan between two passes hands
+// the finished columns' last values on.  The first pass finishes everything but the runs of inheriting points at
+// the first cold point of a column (in the model's loop these sit on the rows and columns that the boundary fills
+// extrapolate); every further pass finishes at least the first unfinished column in visiting order.
+__global__ __launch_bounds__(1024) void k_adj_pass(AdjArgs a) {
+    extern __shared__ double lds[];  // [im][COLS] q_v_hyp of finished cold points, [COLS] ground t, then bytes
     const int COLS = (int)blockDim.x;
     const int im = a.im, tx = threadIdx.x, i = threadIdx.y;
     double* s_hyp = lds;
     double* s_t0 = lds + (size_t)im * COLS;
-    uint8_t* s_flag = (uint8_t*)(s_t0 + COLS);   // [im][COLS]: 1 cold, 2 inherits q_v_hyp, 4 done
-    uint8_t* s_kind = s_flag + (size_t)im * COLS; // [COLS]
+    uint8_t* s_flag = (uint8_t*)(s_t0 + COLS);   // [im][COLS]: 1 cold, 2 inherits q_v_hyp, 4 finished
     const size_t n2 = (size_t)a.jm * a.km;
     size_t q = (size_t)blockIdx.x * COLS + tx;
     const bool valid = q < n2;
@@ -644,66 +656,114 @@ __global__ __launch_bounds__(1024) void k_adj_points(AdjArgs a) {
     const size_t id = (size_t)i * n2 + q;
     const size_t jj = q / a.km, kk = q - jj * a.km;
     const size_t rank = kk * a.jm + jj;
-    const double t_in = a.t[id], c_in = a.c[id], cl_in = a.cloud[id], ic_in = a.ice[id];
-    const double t_Celsius = t_in * a.t_0 - a.t_0;
-    const bool cold = t_Celsius < 0.;
-    const bool inherits = cold && !hyp_assigned((t_Celsius < t_00 - a.t_0) ? 0. : cl_in, ic_in);
-    s_flag[i * COLS + tx] = (uint8_t)((cold ? 1 : 0) | (inherits ? 2 : 0));
+    const bool col_open = valid && a.col_state[rank] == 0;
+    if (!__syncthreads_or(col_open)) return;  // nothing left to do for these columns
+    // the point's own state; its input fields are untouched as long as it is unfinished
+    const uint8_t st = a.status[id];
+    bool done = (st & 1) != 0, cold = (st & 2) != 0, inherits = false;
+    double t_in = 0., c_in = 0., cl_in = 0., ic_in = 0.;
+    if (!done) {
+        t_in = a.t[id]; c_in = a.c[id]; cl_in = a.cloud[id]; ic_in = a.ice[id];
+        const double t_Celsius = t_in * a.t_0 - a.t_0;
+        cold = t_Celsius < 0.;
+        inherits = cold && !hyp_assigned((t_Celsius < t_00 - a.t_0) ? 0. : cl_in, ic_in);
+    } else if (cold) s_hyp[i * COLS + tx] = a.hyp[id];
+    s_flag[i * COLS + tx] = (uint8_t)((cold ? 1 : 0) | (inherits ? 2 : 0) | (done ? 4 : 0));
+    // what the column inherits, if that is known by now
+    bool carry_known = false; double carry = 0.;
+    if (col_open) {
+        uint8_t cs = a.carry_state[rank]; carry = a.carry[rank];
+        if (cs == 2) { const size_t c = rank / CHUNK; cs = a.chunk_carry_state[c]; carry = a.chunk_carry[c]; }
+        carry_known = cs == 1;
+    }
     __syncthreads();
-    if (i == 0) {
-        int kind = 0;
+    bool first_cold = cold;  // no cold point below this one
+    for (int l = i - 1; l >= 0 && first_cold; l--) if (s_flag[l * COLS + tx] & 1) first_cold = false;
+    auto finish = [&](double t_ground, double hyp_in) {
+        const AdjOut o = adj_point(a, i, t_in, t_ground, c_in, cl_in, ic_in, hyp_in);
+        adj_store(a, id, o, c_in);
+        a.status[id] = (uint8_t)(1 | (cold ? 2 : 0));
+        if (cold) { a.hyp[id] = o.q_v_hyp; s_hyp[i * COLS + tx] = o.q_v_hyp; }
+        done = true;
+        return o;
+    };
+    if (i == 0) {  // the ground point
+        double t0 = a.t[id];
+        if (col_open && !done && (!inherits || carry_known)) t0 = finish(t_in, carry).t;
+        s_t0[tx] = t0;
+        if (done) s_flag[tx] |= 4;
+    }
+    __syncthreads();
+    const bool ground_done = (s_flag[tx] & 4) != 0;
+    const bool open = col_open && !done && i > 0 && ground_done;
+    if (open && !inherits) finish(s_t0[tx], 0.);
+    __syncthreads();
+    if (done) s_flag[i * COLS + tx] |= 4;
+    // the inheriting points, lowest first: every round finishes those whose cold point below is finished
+    for (int round = 0; round < im; round++) {
+        __syncthreads();
+        bool ready = false; double hyp_in = 0.;
+        if (open && !done) {
+            if (first_cold) { ready = carry_known; hyp_in = carry; }
+            else
+                for (int l = i - 1; l >= 0; l--) {
+                    const uint8_t f = s_flag[l * COLS + tx];
+                    if (f & 1) { ready = (f & 4) != 0; hyp_in = s_hyp[l * COLS + tx]; break; }
+                }
+        }
+        if (!__syncthreads_or(ready)) break;
+        if (ready) { finish(s_t0[tx], hyp_in); s_flag[i * COLS + tx] |= 4; }
+    }
+    __syncthreads();
+    if (i == 0 && col_open) {  // finished columns hand their last value on: the highest cold level is visited last
+        bool all = true; int top_cold = -1;
         for (int l = 0; l < im; l++) {
             const uint8_t f = s_flag[l * COLS + tx];
-            if (f & 1) { kind = (f & 2) ? 2 : 1; break; }
+            if (!(f & 4)) all = false;
+            if (f & 1) top_cold = l;
         }
-        s_kind[tx] = (uint8_t)kind;
-        if (valid) a.kind[rank] = (uint8_t)kind;
-    }
-    __syncthreads();
-    const bool mine = valid && s_kind[tx] != 2;  // columns of kind 2 are left for the serial kernel
-    if (i == 0) {
-        double t0 = t_in;
-        if (mine) {
-            const AdjOut o = adj_point(a, 0, t_in, t_in, c_in, cl_in, ic_in, 0.);
-            adj_store(a, id, o, c_in);
-            s_hyp[tx] = o.q_v_hyp; t0 = o.t;
-            s_flag[tx] |= 4;
+        if (all) {
+            if (top_cold >= 0) a.out[rank] = s_hyp[top_cold * COLS + tx];
+            a.col_state[rank] = top_cold >= 0 ? 1 : 2;
         }
-        s_t0[tx] = t0;
     }
+}
+
+// Between two passes: for every column the value it inherits (exclusive scan of "the last column that is not of
+// state 2" inside chunks of CHUNK ranks), the chunk totals, and the number of unfinished columns.
+__global__ __launch_bounds__(CHUNK) void k_adj_carry_scan(AdjArgs a) {
+    __shared__ uint8_t ss[2][CHUNK];
+    __shared__ double sv[2][CHUNK];
+    const size_t n2 = (size_t)a.jm * a.km;
+    const int t = threadIdx.x;
+    const size_t r = (size_t)blockIdx.x * CHUNK + t;
+    uint8_t state = 2; double val = 0.;
+    if (r < n2) { state = a.col_state[r]; if (state == 1) val = a.out[r]; }
+    const int unfinished = __syncthreads_count(state == 0);
+    int cur = 0;
+    ss[0][t] = state; sv[0][t] = val;
     __syncthreads();
-    bool pending = mine && i > 0;
-    if (pending && !inherits) {
-        const AdjOut o = adj_point(a, i, t_in, s_t0[tx], c_in, cl_in, ic_in, 0.);
-        adj_store(a, id, o, c_in);
-        s_hyp[i * COLS + tx] = o.q_v_hyp;
-        pending = false;
-    }
-    __syncthreads();
-    if (!pending && mine && i > 0) s_flag[i * COLS + tx] |= 4;
-    __syncthreads();
-    // every round finishes at least the lowest pending point of every column, so im rounds always suffice
-    for (int round = 0; round < im && __syncthreads_or(pending); round++) {
-        bool ready = false; double hyp_in = 0.;
-        if (pending) {
-            for (int l = i - 1; l >= 0; l--) {
-                const uint8_t f = s_flag[l * COLS + tx];
-                if (f & 1) { ready = (f & 4) != 0; hyp_in = s_hyp[l * COLS + tx]; break; }
-            }
-        }
+    for (int off = 1; off < CHUNK; off <<= 1) {  // inclusive scan: the right operand wins unless it is of state 2
+        if (t >= off && state == 2) { state = ss[cur][t - off]; val = sv[cur][t - off]; }
+        cur ^= 1;
+        ss[cur][t] = state; sv[cur][t] = val;
         __syncthreads();
-        if (ready) {
-            const AdjOut o = adj_point(a, i, t_in, s_t0[tx], c_in, cl_in, ic_in, hyp_in);
-            adj_store(a, id, o, c_in);
-            s_hyp[i * COLS + tx] = o.q_v_hyp;
-            s_flag[i * COLS + tx] |= 4;
-            pending = false;
-        }
     }
-    if (i == 0 && mine && s_kind[tx] == 1) {  // the highest cold level is the one visited last
-        for (int l = im - 1; l >= 0; l--)
-            if (s_flag[l * COLS + tx] & 1) { a.out[rank] = s_hyp[l * COLS + tx]; break; }
+    if (r < n2) { a.carry_state[r] = t ? ss[cur][t - 1] : 2; a.carry[r] = t ? sv[cur][t - 1] : 0.; }
+    if (t == CHUNK - 1) { a.chunk_carry_state[blockIdx.x] = state; a.chunk_carry[blockIdx.x] = val; a.chunk_unfinished[blockIdx.x] = unfinished; }
+}
+
+__global__ void k_adj_carry_finish(AdjArgs a) {
+    if (blockIdx.x || threadIdx.x) return;
+    uint8_t state = 1; double val = a.state;  // before the first column: the member as the call found it
+    int unfinished = 0;
+    for (int c = 0; c < a.nchunks; c++) {
+        const uint8_t cs = a.chunk_carry_state[c]; const double cv = a.chunk_carry[c];
+        a.chunk_carry_state[c] = state; a.chunk_carry[c] = val;  // the total becomes what the chunk inherits
+        if (cs != 2) { state = cs; val = cv; }
+        unfinished += a.chunk_unfinished[c];
     }
+    a.last[0] = val; a.last[1] = (double)unfinished;
 }
 
 // No column left over (the usual case): the member ends as the last column with a cold point left it - the
@@ -839,31 +899,59 @@ extern "C" int atomdev_atm_ice_water_saturation_adjustment(atomdev_t* h, double*
     a.t_0 = P.t_0; a.g = P.g; a.gam = P.gam; a.R_Air = P.R_Air; a.r_air = P.r_air; a.R_WaterVapour = P.R_WaterVapour;
     a.L_atm = P.L_atm; a.hp = P.hp; a.ep = P.ep; a.lv = P.lv; a.ls = P.ls; a.cp_l = P.cp_l;
     a.dt_dim = P.L_atm / P.u_0 * P.dt;  // BC_Thermo.cpp:121
-    const size_t n2 = h->n2;
-    double* s = h->scr[0];
-    a.out = s; a.kind = (uint8_t*)(s + n2); a.last = s + 2 * n2;
+    const size_t n2 = h->n2, n3 = h->n3;
     a.nchunks = (int)((n2 + CHUNK - 1) / CHUNK);
-    a.chunk_out = a.last + 2; a.chunk_kind = (uint8_t*)(a.chunk_out + a.nchunks);
-    ATOMDEV_REQUIRE(2 * n2 + 2 + 2 * (size_t)a.nchunks <= h->n3, "atomdev_atm_ice_water_saturation_adjustment: grid too small for the scratch layout");
     a.state = *q_v_hyp;
-    if (h->im <= MAX_LEVELS) {
-        const int COLS = cols_per_group(h->im);
-        const size_t lds = ((size_t)h->im * COLS + COLS) * sizeof(double) + (size_t)h->im * COLS + COLS;
-        hipLaunchKernelGGL(k_adj_points, dim3((unsigned)((n2 + COLS - 1) / COLS)), dim3(COLS, h->im), lds, h->stream, a);
-    } else {
-        hipLaunchKernelGGL(k_adj_columns, dim3((unsigned)((n2 + TPB - 1) / TPB)), dim3(TPB), 0, h->stream, a);
-    }
-    hipLaunchKernelGGL(k_adj_chunk_last, dim3(a.nchunks), dim3(CHUNK), 0, h->stream, a);
-    hipLaunchKernelGGL(k_adj_finish, dim3(1), dim3(64), 0, h->stream, a);
-    ATOMDEV_TRY(hipGetLastError());
     double last[2];
-    ATOMDEV_TRY(hipMemcpyAsync(last, a.last, sizeof(last), hipMemcpyDeviceToHost, h->stream));
-    ATOMDEV_TRY(hipStreamSynchronize(h->stream));
-    if (last[1] != 0.) {  // rare: columns whose first cold point inherits q_v_hyp, done in visiting order
-        hipLaunchKernelGGL(k_adj_inherit, dim3(1), dim3(1024), 0, h->stream, a);
+    if (h->im <= MAX_LEVELS) {
+        // scratch: the per-point values in the first scratch field, everything else in the second (the sweep's
+        // prep kernel rebuilds what it keeps there)
+        a.hyp = h->scr[0];
+        double* s = h->scr[1];
+        h->h0i_valid = false;
+        a.out = s; a.carry = s + n2; a.chunk_carry = s + 2 * n2; a.last = a.chunk_carry + a.nchunks;
+        a.chunk_unfinished = (int*)(a.last + 2);
+        a.status = (uint8_t*)(a.chunk_unfinished + a.nchunks + (a.nchunks & 1));
+        a.col_state = a.status + n3; a.carry_state = a.col_state + n2; a.chunk_carry_state = a.carry_state + n2;
+        const size_t bytes = (size_t)(a.chunk_carry_state + a.nchunks - (uint8_t*)s);
+        ATOMDEV_REQUIRE(bytes <= n3 * sizeof(double), "atomdev_atm_ice_water_saturation_adjustment: grid too small for the scratch layout");
+        ATOMDEV_TRY(hipMemsetAsync(a.status, 0, n3 + n2, h->stream));  // no point finished, every column open
+        const int COLS = cols_per_group(h->im);
+        const size_t lds = ((size_t)h->im * COLS + COLS) * sizeof(double) + (size_t)h->im * COLS;
+        size_t unfinished = n2;
+        for (size_t pass = 0;; pass++) {
+            hipLaunchKernelGGL(k_adj_carry_scan, dim3(a.nchunks), dim3(CHUNK), 0, h->stream, a);
+            hipLaunchKernelGGL(k_adj_carry_finish, dim3(1), dim3(64), 0, h->stream, a);
+            if (pass > 0) {
+                ATOMDEV_TRY(hipGetLastError());
+                ATOMDEV_TRY(hipMemcpyAsync(last, a.last, sizeof(last), hipMemcpyDeviceToHost, h->stream));
+                ATOMDEV_TRY(hipStreamSynchronize(h->stream));
+                const size_t left = (size_t)last[1];
+                if (left == 0) break;
+                // the first unfinished column in visiting order always has what it needs
+                ATOMDEV_REQUIRE(left < unfinished, "atomdev_atm_ice_water_saturation_adjustment: a pass finished no column");
+                unfinished = left;
+            }
+            hipLaunchKernelGGL(k_adj_pass, dim3((unsigned)((n2 + COLS - 1) / COLS)), dim3(COLS, h->im), lds, h->stream, a);
+        }
+    } else {
+        // very tall grids: one thread per column, columns that inherit from the column before them one by one
+        double* s = h->scr[0];
+        a.out = s; a.kind = (uint8_t*)(s + n2); a.last = s + 2 * n2;
+        a.chunk_out = a.last + 2; a.chunk_kind = (uint8_t*)(a.chunk_out + a.nchunks);
+        ATOMDEV_REQUIRE(2 * n2 + 2 + 2 * (size_t)a.nchunks <= n3, "atomdev_atm_ice_water_saturation_adjustment: grid too small for the scratch layout");
+        hipLaunchKernelGGL(k_adj_columns, dim3((unsigned)((n2 + TPB - 1) / TPB)), dim3(TPB), 0, h->stream, a);
+        hipLaunchKernelGGL(k_adj_chunk_last, dim3(a.nchunks), dim3(CHUNK), 0, h->stream, a);
+        hipLaunchKernelGGL(k_adj_finish, dim3(1), dim3(64), 0, h->stream, a);
         ATOMDEV_TRY(hipGetLastError());
-        ATOMDEV_TRY(hipMemcpyAsync(last, a.last, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        ATOMDEV_TRY(hipMemcpyAsync(last, a.last, sizeof(last), hipMemcpyDeviceToHost, h->stream));
         ATOMDEV_TRY(hipStreamSynchronize(h->stream));
+        if (last[1] != 0.) {
+            hipLaunchKernelGGL(k_adj_inherit, dim3(1), dim3(1024), 0, h->stream, a);
+            ATOMDEV_TRY(hipGetLastError());
+            ATOMDEV_TRY(hipMemcpyAsync(last, a.last, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            ATOMDEV_TRY(hipStreamSynchronize(h->stream));
+        }
     }
     *q_v_hyp = last[0];
     return 0;

@@ -1,0 +1,27 @@
+#!/bin/bash
+# On the GPU box, from the repo root: the whole GPU suite, then (only while everything passes) the measurements the
+# committed profiles come from.  Every GPU step has its own time limit; the script ends at the first failing step.
+set -u
+R=$PWD
+mkdir -p gpurun_out/final
+step() {  # step <seconds> <log> <command...>
+  local secs=$1 log=$2; shift 2
+  echo "== $* (limit ${secs}s)"
+  timeout -k 10 $secs "$@" > $log 2>&1
+  local rc=$?
+  if [ $rc -ne 0 ]; then echo "FAILED rc=$rc: $*"; tail -30 $log; exit $rc; fi
+}
+step 900 gpurun_out/final/pytest.log python -u -m pytest tests -m gpu -x -q --timeout 150 --timeout-method thread
+tail -3 gpurun_out/final/pytest.log
+step 200 gpurun_out/final/smoke.log python -u -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')"
+tail -1 gpurun_out/final/smoke.log
+step 300 gpurun_out/final/bench.json python -u bench.py
+tail -1 gpurun_out/final/bench.json
+cd /tmp && export TMPDIR=/tmp
+step 300 $R/gpurun_out/final/rocprof.log rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/prof -o bench -- python3 $R/bench.py --steps 20 --warmup 5
+cd $R
+step 400 gpurun_out/final/op_table.md python -u tools/op_table.py 20
+tail -36 gpurun_out/final/op_table.md
+step 300 gpurun_out/final/loop_time.txt python -u tools/loop_time.py 4
+cat gpurun_out/final/loop_time.txt
+echo "ALL STEPS PASSED"
