@@ -21,7 +21,8 @@ F3 = dict(T=0, U=1, V=2, W=3, P_DYN=4, C=5, CLOUD=6, ICE=7, CO2=8,
           RESIDUUM=33, P_STAT=34, Q_LATENT=35, Q_SENSIBLE=36, RADIATION_3D=37, P_RAIN=38, P_SNOW=39, EPSILON_3D=40, S_C_C=41)
 F2 = dict(TOPOGRAPHY=0, EVAPORATION_DALTON=1, PRECIPITATION=2, Q_RADIATION=3, PRECIPITABLE_WATER=4,
           EVAPORATION_PENMAN=5, Q_EVAPORATION=6, Q_LATENT_2D=7, Q_SENSIBLE_2D=8, Q_BOTTOM=9, CO2_TOTAL=10, VEGETATION=11,
-          ALBEDO=12, EPSILON=13, RADIATION_SURFACE=14)
+          ALBEDO=12, EPSILON=13, RADIATION_SURFACE=14, UPWELLING=15, DOWNWELLING=16,
+          BOTTOM_WATER=17, SALT_FINGER_2D=18, SALT_DIFFUSION_2D=19, BUOYANCY_FORCE_2D=20, SALT_TOTAL=21)
 
 
 class Radiation(C.Structure):
@@ -46,7 +47,7 @@ class AtomDevError(RuntimeError):
 _OPS = ["atm_bc_radius", "atm_bc_theta", "atm_bc_phi", "atm_value_limitation", "atm_solid_ground",
         "atm_rk3d", "atm_rk2d", "atm_pressure3d", "atm_pressure2d",
         "hyd_bc_radius", "hyd_bc_theta", "hyd_bc_phi", "hyd_value_limitation", "hyd_solid_ground",
-        "hyd_rk3d", "hyd_rk2d", "hyd_pressure3d", "hyd_pressure2d", "hyd_pressure_density", "atm_latent_heat"]
+        "hyd_rk3d", "hyd_rk2d", "hyd_pressure3d", "hyd_pressure2d", "hyd_pressure_density", "atm_latent_heat", "hyd_run_data"]
 
 _lib = None
 
@@ -84,6 +85,8 @@ def load_library():
     lib.atomdev_atm_msl_data.argtypes = [vp, C.c_int]
     lib.atomdev_atm_vegetation_distribution.argtypes = [vp, C.c_double]
     lib.atomdev_atm_two_category_ice_scheme.argtypes = [vp, dp]
+    lib.atomdev_atm_write_plot_data.argtypes = [vp, C.c_char_p]
+    lib.atomdev_hyd_write_plot_data.argtypes = [vp, C.c_char_p]
     lib.atomdev_atm_ice_water_saturation_adjustment.argtypes = [vp, dp]
     lib.atomdev_default_radiation.argtypes = [C.POINTER(Radiation)]
     lib.atomdev_default_radiation.restype = None
@@ -223,6 +226,11 @@ class DeviceModel:
         if it.shape != (self.jm,):
             raise AtomDevError("i_trop must have jm entries")
         self._check(self.lib.atomdev_atm_radiation_multi_layer(self._h, C.byref(radiation), it.ctypes.data_as(C.POINTER(C.c_int))))
+
+    def write_plot_data(self, path):
+        """Atmosphere_PlotData / Hydrosphere_PlotData: the surface table of the slice as text."""
+        fn = self.lib.atomdev_atm_write_plot_data if self.model == 0 else self.lib.atomdev_hyd_write_plot_data
+        self._check(fn(self._h, os.fsencode(path)))
 
     def ice_water_saturation_adjustment(self, q_v_hyp=0.0):
         """BC_Thermo::Ice_Water_Saturation_Adjustment; q_v_hyp as the previous call left it. Returns the new value."""

@@ -62,7 +62,10 @@ enum atomdev_field2d {
     ATOMDEV_Q_LATENT_2D, ATOMDEV_Q_SENSIBLE_2D, ATOMDEV_Q_BOTTOM, ATOMDEV_CO2_TOTAL,
     ATOMDEV_VEGETATION = 11,
     ATOMDEV_ALBEDO = 12, ATOMDEV_EPSILON, ATOMDEV_RADIATION_SURFACE,   /* written by the radiation model */
-    ATOMDEV_N2D = 15
+    /* hydrosphere surface diagnostics written by Results_Hyd::run_data (hydrosphere/cHydrosphereModel.h) */
+    ATOMDEV_UPWELLING = 15, ATOMDEV_DOWNWELLING, ATOMDEV_BOTTOM_WATER, ATOMDEV_SALT_FINGER_2D,
+    ATOMDEV_SALT_DIFFUSION_2D, ATOMDEV_BUOYANCY_FORCE_2D, ATOMDEV_SALT_TOTAL,
+    ATOMDEV_N2D = 22
 };
 
 /* Scalars the hot path reads.  Names and meaning are those of the reference's
@@ -193,6 +196,22 @@ int atomdev_atm_ice_water_saturation_adjustment(atomdev_t* h, double* q_v_hyp);
  * up to level im-3.  Reads t, c, ice, p_stat, h.  BC_Thermo.cpp cannot be compiled outside the reference's own
  * build (generated headers), so this operator is checked against a restatement only: parity unpinned. */
 int atomdev_atm_latent_heat(atomdev_t* h);
+/* Results_Hyd::run_data (hydrosphere/Results_Hyd.cpp:102-320) without its printout: Ekman-layer integrals of v and w
+ * (Simpson's rule over the array as the reference indexes it: entries 0..i_max-i_Ekman of a buffer that is filled at
+ * i_Ekman..im-2), BottomWater / Upwelling / Downwelling from them, the column sums SaltFinger, SaltDiffusion,
+ * BuoyancyForce_2D, Salt_total over the upper half, and the boundary values (r, then theta, then phi) of
+ * BuoyancyForce_3D, Salt_Finger, Salt_Diffusion and Salt_Balance.  The phi term of BottomWater is the reference's
+ * (aux_w[j][k+1] - aux_w[j][k+1]) divided by a member the class never sets: it is taken as the +0 it is for any
+ * finite positive value of that member. */
+int atomdev_hyd_run_data(atomdev_t* h);
+
+/* PostProcess_Atmosphere::Atmosphere_PlotData (atmosphere/PostProcess_Atm.cpp:624-652) and
+ * PostProcess_Hydrosphere::Hydrosphere_PlotData (hydrosphere/PostProcess_Hyd.cpp:676-705): the surface table of a
+ * time slice as text, fixed notation with 4 decimals, one row per (k, j).  path is the whole file name (the reference
+ * builds it as output_path + "/[" + name + "]_PlotData_Atm" + ("_" + iter_cnt if iter_cnt > 0) + ".xyz"). */
+int atomdev_atm_write_plot_data(atomdev_t* h, const char* path);
+int atomdev_hyd_write_plot_data(atomdev_t* h, const char* path);
+
 /* BC_Bathymetry_Atmosphere::vegetationDistribution (atmosphere/BC_Bath_Atm.cpp:129-142): Vegetation =
  * Precipitation / max_Precipitation on land surface cells that are not colder than t = 1, else 0. */
 int atomdev_atm_vegetation_distribution(atomdev_t* h, double max_Precipitation);

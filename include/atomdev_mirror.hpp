@@ -439,6 +439,18 @@ public:
         const std::string path = out_ + "/[" + Name_Bathymetry_File + "]_Transfer_Atm.vw";
         d.run(atomdev_atm_write_transfer_file(d.handle(), path.c_str()), "atomdev_atm_write_transfer_file");
     }
+    // atmosphere/PostProcess_Atm.cpp:624-652
+    void Atmosphere_PlotData(std::string& Name_Bathymetry_File, int iter_cnt, double u_0, double t_0, Array& h, Array& v, Array& w,
+                             Array& t, Array& c, Array_2D& Precipitation, Array_2D& precipitable_water) {
+        Device& d = Device::of(ATOMDEV_ATM);
+        d.grid(im_, jm_, km_);
+        d.params().u_0 = u_0; d.params().t_0 = t_0;
+        push_all(d, { { ATOMDEV_H, &h }, { ATOMDEV_V, &v }, { ATOMDEV_W, &w }, { ATOMDEV_T, &t }, { ATOMDEV_C, &c } });
+        d.push2d(ATOMDEV_PRECIPITATION, Precipitation); d.push2d(ATOMDEV_PRECIPITABLE_WATER, precipitable_water);
+        const std::string path = out_ + "/[" + Name_Bathymetry_File + "]_PlotData_Atm" +
+                                 (iter_cnt > 0 ? "_" + std::to_string(iter_cnt) : "") + ".xyz";
+        d.run(atomdev_atm_write_plot_data(d.handle(), path.c_str()), "atomdev_atm_write_plot_data");
+    }
 
 private:
     int im_, jm_, km_;
@@ -636,9 +648,52 @@ public:
         d.pull2d(ATOMDEV_EVAPORATION_DALTON, Evaporation_Dalton); d.pull2d(ATOMDEV_PRECIPITATION, Precipitation);
     }
 
+    // hydrosphere/PostProcess_Hyd.cpp:676-705
+    void Hydrosphere_PlotData(const std::string& Name_Bathymetry_File, int iter_cnt, double& u_0, Array& h, Array& v, Array& w,
+                              Array& t, Array& c, Array_2D& BottomWater, Array_2D& Upwelling, Array_2D& Downwelling) {
+        Device& d = Device::of(ATOMDEV_HYD);
+        d.grid(im_, jm_, km_);
+        d.params().u_0 = u_0;
+        push_all(d, { { ATOMDEV_H, &h }, { ATOMDEV_V, &v }, { ATOMDEV_W, &w }, { ATOMDEV_T, &t }, { ATOMDEV_C, &c } });
+        d.push2d(ATOMDEV_BOTTOM_WATER, BottomWater); d.push2d(ATOMDEV_UPWELLING, Upwelling); d.push2d(ATOMDEV_DOWNWELLING, Downwelling);
+        const std::string path = out_ + "/[" + Name_Bathymetry_File + "]_PlotData_Hyd" +
+                                 (iter_cnt > 0 ? "_" + std::to_string(iter_cnt) : "") + ".xyz";
+        d.run(atomdev_hyd_write_plot_data(d.handle(), path.c_str()), "atomdev_hyd_write_plot_data");
+    }
+
 private:
     int im_, jm_, km_;
     std::string out_;
+};
+
+// hydrosphere/Results_Hyd.h: run_data without its printout (Results_Hyd.cpp:322-395 prints six values at one fixed
+// 1-degree location; nothing of that is fed back into the model)
+class Results_Hyd {
+public:
+    Results_Hyd(int im, int jm, int km) : im_(im), jm_(jm), km_(km) {}
+    // hydrosphere/Results_Hyd.cpp:102-320
+    void run_data(int, double dr, double dthe, double L_hyd, double u_0, double c_0, Array_1D& rad, Array_1D& the, Array& h,
+                  Array&, Array& v, Array& w, Array& c, Array& Salt_Balance, Array& Salt_Finger, Array& Salt_Diffusion,
+                  Array& Buoyancy_Force_3D, Array_2D& Upwelling, Array_2D& Downwelling, Array_2D& SaltFinger,
+                  Array_2D& SaltDiffusion, Array_2D& BuoyancyForce_2D, Array_2D& Salt_total, Array_2D& BottomWater) {
+        Device& d = Device::of(ATOMDEV_HYD);
+        d.grid(im_, jm_, km_);
+        d.origin(rad, the);
+        atomdev_params& p = d.params();
+        p.dr = dr; p.dthe = dthe; p.L_hyd = L_hyd; p.u_0 = u_0; p.c_0 = c_0;
+        push_all(d, { { ATOMDEV_H, &h }, { ATOMDEV_V, &v }, { ATOMDEV_W, &w }, { ATOMDEV_C, &c },
+                      { ATOMDEV_SALT_BALANCE, &Salt_Balance }, { ATOMDEV_SALT_FINGER, &Salt_Finger },
+                      { ATOMDEV_SALT_DIFFUSION, &Salt_Diffusion }, { ATOMDEV_BUOYANCY, &Buoyancy_Force_3D } });
+        d.run(atomdev_hyd_run_data(d.handle()), "atomdev_hyd_run_data");
+        pull_all(d, { { ATOMDEV_SALT_BALANCE, &Salt_Balance }, { ATOMDEV_SALT_FINGER, &Salt_Finger },
+                      { ATOMDEV_SALT_DIFFUSION, &Salt_Diffusion }, { ATOMDEV_BUOYANCY, &Buoyancy_Force_3D } });
+        d.pull2d(ATOMDEV_UPWELLING, Upwelling); d.pull2d(ATOMDEV_DOWNWELLING, Downwelling); d.pull2d(ATOMDEV_SALT_FINGER_2D, SaltFinger);
+        d.pull2d(ATOMDEV_SALT_DIFFUSION_2D, SaltDiffusion); d.pull2d(ATOMDEV_BUOYANCY_FORCE_2D, BuoyancyForce_2D);
+        d.pull2d(ATOMDEV_SALT_TOTAL, Salt_total); d.pull2d(ATOMDEV_BOTTOM_WATER, BottomWater);
+    }
+
+private:
+    int im_, jm_, km_;
 };
 
 }  // namespace atomdev_mirror

@@ -1548,6 +1548,134 @@ void oracle_transfer_atm_to_hyd(oracle_ctx* a, oracle_ctx* h) {
         }
 }
 
+/* Results_Hyd::run_data, hydrosphere/Results_Hyd.cpp:102-320, without the printout.  The reference integrates a
+ * buffer that it fills at indices i_Ekman..im-2 over indices 0..i_diff (lib/Utils.h:58-65); the buffer is restated
+ * as it is used.  The phi term of BottomWater is (x - x) / (2 rmsinthe dphi) with a dphi the class never sets
+ * (Results_Hyd.h:26): evaluated here with the grid's dphi, which gives the same +0 as any finite positive value. */
+static double simpson_as_shipped(int n, double dstep, const double* value) {
+    double sum_even = 0, sum_odd = 0;
+    if (n % 2 == 0) {
+        for (int i = 1; i < n; i += 2) sum_odd += 4 * value[i];
+        for (int i = 2; i < n; i += 2) sum_even += 2 * value[i];
+    }
+    return dstep / 3 * (value[0] + sum_odd + sum_even + value[n]);
+}
+void oracle_hyd_run_data(oracle_ctx* c) {
+    const atomdev_params* P = &c->p;
+    const int im = c->im, jm = c->jm, km = c->km;
+    const double c43 = 4. / 3., c13 = 1. / 3., dr = P->dr, dthe = P->dthe, dphi = P->dphi;
+    static const int G0[7] = { ATOMDEV_UPWELLING, ATOMDEV_DOWNWELLING, ATOMDEV_BOTTOM_WATER, ATOMDEV_SALT_FINGER_2D,
+                               ATOMDEV_SALT_DIFFUSION_2D, ATOMDEV_BUOYANCY_FORCE_2D, ATOMDEV_SALT_TOTAL };
+    double* aux_v = (double*)calloc((size_t)jm * km, sizeof(double));
+    double* aux_w = (double*)calloc((size_t)jm * km, sizeof(double));
+    double* aux_grad_v = (double*)calloc((size_t)im + 1, sizeof(double));
+    double* aux_grad_w = (double*)calloc((size_t)im + 1, sizeof(double));
+    for (int n = 0; n < 7; n++) memset(c->g[G0[n]], 0, sizeof(double) * (size_t)jm * km);
+    const int i_half = (im - 1) / 2;
+    const double i_Ekman_layer = 500.;
+    const double coeff = i_Ekman_layer / P->L_hyd;
+    const int i_Ekman = (im - 1) * (1. - coeff);
+    const int j_half = (jm - 1) / 2, i_max = im - 1, i_diff = i_max - i_Ekman;
+#define AV(j, k) aux_v[(size_t)(j) * km + (k)]
+#define AW(j, k) aux_w[(size_t)(j) * km + (k)]
+    for (int k = 0; k < km; k++)
+        for (int j = 0; j < jm; j++) {
+            for (int i = i_Ekman; i < im - 1; i++) {
+                if (is_fluid(c, i, j, k)) { aux_grad_v[i] = A3(c, ATOMDEV_V, i, j, k); aux_grad_w[i] = A3(c, ATOMDEV_W, i, j, k); }
+                else { AV(j, k) = 0.; AW(j, k) = 0.; aux_grad_v[i] = 0.; aux_grad_w[i] = 0.; }
+            }
+            if (i_diff % 2 == 0) {
+                AV(j, k) = simpson_as_shipped(i_diff, dr, aux_grad_v);
+                AW(j, k) = simpson_as_shipped(i_diff, dr, aux_grad_w);
+            }
+        }
+    for (int k = 1; k < km - 1; k++) {
+        for (int j = 1; j < jm - 1; j++) {
+            if (!(j < j_half - 1 || j >= j_half + 2)) continue;
+            double rmsinthe = c->rad[im - 1] * sin(c->the[j]);
+            double b = (AV(j + 1, k) - AV(j - 1, k)) / (2. * c->rad[im - 1] * dthe) + (AW(j, k + 1) - AW(j, k + 1)) / (2. * rmsinthe * dphi);
+            A2(c, ATOMDEV_BOTTOM_WATER, j, k) = b * P->u_0;
+        }
+        for (int j = 1; j < jm - 1; j++) {
+            double b = A2(c, ATOMDEV_BOTTOM_WATER, j, k);
+            A2(c, ATOMDEV_UPWELLING, j, k) = b >= 0. ? b : 0.;
+            A2(c, ATOMDEV_DOWNWELLING, j, k) = b < 0. ? b : 0.;
+        }
+    }
+    for (int k = 0; k < km; k++)
+        for (int j = 0; j < jm; j++) A2(c, ATOMDEV_DOWNWELLING, j, k) = fabs(A2(c, ATOMDEV_DOWNWELLING, j, k));
+    static const int UD[2] = { ATOMDEV_UPWELLING, ATOMDEV_DOWNWELLING };
+    for (int k = 0; k < km; k++)
+        for (int n = 0; n < 2; n++) {
+            A2(c, UD[n], 0, k) = c43 * A2(c, UD[n], 1, k) - c13 * A2(c, UD[n], 2, k);
+            A2(c, UD[n], jm - 1, k) = c43 * A2(c, UD[n], jm - 2, k) - c13 * A2(c, UD[n], jm - 3, k);
+        }
+    for (int j = 0; j < jm; j++)
+        for (int n = 0; n < 2; n++) {
+            A2(c, UD[n], j, 0) = c43 * A2(c, UD[n], j, 1) - c13 * A2(c, UD[n], j, 2);
+            A2(c, UD[n], j, km - 1) = c43 * A2(c, UD[n], j, km - 2) - c13 * A2(c, UD[n], j, km - 3);
+            A2(c, UD[n], j, 0) = A2(c, UD[n], j, km - 1) = (A2(c, UD[n], j, 0) + A2(c, UD[n], j, km - 1)) / 2.;
+        }
+    for (int k = 0; k < km; k++)
+        for (int j = 0; j < jm; j++)
+            for (int i = i_half; i < im; i++)
+                if (is_fluid(c, i, j, k)) {
+                    A2(c, ATOMDEV_SALT_FINGER_2D, j, k) += A3(c, ATOMDEV_SALT_FINGER, i, j, k);
+                    A2(c, ATOMDEV_SALT_DIFFUSION_2D, j, k) += A3(c, ATOMDEV_SALT_DIFFUSION, i, j, k);
+                    A2(c, ATOMDEV_BUOYANCY_FORCE_2D, j, k) += A3(c, ATOMDEV_BUOYANCY, i, j, k);
+                    A2(c, ATOMDEV_SALT_TOTAL, j, k) += A3(c, ATOMDEV_C, i, j, k) * P->c_0;
+                }
+    static const int F4[4] = { ATOMDEV_BUOYANCY, ATOMDEV_SALT_FINGER, ATOMDEV_SALT_DIFFUSION, ATOMDEV_SALT_BALANCE };
+    for (int n = 0; n < 4; n++) {
+        const int F = F4[n];
+        for (int k = 0; k < km; k++)
+            for (int j = 0; j < jm; j++) {
+                A3(c, F, 0, j, k) = c43 * A3(c, F, 1, j, k) - c13 * A3(c, F, 2, j, k);
+                A3(c, F, im - 1, j, k) = c43 * A3(c, F, im - 2, j, k) - c13 * A3(c, F, im - 3, j, k);
+            }
+        for (int k = 0; k < km; k++)
+            for (int i = 0; i < im; i++) {
+                A3(c, F, i, 0, k) = c43 * A3(c, F, i, 1, k) - c13 * A3(c, F, i, 2, k);
+                A3(c, F, i, jm - 1, k) = c43 * A3(c, F, i, jm - 2, k) - c13 * A3(c, F, i, jm - 3, k);
+            }
+        for (int i = 0; i < im; i++)
+            for (int j = 0; j < jm; j++) {
+                A3(c, F, i, j, 0) = c43 * A3(c, F, i, j, 1) - c13 * A3(c, F, i, j, 2);
+                A3(c, F, i, j, km - 1) = c43 * A3(c, F, i, j, km - 2) - c13 * A3(c, F, i, j, km - 3);
+                A3(c, F, i, j, 0) = A3(c, F, i, j, km - 1) = (A3(c, F, i, j, 0) + A3(c, F, i, j, km - 1)) / 2.;
+            }
+    }
+#undef AV
+#undef AW
+    free(aux_v); free(aux_w); free(aux_grad_v); free(aux_grad_w);
+}
+
+/* PostProcess_Atmosphere::Atmosphere_PlotData (atmosphere/PostProcess_Atm.cpp:624-652) and
+ * PostProcess_Hydrosphere::Hydrosphere_PlotData (hydrosphere/PostProcess_Hyd.cpp:676-705): "%.4f" is what an
+ * ofstream with precision(4) and ios::fixed prints. */
+int oracle_write_plot_data(oracle_ctx* c, const char* path) {
+    FILE* f = fopen(path, "w");
+    if (!f) return 1;
+    const int atm = c->model == ATOMDEV_ATM, L = atm ? 0 : c->im - 1;
+    const double u_0 = c->p.u_0, t_0 = c->p.t_0;
+    if (atm) fprintf(f, "lons(deg), lats(deg), topography, v-velocity(m/s), w-velocity(m/s), velocity-mag(m/s), temperature(Celsius), water_vapour(g/kg), precipitation(mm), precipitable water(mm)\n");
+    else fprintf(f, "lons(deg), lats(deg), topography, v-velocity(m/s), w-velocity(m/s), velocity-mag(m/s), temperature(Celsius), salinity(psu), bottom_water(m/s), upwelling(m/s), downwelling(m/s)\n");
+    for (int k = 0; k < c->km; k++)
+        for (int j = 0; j < c->jm; j++) {
+            const double v = A3(c, ATOMDEV_V, L, j, k) * u_0, w = A3(c, ATOMDEV_W, L, j, k) * u_0;
+            const double vel_mag = sqrt(pow(v, 2) + pow(w, 2));
+            if (atm)
+                fprintf(f, "%d %d %.4f %.4f %.4f %.4f %.4f %.4f %.4f %.4f \n", k, 90 - j, A3(c, ATOMDEV_H, L, j, k), v, w, vel_mag,
+                        A3(c, ATOMDEV_T, L, j, k) * t_0 - t_0, A3(c, ATOMDEV_C, L, j, k) * 1000., A2(c, ATOMDEV_PRECIPITATION, j, k),
+                        A2(c, ATOMDEV_PRECIPITABLE_WATER, j, k));
+            else
+                fprintf(f, "%d %d %.4f %.4f %.4f %.4f %.4f %.4f %.4f %.4f   %.4f \n", k, 90 - j, A3(c, ATOMDEV_H, L, j, k), v, w, vel_mag,
+                        A3(c, ATOMDEV_T, L, j, k) * 273.15 - 273.15, A3(c, ATOMDEV_C, L, j, k) * 35., A2(c, ATOMDEV_BOTTOM_WATER, j, k),
+                        A2(c, ATOMDEV_UPWELLING, j, k), A2(c, ATOMDEV_DOWNWELLING, j, k));
+        }
+    return fclose(f) != 0;
+}
+
 /* BC_Thermohalin::BC_Pressure_Density, hydrosphere/BC_Thermohalin.cpp:518-583.  The local
  * r_air / R_Air of the reference function (:533-534) shadow the model parameters. */
 void oracle_hyd_pressure_density(oracle_ctx* c) {

@@ -11,6 +11,7 @@
  * objects, calls the reference method, and copies everything back.
  */
 #include <cstring>
+#include <new>
 #include <iostream>
 #include <sstream>
 #include <tuple>
@@ -42,6 +43,7 @@
 #include "Accuracy_Hyd.h"
 #include "PostProcess_Hyd.h"
 #include "MinMax_Hyd.h"
+#include "Results_Hyd.h"
 
 #include "../include/atomdev.h"
 
@@ -393,6 +395,38 @@ int ref_transfer_atm_to_hyd(void* va, void* vh, const char* dir) {
     PostProcess_Hydrosphere read_Transfer(c->im, c->jm, c->km, out);
     read_Transfer.Atmosphere_TransferFile_read(name, A(V), A(W), A(T), A(P_DYN), B(EVAPORATION_DALTON), B(PRECIPITATION));
     copy_out(c);
+    return 0;
+}
+
+/* Results_Hyd::run_data.  The class divides by a member (dphi) that no constructor sets (Results_Hyd.h:26); the
+ * numerator is x - x, so any finite positive value gives the same +0.  The object is built in storage filled with
+ * the byte 0x3f, which makes that member 4.8e-4 instead of whatever the stack held. */
+void ref_hyd_run_data(void* v) {
+    RefCtx* c = (RefCtx*)v; CoutSilencer s; copy_in(c);
+    const atomdev_params& P = c->p;
+    alignas(16) static unsigned char storage[sizeof(Results_Hyd)];
+    std::memset(storage, 0x3f, sizeof(storage));
+    Results_Hyd* calculate_MSL = new (storage) Results_Hyd(c->im, c->jm, c->km);
+    double dr = P.dr, dthe = P.dthe, L_hyd = P.L_hyd, u_0 = P.u_0, c_0 = P.c_0;
+    calculate_MSL->run_data(0, dr, dthe, L_hyd, u_0, c_0, c->rad, c->the, A(H), A(U), A(V), A(W), A(C), A(SALT_BALANCE),
+                            A(SALT_FINGER), A(SALT_DIFFUSION), A(BUOYANCY), B(UPWELLING), B(DOWNWELLING), B(SALT_FINGER_2D),
+                            B(SALT_DIFFUSION_2D), B(BUOYANCY_FORCE_2D), B(SALT_TOTAL), B(BOTTOM_WATER));
+    calculate_MSL->~Results_Hyd();
+    copy_out(c);
+}
+
+/* the reference's PlotData writers; the file appears as dir/[bridge]_PlotData_{Atm,Hyd}.xyz */
+int ref_write_plot_data(void* v, const char* dir) {
+    RefCtx* c = (RefCtx*)v; CoutSilencer s; copy_in(c);
+    std::string out(dir), name("bridge");
+    double u_0 = c->p.u_0;
+    if (c->model == ATOMDEV_ATM) {
+        PostProcess_Atmosphere ppa(c->im, c->jm, c->km, out);
+        ppa.Atmosphere_PlotData(name, -1, u_0, c->p.t_0, A(H), A(V), A(W), A(T), A(C), B(PRECIPITATION), B(PRECIPITABLE_WATER));
+    } else {
+        PostProcess_Hydrosphere ppa(c->im, c->jm, c->km, out);
+        ppa.Hydrosphere_PlotData(name, -1, u_0, A(H), A(V), A(W), A(T), A(C), B(BOTTOM_WATER), B(UPWELLING), B(DOWNWELLING));
+    }
     return 0;
 }
 

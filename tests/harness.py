@@ -31,7 +31,8 @@ F3 = dict(T=0, U=1, V=2, W=3, P_DYN=4, C=5, CLOUD=6, ICE=7, CO2=8,
           RESIDUUM=33, P_STAT=34, Q_LATENT=35, Q_SENSIBLE=36, RADIATION_3D=37, P_RAIN=38, P_SNOW=39, EPSILON_3D=40, S_C_C=41)
 F2 = dict(TOPOGRAPHY=0, EVAPORATION_DALTON=1, PRECIPITATION=2, Q_RADIATION=3, PRECIPITABLE_WATER=4,
           EVAPORATION_PENMAN=5, Q_EVAPORATION=6, Q_LATENT_2D=7, Q_SENSIBLE_2D=8, Q_BOTTOM=9, CO2_TOTAL=10, VEGETATION=11,
-          ALBEDO=12, EPSILON=13, RADIATION_SURFACE=14)
+          ALBEDO=12, EPSILON=13, RADIATION_SURFACE=14, UPWELLING=15, DOWNWELLING=16,
+          BOTTOM_WATER=17, SALT_FINGER_2D=18, SALT_DIFFUSION_2D=19, BUOYANCY_FORCE_2D=20, SALT_TOTAL=21)
 
 ATM_FIELDS = ["T", "U", "V", "W", "P_DYN", "C", "CLOUD", "ICE", "CO2",
               "TN", "UN", "VN", "WN", "P_DYNN", "CN", "CLOUDN", "ICEN", "CO2N",
@@ -250,6 +251,26 @@ def make_msl_inputs(im, jm, km, seed, params):
     return f, g
 
 
+RUN_DATA_FIELDS2D = ["UPWELLING", "DOWNWELLING", "BOTTOM_WATER", "SALT_FINGER_2D", "SALT_DIFFUSION_2D",
+                     "BUOYANCY_FORCE_2D", "SALT_TOTAL"]
+
+
+def make_run_data_inputs(im, jm, km, seed, L_hyd=None):
+    """Hydrosphere inputs of Results_Hyd::run_data: the diagnostic 3-D fields of the RK sweep filled, the seven
+    surface fields it writes pre-set to rubbish.  L_hyd decides where the Ekman layer starts (500 m below the top)."""
+    p = default_params(HYD, im, jm, km)
+    if L_hyd is not None:
+        p.L_hyd = L_hyd
+    f, g = make_inputs(HYD, im, jm, km, seed, "blobs", p)
+    f = {k: f[k] for k in HYD_FIELDS}
+    rng = np.random.default_rng(seed + 99)
+    for k in ("BUOYANCY", "SALT_BALANCE", "SALT_FINGER", "SALT_DIFFUSION"):
+        f[k] = rng.uniform(-1.0, 1.0, (im, jm, km))
+    for k in RUN_DATA_FIELDS2D:
+        g[k] = rng.uniform(-7.0, 7.0, (jm, km))
+    return p, f, g
+
+
 def bits_equal(a, b):
     """Bitwise equality up to the sign of zero (NaN == NaN)."""
     a = np.asarray(a); b = np.asarray(b)
@@ -372,8 +393,10 @@ def _move3d(m):
         m.op("move_data_to_new_arrays", C.c_int(-1))
 
 
-def hyd_3d_loop(m, pressure_iters=2, velocity_iters=2):
-    """cHydrosphereModel.cpp:420-610 without its printing: returns the queries' results in call order."""
+def hyd_3d_loop(m, pressure_iters=2, velocity_iters=2, run_data=False):
+    """cHydrosphereModel.cpp:420-610 without its printing: returns the queries' results in call order.
+    run_data=True adds Results_Hyd::run_data where the reference calls it (:597); its seven surface fields must be
+    bound then."""
     log = []
     for _ in range(pressure_iters):
         for _ in range(velocity_iters):
@@ -383,6 +406,8 @@ def hyd_3d_loop(m, pressure_iters=2, velocity_iters=2):
                 m.op(op)
             log.append(m.residuum("hyd_residuum3d"))
             log.append(m.steady("hyd_steady3d", 6))
+            if run_data:
+                m.op("hyd_run_data")
             _move3d(m)
         m.op("hyd_pressure3d")
     return log

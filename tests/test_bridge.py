@@ -28,10 +28,10 @@ def test_mirror_header_cites_every_reference_class():
 
 
 @pytest.mark.gpu
-def test_reference_call_sites_through_mirror_classes():
+def test_reference_call_sites_through_mirror_classes(tmp_path):
     if not os.path.exists(BIN):
         pytest.skip("oracle/_ref/bridge_test not built (needs the reference sources)")
-    r = subprocess.run([BIN], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([BIN, str(tmp_path)], capture_output=True, text=True, timeout=300)
     print(r.stdout)
     print(r.stderr)
     assert r.returncode == 0 and "BRIDGE PASS" in r.stdout, r.stdout + r.stderr

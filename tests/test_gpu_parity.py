@@ -464,6 +464,50 @@ def test_atm_ice_water_saturation_adjustment(dims, seed):
     d.close()
 
 
+@pytest.mark.parametrize("dims,L_hyd", [((41, 19, 23), 1000.0), ((41, 19, 23), 6000.0), ((9, 21, 70), 1000.0),
+                                        ((12, 13, 17), 2000.0)])
+def test_hyd_run_data_bitexact(dims, L_hyd):
+    """Results_Hyd::run_data: every 3-D and surface field, bits and sign of zero (the oracle is pinned by the compiled
+    class in tests/test_oracle_vs_reference.py).  (12, ., .) with 2000 m: odd number of Simpson intervals."""
+    im, jm, km = dims
+    p, f, g = H.make_run_data_inputs(im, jm, km, 94, L_hyd)
+    o = H.CpuModel("oracle", H.HYD, im, jm, km, p, f, g)
+    d = atom_amd.DeviceModel(H.HYD, im, jm, km, atom_amd.Params.from_buffer_copy(bytes(p)))
+    d.upload_all(f, g)
+    o.op("hyd_run_data"); d.op("hyd_run_data")
+    for k in list(f) + list(g):
+        got, ref = d.download(k), (o.f[k] if k in f else o.g[k])
+        assert np.array_equal(got, ref) and np.array_equal(np.signbit(got), np.signbit(ref)), k
+    for k in H.RUN_DATA_FIELDS2D:
+        assert not np.array_equal(o.g[k], g[k]), k
+    d.close()
+
+
+@pytest.mark.parametrize("model", [H.ATM, H.HYD])
+def test_plot_data_file_bytes(model, tmp_path):
+    """The PlotData table written from device-resident fields is byte for byte the oracle's file, which
+    tests/test_oracle_vs_reference.py pins to the file of the reference's own writer."""
+    import ctypes as C
+    im, jm, km = 7, 13, 17
+    if model == H.ATM:
+        p = H.default_params(H.ATM, im, jm, km)
+        f, g = H.make_msl_inputs(im, jm, km, 92, p)
+    else:
+        p, f, g = H.make_run_data_inputs(im, jm, km, 93)
+    f["V"][0 if model == H.ATM else im - 1, 3, 4] = -2e-6     # prints as -0.0000
+    o = H.CpuModel("oracle", model, im, jm, km, p, f, g)
+    d = atom_amd.DeviceModel(model, im, jm, km, atom_amd.Params.from_buffer_copy(bytes(p)))
+    d.upload_all(f, g)
+    o.lib.oracle_write_plot_data.argtypes = [C.c_void_p, C.c_char_p]
+    assert o.lib.oracle_write_plot_data(o.ctx, str(tmp_path / "oracle.xyz").encode()) == 0
+    d.write_plot_data(str(tmp_path / "device.xyz"))
+    mine, theirs = (tmp_path / "device.xyz").read_bytes(), (tmp_path / "oracle.xyz").read_bytes()
+    assert mine == theirs and mine.count(b"\n") == 1 + jm * km and b"-0.0000" in mine
+    with pytest.raises(atom_amd.AtomDevError):
+        d.write_plot_data(str(tmp_path / "no_such_dir" / "x.xyz"))
+    d.close()
+
+
 def test_golden_small_hyd_bitexact():
     """HIP path against the compiled reference's own outputs (tests/golden/hyd_small.npz)."""
     z = np.load(os.path.join(GOLD, "hyd_small.npz"))

@@ -52,14 +52,19 @@ def test_hyd_loop_oracle_vs_reference():
 @pytest.mark.gpu
 @pytest.mark.parametrize("dims,seed", [((9, 21, 70), 72), ((41, 43, 19), 73)])
 def test_hyd_loop_device_bitexact(dims, seed):
+    """Every operator of the hydrosphere's velocity iteration on the device, Results_Hyd::run_data included."""
     p, f, g = _hyd_inputs(dims, seed)
+    for k in H.RUN_DATA_FIELDS2D:
+        g[k] = np.zeros(dims[1:])
     o = H.CpuModel("oracle", H.HYD, *dims, p, f, g)
     d = atom_amd.DeviceModel(H.HYD, *dims, atom_amd.Params.from_buffer_copy(bytes(p)))
     d.upload_all(f, g)
-    _same_queries(H.hyd_3d_loop(d), H.hyd_3d_loop(o), exact=True)
+    _same_queries(H.hyd_3d_loop(d, run_data=True), H.hyd_3d_loop(o, run_data=True), exact=True)
     for k in H.HYD_FIELDS:
         if k != "RESIDUUM":
             assert H.bits_equal(d.download(k), o.f[k]), k
+    for k in H.RUN_DATA_FIELDS2D:
+        assert H.bits_equal(d.download(k), o.g[k]), k
     d.close()
 
 

@@ -1,6 +1,8 @@
 """atom_oracle.c against the reference's own compiled classes (oracle/_ref),
 on fresh seeds, masks and grid shapes.  Runs only where the reference was
 compiled (the build container); the committed goldens cover the GPU box."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -94,6 +96,47 @@ def test_transfer_atm_to_hyd(tmp_path):
     for k in gh:
         assert np.array_equal(ob.g[k], rb.g[k]) and np.array_equal(np.signbit(ob.g[k]), np.signbit(rb.g[k])), k
     assert not np.array_equal(ob.f["V"][5], fh["V"][5])
+
+
+@pytest.mark.parametrize("dims,L_hyd", [((41, 91, 181), 1000.0), ((41, 91, 181), 6000.0), ((9, 91, 181), 1000.0),
+                                        ((12, 91, 181), 2000.0), ((10, 91, 181), 1500.0)])
+def test_hyd_run_data(dims, L_hyd):
+    """Results_Hyd::run_data against the compiled class: Ekman layers that start at level 20 of 40, 36 of 40, 4 of 8,
+    8 of 11 (odd number of intervals: Simpson refused, integrals stay 0) and 6 of 9.  The class prints the values at
+    (j, k) = (90, 180) whatever the grid (Results_Hyd.cpp:344-373), so the surface has at least 91 x 181 points."""
+    im, jm, km = dims
+    p, f, g = H.make_run_data_inputs(im, jm, km, 91, L_hyd)
+    a, b = H.CpuModel("oracle", H.HYD, im, jm, km, p, f, g), H.CpuModel("ref", H.HYD, im, jm, km, p, f, g)
+    a.op("hyd_run_data"); b.op("hyd_run_data")
+    for k in f:
+        assert np.array_equal(a.f[k], b.f[k]) and np.array_equal(np.signbit(a.f[k]), np.signbit(b.f[k])), k
+    for k in g:
+        assert np.array_equal(a.g[k], b.g[k]) and np.array_equal(np.signbit(a.g[k]), np.signbit(b.g[k])), k
+    for k in H.RUN_DATA_FIELDS2D + ["SALT_FINGER", "BUOYANCY"]:
+        assert not np.array_equal(a.g[k] if k in g else a.f[k], g[k] if k in g else f[k]), k
+
+
+@pytest.mark.parametrize("model", [H.ATM, H.HYD])
+def test_plot_data_file(model, tmp_path):
+    """The PlotData table of a time slice: the oracle's file is byte for byte the file of the reference's writer."""
+    im, jm, km = 7, 13, 17
+    if model == H.ATM:
+        p = H.default_params(H.ATM, im, jm, km)
+        f, g = H.make_msl_inputs(im, jm, km, 92, p)
+        name = "[bridge]_PlotData_Atm.xyz"
+    else:
+        p, f, g = H.make_run_data_inputs(im, jm, km, 93)
+        name = "[bridge]_PlotData_Hyd.xyz"
+    f["V"][0 if model == H.ATM else im - 1, 3, 4] = -2e-6     # prints as -0.0000
+    a, b = H.CpuModel("oracle", model, im, jm, km, p, f, g), H.CpuModel("ref", model, im, jm, km, p, f, g)
+    mine = tmp_path / "mine.xyz"
+    a.lib.oracle_write_plot_data.argtypes = [C.c_void_p, C.c_char_p]
+    b.lib.ref_write_plot_data.argtypes = [C.c_void_p, C.c_char_p]
+    assert a.lib.oracle_write_plot_data(a.ctx, str(mine).encode()) == 0
+    b.lib.ref_write_plot_data(b.ctx, str(tmp_path).encode())
+    theirs = (tmp_path / name).read_bytes()
+    assert mine.read_bytes() == theirs
+    assert theirs.count(b"\n") == 1 + jm * km and b"-0.0000" in theirs
 
 
 @pytest.mark.parametrize("max_precipitation", [7.5, 0.0])
