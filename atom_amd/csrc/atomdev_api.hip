@@ -30,7 +30,7 @@ extern "C" void atomdev_default_params(int model, atomdev_params* p) {
     p->dt = 0.00001; p->dr = 0.025; p->dthe = 1. / pi180; p->dphi = 1. / pi180;
     p->r0 = 1.; p->the0 = 0.; p->phi0 = 0.;
     p->g = 9.8066; p->Buoyancy = 1.0; p->t_0 = 273.15; p->p_0 = 1013.25;
-    p->ep = .623; p->hp = 6.1078; p->lv = 2.52e6; p->ls = 2.83e6; p->r_water_vapour = .0094;
+    p->ep = .623; p->hp = 6.1078; p->lv = 2.52e6; p->ls = 2.83e6; p->r_water_vapour = .0094; p->co2_0 = 280.;
     if (model == ATOMDEV_ATM) { p->re = 1000.; p->pr = .7179; p->u_0 = 8.; p->c_0 = .035; }
     else { p->re = 10.; p->pr = 6.957; p->u_0 = .25; p->c_0 = 34.6; }
     p->sc_WaterVapour = .61; p->sc_CO2 = .96; p->gam = .65; p->r_air = 1.2041; p->R_Air = 287.1;

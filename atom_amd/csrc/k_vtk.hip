@@ -1,0 +1,286 @@
+// The ASCII VTK sections of both models: PostProcess_Atmosphere::paraview_vtk_radial / _longal / _zonal
+// (atmosphere/PostProcess_Atm.cpp:240-621) and PostProcess_Hydrosphere::paraview_vtk_longal / _radial / _zonal
+// (hydrosphere/PostProcess_Hyd.cpp:373-636).  Host code over downloads of the section's slices: one table of
+// columns per file, the derived columns computed as the reference computes them (with the host's libm, as there),
+// and what the reference leaves behind in aux_u / aux_v / aux_w written back to the device fields.
+#include <cmath>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "atomdev_internal.h"
+
+namespace {
+
+// one section of a 3-D field in the order the writers walk it: radial [j][k], longal [i][k], zonal [i][j]
+struct Section {
+    atomdev* h;
+    int kind, index, n_outer, n_inner;
+    Section(atomdev* h_, int kind_, int index_) : h(h_), kind(kind_), index(index_) {
+        n_outer = kind == ATOMDEV_RADIAL ? h->jm : h->im;
+        n_inner = kind == ATOMDEV_ZONAL ? h->jm : h->km;
+    }
+    size_t size() const { return (size_t)n_outer * n_inner; }
+    // source geometry of the section inside a field: rows of `width` bytes, `pitch` bytes apart
+    void geometry(size_t& offset, size_t& width, size_t& pitch, size_t& rows) const {
+        const size_t km = h->km, jm = h->jm;
+        if (kind == ATOMDEV_RADIAL) { offset = (size_t)index * jm * km; width = jm * km * 8; pitch = width; rows = 1; }
+        else if (kind == ATOMDEV_LONGAL) { offset = (size_t)index * km; width = km * 8; pitch = jm * km * 8; rows = h->im; }
+        else { offset = (size_t)index; width = 8; pitch = km * 8; rows = (size_t)h->im * jm; }
+    }
+    int get(int field, std::vector<double>& out) const {
+        out.resize(size());
+        size_t off, width, pitch, rows;
+        geometry(off, width, pitch, rows);
+        ATOMDEV_TRY(hipMemcpy2DAsync(out.data(), width, h->f[field] + off, pitch, width, rows, hipMemcpyDeviceToHost, h->stream));
+        return 0;
+    }
+    int put(int field, const std::vector<double>& in) const {
+        size_t off, width, pitch, rows;
+        geometry(off, width, pitch, rows);
+        ATOMDEV_TRY(hipMemcpy2DAsync(h->f[field] + off, pitch, in.data(), width, width, rows, hipMemcpyHostToDevice, h->stream));
+        return 0;
+    }
+};
+
+struct Text {
+    std::string s;
+    void num(double x) { char b[400]; std::snprintf(b, sizeof(b), "%.4f", x); s += b; }  // precision(4), ios::fixed
+    void line(double x) { num(x); s += '\n'; }
+    void triple(double x, double y, double z) { num(x); s += ' '; num(y); s += ' '; num(z); s += '\n'; }
+    void scalars(const char* name) { s += "SCALARS "; s += name; s += " float 1\nLOOKUP_TABLE default\n"; }
+    void column(const char* name, const std::vector<double>& a, double multiplier) {
+        scalars(name);
+        for (double x : a) line(x * multiplier);
+    }
+};
+
+// lib/Utils.h:79-81
+double exp_func(double T_K, double co_1, double co_2) { return std::exp(co_1 * (T_K - 273.15) / (T_K - co_2)); }
+
+struct Column { const char* name; int field; double multiplier; bool two_d; };
+
+int write_vtk(atomdev* h, int kind, int index, int Ma, const char* path) {
+    ATOMDEV_TRY(hipSetDevice(h->device));
+    const bool atm = h->model == ATOMDEV_ATM;
+    const int im = h->im, jm = h->jm, km = h->km;
+    const atomdev_params& P = h->p;
+    const Section sec(h, kind, index);
+    const size_t n = sec.size(), n2 = h->n2;
+    auto slice = [&](int field, std::vector<double>& v) { return sec.get(field, v); };
+    auto surface = [&](int field, std::vector<double>& v) {
+        v.resize(n2);
+        return atomdev_check(hipMemcpyAsync(v.data(), h->g[field], n2 * 8, hipMemcpyDeviceToHost, h->stream), "hipMemcpyAsync(2-D field)");
+    };
+    auto sync = [&]() { return atomdev_check(hipStreamSynchronize(h->stream), "hipStreamSynchronize"); };
+
+    Text out;
+    // header and the point coordinates, built by repeated addition as in the reference
+    static const char* title[2][3] = {
+        { "Radial_Data_Atmosphere_Circulation", "Longitudinal_Data_Atmosphere_Circulation", "Zonal_Data_Atmosphere_Circulation" },
+        { "Radial_Data_Hydrosphere_Circulation", "Longitudinal_Data_Hydrosphere_Circulation", "Zonal_Data_Hydrosphere_Circulation" } };
+    out.s += "# vtk DataFile Version 3.0\n";
+    out.s += title[atm ? 0 : 1][kind]; out.s += "\nASCII\nDATASET STRUCTURED_GRID\n";
+    out.s += "DIMENSIONS " + std::to_string(sec.n_inner) + " " + std::to_string(sec.n_outer) + " 1\n";
+    out.s += "POINTS " + std::to_string(sec.n_outer * sec.n_inner) + " float\n";
+    {
+        double x = 0., y = 0., z = 0.;
+        const double dx = .1, step = kind == ATOMDEV_RADIAL ? .1 : (kind == ATOMDEV_LONGAL ? .025 : .05);
+        for (int a = 0; a < sec.n_outer; a++) {
+            for (int b = 0; b < sec.n_inner; b++) {
+                double& moving = kind == ATOMDEV_LONGAL ? z : y;
+                if (b == 0) moving = 0.; else moving = moving + step;
+                out.triple(x, y, z);
+            }
+            (kind == ATOMDEV_LONGAL ? z : y) = 0.;
+            x = x + dx;
+        }
+    }
+    const std::string point_data = "POINT_DATA " + std::to_string(sec.n_outer * sec.n_inner) + "\n";
+
+    std::vector<double> u, v, w, t, tmp;
+    if (int rc = slice(ATOMDEV_U, u)) return rc;
+    if (int rc = slice(ATOMDEV_V, v)) return rc;
+    if (int rc = slice(ATOMDEV_W, w)) return rc;
+    if (int rc = slice(ATOMDEV_T, t)) return rc;
+    auto columns = [&](std::initializer_list<Column> list) {
+        for (const Column& c : list) {
+            if (int rc = c.two_d ? surface(c.field, tmp) : slice(c.field, tmp)) return rc;
+            if (int rc = sync()) return rc;
+            out.column(c.name, tmp, c.multiplier);
+        }
+        return 0;
+    };
+    auto temperature_celsius = [&]() {
+        out.scalars("Temperature");
+        for (double x : t) out.line(x * P.t_0 - P.t_0);
+    };
+    if (int rc = sync()) return rc;
+
+    if (atm) {
+        const double p_scale = P.u_0 * P.u_0 * P.r_air * .01;
+        std::vector<double> c, cloud, ice;
+        if (int rc = slice(ATOMDEV_C, c)) return rc;
+        if (int rc = slice(ATOMDEV_CLOUD, cloud)) return rc;
+        if (int rc = slice(ATOMDEV_ICE, ice)) return rc;
+        if (int rc = sync()) return rc;
+        if (kind == ATOMDEV_RADIAL) {
+            if (Ma == 0) {  // :287-309: Celsius copy of the NASA temperature, its difference to t, evaporation - precipitation
+                std::vector<double> t_nasa, t0, evap, precip, aux_v, aux_w;
+                std::vector<uint8_t> flags((size_t)im * n2);
+                if (int rc = atomdev_refresh_flags(h)) return rc;
+                if (int rc = surface(ATOMDEV_TEMPERATURE_NASA, t_nasa)) return rc;
+                if (int rc = surface(ATOMDEV_EVAPORATION_DALTON, evap)) return rc;
+                if (int rc = surface(ATOMDEV_PRECIPITATION, precip)) return rc;
+                if (int rc = slice(ATOMDEV_AUX_V, aux_v)) return rc;
+                t0.resize(n2); aux_w.resize(n2);
+                ATOMDEV_TRY(hipMemcpyAsync(t0.data(), h->f[ATOMDEV_T], n2 * 8, hipMemcpyDeviceToHost, h->stream));
+                ATOMDEV_TRY(hipMemcpyAsync(flags.data(), h->flags, flags.size(), hipMemcpyDeviceToHost, h->stream));
+                if (int rc = sync()) return rc;
+                std::vector<double> celsius(n2);
+                for (size_t q = 0; q < n2; q++) {
+                    celsius[q] = t_nasa[q] * P.t_0 - P.t_0;
+                    bool assigned = !(flags[q] & FL_LAND);  // is_air(h, 0, j, k)
+                    for (int i = im - 2; i >= 0 && !assigned; i--)
+                        if (!(flags[(size_t)(i + 1) * n2 + q] & FL_LAND) && (flags[(size_t)i * n2 + q] & FL_LAND)) assigned = true;
+                    if (assigned) aux_v[q] = (t0[q] - t_nasa[q]) * P.t_0;
+                    aux_w[q] = evap[q] - precip[q];
+                }
+                ATOMDEV_TRY(hipMemcpyAsync(h->g[ATOMDEV_TEMP_NASA_CELSIUS], celsius.data(), n2 * 8, hipMemcpyHostToDevice, h->stream));
+                if (int rc = sec.put(ATOMDEV_AUX_V, aux_v)) return rc;
+                if (int rc = sec.put(ATOMDEV_AUX_W, aux_w)) return rc;
+                if (int rc = sync()) return rc;
+            }
+            out.s += point_data;
+            out.column("u-Component", u, 1.); out.column("v-Component", v, 1.); out.column("w-Component", w, 1.);
+            temperature_celsius();
+            if (int rc = columns({ { "Temp_NASA", ATOMDEV_TEMP_NASA_CELSIUS, 1., true }, { "Temp_NASA_diff", ATOMDEV_AUX_V, 1., false },
+                                   { "Topography", ATOMDEV_H, 1., false }, { "Topography_m", ATOMDEV_TOPOGRAPHY, 1., true } })) return rc;
+            out.column("WaterVapour", c, 1000.); out.column("CloudWater", cloud, 1000.); out.column("CloudIce", ice, 1000.);
+            if (int rc = columns({ { "PrecipitationRain", ATOMDEV_P_RAIN, 86400., false }, { "PrecipitationSnow", ATOMDEV_P_SNOW, 86400., false },
+                                   { "Precipitation", ATOMDEV_PRECIPITATION, 1., true }, { "PrecipitableWater_2D", ATOMDEV_PRECIPITABLE_WATER, 1., true },
+                                   { "Precipitation_NASA", ATOMDEV_PRECIPITATION_NASA, 1., true }, { "PressureDynamic", ATOMDEV_P_DYN, p_scale, false },
+                                   { "PressureStatic", ATOMDEV_P_STAT, 1., false }, { "Epsilon_3D", ATOMDEV_EPSILON_3D, 1., false },
+                                   { "albedo_2D", ATOMDEV_ALBEDO, 1., true }, { "epsilon_2D", ATOMDEV_EPSILON, 1., true },
+                                   { "Q_radiation_2D", ATOMDEV_Q_RADIATION, 1., true }, { "Q_bottom_2D", ATOMDEV_Q_BOTTOM, 1., true },
+                                   { "Q_latent_2D", ATOMDEV_Q_LATENT_2D, 1., true }, { "Q_sensible_2D", ATOMDEV_Q_SENSIBLE_2D, 1., true },
+                                   { "BuoyancyForce", ATOMDEV_BUOYANCY, 1., false }, { "Q_Radiation", ATOMDEV_RADIATION_3D, 1., false },
+                                   { "Q_Latent", ATOMDEV_Q_LATENT, 1., false }, { "Q_Sensible", ATOMDEV_Q_SENSIBLE, 1., false },
+                                   { "Evaporation_Penman", ATOMDEV_EVAPORATION_PENMAN, 1., true }, { "Evaporation_Dalton", ATOMDEV_EVAPORATION_DALTON, 1., true },
+                                   { "Heat_Evaporation", ATOMDEV_Q_EVAPORATION, 1., true }, { "Evap-Precip", ATOMDEV_AUX_W, 1., false },
+                                   { "Vegetation", ATOMDEV_VEGETATION, 1., true }, { "CO2-Concentration", ATOMDEV_CO2, P.co2_0, false } })) return rc;
+            out.s += "VECTORS v-w-Cell float \n";
+            for (size_t q = 0; q < n; q++) out.triple(v[q], w[q], 0.);
+        } else if (kind == ATOMDEV_LONGAL) {
+            out.s += point_data;
+            out.column("u-Component", u, 1.); out.column("v-Component", v, 1.); out.column("w-Component", w, 1.);
+            temperature_celsius();
+            std::vector<double> total(n);
+            for (size_t q = 0; q < n; q++) total[q] = c[q] + cloud[q] + ice[q];  // :586-592, kept in aux_w
+            if (int rc = sec.put(ATOMDEV_AUX_W, total)) return rc;
+            if (int rc = columns({ { "Topography", ATOMDEV_H, 1., false } })) return rc;
+            out.column("WaterVapour", c, 1000.); out.column("CloudWater", cloud, 1000.); out.column("CloudIce", ice, 1000.);
+            out.column("Total_Water", total, 1000.);
+            if (int rc = columns({ { "PrecipitationRain", ATOMDEV_P_RAIN, 86400., false }, { "PrecipitationSnow", ATOMDEV_P_SNOW, 86400., false },
+                                   { "PressureDynamic", ATOMDEV_P_DYN, p_scale, false }, { "PressureStatic", ATOMDEV_P_STAT, 1., false },
+                                   { "BuoyancyForce", ATOMDEV_BUOYANCY, 1., false }, { "Q_Latent", ATOMDEV_Q_LATENT, 1., false },
+                                   { "Q_Sensible", ATOMDEV_Q_SENSIBLE, 1., false }, { "Epsilon_3D", ATOMDEV_EPSILON_3D, 1., false },
+                                   { "CO2-Concentration", ATOMDEV_CO2, P.co2_0, false } })) return rc;
+            out.s += "VECTORS u-w-Cell float\n";
+            for (size_t q = 0; q < n; q++) out.triple(u[q], 0., w[q]);
+        } else {
+            out.s += point_data;
+            out.column("u-Component", u, 1.); out.column("v-Component", v, 1.); out.column("w-Component", w, 1.);
+            temperature_celsius();
+            // :452-482: total water and the two saturation ratios, kept in aux_w, aux_u, aux_v
+            std::vector<double> total(n), sat_water(n), sat_ice(n), t0(jm);
+            ATOMDEV_TRY(hipMemcpy2DAsync(t0.data(), 8, h->f[ATOMDEV_T] + index, (size_t)km * 8, 8, jm, hipMemcpyDeviceToHost, h->stream));
+            if (int rc = sync()) return rc;
+            for (int i = 0; i < im; i++)
+                for (int j = 0; j < jm; j++) {
+                    const size_t q = (size_t)i * jm + j;
+                    total[q] = c[q] + cloud[q] + ice[q];
+                    const double t_u = t[q] * P.t_0, T = t_u;
+                    const double p_SL = .01 * (P.r_air * P.R_Air * t0[j] * P.t_0);
+                    double p_h;
+                    if (i != 0) p_h = std::exp(-P.g * (double)i * (P.L_atm / (double)(im - 1)) / (P.R_Air * t_u)) * p_SL;
+                    else p_h = p_SL;
+                    const double E_Rain = P.hp * exp_func(T, 17.2694, 35.86), E_Ice = P.hp * exp_func(T, 21.8746, 7.66);
+                    const double q_Rain = P.ep * E_Rain / (p_h - E_Rain), q_Ice = P.ep * E_Ice / (p_h - E_Ice);
+                    sat_water[q] = c[q] / q_Rain;
+                    sat_ice[q] = T <= P.t_0 ? c[q] / q_Ice : 0.;
+                }
+            if (int rc = sec.put(ATOMDEV_AUX_W, total)) return rc;
+            if (int rc = sec.put(ATOMDEV_AUX_U, sat_water)) return rc;
+            if (int rc = sec.put(ATOMDEV_AUX_V, sat_ice)) return rc;
+            if (int rc = columns({ { "Topography", ATOMDEV_H, 1., false } })) return rc;
+            out.column("WaterVapour", c, 1000.); out.column("CloudWater", cloud, 1000.); out.column("CloudIce", ice, 1000.);
+            out.column("Saturation_Water", sat_water, 1.); out.column("Saturation_Ice", sat_ice, 1.); out.column("Total_Water", total, 1000.);
+            if (int rc = columns({ { "PrecipitationRain", ATOMDEV_P_RAIN, 86400., false }, { "PrecipitationSnow", ATOMDEV_P_SNOW, 86400., false },
+                                   { "Source_WaterVapour", ATOMDEV_S_V, 1000., false }, { "Source_CloudWater", ATOMDEV_S_C, 1000., false },
+                                   { "Source_CloudIce", ATOMDEV_S_I, 1000., false }, { "Source_Rain", ATOMDEV_S_R, 1000., false },
+                                   { "Source_Snow", ATOMDEV_S_S, 1000., false }, { "Source_CloudWater_CondEvap", ATOMDEV_S_C_C, 1000., false },
+                                   { "BuoyancyForce", ATOMDEV_BUOYANCY, 1., false }, { "Q_Radiation", ATOMDEV_RADIATION_3D, 1., false },
+                                   { "Epsilon_3D", ATOMDEV_EPSILON_3D, 1., false }, { "Q_Latent", ATOMDEV_Q_LATENT, 1., false },
+                                   { "Q_Sensible", ATOMDEV_Q_SENSIBLE, 1., false }, { "PressureDynamic", ATOMDEV_P_DYN, p_scale, false },
+                                   { "PressureStatic", ATOMDEV_P_STAT, 1., false }, { "CO2-Concentration", ATOMDEV_CO2, P.co2_0, false } })) return rc;
+            out.s += "VECTORS u-v-Cell float\n";
+            for (size_t q = 0; q < n; q++) out.triple(u[q], v[q], 0.);
+        }
+    } else {
+        const double p_scale = P.u_0 * P.u_0 * P.r_0_water * 1e-3;
+        out.s += point_data;
+        if (kind == ATOMDEV_RADIAL) {
+            temperature_celsius();
+            // :514-520: evaporation - precipitation over water, kept in aux_v
+            std::vector<double> evap, precip, diff(n2);
+            std::vector<uint8_t> ground(n2);
+            if (int rc = atomdev_refresh_flags(h)) return rc;
+            if (int rc = surface(ATOMDEV_EVAPORATION_DALTON, evap)) return rc;
+            if (int rc = surface(ATOMDEV_PRECIPITATION, precip)) return rc;
+            ATOMDEV_TRY(hipMemcpyAsync(ground.data(), h->flags, n2, hipMemcpyDeviceToHost, h->stream));
+            if (int rc = sync()) return rc;
+            for (size_t q = 0; q < n2; q++) diff[q] = (ground[q] & FL_LAND) ? 0. : evap[q] - precip[q];
+            if (int rc = sec.put(ATOMDEV_AUX_V, diff)) return rc;
+            if (int rc = columns({ { "Topography", ATOMDEV_H, 1., false }, { "Bathymetry_m", ATOMDEV_TOPOGRAPHY, 1., true } })) return rc;
+        } else {
+            if (int rc = columns({ { "Topography", ATOMDEV_H, 1., false } })) return rc;
+        }
+        out.column("u-Component", u, 1000.); out.column("v-Component", v, 1.); out.column("w-Component", w, 1.);
+        if (kind != ATOMDEV_RADIAL) out.column("Temperature", t, 1.);
+        if (int rc = columns({ { "PressureDynamic", ATOMDEV_P_DYN, p_scale, false }, { "PressureStatic", ATOMDEV_P_STAT, 1., false },
+                               { "Salinity", ATOMDEV_C, 1., false }, { "DensityWater", ATOMDEV_R_WATER, 1., false },
+                               { "DensitySaltWater", ATOMDEV_R_SALT_WATER, 1., false }, { "SaltFinger", ATOMDEV_SALT_FINGER, 1., false },
+                               { "SaltDiffusion", ATOMDEV_SALT_DIFFUSION, 1., false }, { "SaltBalance", ATOMDEV_SALT_BALANCE, 1., false },
+                               { "BuoyancyForce", ATOMDEV_BUOYANCY, 1., false } })) return rc;
+        if (kind == ATOMDEV_RADIAL) {
+            if (int rc = columns({ { "Upwelling", ATOMDEV_UPWELLING, 1., true }, { "Downwelling", ATOMDEV_DOWNWELLING, 1., true },
+                                   { "BottomWater", ATOMDEV_BOTTOM_WATER, 1., true }, { "Evaporation_Dalton", ATOMDEV_EVAPORATION_DALTON, 1., true },
+                                   { "Precipitation", ATOMDEV_PRECIPITATION, 1., true }, { "Evap-Precip", ATOMDEV_AUX_V, 1., false } })) return rc;
+            out.s += "VECTORS v-w-Cell float\n";
+            for (size_t q = 0; q < n; q++) out.triple(v[q], w[q], 0.);
+        } else if (kind == ATOMDEV_LONGAL) {
+            out.s += "VECTORS u-w-Cell float\n";
+            for (size_t q = 0; q < n; q++) out.triple(u[q], 0., w[q]);
+        } else {
+            out.s += "VECTORS u-v-Cell float\n";
+            for (size_t q = 0; q < n; q++) out.triple(u[q], v[q], 0.);
+        }
+    }
+    if (int rc = sync()) return rc;
+    FILE* f = std::fopen(path, "w");
+    ATOMDEV_REQUIRE(f, std::string("could not open VTK file ") + path);
+    const bool ok = std::fwrite(out.s.data(), 1, out.s.size(), f) == out.s.size();
+    ATOMDEV_REQUIRE(std::fclose(f) == 0 && ok, std::string("write failed: ") + path);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int atomdev_write_vtk(atomdev_t* h, int section, int index, int Ma, const char* path) {
+    ATOMDEV_REQUIRE(h && path, "atomdev_write_vtk: bad argument");
+    ATOMDEV_REQUIRE(section >= ATOMDEV_RADIAL && section <= ATOMDEV_ZONAL, "atomdev_write_vtk: section is 0 (radial), 1 (longal) or 2 (zonal)");
+    const int limit = section == ATOMDEV_RADIAL ? h->im : (section == ATOMDEV_LONGAL ? h->jm : h->km);
+    ATOMDEV_REQUIRE(index >= 0 && index < limit, "atomdev_write_vtk: index outside the grid");
+    return write_vtk(h, section, index, Ma, path);
+}

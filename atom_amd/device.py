@@ -22,7 +22,8 @@ F3 = dict(T=0, U=1, V=2, W=3, P_DYN=4, C=5, CLOUD=6, ICE=7, CO2=8,
 F2 = dict(TOPOGRAPHY=0, EVAPORATION_DALTON=1, PRECIPITATION=2, Q_RADIATION=3, PRECIPITABLE_WATER=4,
           EVAPORATION_PENMAN=5, Q_EVAPORATION=6, Q_LATENT_2D=7, Q_SENSIBLE_2D=8, Q_BOTTOM=9, CO2_TOTAL=10, VEGETATION=11,
           ALBEDO=12, EPSILON=13, RADIATION_SURFACE=14, UPWELLING=15, DOWNWELLING=16,
-          BOTTOM_WATER=17, SALT_FINGER_2D=18, SALT_DIFFUSION_2D=19, BUOYANCY_FORCE_2D=20, SALT_TOTAL=21)
+          BOTTOM_WATER=17, SALT_FINGER_2D=18, SALT_DIFFUSION_2D=19, BUOYANCY_FORCE_2D=20, SALT_TOTAL=21,
+          TEMPERATURE_NASA=22, PRECIPITATION_NASA=23, TEMP_NASA_CELSIUS=24)
 
 
 class Radiation(C.Structure):
@@ -37,7 +38,7 @@ class Params(C.Structure):
         "dt", "dr", "dthe", "dphi", "r0", "the0", "phi0",
         "re", "pr", "g", "Buoyancy", "u_0", "t_0", "c_0",
         "sc_WaterVapour", "sc_CO2", "gam", "r_air", "R_Air", "R_WaterVapour", "L_atm", "cp_l", "t_tropopause",
-        "sc", "L_hyd", "r_0_water", "ta", "pa", "ca", "p_0", "ep", "hp", "lv", "ls", "r_water_vapour")]
+        "sc", "L_hyd", "r_0_water", "ta", "pa", "ca", "p_0", "ep", "hp", "lv", "ls", "r_water_vapour", "co2_0")]
 
 
 class AtomDevError(RuntimeError):
@@ -85,6 +86,7 @@ def load_library():
     lib.atomdev_atm_msl_data.argtypes = [vp, C.c_int]
     lib.atomdev_atm_vegetation_distribution.argtypes = [vp, C.c_double]
     lib.atomdev_atm_two_category_ice_scheme.argtypes = [vp, dp]
+    lib.atomdev_write_vtk.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_char_p]
     lib.atomdev_atm_write_plot_data.argtypes = [vp, C.c_char_p]
     lib.atomdev_hyd_write_plot_data.argtypes = [vp, C.c_char_p]
     lib.atomdev_atm_ice_water_saturation_adjustment.argtypes = [vp, dp]
@@ -226,6 +228,10 @@ class DeviceModel:
         if it.shape != (self.jm,):
             raise AtomDevError("i_trop must have jm entries")
         self._check(self.lib.atomdev_atm_radiation_multi_layer(self._h, C.byref(radiation), it.ctypes.data_as(C.POINTER(C.c_int))))
+
+    def write_vtk(self, section, index, path, Ma=0):
+        """paraview_vtk_radial / _longal / _zonal (section 0 / 1 / 2) of the handle's model at level / row / column index."""
+        self._check(self.lib.atomdev_write_vtk(self._h, section, index, Ma, os.fsencode(path)))
 
     def write_plot_data(self, path):
         """Atmosphere_PlotData / Hydrosphere_PlotData: the surface table of the slice as text."""

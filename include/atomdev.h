@@ -65,7 +65,9 @@ enum atomdev_field2d {
     /* hydrosphere surface diagnostics written by Results_Hyd::run_data (hydrosphere/cHydrosphereModel.h) */
     ATOMDEV_UPWELLING = 15, ATOMDEV_DOWNWELLING, ATOMDEV_BOTTOM_WATER, ATOMDEV_SALT_FINGER_2D,
     ATOMDEV_SALT_DIFFUSION_2D, ATOMDEV_BUOYANCY_FORCE_2D, ATOMDEV_SALT_TOTAL,
-    ATOMDEV_N2D = 22
+    /* atmosphere: surface data read once per time slice and the Celsius copy the radial VTK writer keeps of it */
+    ATOMDEV_TEMPERATURE_NASA = 22, ATOMDEV_PRECIPITATION_NASA, ATOMDEV_TEMP_NASA_CELSIUS,
+    ATOMDEV_N2D = 25
 };
 
 /* Scalars the hot path reads.  Names and meaning are those of the reference's
@@ -87,6 +89,7 @@ typedef struct atomdev_params {
        latent heats of evaporation and sublimation in J/kg */
     double ep, hp, lv, ls;
     double r_water_vapour;      /* density of saturated water vapour in kg/m3 (param.py:82) */
+    double co2_0;               /* preindustrial CO2 in ppm (param.py:95): scale of the CO2 column in the VTK files */
 } atomdev_params;
 
 /* Fills *p with the reference defaults for `model` on the 1-degree grid. */
@@ -211,6 +214,16 @@ int atomdev_hyd_run_data(atomdev_t* h);
  * builds it as output_path + "/[" + name + "]_PlotData_Atm" + ("_" + iter_cnt if iter_cnt > 0) + ".xyz"). */
 int atomdev_atm_write_plot_data(atomdev_t* h, const char* path);
 int atomdev_hyd_write_plot_data(atomdev_t* h, const char* path);
+
+/* The ASCII VTK sections the models write for ParaView: PostProcess_Atmosphere::paraview_vtk_radial / _longal /
+ * _zonal (atmosphere/PostProcess_Atm.cpp:240-621) and PostProcess_Hydrosphere::paraview_vtk_longal / _radial /
+ * _zonal (hydrosphere/PostProcess_Hyd.cpp:373-636), chosen by the handle's model and `section`: the level i, the
+ * row j or the column k = index.  path is the whole file name (the reference builds it as output_path + "/[" +
+ * name + "]_Atm_radial_" + index + "_" + n + ".vtk" and alike).  The reference's writers use aux_u / aux_v / aux_w
+ * (and, radial atmosphere, the 2-D Celsius copy of temperature_NASA) as scratch for derived columns; the same
+ * values are left in the same places here.  Ma is read by the atmosphere's radial section only (:287). */
+enum atomdev_section { ATOMDEV_RADIAL = 0, ATOMDEV_LONGAL = 1, ATOMDEV_ZONAL = 2 };
+int atomdev_write_vtk(atomdev_t* h, int section, int index, int Ma, const char* path);
 
 /* BC_Bathymetry_Atmosphere::vegetationDistribution (atmosphere/BC_Bath_Atm.cpp:129-142): Vegetation =
  * Precipitation / max_Precipitation on land surface cells that are not colder than t = 1, else 0. */

@@ -439,6 +439,76 @@ public:
         const std::string path = out_ + "/[" + Name_Bathymetry_File + "]_Transfer_Atm.vw";
         d.run(atomdev_atm_write_transfer_file(d.handle(), path.c_str()), "atomdev_atm_write_transfer_file");
     }
+    // atmosphere/PostProcess_Atm.cpp:240-389
+    void paraview_vtk_radial(std::string& Name_Bathymetry_File, int Ma, int i_radial, int n, double& u_0, double& t_0, double&,
+                             double& r_air, double&, double& co2_0, Array& h, Array& p_dyn, Array& p_stat, Array& BuoyancyForce,
+                             Array& t, Array& u, Array& v, Array& w, Array& c, Array& co2, Array& cloud, Array& ice, Array&,
+                             Array& aux_v, Array& aux_w, Array& radiation_3D, Array& Q_Latent, Array& Q_Sensible, Array& epsilon_3D,
+                             Array& P_rain, Array& P_snow, Array_2D& precipitable_water, Array_2D& Q_bottom, Array_2D& Q_radiation,
+                             Array_2D& Q_latent, Array_2D& Q_sensible, Array_2D& Evaporation_Penman, Array_2D& Evaporation_Dalton,
+                             Array_2D& Q_Evaporation, Array_2D& temperature_NASA, Array_2D& precipitation_NASA, Array_2D& Vegetation,
+                             Array_2D& albedo, Array_2D& epsilon, Array_2D& Precipitation, Array_2D& Topography, Array_2D& temp_NASA) {
+        Device& d = Device::of(ATOMDEV_ATM);
+        d.grid(im_, jm_, km_);
+        atomdev_params& p = d.params();
+        p.u_0 = u_0; p.t_0 = t_0; p.r_air = r_air; p.co2_0 = co2_0;
+        push_all(d, { { ATOMDEV_H, &h }, { ATOMDEV_P_DYN, &p_dyn }, { ATOMDEV_P_STAT, &p_stat }, { ATOMDEV_BUOYANCY, &BuoyancyForce },
+                      { ATOMDEV_T, &t }, { ATOMDEV_U, &u }, { ATOMDEV_V, &v }, { ATOMDEV_W, &w }, { ATOMDEV_C, &c }, { ATOMDEV_CO2, &co2 },
+                      { ATOMDEV_CLOUD, &cloud }, { ATOMDEV_ICE, &ice }, { ATOMDEV_AUX_V, &aux_v }, { ATOMDEV_AUX_W, &aux_w },
+                      { ATOMDEV_RADIATION_3D, &radiation_3D }, { ATOMDEV_Q_LATENT, &Q_Latent }, { ATOMDEV_Q_SENSIBLE, &Q_Sensible },
+                      { ATOMDEV_EPSILON_3D, &epsilon_3D }, { ATOMDEV_P_RAIN, &P_rain }, { ATOMDEV_P_SNOW, &P_snow } });
+        d.push2d(ATOMDEV_PRECIPITABLE_WATER, precipitable_water); d.push2d(ATOMDEV_Q_BOTTOM, Q_bottom);
+        d.push2d(ATOMDEV_Q_RADIATION, Q_radiation); d.push2d(ATOMDEV_Q_LATENT_2D, Q_latent); d.push2d(ATOMDEV_Q_SENSIBLE_2D, Q_sensible);
+        d.push2d(ATOMDEV_EVAPORATION_PENMAN, Evaporation_Penman); d.push2d(ATOMDEV_EVAPORATION_DALTON, Evaporation_Dalton);
+        d.push2d(ATOMDEV_Q_EVAPORATION, Q_Evaporation); d.push2d(ATOMDEV_TEMPERATURE_NASA, temperature_NASA);
+        d.push2d(ATOMDEV_PRECIPITATION_NASA, precipitation_NASA); d.push2d(ATOMDEV_VEGETATION, Vegetation);
+        d.push2d(ATOMDEV_ALBEDO, albedo); d.push2d(ATOMDEV_EPSILON, epsilon); d.push2d(ATOMDEV_PRECIPITATION, Precipitation);
+        d.push2d(ATOMDEV_TOPOGRAPHY, Topography); d.push2d(ATOMDEV_TEMP_NASA_CELSIUS, temp_NASA);
+        const std::string path = out_ + "/[" + Name_Bathymetry_File + "]_Atm_radial_" + std::to_string(i_radial) + "_" + std::to_string(n) + ".vtk";
+        d.run(atomdev_write_vtk(d.handle(), ATOMDEV_RADIAL, i_radial, Ma, path.c_str()), "atomdev_write_vtk");
+        pull_all(d, { { ATOMDEV_AUX_V, &aux_v }, { ATOMDEV_AUX_W, &aux_w } });
+        d.pull2d(ATOMDEV_TEMP_NASA_CELSIUS, temp_NASA);
+    }
+    // atmosphere/PostProcess_Atm.cpp:391-520
+    void paraview_vtk_zonal(std::string& Name_Bathymetry_File, int k_zonal, int n, double& hp, double& ep, double& R_Air, double& g,
+                            double& L_atm, double& u_0, double& t_0, double&, double& r_air, double&, double& co2_0, Array& h,
+                            Array& p_dyn, Array& p_stat, Array& BuoyancyForce, Array& t, Array& u, Array& v, Array& w, Array& c,
+                            Array& co2, Array& cloud, Array& ice, Array& aux_u, Array& aux_v, Array& aux_w, Array& Q_Latent,
+                            Array& Q_Sensible, Array& radiation_3D, Array& epsilon_3D, Array& P_rain, Array& P_snow, Array& S_v,
+                            Array& S_c, Array& S_i, Array& S_r, Array& S_s, Array& S_c_c) {
+        Device& d = Device::of(ATOMDEV_ATM);
+        d.grid(im_, jm_, km_);
+        atomdev_params& p = d.params();
+        p.hp = hp; p.ep = ep; p.R_Air = R_Air; p.g = g; p.L_atm = L_atm; p.u_0 = u_0; p.t_0 = t_0; p.r_air = r_air; p.co2_0 = co2_0;
+        push_all(d, { { ATOMDEV_H, &h }, { ATOMDEV_P_DYN, &p_dyn }, { ATOMDEV_P_STAT, &p_stat }, { ATOMDEV_BUOYANCY, &BuoyancyForce },
+                      { ATOMDEV_T, &t }, { ATOMDEV_U, &u }, { ATOMDEV_V, &v }, { ATOMDEV_W, &w }, { ATOMDEV_C, &c }, { ATOMDEV_CO2, &co2 },
+                      { ATOMDEV_CLOUD, &cloud }, { ATOMDEV_ICE, &ice }, { ATOMDEV_AUX_U, &aux_u }, { ATOMDEV_AUX_V, &aux_v },
+                      { ATOMDEV_AUX_W, &aux_w }, { ATOMDEV_Q_LATENT, &Q_Latent }, { ATOMDEV_Q_SENSIBLE, &Q_Sensible },
+                      { ATOMDEV_RADIATION_3D, &radiation_3D }, { ATOMDEV_EPSILON_3D, &epsilon_3D }, { ATOMDEV_P_RAIN, &P_rain },
+                      { ATOMDEV_P_SNOW, &P_snow }, { ATOMDEV_S_V, &S_v }, { ATOMDEV_S_C, &S_c }, { ATOMDEV_S_I, &S_i },
+                      { ATOMDEV_S_R, &S_r }, { ATOMDEV_S_S, &S_s }, { ATOMDEV_S_C_C, &S_c_c } });
+        const std::string path = out_ + "/[" + Name_Bathymetry_File + "]_Atm_zonal_" + std::to_string(k_zonal) + "_" + std::to_string(n) + ".vtk";
+        d.run(atomdev_write_vtk(d.handle(), ATOMDEV_ZONAL, k_zonal, 0, path.c_str()), "atomdev_write_vtk");
+        pull_all(d, { { ATOMDEV_AUX_U, &aux_u }, { ATOMDEV_AUX_V, &aux_v }, { ATOMDEV_AUX_W, &aux_w } });
+    }
+    // atmosphere/PostProcess_Atm.cpp:522-621
+    void paraview_vtk_longal(std::string& Name_Bathymetry_File, int j_longal, int n, double& u_0, double& t_0, double&, double& r_air,
+                             double&, double& co2_0, Array& h, Array& p_dyn, Array& p_stat, Array& BuoyancyForce, Array& t, Array& u,
+                             Array& v, Array& w, Array& c, Array& co2, Array& cloud, Array& ice, Array&, Array&, Array& aux_w,
+                             Array& Q_Latent, Array& Q_Sensible, Array& epsilon_3D, Array& P_rain, Array& P_snow) {
+        Device& d = Device::of(ATOMDEV_ATM);
+        d.grid(im_, jm_, km_);
+        atomdev_params& p = d.params();
+        p.u_0 = u_0; p.t_0 = t_0; p.r_air = r_air; p.co2_0 = co2_0;
+        push_all(d, { { ATOMDEV_H, &h }, { ATOMDEV_P_DYN, &p_dyn }, { ATOMDEV_P_STAT, &p_stat }, { ATOMDEV_BUOYANCY, &BuoyancyForce },
+                      { ATOMDEV_T, &t }, { ATOMDEV_U, &u }, { ATOMDEV_V, &v }, { ATOMDEV_W, &w }, { ATOMDEV_C, &c }, { ATOMDEV_CO2, &co2 },
+                      { ATOMDEV_CLOUD, &cloud }, { ATOMDEV_ICE, &ice }, { ATOMDEV_AUX_W, &aux_w }, { ATOMDEV_Q_LATENT, &Q_Latent },
+                      { ATOMDEV_Q_SENSIBLE, &Q_Sensible }, { ATOMDEV_EPSILON_3D, &epsilon_3D }, { ATOMDEV_P_RAIN, &P_rain },
+                      { ATOMDEV_P_SNOW, &P_snow } });
+        const std::string path = out_ + "/[" + Name_Bathymetry_File + "]_Atm_longal_" + std::to_string(j_longal) + "_" + std::to_string(n) + ".vtk";
+        d.run(atomdev_write_vtk(d.handle(), ATOMDEV_LONGAL, j_longal, 0, path.c_str()), "atomdev_write_vtk");
+        pull_all(d, { { ATOMDEV_AUX_W, &aux_w } });
+    }
     // atmosphere/PostProcess_Atm.cpp:624-652
     void Atmosphere_PlotData(std::string& Name_Bathymetry_File, int iter_cnt, double u_0, double t_0, Array& h, Array& v, Array& w,
                              Array& t, Array& c, Array_2D& Precipitation, Array_2D& precipitable_water) {
@@ -648,6 +718,37 @@ public:
         d.pull2d(ATOMDEV_EVAPORATION_DALTON, Evaporation_Dalton); d.pull2d(ATOMDEV_PRECIPITATION, Precipitation);
     }
 
+    // hydrosphere/PostProcess_Hyd.cpp:373-449, 559-636: the two sections that need no surface fields
+    void paraview_vtk_longal(const std::string& Name_Bathymetry_File, int j_longal, int n, double& u_0, double& r_0_water, Array& h,
+                             Array& p_dyn, Array& p_stat, Array& r_water, Array& r_salt_water, Array& t, Array& u, Array& v, Array& w,
+                             Array& c, Array&, Array&, Array& Salt_Finger, Array& Salt_Diffusion, Array& Buoyancy_Force,
+                             Array& Salt_Balance) {
+        section(ATOMDEV_LONGAL, j_longal, "_Hyd_longal_", Name_Bathymetry_File, n, u_0, r_0_water, h, p_dyn, p_stat, r_water,
+                r_salt_water, t, u, v, w, c, Salt_Finger, Salt_Diffusion, Buoyancy_Force, Salt_Balance);
+    }
+    void paraview_vtk_zonal(const std::string& Name_Bathymetry_File, int k_zonal, int n, double& u_0, double& r_0_water, Array& h,
+                            Array& p_dyn, Array& p_stat, Array& r_water, Array& r_salt_water, Array& t, Array& u, Array& v, Array& w,
+                            Array& c, Array& Salt_Finger, Array& Salt_Diffusion, Array& Buoyancy_Force, Array& Salt_Balance) {
+        section(ATOMDEV_ZONAL, k_zonal, "_Hyd_zonal_", Name_Bathymetry_File, n, u_0, r_0_water, h, p_dyn, p_stat, r_water,
+                r_salt_water, t, u, v, w, c, Salt_Finger, Salt_Diffusion, Buoyancy_Force, Salt_Balance);
+    }
+    // hydrosphere/PostProcess_Hyd.cpp:456-552
+    void paraview_vtk_radial(const std::string& Name_Bathymetry_File, int i_radial, int n, double& u_0, double& t_0, double& r_0_water,
+                             Array& h, Array& p_dyn, Array& p_stat, Array& r_water, Array& r_salt_water, Array& t, Array& u, Array& v,
+                             Array& w, Array& c, Array&, Array& aux_v, Array& Salt_Finger, Array& Salt_Diffusion, Array& Buoyancy_Force,
+                             Array& Salt_Balance, Array_2D& Upwelling, Array_2D& Downwelling, Array_2D&, Array_2D&, Array_2D&,
+                             Array_2D& BottomWater, Array_2D& Evaporation_Dalton, Array_2D& Precipitation, Array_2D& Bathymetry) {
+        Device& d = Device::of(ATOMDEV_HYD);
+        d.grid(im_, jm_, km_);
+        d.params().t_0 = t_0;
+        d.push(ATOMDEV_AUX_V, aux_v);
+        d.push2d(ATOMDEV_UPWELLING, Upwelling); d.push2d(ATOMDEV_DOWNWELLING, Downwelling); d.push2d(ATOMDEV_BOTTOM_WATER, BottomWater);
+        d.push2d(ATOMDEV_EVAPORATION_DALTON, Evaporation_Dalton); d.push2d(ATOMDEV_PRECIPITATION, Precipitation);
+        d.push2d(ATOMDEV_TOPOGRAPHY, Bathymetry);
+        section(ATOMDEV_RADIAL, i_radial, "_Hyd_radial_", Name_Bathymetry_File, n, u_0, r_0_water, h, p_dyn, p_stat, r_water,
+                r_salt_water, t, u, v, w, c, Salt_Finger, Salt_Diffusion, Buoyancy_Force, Salt_Balance);
+        d.pull(ATOMDEV_AUX_V, aux_v);
+    }
     // hydrosphere/PostProcess_Hyd.cpp:676-705
     void Hydrosphere_PlotData(const std::string& Name_Bathymetry_File, int iter_cnt, double& u_0, Array& h, Array& v, Array& w,
                               Array& t, Array& c, Array_2D& BottomWater, Array_2D& Upwelling, Array_2D& Downwelling) {
@@ -662,6 +763,19 @@ public:
     }
 
 private:
+    void section(int kind, int index, const char* tag, const std::string& name, int n, double u_0, double r_0_water, Array& h,
+                 Array& p_dyn, Array& p_stat, Array& r_water, Array& r_salt_water, Array& t, Array& u, Array& v, Array& w, Array& c,
+                 Array& Salt_Finger, Array& Salt_Diffusion, Array& Buoyancy_Force, Array& Salt_Balance) {
+        Device& d = Device::of(ATOMDEV_HYD);
+        d.grid(im_, jm_, km_);
+        d.params().u_0 = u_0; d.params().r_0_water = r_0_water;
+        push_all(d, { { ATOMDEV_H, &h }, { ATOMDEV_P_DYN, &p_dyn }, { ATOMDEV_P_STAT, &p_stat }, { ATOMDEV_R_WATER, &r_water },
+                      { ATOMDEV_R_SALT_WATER, &r_salt_water }, { ATOMDEV_T, &t }, { ATOMDEV_U, &u }, { ATOMDEV_V, &v }, { ATOMDEV_W, &w },
+                      { ATOMDEV_C, &c }, { ATOMDEV_SALT_FINGER, &Salt_Finger }, { ATOMDEV_SALT_DIFFUSION, &Salt_Diffusion },
+                      { ATOMDEV_BUOYANCY, &Buoyancy_Force }, { ATOMDEV_SALT_BALANCE, &Salt_Balance } });
+        const std::string path = out_ + "/[" + name + "]" + tag + std::to_string(index) + "_" + std::to_string(n) + ".vtk";
+        d.run(atomdev_write_vtk(d.handle(), kind, index, 0, path.c_str()), "atomdev_write_vtk");
+    }
     int im_, jm_, km_;
     std::string out_;
 };

@@ -1676,6 +1676,266 @@ int oracle_write_plot_data(oracle_ctx* c, const char* path) {
     return fclose(f) != 0;
 }
 
+/* The ASCII VTK sections: PostProcess_Atmosphere::paraview_vtk_radial / _zonal / _longal
+ * (atmosphere/PostProcess_Atm.cpp:240-389, 391-520, 522-621; dump_* helpers :50-96) and
+ * PostProcess_Hydrosphere::paraview_vtk_longal / _radial / _zonal (hydrosphere/PostProcess_Hyd.cpp:373-449, 456-552,
+ * 559-636), one function per writer, statement order as there.  What the writers store into aux_u / aux_v / aux_w
+ * and into the Celsius copy of temperature_NASA stays in the bound arrays, as in the reference. */
+enum { SEC_RADIAL = 0, SEC_LONGAL = 1, SEC_ZONAL = 2 };
+
+static double sec_value(const oracle_ctx* c, int F, int sec, int fixed, int a, int b) {
+    return sec == SEC_RADIAL ? A3(c, F, fixed, a, b) : (sec == SEC_LONGAL ? A3(c, F, a, fixed, b) : A3(c, F, a, b, fixed));
+}
+static void sec_dims(const oracle_ctx* c, int sec, int* na, int* nb_) {
+    *na = sec == SEC_RADIAL ? c->jm : c->im;
+    *nb_ = sec == SEC_ZONAL ? c->jm : c->km;
+}
+/* dump_radial / dump_longal / dump_zonal */
+static void vtk_dump(FILE* f, const oracle_ctx* c, const char* desc, int F, double multiplier, int sec, int fixed) {
+    int na, nb_;
+    sec_dims(c, sec, &na, &nb_);
+    fprintf(f, "SCALARS %s float 1\nLOOKUP_TABLE default\n", desc);
+    for (int a = 0; a < na; a++)
+        for (int b = 0; b < nb_; b++) fprintf(f, "%.4f\n", sec_value(c, F, sec, fixed, a, b) * multiplier);
+}
+/* dump_radial_2d */
+static void vtk_dump_2d(FILE* f, const oracle_ctx* c, const char* desc, int G, double multiplier) {
+    fprintf(f, "SCALARS %s float 1\nLOOKUP_TABLE default\n", desc);
+    for (int j = 0; j < c->jm; j++)
+        for (int k = 0; k < c->km; k++) fprintf(f, "%.4f\n", A2(c, G, j, k) * multiplier);
+}
+static void vtk_head(FILE* f, const oracle_ctx* c, const char* title, int sec, double d_inner) {
+    int na, nb_;
+    sec_dims(c, sec, &na, &nb_);
+    fprintf(f, "# vtk DataFile Version 3.0\n%s\nASCII\nDATASET STRUCTURED_GRID\nDIMENSIONS %d %d 1\nPOINTS %d float\n", title, nb_, na, na * nb_);
+    double x = 0., y = 0., z = 0.;
+    const double dx = .1;
+    for (int a = 0; a < na; a++) {
+        for (int b = 0; b < nb_; b++) {
+            if (sec == SEC_LONGAL) { if (b == 0) z = 0.; else z = z + d_inner; }
+            else { if (b == 0) y = 0.; else y = y + d_inner; }
+            fprintf(f, "%.4f %.4f %.4f\n", x, y, z);
+        }
+        if (sec == SEC_LONGAL) z = 0.; else y = 0.;
+        x = x + dx;
+    }
+    fprintf(f, "POINT_DATA %d\n", na * nb_);
+}
+static void vtk_temperature_celsius(FILE* f, const oracle_ctx* c, int sec, int fixed) {
+    int na, nb_;
+    sec_dims(c, sec, &na, &nb_);
+    fprintf(f, "SCALARS Temperature float 1\nLOOKUP_TABLE default\n");
+    for (int a = 0; a < na; a++)
+        for (int b = 0; b < nb_; b++) fprintf(f, "%.4f\n", sec_value(c, ATOMDEV_T, sec, fixed, a, b) * c->p.t_0 - c->p.t_0);
+}
+static void vtk_vectors(FILE* f, const oracle_ctx* c, const char* head, int sec, int fixed) {
+    int na, nb_;
+    sec_dims(c, sec, &na, &nb_);
+    fprintf(f, "%s\n", head);
+    for (int a = 0; a < na; a++)
+        for (int b = 0; b < nb_; b++) {
+            const double u = sec_value(c, ATOMDEV_U, sec, fixed, a, b), v = sec_value(c, ATOMDEV_V, sec, fixed, a, b),
+                         w = sec_value(c, ATOMDEV_W, sec, fixed, a, b);
+            if (sec == SEC_RADIAL) fprintf(f, "%.4f %.4f %.4f\n", v, w, 0.);
+            else if (sec == SEC_LONGAL) fprintf(f, "%.4f %.4f %.4f\n", u, 0., w);
+            else fprintf(f, "%.4f %.4f %.4f\n", u, v, 0.);
+        }
+}
+
+static void vtk_atm_radial(FILE* f, oracle_ctx* c, int Ma, int i_radial) {
+    const atomdev_params* P = &c->p;
+    const int im = c->im, jm = c->jm, km = c->km, S = SEC_RADIAL;
+    vtk_head(f, c, "Radial_Data_Atmosphere_Circulation", S, .1);
+    /* the POINT_DATA line follows the Ma block in the reference; the block writes nothing to the file */
+    if (Ma == 0)
+        for (int k = 0; k < km; k++)
+            for (int j = 0; j < jm; j++) {
+                A2(c, ATOMDEV_TEMP_NASA_CELSIUS, j, k) = A2(c, ATOMDEV_TEMPERATURE_NASA, j, k) * P->t_0 - P->t_0;
+                for (int i = im - 2; i >= 0; i--) {
+                    if (is_fluid(c, i + 1, j, k) && is_land(c, i, j, k))
+                        A3(c, ATOMDEV_AUX_V, i_radial, j, k) = (A3(c, ATOMDEV_T, 0, j, k) - A2(c, ATOMDEV_TEMPERATURE_NASA, j, k)) * P->t_0;
+                    if (is_fluid(c, 0, j, k))
+                        A3(c, ATOMDEV_AUX_V, i_radial, j, k) = (A3(c, ATOMDEV_T, 0, j, k) - A2(c, ATOMDEV_TEMPERATURE_NASA, j, k)) * P->t_0;
+                    A3(c, ATOMDEV_AUX_W, i_radial, j, k) = A2(c, ATOMDEV_EVAPORATION_DALTON, j, k) - A2(c, ATOMDEV_PRECIPITATION, j, k);
+                }
+            }
+    vtk_dump(f, c, "u-Component", ATOMDEV_U, 1., S, i_radial);
+    vtk_dump(f, c, "v-Component", ATOMDEV_V, 1., S, i_radial);
+    vtk_dump(f, c, "w-Component", ATOMDEV_W, 1., S, i_radial);
+    vtk_temperature_celsius(f, c, S, i_radial);
+    vtk_dump_2d(f, c, "Temp_NASA", ATOMDEV_TEMP_NASA_CELSIUS, 1.);
+    vtk_dump(f, c, "Temp_NASA_diff", ATOMDEV_AUX_V, 1., S, i_radial);
+    vtk_dump(f, c, "Topography", ATOMDEV_H, 1., S, i_radial);
+    vtk_dump_2d(f, c, "Topography_m", ATOMDEV_TOPOGRAPHY, 1.);
+    vtk_dump(f, c, "WaterVapour", ATOMDEV_C, 1000., S, i_radial);
+    vtk_dump(f, c, "CloudWater", ATOMDEV_CLOUD, 1000., S, i_radial);
+    vtk_dump(f, c, "CloudIce", ATOMDEV_ICE, 1000., S, i_radial);
+    vtk_dump(f, c, "PrecipitationRain", ATOMDEV_P_RAIN, 86400., S, i_radial);
+    vtk_dump(f, c, "PrecipitationSnow", ATOMDEV_P_SNOW, 86400., S, i_radial);
+    vtk_dump_2d(f, c, "Precipitation", ATOMDEV_PRECIPITATION, 1.);
+    vtk_dump_2d(f, c, "PrecipitableWater_2D", ATOMDEV_PRECIPITABLE_WATER, 1.);
+    vtk_dump_2d(f, c, "Precipitation_NASA", ATOMDEV_PRECIPITATION_NASA, 1.);
+    vtk_dump(f, c, "PressureDynamic", ATOMDEV_P_DYN, P->u_0 * P->u_0 * P->r_air * .01, S, i_radial);
+    vtk_dump(f, c, "PressureStatic", ATOMDEV_P_STAT, 1., S, i_radial);
+    vtk_dump(f, c, "Epsilon_3D", ATOMDEV_EPSILON_3D, 1., S, i_radial);
+    vtk_dump_2d(f, c, "albedo_2D", ATOMDEV_ALBEDO, 1.);
+    vtk_dump_2d(f, c, "epsilon_2D", ATOMDEV_EPSILON, 1.);
+    vtk_dump_2d(f, c, "Q_radiation_2D", ATOMDEV_Q_RADIATION, 1.);
+    vtk_dump_2d(f, c, "Q_bottom_2D", ATOMDEV_Q_BOTTOM, 1.);
+    vtk_dump_2d(f, c, "Q_latent_2D", ATOMDEV_Q_LATENT_2D, 1.);
+    vtk_dump_2d(f, c, "Q_sensible_2D", ATOMDEV_Q_SENSIBLE_2D, 1.);
+    vtk_dump(f, c, "BuoyancyForce", ATOMDEV_BUOYANCY, 1., S, i_radial);
+    vtk_dump(f, c, "Q_Radiation", ATOMDEV_RADIATION_3D, 1., S, i_radial);
+    vtk_dump(f, c, "Q_Latent", ATOMDEV_Q_LATENT, 1., S, i_radial);
+    vtk_dump(f, c, "Q_Sensible", ATOMDEV_Q_SENSIBLE, 1., S, i_radial);
+    vtk_dump_2d(f, c, "Evaporation_Penman", ATOMDEV_EVAPORATION_PENMAN, 1.);
+    vtk_dump_2d(f, c, "Evaporation_Dalton", ATOMDEV_EVAPORATION_DALTON, 1.);
+    vtk_dump_2d(f, c, "Heat_Evaporation", ATOMDEV_Q_EVAPORATION, 1.);
+    vtk_dump(f, c, "Evap-Precip", ATOMDEV_AUX_W, 1., S, i_radial);
+    vtk_dump_2d(f, c, "Vegetation", ATOMDEV_VEGETATION, 1.);
+    vtk_dump(f, c, "CO2-Concentration", ATOMDEV_CO2, P->co2_0, S, i_radial);
+    vtk_vectors(f, c, "VECTORS v-w-Cell float ", S, i_radial);
+}
+
+static void vtk_atm_zonal(FILE* f, oracle_ctx* c, int k_zonal) {
+    const atomdev_params* P = &c->p;
+    const int im = c->im, jm = c->jm, S = SEC_ZONAL;
+    const double t_0 = P->t_0, r_air = P->r_air, R_Air = P->R_Air, g = P->g, L_atm = P->L_atm, hp = P->hp, ep = P->ep;
+    vtk_head(f, c, "Zonal_Data_Atmosphere_Circulation", S, .05);
+    vtk_dump(f, c, "u-Component", ATOMDEV_U, 1., S, k_zonal);
+    vtk_dump(f, c, "v-Component", ATOMDEV_V, 1., S, k_zonal);
+    vtk_dump(f, c, "w-Component", ATOMDEV_W, 1., S, k_zonal);
+    vtk_temperature_celsius(f, c, S, k_zonal);
+    for (int i = 0; i < im; i++)
+        for (int j = 0; j < jm; j++) {
+            A3(c, ATOMDEV_AUX_W, i, j, k_zonal) = A3(c, ATOMDEV_C, i, j, k_zonal) + A3(c, ATOMDEV_CLOUD, i, j, k_zonal) + A3(c, ATOMDEV_ICE, i, j, k_zonal);
+            double t_u = A3(c, ATOMDEV_T, i, j, k_zonal) * t_0;
+            double T = t_u;
+            double p_SL = .01 * (r_air * R_Air * A3(c, ATOMDEV_T, 0, j, k_zonal) * t_0);
+            double p_h;
+            if (i != 0) p_h = exp(-g * (double)i * (L_atm / (double)(im - 1)) / (R_Air * t_u)) * p_SL;
+            else p_h = p_SL;
+            double E_Rain = hp * exp_func(T, 17.2694, 35.86);
+            double E_Ice = hp * exp_func(T, 21.8746, 7.66);
+            double q_Rain = ep * E_Rain / (p_h - E_Rain);
+            double q_Ice = ep * E_Ice / (p_h - E_Ice);
+            A3(c, ATOMDEV_AUX_U, i, j, k_zonal) = A3(c, ATOMDEV_C, i, j, k_zonal) / q_Rain;
+            if (T <= t_0) A3(c, ATOMDEV_AUX_V, i, j, k_zonal) = A3(c, ATOMDEV_C, i, j, k_zonal) / q_Ice;
+            else A3(c, ATOMDEV_AUX_V, i, j, k_zonal) = 0.;
+        }
+    vtk_dump(f, c, "Topography", ATOMDEV_H, 1., S, k_zonal);
+    vtk_dump(f, c, "WaterVapour", ATOMDEV_C, 1000., S, k_zonal);
+    vtk_dump(f, c, "CloudWater", ATOMDEV_CLOUD, 1000., S, k_zonal);
+    vtk_dump(f, c, "CloudIce", ATOMDEV_ICE, 1000., S, k_zonal);
+    vtk_dump(f, c, "Saturation_Water", ATOMDEV_AUX_U, 1., S, k_zonal);
+    vtk_dump(f, c, "Saturation_Ice", ATOMDEV_AUX_V, 1., S, k_zonal);
+    vtk_dump(f, c, "Total_Water", ATOMDEV_AUX_W, 1000., S, k_zonal);
+    vtk_dump(f, c, "PrecipitationRain", ATOMDEV_P_RAIN, 86400., S, k_zonal);
+    vtk_dump(f, c, "PrecipitationSnow", ATOMDEV_P_SNOW, 86400., S, k_zonal);
+    vtk_dump(f, c, "Source_WaterVapour", ATOMDEV_S_V, 1000., S, k_zonal);
+    vtk_dump(f, c, "Source_CloudWater", ATOMDEV_S_C, 1000., S, k_zonal);
+    vtk_dump(f, c, "Source_CloudIce", ATOMDEV_S_I, 1000., S, k_zonal);
+    vtk_dump(f, c, "Source_Rain", ATOMDEV_S_R, 1000., S, k_zonal);
+    vtk_dump(f, c, "Source_Snow", ATOMDEV_S_S, 1000., S, k_zonal);
+    vtk_dump(f, c, "Source_CloudWater_CondEvap", ATOMDEV_S_C_C, 1000., S, k_zonal);
+    vtk_dump(f, c, "BuoyancyForce", ATOMDEV_BUOYANCY, 1., S, k_zonal);
+    vtk_dump(f, c, "Q_Radiation", ATOMDEV_RADIATION_3D, 1., S, k_zonal);
+    vtk_dump(f, c, "Epsilon_3D", ATOMDEV_EPSILON_3D, 1., S, k_zonal);
+    vtk_dump(f, c, "Q_Latent", ATOMDEV_Q_LATENT, 1., S, k_zonal);
+    vtk_dump(f, c, "Q_Sensible", ATOMDEV_Q_SENSIBLE, 1., S, k_zonal);
+    vtk_dump(f, c, "PressureDynamic", ATOMDEV_P_DYN, P->u_0 * P->u_0 * r_air * .01, S, k_zonal);
+    vtk_dump(f, c, "PressureStatic", ATOMDEV_P_STAT, 1., S, k_zonal);
+    vtk_dump(f, c, "CO2-Concentration", ATOMDEV_CO2, P->co2_0, S, k_zonal);
+    vtk_vectors(f, c, "VECTORS u-v-Cell float", S, k_zonal);
+}
+
+static void vtk_atm_longal(FILE* f, oracle_ctx* c, int j_longal) {
+    const atomdev_params* P = &c->p;
+    const int S = SEC_LONGAL;
+    vtk_head(f, c, "Longitudinal_Data_Atmosphere_Circulation", S, .025);
+    vtk_dump(f, c, "u-Component", ATOMDEV_U, 1., S, j_longal);
+    vtk_dump(f, c, "v-Component", ATOMDEV_V, 1., S, j_longal);
+    vtk_dump(f, c, "w-Component", ATOMDEV_W, 1., S, j_longal);
+    vtk_temperature_celsius(f, c, S, j_longal);
+    for (int i = 0; i < c->im; i++)
+        for (int k = 0; k < c->km; k++)
+            A3(c, ATOMDEV_AUX_W, i, j_longal, k) = A3(c, ATOMDEV_C, i, j_longal, k) + A3(c, ATOMDEV_CLOUD, i, j_longal, k) + A3(c, ATOMDEV_ICE, i, j_longal, k);
+    vtk_dump(f, c, "Topography", ATOMDEV_H, 1., S, j_longal);
+    vtk_dump(f, c, "WaterVapour", ATOMDEV_C, 1000., S, j_longal);
+    vtk_dump(f, c, "CloudWater", ATOMDEV_CLOUD, 1000., S, j_longal);
+    vtk_dump(f, c, "CloudIce", ATOMDEV_ICE, 1000., S, j_longal);
+    vtk_dump(f, c, "Total_Water", ATOMDEV_AUX_W, 1000., S, j_longal);
+    vtk_dump(f, c, "PrecipitationRain", ATOMDEV_P_RAIN, 86400., S, j_longal);
+    vtk_dump(f, c, "PrecipitationSnow", ATOMDEV_P_SNOW, 86400., S, j_longal);
+    vtk_dump(f, c, "PressureDynamic", ATOMDEV_P_DYN, P->u_0 * P->u_0 * P->r_air * .01, S, j_longal);
+    vtk_dump(f, c, "PressureStatic", ATOMDEV_P_STAT, 1., S, j_longal);
+    vtk_dump(f, c, "BuoyancyForce", ATOMDEV_BUOYANCY, 1., S, j_longal);
+    vtk_dump(f, c, "Q_Latent", ATOMDEV_Q_LATENT, 1., S, j_longal);
+    vtk_dump(f, c, "Q_Sensible", ATOMDEV_Q_SENSIBLE, 1., S, j_longal);
+    vtk_dump(f, c, "Epsilon_3D", ATOMDEV_EPSILON_3D, 1., S, j_longal);
+    vtk_dump(f, c, "CO2-Concentration", ATOMDEV_CO2, P->co2_0, S, j_longal);
+    vtk_vectors(f, c, "VECTORS u-w-Cell float", S, j_longal);
+}
+
+/* the columns the three hydrosphere writers share (PostProcess_Hyd.cpp:425-437, 525-536, 613-625) */
+static void vtk_hyd_common(FILE* f, oracle_ctx* c, int S, int fixed, int with_temperature) {
+    const atomdev_params* P = &c->p;
+    vtk_dump(f, c, "u-Component", ATOMDEV_U, 1000., S, fixed);
+    vtk_dump(f, c, "v-Component", ATOMDEV_V, 1., S, fixed);
+    vtk_dump(f, c, "w-Component", ATOMDEV_W, 1., S, fixed);
+    if (with_temperature) vtk_dump(f, c, "Temperature", ATOMDEV_T, 1., S, fixed);
+    vtk_dump(f, c, "PressureDynamic", ATOMDEV_P_DYN, P->u_0 * P->u_0 * P->r_0_water * 1e-3, S, fixed);
+    vtk_dump(f, c, "PressureStatic", ATOMDEV_P_STAT, 1., S, fixed);
+    vtk_dump(f, c, "Salinity", ATOMDEV_C, 1., S, fixed);
+    vtk_dump(f, c, "DensityWater", ATOMDEV_R_WATER, 1., S, fixed);
+    vtk_dump(f, c, "DensitySaltWater", ATOMDEV_R_SALT_WATER, 1., S, fixed);
+    vtk_dump(f, c, "SaltFinger", ATOMDEV_SALT_FINGER, 1., S, fixed);
+    vtk_dump(f, c, "SaltDiffusion", ATOMDEV_SALT_DIFFUSION, 1., S, fixed);
+    vtk_dump(f, c, "SaltBalance", ATOMDEV_SALT_BALANCE, 1., S, fixed);
+    vtk_dump(f, c, "BuoyancyForce", ATOMDEV_BUOYANCY, 1., S, fixed);
+}
+
+static void vtk_hyd_radial(FILE* f, oracle_ctx* c, int i_radial) {
+    const int S = SEC_RADIAL;
+    vtk_head(f, c, "Radial_Data_Hydrosphere_Circulation", S, .1);
+    fprintf(f, "SCALARS Temperature float 1\nLOOKUP_TABLE default\n");
+    for (int j = 0; j < c->jm; j++)
+        for (int k = 0; k < c->km; k++) {
+            fprintf(f, "%.4f\n", A3(c, ATOMDEV_T, i_radial, j, k) * c->p.t_0 - c->p.t_0);
+            A3(c, ATOMDEV_AUX_V, i_radial, j, k) = A2(c, ATOMDEV_EVAPORATION_DALTON, j, k) - A2(c, ATOMDEV_PRECIPITATION, j, k);
+            if (is_land(c, 0, j, k)) A3(c, ATOMDEV_AUX_V, i_radial, j, k) = 0.;
+        }
+    vtk_dump(f, c, "Topography", ATOMDEV_H, 1., S, i_radial);
+    vtk_dump_2d(f, c, "Bathymetry_m", ATOMDEV_TOPOGRAPHY, 1.);
+    vtk_hyd_common(f, c, S, i_radial, 0);
+    vtk_dump_2d(f, c, "Upwelling", ATOMDEV_UPWELLING, 1.);
+    vtk_dump_2d(f, c, "Downwelling", ATOMDEV_DOWNWELLING, 1.);
+    vtk_dump_2d(f, c, "BottomWater", ATOMDEV_BOTTOM_WATER, 1.);
+    vtk_dump_2d(f, c, "Evaporation_Dalton", ATOMDEV_EVAPORATION_DALTON, 1.);
+    vtk_dump_2d(f, c, "Precipitation", ATOMDEV_PRECIPITATION, 1.);
+    vtk_dump(f, c, "Evap-Precip", ATOMDEV_AUX_V, 1., S, i_radial);
+    vtk_vectors(f, c, "VECTORS v-w-Cell float", S, i_radial);
+}
+
+int oracle_write_vtk(oracle_ctx* c, int section, int index, int Ma, const char* path) {
+    FILE* f = fopen(path, "w");
+    if (!f) return 1;
+    if (c->model == ATOMDEV_ATM) {
+        if (section == SEC_RADIAL) vtk_atm_radial(f, c, Ma, index);
+        else if (section == SEC_LONGAL) vtk_atm_longal(f, c, index);
+        else vtk_atm_zonal(f, c, index);
+    } else if (section == SEC_RADIAL) {
+        vtk_hyd_radial(f, c, index);
+    } else {
+        vtk_head(f, c, section == SEC_LONGAL ? "Longitudinal_Data_Hydrosphere_Circulation" : "Zonal_Data_Hydrosphere_Circulation",
+                 section, section == SEC_LONGAL ? .025 : .05);
+        vtk_dump(f, c, "Topography", ATOMDEV_H, 1., section, index);
+        vtk_hyd_common(f, c, section, index, 1);
+        vtk_vectors(f, c, section == SEC_LONGAL ? "VECTORS u-w-Cell float" : "VECTORS u-v-Cell float", section, index);
+    }
+    return fclose(f) != 0;
+}
+
 /* BC_Thermohalin::BC_Pressure_Density, hydrosphere/BC_Thermohalin.cpp:518-583.  The local
  * r_air / R_Air of the reference function (:533-534) shadow the model parameters. */
 void oracle_hyd_pressure_density(oracle_ctx* c) {
@@ -1966,6 +2226,7 @@ void oracle_default_params(int model, atomdev_params* p) {
     p->r0 = 1.; p->the0 = 0.; p->phi0 = 0.;
     p->g = 9.8066; p->Buoyancy = 1.0; p->t_0 = 273.15; p->p_0 = 1013.25; /* param.py:92,151 */
     p->ep = .623; p->hp = 6.1078; p->lv = 2.52e6; p->ls = 2.83e6; p->r_water_vapour = .0094; /* param.py:77-85 */
+    p->co2_0 = 280.; /* param.py:95 */
     if (model == ATOMDEV_ATM) {
         p->re = 1000.; p->pr = .7179; p->u_0 = 8.; p->c_0 = .035;
     } else {

@@ -364,6 +364,47 @@ void atm_plot_calls(Fields& F, const Scalars& s, std::string dir) {
     ppa.Atmosphere_PlotData(name, 3, s.u_0, s.t_0, F["h"], F["v"], F["w"], F["t"], F["c"], F.precip, F.g("precipitable_water"));
 }
 
+// ---- cAtmosphereModel.cpp:612-629 and cHydrosphereModel.cpp:747-765: the ParaView sections of a time slice ----
+template <class NS>
+void atm_vtk_calls(Fields& F, const Scalars& s, std::string dir, int i_radial, int j_longal, int k_zonal) {
+    typename NS::PP_A write_File(F.im, F.jm, F.km, dir);
+    std::string bathymetry_name("bridge");
+    int Ma = 0, iter_cnt = 1;
+    double u_0 = s.u_0, t_0 = s.t_0, p_0 = 1013.25, r_air = s.r_air, c_0 = s.c_0, co2_0 = 280., hp = 6.1078, ep = .623,
+           R_Air = s.R_Air, g = s.g, L_atm = s.L_atm;
+    write_File.paraview_vtk_radial(bathymetry_name, Ma, i_radial, iter_cnt - 1, u_0, t_0, p_0, r_air, c_0, co2_0, F["h"], F["p_dyn"],
+        F["p_stat"], F["BuoyancyForce"], F["t"], F["u"], F["v"], F["w"], F["c"], F["co2"], F["cloud"], F["ice"], F["aux_u"], F["aux_v"],
+        F["aux_w"], F["radiation_3D"], F["Q_Latent"], F["Q_Sensible"], F["epsilon_3D"], F["P_rain"], F["P_snow"],
+        F.g("precipitable_water"), F.g("Q_bottom"), F.g("Q_radiation"), F.g("Q_latent"), F.g("Q_sensible"), F.g("Evaporation_Penman"),
+        F.evap, F.g("Q_Evaporation"), F.g("temperature_NASA"), F.g("precipitation_NASA"), F.g("Vegetation"), F.g("albedo"),
+        F.g("epsilon"), F.precip, F.topo, F.g("temp_NASA"));
+    write_File.paraview_vtk_longal(bathymetry_name, j_longal, iter_cnt - 1, u_0, t_0, p_0, r_air, c_0, co2_0, F["h"], F["p_dyn"],
+        F["p_stat"], F["BuoyancyForce"], F["t"], F["u"], F["v"], F["w"], F["c"], F["co2"], F["cloud"], F["ice"], F["aux_u"], F["aux_v"],
+        F["aux_w"], F["Q_Latent"], F["Q_Sensible"], F["epsilon_3D"], F["P_rain"], F["P_snow"]);
+    write_File.paraview_vtk_zonal(bathymetry_name, k_zonal, iter_cnt - 1, hp, ep, R_Air, g, L_atm, u_0, t_0, p_0, r_air, c_0, co2_0,
+        F["h"], F["p_dyn"], F["p_stat"], F["BuoyancyForce"], F["t"], F["u"], F["v"], F["w"], F["c"], F["co2"], F["cloud"], F["ice"],
+        F["aux_u"], F["aux_v"], F["aux_w"], F["Q_Latent"], F["Q_Sensible"], F["radiation_3D"], F["epsilon_3D"], F["P_rain"],
+        F["P_snow"], F["S_v"], F["S_c"], F["S_i"], F["S_r"], F["S_s"], F["S_c_c"]);
+}
+
+template <class NS>
+void hyd_vtk_calls(Fields& F, const Scalars& s, const std::string& dir, int i_radial, int j_longal, int k_zonal) {
+    typename NS::PP_H write_File(F.im, F.jm, F.km, dir);
+    const std::string bathymetry_name("bridge");
+    int iter_cnt = 1;
+    double u_0 = s.u_0, t_0 = s.t_0, r_0_water = s.r_0_water;
+    write_File.paraview_vtk_longal(bathymetry_name, j_longal, iter_cnt - 1, u_0, r_0_water, F["h"], F["p_dyn"], F["p_stat"], F["r_water"],
+        F["r_salt_water"], F["t"], F["u"], F["v"], F["w"], F["c"], F["aux_u"], F["aux_v"], F["Salt_Finger"], F["Salt_Diffusion"],
+        F["Buoyancy_Force"], F["Salt_Balance"]);
+    write_File.paraview_vtk_zonal(bathymetry_name, k_zonal, iter_cnt - 1, u_0, r_0_water, F["h"], F["p_dyn"], F["p_stat"], F["r_water"],
+        F["r_salt_water"], F["t"], F["u"], F["v"], F["w"], F["c"], F["Salt_Finger"], F["Salt_Diffusion"], F["Buoyancy_Force"],
+        F["Salt_Balance"]);
+    write_File.paraview_vtk_radial(bathymetry_name, i_radial, iter_cnt - 1, u_0, t_0, r_0_water, F["h"], F["p_dyn"], F["p_stat"],
+        F["r_water"], F["r_salt_water"], F["t"], F["u"], F["v"], F["w"], F["c"], F["aux_u"], F["aux_v"], F["Salt_Finger"],
+        F["Salt_Diffusion"], F["Buoyancy_Force"], F["Salt_Balance"], F.g("Upwelling"), F.g("Downwelling"), F.g("SaltFinger"),
+        F.g("SaltDiffusion"), F.g("BuoyancyForce_2D"), F.g("BottomWater"), F.evap, F.precip, F.topo);
+}
+
 std::string slurp(const std::string& path) {
     std::ifstream f(path, std::ios::binary);
     return std::string(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
@@ -501,6 +542,46 @@ int main(int argc, char** argv) {
         { Quiet q; atm_plot_calls<RefClasses>(RA, sa, dr_); }
         atm_plot_calls<DevClasses>(DA, sa, dd_);
         bad += same_file(dr_ + "/[bridge]_PlotData_Atm_3.xyz", dd_ + "/[bridge]_PlotData_Atm_3.xyz", "atmosphere, PlotData file");
+    }
+    {   // the ParaView section files of both models, and what their writers leave in aux_u / aux_v / aux_w
+        const int im = 9, jm = 21, km = 31;
+        const std::string dr_ = tmp + "/bridge_ref", dd_ = tmp + "/bridge_dev";
+        (void)std::system(("mkdir -p " + dr_ + " " + dd_).c_str());
+        Scalars sa; sa.re = 1000.; sa.pr = .7179; sa.u_0 = 8.; sa.c_0 = .035;
+        sa.dr = 1. / (im - 1); sa.dthe = M_PI / (jm - 1); sa.dphi = sa.dthe;
+        Fields RA(im, jm, km, sa), DA(im, jm, km, sa);
+        init_msl(RA, 17, sa); init_msl(DA, 17, sa);
+        for (Fields* F : { &RA, &DA }) {
+            std::mt19937_64 rng(18);
+            fill((*F)["epsilon_3D"], im, jm, km, rng, 0., 1.); fill((*F)["S_c_c"], im, jm, km, rng, -1e-6, 1e-6);
+            std::uniform_real_distribution<double> d(0., 1.2);
+            for (const char* n : { "temperature_NASA", "precipitation_NASA", "Vegetation", "albedo", "epsilon", "precipitable_water",
+                                   "Evaporation_Penman", "temp_NASA" })
+                for (int j = 0; j < jm; j++) for (int k = 0; k < km; k++) F->g(n).y[j][k] = d(rng);
+        }
+        { Quiet q; atm_vtk_calls<RefClasses>(RA, sa, dr_, 0, 7, 11); }
+        atm_vtk_calls<DevClasses>(DA, sa, dd_, 0, 7, 11);
+        bad += compare(RA, DA, 0., "atmosphere, ParaView sections");
+        bad += same_file(dr_ + "/[bridge]_Atm_radial_0_0.vtk", dd_ + "/[bridge]_Atm_radial_0_0.vtk", "atmosphere, radial section file");
+        bad += same_file(dr_ + "/[bridge]_Atm_longal_7_0.vtk", dd_ + "/[bridge]_Atm_longal_7_0.vtk", "atmosphere, longitudinal section file");
+        bad += same_file(dr_ + "/[bridge]_Atm_zonal_11_0.vtk", dd_ + "/[bridge]_Atm_zonal_11_0.vtk", "atmosphere, zonal section file");
+        Scalars s; s.re = 10.; s.pr = 6.957; s.u_0 = .25; s.c_0 = 34.6;
+        s.dr = sa.dr; s.dthe = sa.dthe; s.dphi = sa.dphi;
+        Fields R(im, jm, km, s), D(im, jm, km, s);
+        init_hyd(R, 19, s); init_hyd(D, 19, s);
+        for (Fields* F : { &R, &D }) {
+            std::mt19937_64 rng(20);
+            for (const char* n : { "Salt_Balance", "Salt_Finger", "Salt_Diffusion", "Buoyancy_Force", "p_stat" }) fill((*F)[n], im, jm, km, rng, -1., 1.);
+            std::uniform_real_distribution<double> d(-2., 2.);
+            for (const char* n : { "Upwelling", "Downwelling", "BottomWater" })
+                for (int j = 0; j < jm; j++) for (int k = 0; k < km; k++) F->g(n).y[j][k] = d(rng);
+        }
+        { Quiet q; hyd_vtk_calls<RefClasses>(R, s, dr_, im - 1, 7, 11); }
+        hyd_vtk_calls<DevClasses>(D, s, dd_, im - 1, 7, 11);
+        bad += compare(R, D, 0., "hydrosphere, ParaView sections");
+        bad += same_file(dr_ + "/[bridge]_Hyd_radial_8_0.vtk", dd_ + "/[bridge]_Hyd_radial_8_0.vtk", "hydrosphere, radial section file");
+        bad += same_file(dr_ + "/[bridge]_Hyd_longal_7_0.vtk", dd_ + "/[bridge]_Hyd_longal_7_0.vtk", "hydrosphere, longitudinal section file");
+        bad += same_file(dr_ + "/[bridge]_Hyd_zonal_11_0.vtk", dd_ + "/[bridge]_Hyd_zonal_11_0.vtk", "hydrosphere, zonal section file");
     }
     std::printf(bad ? "BRIDGE FAIL\n" : "BRIDGE PASS\n");
     return bad ? 1 : 0;

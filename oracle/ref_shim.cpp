@@ -430,6 +430,48 @@ int ref_write_plot_data(void* v, const char* dir) {
     return 0;
 }
 
+/* the reference's ParaView section writers; the file appears as dir/[bridge]_{Atm,Hyd}_{radial,longal,zonal}_<index>_0.vtk */
+int ref_write_vtk(void* v, int section, int index, int Ma, const char* dir) {
+    RefCtx* c = (RefCtx*)v; CoutSilencer s; copy_in(c);
+    std::string out(dir), name("bridge");
+    atomdev_params& P = c->p;
+    double p_0 = P.p_0, c_0 = P.c_0;
+    if (c->model == ATOMDEV_ATM) {
+        PostProcess_Atmosphere w(c->im, c->jm, c->km, out);
+        if (section == ATOMDEV_RADIAL)
+            w.paraview_vtk_radial(name, Ma, index, 0, P.u_0, P.t_0, p_0, P.r_air, c_0, P.co2_0, A(H), A(P_DYN), A(P_STAT), A(BUOYANCY),
+                                  A(T), A(U), A(V), A(W), A(C), A(CO2), A(CLOUD), A(ICE), A(AUX_U), A(AUX_V), A(AUX_W), A(RADIATION_3D),
+                                  A(Q_LATENT), A(Q_SENSIBLE), A(EPSILON_3D), A(P_RAIN), A(P_SNOW), B(PRECIPITABLE_WATER), B(Q_BOTTOM),
+                                  B(Q_RADIATION), B(Q_LATENT_2D), B(Q_SENSIBLE_2D), B(EVAPORATION_PENMAN), B(EVAPORATION_DALTON),
+                                  B(Q_EVAPORATION), B(TEMPERATURE_NASA), B(PRECIPITATION_NASA), B(VEGETATION), B(ALBEDO), B(EPSILON),
+                                  B(PRECIPITATION), B(TOPOGRAPHY), B(TEMP_NASA_CELSIUS));
+        else if (section == ATOMDEV_ZONAL)
+            w.paraview_vtk_zonal(name, index, 0, P.hp, P.ep, P.R_Air, P.g, P.L_atm, P.u_0, P.t_0, p_0, P.r_air, c_0, P.co2_0, A(H), A(P_DYN),
+                                 A(P_STAT), A(BUOYANCY), A(T), A(U), A(V), A(W), A(C), A(CO2), A(CLOUD), A(ICE), A(AUX_U), A(AUX_V), A(AUX_W),
+                                 A(Q_LATENT), A(Q_SENSIBLE), A(RADIATION_3D), A(EPSILON_3D), A(P_RAIN), A(P_SNOW), A(S_V), A(S_C), A(S_I),
+                                 A(S_R), A(S_S), A(S_C_C));
+        else
+            w.paraview_vtk_longal(name, index, 0, P.u_0, P.t_0, p_0, P.r_air, c_0, P.co2_0, A(H), A(P_DYN), A(P_STAT), A(BUOYANCY), A(T),
+                                  A(U), A(V), A(W), A(C), A(CO2), A(CLOUD), A(ICE), A(AUX_U), A(AUX_V), A(AUX_W), A(Q_LATENT), A(Q_SENSIBLE),
+                                  A(EPSILON_3D), A(P_RAIN), A(P_SNOW));
+    } else {
+        PostProcess_Hydrosphere w(c->im, c->jm, c->km, out);
+        if (section == ATOMDEV_RADIAL)
+            w.paraview_vtk_radial(name, index, 0, P.u_0, P.t_0, P.r_0_water, A(H), A(P_DYN), A(P_STAT), A(R_WATER), A(R_SALT_WATER), A(T),
+                                  A(U), A(V), A(W), A(C), A(AUX_U), A(AUX_V), A(SALT_FINGER), A(SALT_DIFFUSION), A(BUOYANCY), A(SALT_BALANCE),
+                                  B(UPWELLING), B(DOWNWELLING), B(SALT_FINGER_2D), B(SALT_DIFFUSION_2D), B(BUOYANCY_FORCE_2D),
+                                  B(BOTTOM_WATER), B(EVAPORATION_DALTON), B(PRECIPITATION), B(TOPOGRAPHY));
+        else if (section == ATOMDEV_ZONAL)
+            w.paraview_vtk_zonal(name, index, 0, P.u_0, P.r_0_water, A(H), A(P_DYN), A(P_STAT), A(R_WATER), A(R_SALT_WATER), A(T), A(U), A(V),
+                                 A(W), A(C), A(SALT_FINGER), A(SALT_DIFFUSION), A(BUOYANCY), A(SALT_BALANCE));
+        else
+            w.paraview_vtk_longal(name, index, 0, P.u_0, P.r_0_water, A(H), A(P_DYN), A(P_STAT), A(R_WATER), A(R_SALT_WATER), A(T), A(U), A(V),
+                                  A(W), A(C), A(AUX_U), A(AUX_V), A(SALT_FINGER), A(SALT_DIFFUSION), A(BUOYANCY), A(SALT_BALANCE));
+    }
+    copy_out(c);
+    return 0;
+}
+
 }  // extern "C"
 
 /* Land masks exactly as the reference's readers build them:

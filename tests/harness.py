@@ -32,7 +32,8 @@ F3 = dict(T=0, U=1, V=2, W=3, P_DYN=4, C=5, CLOUD=6, ICE=7, CO2=8,
 F2 = dict(TOPOGRAPHY=0, EVAPORATION_DALTON=1, PRECIPITATION=2, Q_RADIATION=3, PRECIPITABLE_WATER=4,
           EVAPORATION_PENMAN=5, Q_EVAPORATION=6, Q_LATENT_2D=7, Q_SENSIBLE_2D=8, Q_BOTTOM=9, CO2_TOTAL=10, VEGETATION=11,
           ALBEDO=12, EPSILON=13, RADIATION_SURFACE=14, UPWELLING=15, DOWNWELLING=16,
-          BOTTOM_WATER=17, SALT_FINGER_2D=18, SALT_DIFFUSION_2D=19, BUOYANCY_FORCE_2D=20, SALT_TOTAL=21)
+          BOTTOM_WATER=17, SALT_FINGER_2D=18, SALT_DIFFUSION_2D=19, BUOYANCY_FORCE_2D=20, SALT_TOTAL=21,
+          TEMPERATURE_NASA=22, PRECIPITATION_NASA=23, TEMP_NASA_CELSIUS=24)
 
 ATM_FIELDS = ["T", "U", "V", "W", "P_DYN", "C", "CLOUD", "ICE", "CO2",
               "TN", "UN", "VN", "WN", "P_DYNN", "CN", "CLOUDN", "ICEN", "CO2N",
@@ -48,7 +49,7 @@ class Params(C.Structure):
         "dt", "dr", "dthe", "dphi", "r0", "the0", "phi0",
         "re", "pr", "g", "Buoyancy", "u_0", "t_0", "c_0",
         "sc_WaterVapour", "sc_CO2", "gam", "r_air", "R_Air", "R_WaterVapour", "L_atm", "cp_l", "t_tropopause",
-        "sc", "L_hyd", "r_0_water", "ta", "pa", "ca", "p_0", "ep", "hp", "lv", "ls", "r_water_vapour")]
+        "sc", "L_hyd", "r_0_water", "ta", "pa", "ca", "p_0", "ep", "hp", "lv", "ls", "r_water_vapour", "co2_0")]
 
 
 def build_oracle():
@@ -268,6 +269,29 @@ def make_run_data_inputs(im, jm, km, seed, L_hyd=None):
         f[k] = rng.uniform(-1.0, 1.0, (im, jm, km))
     for k in RUN_DATA_FIELDS2D:
         g[k] = rng.uniform(-7.0, 7.0, (jm, km))
+    return p, f, g
+
+
+VTK_SECTIONS = {0: "radial", 1: "longal", 2: "zonal"}
+
+
+def make_vtk_inputs(model, im, jm, km, seed):
+    """Every field the ParaView section writers of a model read, all non-trivial; values that print as -0.0000;
+    temperatures on both sides of t = 1 (the zonal atmosphere section keeps the ice saturation ratio only below)."""
+    rng = np.random.default_rng(seed + 31337)
+    shp = (im, jm, km)
+    if model == ATM:
+        p = default_params(ATM, im, jm, km)
+        f, g = make_msl_inputs(im, jm, km, seed, p)
+        for k in ("EPSILON_3D", "S_C_C"):
+            f[k] = rng.uniform(-1e-3, 1.0, shp)
+        f["T"][:, ::3, :] = rng.uniform(0.7, 0.99, (im, len(range(0, jm, 3)), km))
+        for k in ("VEGETATION", "ALBEDO", "EPSILON", "TEMPERATURE_NASA", "PRECIPITATION_NASA", "TEMP_NASA_CELSIUS"):
+            g[k] = rng.uniform(0.0, 1.5, (jm, km))
+    else:
+        p, f, g = make_run_data_inputs(im, jm, km, seed)
+    f["V"][:, 3, :] = -2e-6     # a row and a column of -0.0000, so that every section holds some
+    f["W"][:, :, 1] = -4e-5
     return p, f, g
 
 

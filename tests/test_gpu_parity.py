@@ -508,6 +508,69 @@ def test_plot_data_file_bytes(model, tmp_path):
     d.close()
 
 
+def _first_difference(a, b):
+    la, lb = a.split(b"\n"), b.split(b"\n")
+    for n, (x, y) in enumerate(zip(la, lb)):
+        if x != y:
+            return "line %d: %r != %r (after %r)" % (n + 1, x, y, la[max(0, n - 3):n])
+    return "lengths %d != %d lines" % (len(la), len(lb))
+
+
+@pytest.mark.parametrize("Ma", [0, 30])
+@pytest.mark.parametrize("section,index", [(0, 0), (0, 3), (1, 5), (2, 9)])
+@pytest.mark.parametrize("model", [H.ATM, H.HYD])
+def test_vtk_section_file_bytes(model, section, index, Ma, tmp_path):
+    """The ParaView section files written from device-resident fields are byte for byte the oracle's files (pinned to
+    the reference's writers in tests/test_oracle_vs_reference.py), and the scratch the writers leave behind in
+    aux_u / aux_v / aux_w and the Celsius copy of temperature_NASA sits in the same device fields, same bits."""
+    import ctypes as C
+    if model == H.HYD and Ma:
+        pytest.skip("the hydrosphere writers take no Ma")
+    im, jm, km = 7, 13, 17
+    p, f, g = H.make_vtk_inputs(model, im, jm, km, 95)
+    o = H.CpuModel("oracle", model, im, jm, km, p, f, g)
+    d = atom_amd.DeviceModel(model, im, jm, km, atom_amd.Params.from_buffer_copy(bytes(p)))
+    d.upload_all(f, g)
+    o.lib.oracle_write_vtk.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p]
+    assert o.lib.oracle_write_vtk(o.ctx, section, index, Ma, str(tmp_path / "oracle.vtk").encode()) == 0
+    d.write_vtk(section, index, str(tmp_path / "device.vtk"), Ma)
+    mine, theirs = (tmp_path / "device.vtk").read_bytes(), (tmp_path / "oracle.vtk").read_bytes()
+    assert mine == theirs, _first_difference(mine, theirs)
+    assert b"-0.0000" in mine
+    for k in list(f) + list(g):
+        got, ref = d.download(k), (o.f[k] if k in f else o.g[k])
+        assert np.array_equal(got, ref) and np.array_equal(np.signbit(got), np.signbit(ref)), k
+    with pytest.raises(atom_amd.AtomDevError):
+        d.write_vtk(section, index, str(tmp_path / "no_such_dir" / "x.vtk"), Ma)
+    with pytest.raises(atom_amd.AtomDevError):
+        d.write_vtk(section, (im, jm, km)[section], str(tmp_path / "outside.vtk"), Ma)
+    d.close()
+
+
+@pytest.mark.parametrize("model", [H.ATM, H.HYD])
+def test_vtk_sections_full_grid(model, tmp_path):
+    """The three sections each model writes per time slice — atmosphere i = 0, j = 62, k = 87
+    (cAtmosphereModel.cpp:610-626), hydrosphere j = 75, k = 185, i = 40 (cHydrosphereModel.cpp:745-759) — on the
+    1-degree grid with the 0 Ma mask: byte for byte the oracle's files."""
+    import ctypes as C
+    import hashlib
+    im, jm, km = 41, 181, 361
+    p, f, g = H.make_vtk_inputs(model, im, jm, km, 96)
+    f["H"], g["TOPOGRAPHY"] = H.load_mask_0Ma(model)
+    o = H.CpuModel("oracle", model, im, jm, km, p, f, g)
+    d = atom_amd.DeviceModel(model, im, jm, km, atom_amd.Params.from_buffer_copy(bytes(p)))
+    d.upload_all(f, g)
+    o.lib.oracle_write_vtk.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p]
+    for section, index in (((0, 0), (1, 62), (2, 87)) if model == H.ATM else ((1, 75), (2, 185), (0, 40))):
+        assert o.lib.oracle_write_vtk(o.ctx, section, index, 0, str(tmp_path / "oracle.vtk").encode()) == 0
+        d.write_vtk(section, index, str(tmp_path / "device.vtk"), 0)
+        mine, theirs = (tmp_path / "device.vtk").read_bytes(), (tmp_path / "oracle.vtk").read_bytes()
+        assert hashlib.sha256(mine).digest() == hashlib.sha256(theirs).digest(), _first_difference(mine, theirs)
+    for k in ("AUX_U", "AUX_V", "AUX_W"):
+        assert np.array_equal(d.download(k), o.f[k]), k
+    d.close()
+
+
 def test_golden_small_hyd_bitexact():
     """HIP path against the compiled reference's own outputs (tests/golden/hyd_small.npz)."""
     z = np.load(os.path.join(GOLD, "hyd_small.npz"))

@@ -139,6 +139,38 @@ def test_plot_data_file(model, tmp_path):
     assert theirs.count(b"\n") == 1 + jm * km and b"-0.0000" in theirs
 
 
+@pytest.mark.parametrize("Ma", [0, 30])
+@pytest.mark.parametrize("section,index", [(0, 0), (0, 3), (1, 5), (2, 9)])
+@pytest.mark.parametrize("model", [H.ATM, H.HYD])
+def test_vtk_section_file(model, section, index, Ma, tmp_path):
+    """The ParaView section files (radial / longal / zonal): the oracle's file is byte for byte the file of the
+    reference's writer, and the scratch the writers leave in aux_u / aux_v / aux_w and in the Celsius copy of
+    temperature_NASA is the same, bits and sign of zero."""
+    if model == H.HYD and Ma:
+        pytest.skip("the hydrosphere writers take no Ma")
+    im, jm, km = 7, 13, 17
+    p, f, g = H.make_vtk_inputs(model, im, jm, km, 95)
+    a, b = H.CpuModel("oracle", model, im, jm, km, p, f, g), H.CpuModel("ref", model, im, jm, km, p, f, g)
+    mine = tmp_path / "mine.vtk"
+    a.lib.oracle_write_vtk.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p]
+    b.lib.ref_write_vtk.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p]
+    assert a.lib.oracle_write_vtk(a.ctx, section, index, Ma, str(mine).encode()) == 0
+    b.lib.ref_write_vtk(b.ctx, section, index, Ma, str(tmp_path).encode())
+    name = "[bridge]_%s_%s_%d_0.vtk" % ("Atm" if model == H.ATM else "Hyd", H.VTK_SECTIONS[section], index)
+    theirs = (tmp_path / name).read_bytes()
+    assert mine.read_bytes() == theirs
+    assert b"-0.0000" in theirs and theirs.count(b"SCALARS") >= 14
+    for k in f:
+        assert np.array_equal(a.f[k], b.f[k]) and np.array_equal(np.signbit(a.f[k]), np.signbit(b.f[k])), k
+    for k in g:
+        assert np.array_equal(a.g[k], b.g[k]) and np.array_equal(np.signbit(a.g[k]), np.signbit(b.g[k])), k
+    changed = [k for k in ("AUX_U", "AUX_V", "AUX_W") if not np.array_equal(a.f[k], f[k])]
+    if model == H.ATM:
+        assert changed == {0: ["AUX_V", "AUX_W"] if Ma == 0 else [], 1: ["AUX_W"], 2: ["AUX_U", "AUX_V", "AUX_W"]}[section]
+    else:
+        assert changed == (["AUX_V"] if section == 0 else [])
+
+
 @pytest.mark.parametrize("max_precipitation", [7.5, 0.0])
 def test_atm_vegetation_distribution(max_precipitation):
     import ctypes as C
