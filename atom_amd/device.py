@@ -41,6 +41,12 @@ class Params(C.Structure):
         "sc", "L_hyd", "r_0_water", "ta", "pa", "ca", "p_0", "ep", "hp", "lv", "ls", "r_water_vapour", "co2_0")]
 
 
+class HydStart(C.Structure):
+    """atomdev_hyd_start: what BC_Thermohalin's constructor receives beyond Params."""
+    _fields_ = [("i_beg", C.c_int), ("i_max", C.c_int), ("Ma", C.c_int), ("Ma_max", C.c_int), ("Ma_max_half", C.c_int),
+                ("t_average", C.c_double), ("t_cretaceous_max", C.c_double)]
+
+
 class AtomDevError(RuntimeError):
     pass
 
@@ -87,6 +93,13 @@ def load_library():
     lib.atomdev_atm_vegetation_distribution.argtypes = [vp, C.c_double]
     lib.atomdev_atm_two_category_ice_scheme.argtypes = [vp, dp]
     lib.atomdev_write_vtk.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_char_p]
+    lib.atomdev_default_hyd_start.argtypes = [C.c_int, C.POINTER(HydStart)]
+    lib.atomdev_default_hyd_start.restype = None
+    lib.atomdev_hyd_read_sea_ground.argtypes = [vp, C.c_char_p]
+    lib.atomdev_hyd_read_surface_salinity.argtypes = [vp, C.c_char_p]
+    lib.atomdev_hyd_ic_ekman_spiral.argtypes = [vp, C.c_int]
+    lib.atomdev_hyd_ic_circumpolar_current.argtypes = [vp, C.c_int]
+    lib.atomdev_hyd_bc_temperature_salinity.argtypes = [vp, C.POINTER(HydStart)]
     lib.atomdev_atm_write_plot_data.argtypes = [vp, C.c_char_p]
     lib.atomdev_hyd_write_plot_data.argtypes = [vp, C.c_char_p]
     lib.atomdev_atm_ice_water_saturation_adjustment.argtypes = [vp, dp]
@@ -214,6 +227,26 @@ class DeviceModel:
     def op(self, name):
         """One reference operator, e.g. 'atm_rk3d', 'hyd_pressure3d'."""
         self._check(getattr(self.lib, "atomdev_" + name)(self._h))
+
+    def read_sea_ground(self, path):
+        """BC_Bathymetry_Hydrosphere::BC_SeaGround: h and Bathymetry from the bathymetry file."""
+        self._check(self.lib.atomdev_hyd_read_sea_ground(self._h, os.fsencode(path)))
+
+    def read_surface_salinity(self, path):
+        """BC_Thermohalin::BC_Surface_Salinity_NASA: c at the sea level from the salinity file."""
+        self._check(self.lib.atomdev_hyd_read_surface_salinity(self._h, os.fsencode(path)))
+
+    def ic_ekman_spiral(self, i_beg=0):
+        self._check(self.lib.atomdev_hyd_ic_ekman_spiral(self._h, i_beg))
+
+    def ic_circumpolar_current(self, i_beg=0):
+        self._check(self.lib.atomdev_hyd_ic_circumpolar_current(self._h, i_beg))
+
+    def bc_temperature_salinity(self, start=None):
+        if start is None:
+            start = HydStart()
+            self.lib.atomdev_default_hyd_start(self.im, C.byref(start))
+        self._check(self.lib.atomdev_hyd_bc_temperature_salinity(self._h, C.byref(start)))
 
     def msl_data(self, radiation_model=1):
         """Results_MSL_Atm::run_MSL_data, the part that changes model fields."""

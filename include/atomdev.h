@@ -242,6 +242,42 @@ int atomdev_hyd_solid_ground(atomdev_t* h);
  * pressure and the densities of water and salt water, integrated down each column from the
  * surface level im-1.  Reads t, c; writes p_stat, r_water, r_salt_water at every point. */
 int atomdev_hyd_pressure_density(atomdev_t* h);
+
+/* ---- the hydrosphere's start of a time slice (cHydrosphereModel.cpp:244-292) ---- */
+
+/* What BC_Thermohalin's constructor receives beyond the scalars of atomdev_params: hydrosphere/BC_Thermohalin.cpp:25-82,
+ * cHydrosphereModel.cpp:182-183, 268-270; defaults param.py:53-54, 168-176. */
+typedef struct atomdev_hyd_start {
+    int i_beg, i_max;            /* first level of the thermocline (0) and the sea level (im - 1) */
+    int Ma, Ma_max, Ma_max_half; /* time slice in million years and the two constants of the Cretaceous parabola */
+    double t_average, t_cretaceous_max;
+} atomdev_hyd_start;
+void atomdev_default_hyd_start(int im, atomdev_hyd_start* s);
+
+/* BC_Bathymetry_Hydrosphere::BC_SeaGround (hydrosphere/BC_Bath_Hyd.cpp:31-114): reads the bathymetry file
+ * (lon lat depth per line, jm x km lines, longitudes -180..180), builds h (1 = solid) and Bathymetry (metres,
+ * positive down), moves both to 0..360 and removes the needles, in the reference's visiting order (the smoothing
+ * is order dependent and, once the first needle was met, keeps clearing diagonal neighbours for the rest of the
+ * grid).  A file with fewer than jm x km entries is an error (the reference aborts).  Host work; the result is
+ * uploaded as ATOMDEV_H and ATOMDEV_TOPOGRAPHY. */
+int atomdev_hyd_read_sea_ground(atomdev_t* h, const char* path);
+/* BC_Thermohalin::BC_Surface_Salinity_NASA (hydrosphere/BC_Thermohalin.cpp:636-670): surface salinity in psu
+ * (lon lat value per line, km x jm lines, j fastest) into c at the sea level, divided by c_0; negative values
+ * leave c as it is. */
+int atomdev_hyd_read_surface_salinity(atomdev_t* h, const char* path);
+/* BC_Thermohalin::IC_v_w_EkmanSpiral (hydrosphere/BC_Thermohalin.cpp:88-360): the surface wind of the transfer
+ * file becomes the surface current (3 %, turned by 45 degrees, band by band in latitude), then every column is
+ * filled downwards from it.  The latitude bands are fixed rows of the 1-degree grid (30, 60, ... 150): jm must
+ * exceed 150, as in the reference, which reads beyond its arrays otherwise.  asin / sin / cos of the surface
+ * step come from the device's math library: v and w agree with the reference within 1e-10 relative. */
+int atomdev_hyd_ic_ekman_spiral(atomdev_t* h, int i_beg);
+/* BC_Thermohalin::IC_CircumPolar_Current (hydrosphere/BC_Thermohalin.cpp:676-690): w = 1 cm/s in the water
+ * cells of rows 147..152 (jm must exceed 152) from level i_beg upwards. */
+int atomdev_hyd_ic_circumpolar_current(atomdev_t* h, int i_beg);
+/* BC_Thermohalin::BC_Temperature_Salinity (hydrosphere/BC_Thermohalin.cpp:367-513): surface temperature not
+ * below 4 C, parabolic decrease of t and c with depth down to level i_beg, (ta, ca) below and on land. */
+int atomdev_hyd_bc_temperature_salinity(atomdev_t* h, const atomdev_hyd_start* s);
+
 /* solveRungeKutta_3D_Hydrosphere + RK_RHS_3D_Hydrosphere
  * (hydrosphere/RungeKutta_Hyd.cpp:30-124, RHS_Hyd.cpp:60-447) */
 int atomdev_hyd_rk3d(atomdev_t* h);

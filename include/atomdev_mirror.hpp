@@ -673,13 +673,47 @@ private:
 // (hydrosphere/cHydrosphereModel.cpp:448-451); the initial-condition builders stay on the host.
 class BC_Thermohalin {
 public:
-    BC_Thermohalin(int im, int jm, int km, int, int, int, int, int, double dr, double g, double r_0_water, double, double, double,
-                   double ta, double ca, double pa, double u_0, double p_0, double t_0, double c_0, double, double L_hyd, double,
-                   double, double, double, const std::string&)
+    BC_Thermohalin(int im, int jm, int km, int i_beg, int i_max, int Ma, int Ma_max, int Ma_max_half, double dr, double g,
+                   double r_0_water, double, double, double, double ta, double ca, double pa, double u_0, double p_0, double t_0,
+                   double c_0, double, double L_hyd, double t_average, double t_cretaceous_max, double, double, const std::string&)
         : im_(im), jm_(jm), km_(km) {
         atomdev_params& p = Device::of(ATOMDEV_HYD).params();
         p.dr = dr; p.g = g; p.r_0_water = r_0_water; p.ta = ta; p.ca = ca; p.pa = pa; p.u_0 = u_0; p.p_0 = p_0; p.t_0 = t_0;
         p.c_0 = c_0; p.L_hyd = L_hyd;
+        start_.i_beg = i_beg; start_.i_max = i_max; start_.Ma = Ma; start_.Ma_max = Ma_max; start_.Ma_max_half = Ma_max_half;
+        start_.t_average = t_average; start_.t_cretaceous_max = t_cretaceous_max;
+    }
+    // hydrosphere/BC_Thermohalin.cpp:88-360 (rad and the are arguments the reference never reads)
+    void IC_v_w_EkmanSpiral(Array_1D&, Array_1D&, Array& h, Array& v, Array& w) {
+        Device& d = Device::of(ATOMDEV_HYD);
+        d.grid(im_, jm_, km_);
+        push_all(d, { { ATOMDEV_H, &h }, { ATOMDEV_V, &v }, { ATOMDEV_W, &w } });
+        d.run(atomdev_hyd_ic_ekman_spiral(d.handle(), start_.i_beg), "atomdev_hyd_ic_ekman_spiral");
+        pull_all(d, { { ATOMDEV_V, &v }, { ATOMDEV_W, &w } });
+    }
+    // hydrosphere/BC_Thermohalin.cpp:676-690 (only w changes)
+    void IC_CircumPolar_Current(Array& h, Array&, Array&, Array& w, Array&) {
+        Device& d = Device::of(ATOMDEV_HYD);
+        d.grid(im_, jm_, km_);
+        push_all(d, { { ATOMDEV_H, &h }, { ATOMDEV_W, &w } });
+        d.run(atomdev_hyd_ic_circumpolar_current(d.handle(), start_.i_beg), "atomdev_hyd_ic_circumpolar_current");
+        pull_all(d, { { ATOMDEV_W, &w } });
+    }
+    // hydrosphere/BC_Thermohalin.cpp:367-513 (p_dyn is not touched; the banner is not printed)
+    void BC_Temperature_Salinity(Array& h, Array& t, Array& c, Array&) {
+        Device& d = Device::of(ATOMDEV_HYD);
+        d.grid(im_, jm_, km_);
+        push_all(d, { { ATOMDEV_H, &h }, { ATOMDEV_T, &t }, { ATOMDEV_C, &c } });
+        d.run(atomdev_hyd_bc_temperature_salinity(d.handle(), &start_), "atomdev_hyd_bc_temperature_salinity");
+        pull_all(d, { { ATOMDEV_T, &t }, { ATOMDEV_C, &c } });
+    }
+    // hydrosphere/BC_Thermohalin.cpp:636-670
+    void BC_Surface_Salinity_NASA(const std::string& Name_SurfaceSalinity_File, Array& c) {
+        Device& d = Device::of(ATOMDEV_HYD);
+        d.grid(im_, jm_, km_);
+        push_all(d, { { ATOMDEV_C, &c } });
+        d.run(atomdev_hyd_read_surface_salinity(d.handle(), Name_SurfaceSalinity_File.c_str()), "atomdev_hyd_read_surface_salinity");
+        pull_all(d, { { ATOMDEV_C, &c } });
     }
     // hydrosphere/BC_Thermohalin.cpp:518-583 (h is an argument the reference never reads)
     void BC_Pressure_Density(Array& p_stat, Array& r_water, Array& r_salt_water, Array& t, Array& c, Array&) {
@@ -696,6 +730,25 @@ public:
         push_all(d, { { ATOMDEV_U, &u }, { ATOMDEV_V, &v }, { ATOMDEV_W, &w }, { ATOMDEV_T, &t }, { ATOMDEV_C, &c } });
         d.run(atomdev_hyd_value_limitation(d.handle()), "atomdev_hyd_value_limitation");
         pull_all(d, { { ATOMDEV_U, &u }, { ATOMDEV_V, &v }, { ATOMDEV_W, &w }, { ATOMDEV_T, &t }, { ATOMDEV_C, &c } });
+    }
+
+private:
+    int im_, jm_, km_;
+    atomdev_hyd_start start_;
+};
+
+// hydrosphere/BC_Bath_Hyd.h: the bathymetry reader.
+class BC_Bathymetry_Hydrosphere {
+public:
+    BC_Bathymetry_Hydrosphere(int im, int jm, int km) : im_(im), jm_(jm), km_(km) {}
+    // hydrosphere/BC_Bath_Hyd.cpp:31-114
+    void BC_SeaGround(const std::string& bathymetry_file, double L_hyd, Array& h, Array_2D& Bathymetry) {
+        Device& d = Device::of(ATOMDEV_HYD);
+        d.grid(im_, jm_, km_);
+        d.params().L_hyd = L_hyd;
+        d.run(atomdev_hyd_read_sea_ground(d.handle(), bathymetry_file.c_str()), "atomdev_hyd_read_sea_ground");
+        d.pull(ATOMDEV_H, h);
+        d.pull2d(ATOMDEV_TOPOGRAPHY, Bathymetry);
     }
 
 private:

@@ -1936,6 +1936,180 @@ int oracle_write_vtk(oracle_ctx* c, int section, int index, int Ma, const char* 
     return fclose(f) != 0;
 }
 
+/* ---- the hydrosphere's start of a time slice (cHydrosphereModel.cpp:244-292) ---- */
+
+/* BC_Thermohalin::IC_v_w_EkmanSpiral, hydrosphere/BC_Thermohalin.cpp:88-360: six latitude bands written out as in
+ * the reference (three assignments in a row, each testing what the one before left), then the walk down the columns. */
+static void ekman_band(oracle_ctx* c, int j0, int j1, int sel, int third, const double sv[3], const double sw[3],
+                       double water_unused, double Ekman_angle) {
+    const int L = c->im - 1;
+    (void)water_unused;
+    for (int j = j0; j < j1; j++)
+        for (int k = 0; k < c->km; k++)
+            if (is_fluid(c, L, j, k)) {
+                double* v = &A3(c, ATOMDEV_V, L, j, k);
+                double* w = &A3(c, ATOMDEV_W, L, j, k);
+                double vel_magnitude = sqrt(*v * *v + *w * *w);
+                if (*w == 0.) *w = 1.e-6;
+                if (*v == 0.) *v = 1.e-6;
+                if (vel_magnitude == 0.) vel_magnitude = 1.e-6;
+                double alfa = asin(fabs(*w) / vel_magnitude), angle;
+                int plus = sel == 0 ? *w >= 0. : (sel == 1 ? *v >= 0. : *v <= 0.);
+                if (plus) angle = +alfa - Ekman_angle;
+                else angle = -alfa - Ekman_angle;
+                if (*w >= 0. && angle >= 0.) { *v = sv[0] * vel_magnitude * cos(angle); *w = sw[0] * vel_magnitude * sin(angle); }
+                if (*w >= 0. && angle <= 0.) { *v = sv[1] * vel_magnitude * cos(angle); *w = sw[1] * vel_magnitude * sin(angle); }
+                if (third == 0 ? *w <= 0. : (third == 1 ? *v <= 0. : *v >= 0.)) {
+                    *v = sv[2] * vel_magnitude * cos(angle); *w = sw[2] * vel_magnitude * sin(angle);
+                }
+            }
+}
+
+void oracle_hyd_ic_ekman_spiral(oracle_ctx* c, int i_beg) {
+    const int im = c->im, jm = c->jm, km = c->km, j_half = (jm - 1) / 2;
+    const double water_wind = .03, u_0 = c->p.u_0;
+    const double pi180 = 180. / M_PI, Ekman_angle = 45.0 / pi180;
+    static const double P3[3] = { +1., +1., +1. }, M3[3] = { -1., -1., -1. };
+    static const double ferrel_n_v[3] = { +1., +1., -1. }, ferrel_n_w[3] = { +1., -1., -1. };
+    static const double ferrel_s_v[3] = { -1., -1., +1. }, ferrel_s_w[3] = { +1., -1., -1. };
+    for (int j = 0; j < jm; j++)
+        for (int k = 0; k < km; k++)
+            if (is_fluid(c, im - 1, j, k)) {
+                A3(c, ATOMDEV_V, im - 1, j, k) = water_wind * A3(c, ATOMDEV_V, im - 1, j, k) / u_0;
+                A3(c, ATOMDEV_W, im - 1, j, k) = water_wind * A3(c, ATOMDEV_W, im - 1, j, k) / u_0;
+            }
+    ekman_band(c, 0, 30, 0, 0, P3, P3, 0., Ekman_angle);                    /* :106-140 */
+    ekman_band(c, 30, 60, 1, 1, ferrel_n_v, ferrel_n_w, 0., Ekman_angle);   /* :143-177 */
+    ekman_band(c, 60, 90, 0, 0, P3, P3, 0., Ekman_angle);                   /* :180-214 */
+    ekman_band(c, 90, 120, 0, 0, M3, P3, 0., Ekman_angle);                  /* :217-251 */
+    ekman_band(c, 120, 150, 2, 2, ferrel_s_v, ferrel_s_w, 0., Ekman_angle); /* :254-288 */
+    ekman_band(c, 150, jm, 0, 0, M3, P3, 0., Ekman_angle);                  /* :291-324 */
+    for (int j = 0; j < jm; j++)
+        for (int i = im - 2; i >= i_beg; i--) {
+            double gam_z = M_PI * (double)(i - i_beg) / (double)(im - 1 - i_beg);
+            double exp_gam_z = exp(-gam_z), sin_gam_z = sin(gam_z), cos_gam_z = cos(gam_z);
+            for (int k = 0; k < km; k++)
+                if (is_fluid(c, i, j, k)) {
+                    double v_g = A3(c, ATOMDEV_V, i + 1, j, k), w_g = A3(c, ATOMDEV_W, i + 1, j, k);
+                    if (j > j_half) sin_gam_z = -sin(gam_z);
+                    A3(c, ATOMDEV_V, i, j, k) = w_g * exp_gam_z * sin_gam_z + v_g * (1. - exp_gam_z * cos_gam_z);
+                    A3(c, ATOMDEV_W, i, j, k) = w_g * (1. - exp_gam_z * cos_gam_z) - v_g * exp_gam_z * sin_gam_z;
+                }
+        }
+}
+
+/* BC_Thermohalin::IC_CircumPolar_Current, hydrosphere/BC_Thermohalin.cpp:676-690 */
+void oracle_hyd_ic_circumpolar_current(oracle_ctx* c, int i_beg) {
+    for (int i = i_beg; i < c->im; i++)
+        for (int j = 147; j < 153; j++)
+            for (int k = 0; k < c->km; k++)
+                if (is_fluid(c, i, j, k)) A3(c, ATOMDEV_W, i, j, k) = .01 / c->p.u_0;
+}
+
+/* BC_Thermohalin::BC_Temperature_Salinity, hydrosphere/BC_Thermohalin.cpp:367-513 (without the printout) */
+void oracle_hyd_bc_temperature_salinity(oracle_ctx* c, const atomdev_hyd_start* s) {
+    const int im = c->im, jm = c->jm, km = c->km, i_beg = s->i_beg, i_max = s->i_max, Ma = s->Ma;
+    const double ta = c->p.ta, ca = c->p.ca, t_0 = c->p.t_0, c_0 = c->p.c_0;
+    double t_cretaceous_coeff = s->t_cretaceous_max / ((double)s->Ma_max_half - (double)(s->Ma_max_half * s->Ma_max_half / s->Ma_max));
+    double t_cretaceous = t_cretaceous_coeff * (double)(-(Ma * Ma) / s->Ma_max + Ma);
+    if (Ma == 0) t_cretaceous = 0.;
+    t_cretaceous = 0.;
+    double c_average = (s->t_average + 346.) / 10.;
+    double c_cretaceous = (s->t_average + t_cretaceous + 346.) / 10.;
+    c_cretaceous = c_cretaceous - c_average;
+    if (Ma == 0) c_cretaceous = 0.;
+    for (int k = 0; k < km; k++)
+        for (int j = 0; j < jm; j++) {
+            if (is_fluid(c, im - 1, j, k)) {
+                A3(c, ATOMDEV_T, im - 1, j, k) = A3(c, ATOMDEV_T, im - 1, j, k) + t_cretaceous;
+                double t_Celsius = A3(c, ATOMDEV_T, im - 1, j, k) * t_0 - t_0;
+                if (t_Celsius < 4.) A3(c, ATOMDEV_T, im - 1, j, k) = ta + t_cretaceous;
+                if (Ma == 0) A3(c, ATOMDEV_C, im - 1, j, k) = A3(c, ATOMDEV_C, im - 1, j, k) + c_cretaceous / c_0;
+            } else {
+                A3(c, ATOMDEV_T, im - 1, j, k) = ta + t_cretaceous;
+                A3(c, ATOMDEV_C, im - 1, j, k) = ca + c_cretaceous / c_0;
+            }
+        }
+    for (int k = 0; k < km; k++)
+        for (int j = 0; j < jm; j++) {
+            double tm_tbeg = (A3(c, ATOMDEV_T, im - 1, j, k) - ta) / (double)(i_max * i_max - i_beg * i_beg);
+            double cm_cbeg = (A3(c, ATOMDEV_C, im - 1, j, k) - ca) / (double)(i_max * i_max - i_beg * i_beg);
+            for (int i = i_beg; i < im - 1; i++) {
+                if (is_fluid(c, i, j, k)) {
+                    A3(c, ATOMDEV_T, i, j, k) = ta + tm_tbeg * (double)(i * i - i_beg * i_beg);
+                    double t_Celsius = A3(c, ATOMDEV_T, i, j, k) * t_0 - t_0;
+                    A3(c, ATOMDEV_C, i, j, k) = ca + cm_cbeg * (double)(i * i - i_beg * i_beg);
+                    if (t_Celsius < 4.) { A3(c, ATOMDEV_T, i, j, k) = ta; A3(c, ATOMDEV_C, i, j, k) = ca; }
+                } else {
+                    A3(c, ATOMDEV_T, i, j, k) = ta; A3(c, ATOMDEV_C, i, j, k) = ca;
+                }
+            }
+        }
+    for (int i = 0; i < i_beg; i++)
+        for (int j = 0; j < jm; j++)
+            for (int k = 0; k < km; k++)
+                if (is_fluid(c, i, j, k)) { A3(c, ATOMDEV_T, i, j, k) = ta; A3(c, ATOMDEV_C, i, j, k) = ca; }
+}
+
+/* BC_Thermohalin::BC_Surface_Salinity_NASA, hydrosphere/BC_Thermohalin.cpp:636-670, for files whose entries are all
+ * numbers (the reference's stream extraction and fscanf part ways on anything else). */
+int oracle_hyd_read_surface_salinity(oracle_ctx* c, const char* path) {
+    FILE* f = fopen(path, "r");
+    if (!f) return 1;
+    double dummy_1, dummy_2, dummy_3 = 0.;
+    for (int k = 0; k < c->km && !feof(f); k++)
+        for (int j = 0; j < c->jm; j++) {
+            if (fscanf(f, "%lf %lf %lf", &dummy_1, &dummy_2, &dummy_3) != 3) dummy_3 = 0.;
+            if (dummy_3 < 0.) dummy_3 = c->p.ca;
+            else A3(c, ATOMDEV_C, c->im - 1, j, k) = dummy_3 / c->p.c_0;
+        }
+    fclose(f);
+    return 0;
+}
+
+/* lib/Utils.cpp:31-37 */
+static void move_data(double* data, int len) {
+    for (int i = 0; i < len / 2; i++) { double x = data[i]; data[i] = data[len / 2 + i]; data[len / 2 + i] = x; }
+    data[len - 1] = data[0];
+}
+
+/* BC_Bathymetry_Hydrosphere::BC_SeaGround, hydrosphere/BC_Bath_Hyd.cpp:31-114, for well-formed files of jm x km lines */
+int oracle_hyd_read_sea_ground(oracle_ctx* c, const char* path) {
+    const int im = c->im, jm = c->jm, km = c->km;
+    FILE* f = fopen(path, "r");
+    if (!f) return 1;
+    memset(c->f[ATOMDEV_H], 0, sizeof(double) * (size_t)im * jm * km);
+    for (int j = 0; j < jm; j++)
+        for (int k = 0; k < km; k++) {
+            double lon, lat, depth = 999;
+            if (fscanf(f, "%lf %lf %lf", &lon, &lat, &depth) != 3) { fclose(f); return 2; }
+            if (depth > 0.) depth = 0;
+            int i_boden = (im - 1) + (int)floor(depth / c->p.L_hyd * (im - 1));
+            A2(c, ATOMDEV_TOPOGRAPHY, j, k) = -depth;
+            for (int i = 0; i <= i_boden; i++) A3(c, ATOMDEV_H, i, j, k) = 1.;
+        }
+    fclose(f);
+    for (int j = 0; j < jm; j++) {
+        move_data(&A2(c, ATOMDEV_TOPOGRAPHY, j, 0), km);
+        for (int i = 0; i < im; i++) move_data(&A3(c, ATOMDEV_H, i, j, 0), km);
+    }
+    double h_center = 0.;
+    for (int k = 2; k < km - 2; k++)
+        for (int j = 2; j < jm - 2; j++)
+            for (int i = 2; i < im - 2; i++) {
+                if (is_land(c, i, j, k) && (is_fluid(c, i, j + 1, k) && is_fluid(c, i, j - 1, k))
+                    && (is_fluid(c, i, j, k + 1) && is_fluid(c, i, j, k - 1))) {
+                    h_center = A3(c, ATOMDEV_H, i, j, k);
+                    A3(c, ATOMDEV_H, i, j, k) = 0.;
+                }
+                if (h_center == 1. && is_fluid(c, i, j - 2, k) && is_fluid(c, i, j, k + 2)) A3(c, ATOMDEV_H, i, j - 1, k + 1) = 0.;
+                if (h_center == 1. && is_fluid(c, i, j - 2, k) && is_fluid(c, i, j, k - 2)) A3(c, ATOMDEV_H, i, j - 1, k - 1) = 0.;
+                if (h_center == 1. && is_fluid(c, i, j + 2, k) && is_fluid(c, i, j, k - 2)) A3(c, ATOMDEV_H, i, j + 1, k - 1) = 0.;
+                if (h_center == 1. && is_fluid(c, i, j + 2, k) && is_fluid(c, i, j, k + 2)) A3(c, ATOMDEV_H, i, j + 1, k + 1) = 0.;
+            }
+    return 0;
+}
+
 /* BC_Thermohalin::BC_Pressure_Density, hydrosphere/BC_Thermohalin.cpp:518-583.  The local
  * r_air / R_Air of the reference function (:533-534) shadow the model parameters. */
 void oracle_hyd_pressure_density(oracle_ctx* c) {

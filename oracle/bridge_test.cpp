@@ -35,6 +35,7 @@
 #include "RungeKutta_Hyd.h"
 #include "Pressure_Hyd.h"
 #include "BC_Hyd.h"
+#include "BC_Bath_Hyd.h"
 #include "BC_Thermohalin.h"
 #include "Results_Hyd.h"
 #include "PostProcess_Atm.h"
@@ -53,6 +54,7 @@ struct RefClasses {
     typedef ::RHS_Hydrosphere RHS_H; typedef ::RungeKutta_Hydrosphere RK_H; typedef ::Pressure_Hyd P_H; typedef ::BC_Hydrosphere BC_H;
     typedef ::BC_Thermohalin TH_H; typedef ::Results_Hyd RES_H;
     typedef ::PostProcess_Atmosphere PP_A; typedef ::PostProcess_Hydrosphere PP_H;
+    typedef ::BC_Bathymetry_Hydrosphere BATH_H;
 };
 struct DevClasses {
     typedef atomdev_mirror::RHS_Atmosphere RHS_A; typedef atomdev_mirror::RungeKutta_Atmosphere RK_A;
@@ -62,6 +64,7 @@ struct DevClasses {
     typedef atomdev_mirror::Pressure_Hyd P_H; typedef atomdev_mirror::BC_Hydrosphere BC_H;
     typedef atomdev_mirror::BC_Thermohalin TH_H; typedef atomdev_mirror::Results_Hyd RES_H;
     typedef atomdev_mirror::PostProcess_Atmosphere PP_A; typedef atomdev_mirror::PostProcess_Hydrosphere PP_H;
+    typedef atomdev_mirror::BC_Bathymetry_Hydrosphere BATH_H;
 };
 
 struct Scalars {
@@ -405,6 +408,25 @@ void hyd_vtk_calls(Fields& F, const Scalars& s, const std::string& dir, int i_ra
         F.g("SaltDiffusion"), F.g("BuoyancyForce_2D"), F.g("BottomWater"), F.evap, F.precip, F.topo);
 }
 
+// ---- cHydrosphereModel.cpp:244-292: the hydrosphere's start of a time slice ----
+template <class NS>
+void hyd_start_calls(Fields& F, const Scalars& s, const std::string& bathymetry_filepath, const std::string& Name_SurfaceSalinity_File) {
+    const int im = F.im, jm = F.jm, km = F.km;
+    int i_max = im - 1, i_beg = 0, Ma = 0, Ma_max = 300, Ma_max_half = 150;
+    double ua = 0., va = 0., wa = 0., p_0 = 1013.25, cp_w = 4182., t_average = 15., t_cretaceous_max = 10., t_equator = 1.1355,
+           t_pole = 1.0146;
+    std::string input_path;
+    typename NS::BATH_H depth(im, jm, km);
+    depth.BC_SeaGround(bathymetry_filepath, s.L_hyd, F["h"], F.topo);
+    typename NS::TH_H oceanflow(im, jm, km, i_beg, i_max, Ma, Ma_max, Ma_max_half, s.dr, s.g, s.r_0_water, ua, va, wa, s.ta, s.ca, s.pa,
+                                s.u_0, p_0, s.t_0, s.c_0, cp_w, s.L_hyd, t_average, t_cretaceous_max, t_equator, t_pole, input_path);
+    oceanflow.BC_Surface_Salinity_NASA(Name_SurfaceSalinity_File, F["c"]);
+    oceanflow.IC_v_w_EkmanSpiral(F.rad, F.the, F["h"], F["v"], F["w"]);
+    if (Ma <= 41) oceanflow.IC_CircumPolar_Current(F["h"], F["u"], F["v"], F["w"], F["c"]);
+    oceanflow.BC_Temperature_Salinity(F["h"], F["t"], F["c"], F["p_dyn"]);
+    oceanflow.BC_Pressure_Density(F["p_stat"], F["r_water"], F["r_salt_water"], F["t"], F["c"], F["h"]);
+}
+
 std::string slurp(const std::string& path) {
     std::ifstream f(path, std::ios::binary);
     return std::string(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
@@ -434,6 +456,8 @@ int compare(Fields& A, Fields& B, double tol, const char* what) {
     }
     B.g("evap") ; A.g("evap");  // compare the constructor-made surface fields as well
     for (int j = 0; j < A.jm; j++) for (int k = 0; k < A.km; k++) { A.g("evap").y[j][k] = A.evap.y[j][k]; B.g("evap").y[j][k] = B.evap.y[j][k]; }
+    A.g("topo"); B.g("topo");
+    for (int j = 0; j < A.jm; j++) for (int k = 0; k < A.km; k++) { A.g("topo").y[j][k] = A.topo.y[j][k]; B.g("topo").y[j][k] = B.topo.y[j][k]; }
     A.g("precip"); B.g("precip");
     for (int j = 0; j < A.jm; j++) for (int k = 0; k < A.km; k++) { A.g("precip").y[j][k] = A.precip.y[j][k]; B.g("precip").y[j][k] = B.precip.y[j][k]; }
     for (size_t n = 0; n < A.names2.size(); n++) {
@@ -582,6 +606,32 @@ int main(int argc, char** argv) {
         bad += same_file(dr_ + "/[bridge]_Hyd_radial_8_0.vtk", dd_ + "/[bridge]_Hyd_radial_8_0.vtk", "hydrosphere, radial section file");
         bad += same_file(dr_ + "/[bridge]_Hyd_longal_7_0.vtk", dd_ + "/[bridge]_Hyd_longal_7_0.vtk", "hydrosphere, longitudinal section file");
         bad += same_file(dr_ + "/[bridge]_Hyd_zonal_11_0.vtk", dd_ + "/[bridge]_Hyd_zonal_11_0.vtk", "hydrosphere, zonal section file");
+    }
+    {   // the hydrosphere's start of a time slice; the Ekman bands are rows of the 1-degree grid
+        Scalars s; s.re = 10.; s.pr = 6.957; s.u_0 = .25; s.c_0 = 34.6;
+        const int im = 9, jm = 181, km = 24;
+        s.dr = 1. / (im - 1); s.dthe = M_PI / (jm - 1); s.dphi = s.dthe;
+        const std::string bath = tmp + "/bridge_bathymetry.xyz", salt = tmp + "/bridge_salinity.xyz";
+        {
+            std::mt19937_64 rng(21);
+            std::uniform_real_distribution<double> z(-1400., 300.), c(-5., 38.);
+            std::ofstream fb(bath), fs(salt);
+            for (int j = 0; j < jm; j++) for (int k = 0; k < km; k++) fb << k - 180 << " " << 90 - j << " " << z(rng) << "\n";
+            for (int k = 0; k < km; k++) for (int j = 0; j < jm; j++) fs << k << " " << 90 - j << " " << c(rng) << "\n";
+        }
+        Fields R(im, jm, km, s), D(im, jm, km, s);
+        init_hyd(R, 22, s); init_hyd(D, 22, s);
+        for (Fields* F : { &R, &D }) {
+            std::mt19937_64 rng(23);
+            std::uniform_real_distribution<double> wind(-10., 10.);
+            for (int j = 0; j < jm; j++) for (int k = 0; k < km; k++) {
+                (*F)["v"].x[im - 1][j][k] = wind(rng); (*F)["w"].x[im - 1][j][k] = wind(rng);
+            }
+            (void)(*F)["p_stat"];
+        }
+        { Quiet q; hyd_start_calls<RefClasses>(R, s, bath, salt); }
+        hyd_start_calls<DevClasses>(D, s, bath, salt);
+        bad += compare(R, D, 1e-10, "hydrosphere, start of a time slice");
     }
     std::printf(bad ? "BRIDGE FAIL\n" : "BRIDGE PASS\n");
     return bad ? 1 : 0;

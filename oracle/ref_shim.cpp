@@ -97,6 +97,8 @@ void copy_out(RefCtx* c) {
 
 }  // namespace
 
+extern "C" void ref_read_mask(void* v, const char* xyz_path);
+
 extern "C" {
 
 void* ref_create(int model, int im, int jm, int km, const atomdev_params* p) {
@@ -348,6 +350,47 @@ void ref_hyd_pressure_density(void* v) {
                              P.ca, P.pa, P.u_0, P.p_0, P.t_0, P.c_0, 4182.0, P.L_hyd, 15.0, 10.0, 1.1355, 1.0146, "");
     oceanflow.BC_Pressure_Density(A(P_STAT), A(R_WATER), A(R_SALT_WATER), A(T), A(C), A(H));
     copy_out(c);
+}
+
+/* the hydrosphere's start of a time slice: BC_Thermohalin's initial conditions and the two readers */
+static BC_Thermohalin make_oceanflow(RefCtx* c, const atomdev_hyd_start* s) {
+    const atomdev_params& P = c->p;
+    return BC_Thermohalin(c->im, c->jm, c->km, s->i_beg, s->i_max, s->Ma, s->Ma_max, s->Ma_max_half, P.dr, P.g, P.r_0_water, 0., 0., 0.,
+                          P.ta, P.ca, P.pa, P.u_0, P.p_0, P.t_0, P.c_0, 4182.0, P.L_hyd, s->t_average, s->t_cretaceous_max, 1.1355,
+                          1.0146, "");
+}
+void ref_hyd_ic_ekman_spiral(void* v, int i_beg) {
+    RefCtx* c = (RefCtx*)v; CoutSilencer q; copy_in(c);
+    atomdev_hyd_start s = { i_beg, c->im - 1, 0, 300, 150, 15., 10. };
+    BC_Thermohalin oceanflow = make_oceanflow(c, &s);
+    oceanflow.IC_v_w_EkmanSpiral(c->rad, c->the, A(H), A(V), A(W));
+    copy_out(c);
+}
+void ref_hyd_ic_circumpolar_current(void* v, int i_beg) {
+    RefCtx* c = (RefCtx*)v; CoutSilencer q; copy_in(c);
+    atomdev_hyd_start s = { i_beg, c->im - 1, 0, 300, 150, 15., 10. };
+    BC_Thermohalin oceanflow = make_oceanflow(c, &s);
+    oceanflow.IC_CircumPolar_Current(A(H), A(U), A(V), A(W), A(C));
+    copy_out(c);
+}
+void ref_hyd_bc_temperature_salinity(void* v, const atomdev_hyd_start* s) {
+    RefCtx* c = (RefCtx*)v; CoutSilencer q; copy_in(c);
+    BC_Thermohalin oceanflow = make_oceanflow(c, s);
+    oceanflow.BC_Temperature_Salinity(A(H), A(T), A(C), A(P_DYN));
+    copy_out(c);
+}
+int ref_hyd_read_surface_salinity(void* v, const char* path) {
+    RefCtx* c = (RefCtx*)v; CoutSilencer q; copy_in(c);
+    atomdev_hyd_start s = { 0, c->im - 1, 0, 300, 150, 15., 10. };
+    BC_Thermohalin oceanflow = make_oceanflow(c, &s);
+    oceanflow.BC_Surface_Salinity_NASA(path, A(C));
+    copy_out(c);
+    return 0;
+}
+int ref_hyd_read_sea_ground(void* v, const char* path) {
+    copy_in((RefCtx*)v);  // the other fields pass through unchanged
+    ref_read_mask(v, path);
+    return 0;
 }
 
 void ref_hyd_solid_ground(void* v) {

@@ -295,6 +295,59 @@ def make_vtk_inputs(model, im, jm, km, seed):
     return p, f, g
 
 
+class HydStart(C.Structure):
+    """atomdev_hyd_start (include/atomdev.h)"""
+    _fields_ = [("i_beg", C.c_int), ("i_max", C.c_int), ("Ma", C.c_int), ("Ma_max", C.c_int), ("Ma_max_half", C.c_int),
+                ("t_average", C.c_double), ("t_cretaceous_max", C.c_double)]
+
+
+def hyd_start(im, i_beg=0, Ma=0):
+    return HydStart(i_beg, im - 1, Ma, 300, 150, 15.0, 10.0)
+
+
+def make_hyd_start_inputs(im, jm, km, seed):
+    """The hydrosphere after Atmosphere_TransferFile_read: surface winds in m/s at the sea level (some exactly zero,
+    alone and in pairs), surface temperatures on both sides of 4 C, everything else as make_inputs leaves it."""
+    p = default_params(HYD, im, jm, km)
+    f, g = make_inputs(HYD, im, jm, km, seed, "blobs", p)
+    f = {k: f[k] for k in HYD_FIELDS}
+    rng = np.random.default_rng(seed + 2718)
+    f["V"][im - 1] = rng.uniform(-10.0, 10.0, (jm, km))
+    f["W"][im - 1] = rng.uniform(-10.0, 10.0, (jm, km))
+    f["V"][im - 1][rng.uniform(0, 1, (jm, km)) < 0.03] = 0.0
+    f["W"][im - 1][rng.uniform(0, 1, (jm, km)) < 0.03] = 0.0
+    both = rng.uniform(0, 1, (jm, km)) < 0.02
+    f["V"][im - 1][both] = 0.0
+    f["W"][im - 1][both] = 0.0
+    f["T"][im - 1] = rng.uniform(0.99, 1.1, (jm, km))
+    return p, f, g
+
+
+def write_bathymetry_file(path, jm, km, seed, L_hyd=1000.0):
+    """A bathymetry file in the reference's format (lon lat depth, jm x km lines, longitudes from -180): smooth
+    continents, trenches deeper than the model ocean, and single-cell islands for the needle smoothing."""
+    rng = np.random.default_rng(seed)
+    jj, kk = np.meshgrid(np.arange(jm), np.arange(km), indexing="ij")
+    z = 900.0 * np.sin(jj / 9.0 + 1.0) * np.cos(kk / 11.0) + rng.uniform(-400.0, 250.0, (jm, km)) - 300.0
+    z[rng.uniform(0, 1, (jm, km)) < 0.01] = -1.6 * L_hyd
+    z[rng.uniform(0, 1, (jm, km)) < 0.02] = 50.0
+    with open(path, "w") as fh:
+        for j in range(jm):
+            for k in range(km):
+                fh.write("%d %d %.2f\n" % (k - 180, 90 - j, z[j, k]))
+
+
+def write_salinity_file(path, jm, km, seed):
+    """Surface salinity in the reference's format (lon lat psu, km x jm lines, j fastest; negative = no data)."""
+    rng = np.random.default_rng(seed)
+    s = rng.uniform(30.0, 38.0, (km, jm))
+    s[rng.uniform(0, 1, (km, jm)) < 0.2] = -99.0
+    with open(path, "w") as fh:
+        for k in range(km):
+            for j in range(jm):
+                fh.write("%.1f %.1f %.4f\n" % (k - 179.5, 89.5 - j, s[k, j]))
+
+
 def bits_equal(a, b):
     """Bitwise equality up to the sign of zero (NaN == NaN)."""
     a = np.asarray(a); b = np.asarray(b)
@@ -435,6 +488,49 @@ def hyd_3d_loop(m, pressure_iters=2, velocity_iters=2, run_data=False):
             _move3d(m)
         m.op("hyd_pressure3d")
     return log
+
+
+def _move2d(m):
+    level = 0 if m.model == ATM else m.im - 1
+    if hasattr(m, "move_data_to_new_arrays"):
+        m.move_data_to_new_arrays(level)
+    else:
+        m.op("move_data_to_new_arrays", C.c_int(level))
+
+
+def hyd_start_of_slice(m, start, bathymetry_file, salinity_file):
+    """cHydrosphereModel.cpp:248-297 for a model whose surface already holds the transfer file's values: the two
+    readers, the initial conditions of BC_Thermohalin in the reference's order, the first old -> new copies."""
+    dev = not hasattr(m, "ctx")
+    if dev:
+        m.read_sea_ground(bathymetry_file)
+        if start.Ma == 0:
+            m.read_surface_salinity(salinity_file)
+        m.ic_ekman_spiral(start.i_beg)
+        if start.Ma <= 41:
+            m.ic_circumpolar_current(start.i_beg)
+        m.bc_temperature_salinity(start)
+    else:
+        m.op("hyd_read_sea_ground", bathymetry_file.encode())
+        if start.Ma == 0:
+            m.op("hyd_read_surface_salinity", salinity_file.encode())
+        m.op("hyd_ic_ekman_spiral", C.c_int(start.i_beg))
+        if start.Ma <= 41:
+            m.op("hyd_ic_circumpolar_current", C.c_int(start.i_beg))
+        m.op("hyd_bc_temperature_salinity", C.byref(start))
+    m.op("hyd_pressure_density")
+    _move3d(m)
+    _move2d(m)
+
+
+def hyd_2d_loop(m, pressure_iters=2, velocity_iters=2):
+    """cHydrosphereModel.cpp:314-404 without the two queries, whose results are printed only."""
+    for _ in range(pressure_iters):
+        for _ in range(velocity_iters):
+            for op in ("hyd_bc_theta", "hyd_bc_phi", "hyd_value_limitation", "hyd_rk2d"):
+                m.op(op)
+            _move2d(m)
+        m.op("hyd_pressure2d")
 
 
 def _is_device(m):

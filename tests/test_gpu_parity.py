@@ -571,6 +571,67 @@ def test_vtk_sections_full_grid(model, tmp_path):
     d.close()
 
 
+@pytest.mark.parametrize("dims,i_beg,seed", [((9, 181, 23), 0, 71), ((12, 181, 70), 3, 72)])
+def test_hyd_start_of_slice(dims, i_beg, seed, tmp_path):
+    """cHydrosphereModel.cpp:248-292 call by call (the oracle is pinned by the compiled classes in
+    tests/test_oracle_vs_reference.py): both readers, IC_CircumPolar_Current, BC_Temperature_Salinity and
+    BC_Pressure_Density bit-exact with the sign of zero; IC_v_w_EkmanSpiral (asin, cos, sin of the device's math
+    library at the surface) within 1e-10 relative in v and w, every other field bit-exact."""
+    im, jm, km = dims
+    p, f, g = H.make_hyd_start_inputs(im, jm, km, seed)
+    o = H.CpuModel("oracle", H.HYD, im, jm, km, p, f, g)
+    d = atom_amd.DeviceModel(H.HYD, im, jm, km, atom_amd.Params.from_buffer_copy(bytes(p)))
+    d.upload_all(f, g)
+    bath, salt = str(tmp_path / "bath.xyz"), str(tmp_path / "salt.xyz")
+    H.write_bathymetry_file(bath, jm, km, seed)
+    H.write_salinity_file(salt, jm, km, seed + 1)
+    st = H.hyd_start(im, i_beg)
+    dst = atom_amd.HydStart.from_buffer_copy(bytes(st))
+    loose = set()
+
+    def check(what):
+        for k in list(f) + list(g):
+            got, ref = d.download(k), (o.f[k] if k in f else o.g[k])
+            if k in loose:
+                e = H.max_rel_err(got, ref)
+                assert e <= TOL, (what, k, e)
+                print("%s: %s max rel err %.3e" % (what, k, e))
+            else:
+                assert np.array_equal(got, ref) and np.array_equal(np.signbit(got), np.signbit(ref)), (what, k)
+
+    o.op("hyd_read_sea_ground", bath.encode()); d.read_sea_ground(bath)
+    check("BC_SeaGround")
+    o.op("hyd_read_surface_salinity", salt.encode()); d.read_surface_salinity(salt)
+    check("BC_Surface_Salinity_NASA")
+    before = o.f["V"].copy()
+    o.op("hyd_ic_ekman_spiral", H.C.c_int(i_beg)); d.ic_ekman_spiral(i_beg)
+    loose |= {"V", "W"}
+    check("IC_v_w_EkmanSpiral")
+    assert not np.array_equal(o.f["V"][i_beg], before[i_beg])
+    o.op("hyd_ic_circumpolar_current", H.C.c_int(i_beg)); d.ic_circumpolar_current(i_beg)
+    check("IC_CircumPolar_Current")
+    o.op("hyd_bc_temperature_salinity", H.C.byref(st)); d.bc_temperature_salinity(dst)
+    check("BC_Temperature_Salinity")
+    o.op("hyd_pressure_density"); d.op("hyd_pressure_density")
+    check("BC_Pressure_Density")
+    with pytest.raises(atom_amd.AtomDevError):
+        d.read_sea_ground(str(tmp_path / "missing.xyz"))
+    (tmp_path / "short.xyz").write_text("0 0 -5\n")
+    with pytest.raises(atom_amd.AtomDevError):
+        d.read_sea_ground(str(tmp_path / "short.xyz"))     # the reference aborts on a file of the wrong size
+    d.close()
+
+
+def test_hyd_start_needs_the_one_degree_rows():
+    p = H.default_params(H.HYD, 9, 21, 31)
+    d = atom_amd.DeviceModel(H.HYD, 9, 21, 31, atom_amd.Params.from_buffer_copy(bytes(p)))
+    with pytest.raises(atom_amd.AtomDevError):
+        d.ic_ekman_spiral(0)
+    with pytest.raises(atom_amd.AtomDevError):
+        d.ic_circumpolar_current(0)
+    d.close()
+
+
 def test_golden_small_hyd_bitexact():
     """HIP path against the compiled reference's own outputs (tests/golden/hyd_small.npz)."""
     z = np.load(os.path.join(GOLD, "hyd_small.npz"))

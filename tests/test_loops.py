@@ -146,3 +146,63 @@ def test_atm_loop_with_column_physics_device():
         assert not np.array_equal(o.f[k], f[k]), k
     print("atm loop with column physics, 2 iterations: max rel err %.3e" % worst)
     d.close()
+
+
+def _hyd_slice(m, start, bath, salt):
+    H.hyd_start_of_slice(m, start, bath, salt)
+    H.hyd_2d_loop(m)
+    return H.hyd_3d_loop(m, run_data=True)
+
+
+def _hyd_slice_inputs(tmp_path, km, seed):
+    im, jm = 41, 181          # the surface RHS hard-codes im = 41 (RHS_Hyd.cpp:466), the Ekman bands the rows of 1 degree
+    p, f, g = H.make_hyd_start_inputs(im, jm, km, seed)
+    rng = np.random.default_rng(seed)
+    for k in H.RUN_DATA_FIELDS2D:
+        g[k] = rng.uniform(-7.0, 7.0, (jm, km))
+    bath, salt = str(tmp_path / "bath.xyz"), str(tmp_path / "salt.xyz")
+    H.write_bathymetry_file(bath, jm, km, seed)
+    H.write_salinity_file(salt, jm, km, seed + 1)
+    return (im, jm, km), p, f, g, bath, salt
+
+
+@pytest.mark.skipif(not H.have_ref(), reason="oracle/_ref/libatomref.so not built")
+def test_hyd_time_slice_oracle_vs_reference(tmp_path):
+    """A hydrosphere time slice as cHydrosphereModel::RunTimeSlice runs it (cHydrosphereModel.cpp:248-610) - readers,
+    initial conditions, 2 x 2 surface iterations, 2 x 2 volume iterations with Results_Hyd::run_data - operator by
+    operator through the oracle and through the compiled classes: every field and every query result, same bits."""
+    dims, p, f, g, bath, salt = _hyd_slice_inputs(tmp_path, 185, 81)
+    a, b = H.CpuModel("oracle", H.HYD, *dims, p, f, g), H.CpuModel("ref", H.HYD, *dims, p, f, g)
+    st = H.hyd_start(dims[0])
+    b.steady = lambda name, n: (np.zeros(n), np.zeros((n, 3), dtype=int))  # printed only by the reference
+    for x, y in zip(_hyd_slice(a, st, bath, salt), _hyd_slice(b, st, bath, salt)):
+        if isinstance(x[1], tuple):
+            assert x == y
+    for k in f:
+        if k != "RESIDUUM":
+            assert H.bits_equal(a.f[k], b.f[k]), k
+    for k in g:
+        assert H.bits_equal(a.g[k], b.g[k]), k
+    assert not np.array_equal(a.f["T"], f["T"]) and not np.array_equal(a.g["UPWELLING"], g["UPWELLING"])
+
+
+@pytest.mark.gpu
+def test_hyd_time_slice_device(tmp_path):
+    """The same time slice with every operator on the device, from the bathymetry file to the last pressure step: no
+    field is uploaded after the transfer-file state.  The Ekman step's asin / cos / sin are the device library's, so
+    the slice is held to the stated 1e-10 relative per field (iteration counts are fixed, query locations identical)."""
+    dims, p, f, g, bath, salt = _hyd_slice_inputs(tmp_path, 185, 81)
+    o = H.CpuModel("oracle", H.HYD, *dims, p, f, g)
+    d = atom_amd.DeviceModel(H.HYD, *dims, atom_amd.Params.from_buffer_copy(bytes(p)))
+    d.upload_all(f, g)
+    st = H.hyd_start(dims[0])
+    _same_queries(_hyd_slice(d, atom_amd.HydStart.from_buffer_copy(bytes(st)), bath, salt), _hyd_slice(o, st, bath, salt), exact=False)
+    worst = 0.0
+    for k in list(f) + list(g):
+        if k == "RESIDUUM":
+            continue
+        e = H.max_rel_err(d.download(k), o.f[k] if k in f else o.g[k])
+        worst = max(worst, e)
+        assert e <= 1e-10, (k, e)
+    print("hydrosphere time slice on the device: max rel err %.3e" % worst)
+    d.close()

@@ -171,6 +171,46 @@ def test_vtk_section_file(model, section, index, Ma, tmp_path):
         assert changed == (["AUX_V"] if section == 0 else [])
 
 
+def _same_bits(a, b, names):
+    for k in names:
+        x, y = (a.f[k], b.f[k]) if k in a.f else (a.g[k], b.g[k])
+        assert np.array_equal(x, y) and np.array_equal(np.signbit(x), np.signbit(y)), k
+
+
+@pytest.mark.parametrize("dims,i_beg,seed", [((9, 181, 23), 0, 71), ((12, 181, 17), 3, 72)])
+def test_hyd_start_of_slice(dims, i_beg, seed, tmp_path):
+    """cHydrosphereModel.cpp:248-292 in its order - BC_SeaGround, BC_Surface_Salinity_NASA, IC_v_w_EkmanSpiral,
+    IC_CircumPolar_Current, BC_Temperature_Salinity, BC_Pressure_Density - oracle against the compiled classes after
+    every call, bits and sign of zero.  (The latitude bands of the Ekman step are rows of the 1-degree grid: jm = 181.)"""
+    im, jm, km = dims
+    p, f, g = H.make_hyd_start_inputs(im, jm, km, seed)
+    a, b = H.CpuModel("oracle", H.HYD, im, jm, km, p, f, g), H.CpuModel("ref", H.HYD, im, jm, km, p, f, g)
+    bath, salt = str(tmp_path / "bath.xyz").encode(), str(tmp_path / "salt.xyz").encode()
+    H.write_bathymetry_file(bath.decode(), jm, km, seed)
+    H.write_salinity_file(salt.decode(), jm, km, seed + 1)
+    names = list(f) + list(g)
+    st = H.hyd_start(im, i_beg)
+    for m in (a, b):
+        m.lib.__getattr__(m.pre + "hyd_read_sea_ground").argtypes = [C.c_void_p, C.c_char_p]
+        m.lib.__getattr__(m.pre + "hyd_read_surface_salinity").argtypes = [C.c_void_p, C.c_char_p]
+    a.op("hyd_read_sea_ground", bath); b.op("hyd_read_sea_ground", bath)
+    _same_bits(a, b, names)
+    land = a.f["H"] == 1.0
+    assert 0.2 < land.mean() < 0.9 and land[im - 1].any() and not land[im - 1].all()
+    a.op("hyd_read_surface_salinity", salt); b.op("hyd_read_surface_salinity", salt)
+    _same_bits(a, b, names)
+    assert not np.array_equal(a.f["C"][im - 1], f["C"][im - 1])
+    a.op("hyd_ic_ekman_spiral", C.c_int(i_beg)); b.op("hyd_ic_ekman_spiral", C.c_int(i_beg))
+    _same_bits(a, b, names)
+    assert not np.array_equal(a.f["V"][i_beg], f["V"][i_beg]) and (i_beg == 0 or np.array_equal(a.f["V"][i_beg - 1], f["V"][i_beg - 1]))
+    a.op("hyd_ic_circumpolar_current", C.c_int(i_beg)); b.op("hyd_ic_circumpolar_current", C.c_int(i_beg))
+    _same_bits(a, b, names)
+    a.op("hyd_bc_temperature_salinity", C.byref(st)); b.op("hyd_bc_temperature_salinity", C.byref(st))
+    _same_bits(a, b, names)
+    a.op("hyd_pressure_density"); b.op("hyd_pressure_density")
+    _same_bits(a, b, names)
+
+
 @pytest.mark.parametrize("max_precipitation", [7.5, 0.0])
 def test_atm_vegetation_distribution(max_precipitation):
     import ctypes as C
