@@ -149,7 +149,7 @@ extern "C" int atomdev_create(int model, int im, int jm, int km, const atomdev_p
     h->profile_rk = false; h->prof_used = 0;
     h->scr[0] = h->scr[1] = nullptr; h->tab_rm2sin = h->tab_irm2sin = h->tab_coefv = nullptr;
     h->rk_variant = 0;
-    h->ws_params = nullptr; h->surf = nullptr; h->xfer = nullptr; h->batch = nullptr; h->batch_bytes = 0;
+    h->ws_params = nullptr; h->ws_err = nullptr; h->surf = nullptr; h->xfer = nullptr; h->batch = nullptr; h->batch_bytes = 0;
     if (const char* e = getenv("ATOMDEV_RK_VARIANT")) h->rk_variant = atoi(e);
     h->rad = h->sinthe = h->costhe = h->plane = nullptr; h->red = nullptr;
     fill_constants(h);
@@ -194,7 +194,7 @@ extern "C" int atomdev_set_params(atomdev_t* h, const atomdev_params* p) {
     h->p = *p;
     fill_constants(h);
     if (int rc = upload_tables(h)) return rc;
-    if (h->ws_params) { ATOMDEV_TRY(hipFree(h->ws_params)); h->ws_params = nullptr; }  // holds a copy of the constants
+    if (h->ws_params) { ATOMDEV_TRY(hipFree(h->ws_params)); h->ws_params = nullptr; h->ws_err = nullptr; }  // holds a copy of the constants
     h->h0i_valid = false;
     return 0;
 }
@@ -304,6 +304,11 @@ extern "C" int atomdev_sync(atomdev_t* h) {
     ATOMDEV_REQUIRE(h != nullptr, "atomdev_sync: null handle");
     ATOMDEV_TRY(hipSetDevice(h->device));
     ATOMDEV_TRY(hipStreamSynchronize(h->stream));
+    if (h->ws_err) {  // a wave of the hydrosphere sweep that waited for another workgroup and gave up
+        int err = 0;
+        ATOMDEV_TRY(hipMemcpy(&err, h->ws_err, sizeof(int), hipMemcpyDeviceToHost));
+        ATOMDEV_REQUIRE(err == 0, "hyd_rk3d: level im-2 gave up waiting for the salinity rows of level im-3; the fields of the last sweep are not valid");
+    }
     return 0;
 }
 

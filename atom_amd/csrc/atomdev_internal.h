@@ -63,6 +63,7 @@ struct atomdev {
     void* surf;                     // skewed copy of the surface fields for the 2-D sweep (lazy)
     void* ws_params;                // device copy of the wave-specialised sweep's argument block(s) (lazy)
     const double* ws_cur0;          // hyd: f[T] at the time the blocks were built (tells the buffer orientation)
+    int* ws_err;                    // hyd: device word the sweep sets when a wait between workgroups gave up (lazy)
     int rk_variant;                 // 0: wave-specialised sweep (default), 1: one thread per theta line
     bool profile_rk;                // bracket RK sweep kernels with events
     std::vector<hipEvent_t> prof_ev;  // pairs (start, stop), prof_used of them recorded

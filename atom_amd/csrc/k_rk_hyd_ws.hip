@@ -15,10 +15,16 @@
 //
 // Five waves on four SIMDs: t and w, the two lightest roles, share one (waves 0 and 4).
 //
-// Level im-2 reads the salinity level im-3 has just computed (RHS_Hyd.cpp:356-357).  The workgroups of
-// level im-3 therefore carry five more waves that sweep level im-2 ONE STEP BEHIND, in the same barrier
-// rhythm: the c wave of level im-3 leaves its new row in LDS, the c wave of level im-2 picks it up one
-// step later.  (As a launch of its own, level im-2 costs a whole second sweep time on six workgroups.)
+// Level im-2 reads the salinity level im-3 has just computed (RHS_Hyd.cpp:356-357).  The c wave of a level im-3
+// workgroup therefore stores its rows with device-scope (write-through) stores and, at the end of every step, when
+// its wait for the step's loads has also completed the stores of the step before, publishes "rows up to j-2 are in
+// memory" in a progress word of its longitude block; the c wave of the level im-2 workgroup of the same block checks
+// that word (read one step ahead, like its other inputs) before it prefetches a row of the level below, and so runs
+// a few rows behind.  The poll is
+// bounded (an error word is set and the sweep finishes with whatever it reads, atomdev_sync reports it); producer
+// workgroups have the lower block index, so they are dispatched before their consumers.  (With three shadow waves
+// recomputing level im-3 inside the workgroups of level im-2 the sweep took 0.53 ms instead of 0.40 ms; as a launch
+// of its own, level im-2 costs a whole second sweep time on six workgroups.)
 //
 // The sweep is out of place (see k_rk_hyd.hip): it reads the current buffers and writes the
 // alternate set, whose boundary shell is refreshed beforehand by k_copy_shell.
@@ -67,6 +73,31 @@ __device__ __forceinline__ void stg(double* base, unsigned off, double x) {
     *(__attribute__((address_space(1))) double*)((gchar_t)base + off) = x;
 }
 
+// Device-scope accesses (sc1: written through / fetched past the XCD's L2), for data that crosses workgroups.
+__device__ __forceinline__ void stg_agent(double* base, unsigned off, double x) {
+    __hip_atomic_store((__attribute__((address_space(1))) double*)((gchar_t)base + off), x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ldg_agent(const double* base, unsigned off) {
+    return __hip_atomic_load((const __attribute__((address_space(1))) double*)((gcchar_t)base + off), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int ld_progress(const int* progress) {
+    return __hip_atomic_load((const __attribute__((address_space(1))) int*)progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Waits until the producer's progress word has reached `need` and returns what it read; gives up after about a second.
+__device__ __forceinline__ int wait_rows(const int* progress, int need, int* err) {
+    int seen = ld_progress(progress);
+    for (int n = 0; seen < need; n++) {
+        __builtin_amdgcn_s_sleep(4);
+        if (n > (1 << 21)) {
+            __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return need;
+        }
+        seen = ld_progress(progress);
+    }
+    return seen;
+}
+
 // 1/b to the accuracy the fp64 division sequence uses: hardware estimate plus two Newton steps.
 __device__ __forceinline__ double rcp_refined(double b) {
     double y = __builtin_amdgcn_rcp(b);
@@ -98,15 +129,15 @@ __device__ __forceinline__ void dtheta(int mode, double hdj, double xm2, double 
 // flags, the level above and the role's extras, row j+2 of the own variable) is issued at the
 // top, the stores of row j-1's results in stage 2; nothing loaded in a step is used before the
 // next one, and the end-of-step wait leaves only the stores outstanding.
-template <int ROLE, bool STORE = true>
+template <int ROLE>
 __device__ __forceinline__ void sweep_role(const HydWsArgs& a, const DevConst& K, Shared& sh, const double* tab,
-                                           int bx, int i, int lag, int extra, double (*cfin)[64],
+                                           int bx, int i, int* progress, int* err,
                                            const double* __restrict__ X, double* __restrict__ XO,
                                            const double* __restrict__ XN) {
-    // lag: steps this wave runs behind the workgroup's clock (1 for the waves of level im-2, whose workgroup
-    // also carries shadow waves of level im-3); extra: additional clock ticks of the workgroup (1 there);
-    // cfin: that workgroup's hand-over buffer for the new salinity row, or null.  STORE = false: a shadow
-    // wave, which computes its variable like the wave that owns the level but writes nothing to memory.
+    // progress: the progress word of this longitude block (level im-3 writes it, level im-2 polls it), null on
+    // the other levels; err: where a poll that gave up leaves its mark.
+    constexpr bool STORE = true;
+    constexpr int lag = 0, extra = 0;
     constexpr bool isT = ROLE == R_T, isU = ROLE == R_U, isV = ROLE == R_V, isW = ROLE == R_W, isC = ROLE == R_C;
     constexpr bool hasH0I = isT || isU || isC;
     constexpr int NST = isU ? 7 : (isV || isW || isC) ? 2 : 1;  // stores per step
@@ -115,6 +146,8 @@ __device__ __forceinline__ void sweep_role(const HydWsArgs& a, const DevConst& K
     const int kk = 1 + bx * 64 + lane;
     const int k = kk <= km - 2 ? kk : km - 2;  // idle lanes shadow the last line and reproduce its bits
     const bool top = (i == im - 2);
+    const bool feeds_top = ROLE == R_C && progress && !top;   // c wave of level im-3
+    const bool polls = ROLE == R_C && progress && top;        // c wave of level im-2
     const bool kwin = (k >= 2) && (k < km - 3);
 
     // ---- constants of the dependent chain, in vector registers ----
@@ -182,7 +215,7 @@ __device__ __forceinline__ void sweep_role(const HydWsArgs& a, const DevConst& K
         if constexpr (isU) n_r1 = ldg(E1, o);
         if constexpr (isC) {
             if (top) {  // RHS_Hyd.cpp:355-359
-                if (!cfin) n_cb = ldg(XO, o - lvlB);  // c at level im-3: already updated (level im-1, in n_xa, never is)
+                n_cb = polls ? ldg_agent(XO, o - lvlB) : ldg(XO, o - lvlB);  // c at level im-3: already updated (level im-1, in n_xa, never is)
                 n_ev = ldg(E2, q); n_pr = ldg(E3, q);
             }
         }
@@ -192,6 +225,9 @@ __device__ __forceinline__ void sweep_role(const HydWsArgs& a, const DevConst& K
         n_cos = row[0]; n_rm2sin = row[1]; n_irm2sin = row[2];
         if constexpr (isV) n_coefv = row[3];
     };
+    // level im-2: rows of the level below known to be in memory, and the progress word as read during the last step
+    int known = 0, n_prog = 0;
+    if (polls) known = wait_rows(progress, 1, err);
     load_next(o0, q1 - rowB);
     load_table(1);
     // c wave: r_water of rows j and j+1; row j+2 is fetched at the top of step j
@@ -221,17 +257,26 @@ __device__ __forceinline__ void sweep_role(const HydWsArgs& a, const DevConst& K
             for (int s = 0; s < 4; s++) lds_barrier();
             continue;
         }
+        if (feeds_top && j >= 3) {
+            // Only the stores of the step before (row j-2, issued three stages ago) can still be in flight here:
+            // once they have completed, the row may be announced.
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+            if (lane == 0) __hip_atomic_store(progress, j - 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         // ---- take over the prefetched inputs of this step, start loading the next step's ----
         const double xn = n_xn, xa_raw = n_xa;
         const uint8_t fl = n_fl;
         const double costhe = n_cos, rm2sin = n_rm2sin, i_rm2sin = n_irm2sin, coef_v = n_coefv;
         const double bathy = n_bathy, rsw_in = n_r1;
-        double c_below = n_cb;
-        if constexpr (isC) {
-            if (top && cfin) c_below = cfin[j & 1][lane];  // row j of level im-3, finished one tick ago
-        }
+        const double c_below = n_cb;
         const double c_top = xa_raw, ep = n_ev - n_pr;
+        if (polls) {  // row j+1 of the level below must be in memory before it is fetched (row jm-1 is a boundary row)
+            const int need = j + 1 < jm - 2 ? j + 1 : jm - 2;
+            known = n_prog > known ? n_prog : known;
+            if (known < need) known = wait_rows(progress, need, err);
+        }
         load_next(o1, q1);  // row j+1 <= jm-1 always exists
+        if (polls) n_prog = ld_progress(progress);  // arrives with the step's other loads: the next step rarely has to wait
         double xp2 = 0., yp2 = 0., up2 = 0.;
         if (j + 2 < jm) {
             xp2 = ldg(X, o2);
@@ -274,7 +319,7 @@ __device__ __forceinline__ void sweep_role(const HydWsArgs& a, const DevConst& K
         for (int s = 0; s < 4; s++) {
             const int rb = s & 1, wb = rb ^ 1;
             if (STORE && s == 1 && j > 1) {  // results of the previous row
-                stg(XO, o0 - rowB, xm1);
+                if (feeds_top) stg_agent(XO, o0 - rowB, xm1); else stg(XO, o0 - rowB, xm1);
                 if constexpr (isU) {
                     stg(O1, o0 - rowB, so1); stg(O2, o0 - rowB, so2); stg(O3, o0 - rowB, so3);
                     stg(O4, o0 - rowB, so4); stg(O5, o0 - rowB, so5); stg(O6, o0 - rowB, so6);
@@ -356,7 +401,6 @@ __device__ __forceinline__ void sweep_role(const HydWsArgs& a, const DevConst& K
             if constexpr (isV) sh.v[wb][lane] = pub;
             if constexpr (isC) {
                 publish_c(wb, pub, (s < 3) ? rw : rw_nxt);
-                if (s == 3 && cfin && !top) cfin[j & 1][lane] = st;  // hand the new row to level im-2
             }
             lds_barrier();
         }
@@ -376,15 +420,20 @@ __device__ __forceinline__ void sweep_role(const HydWsArgs& a, const DevConst& K
         // Vector-memory operations complete in issue order: waiting until only this step's stores may
         // be outstanding completes its loads without waiting for the write acknowledgements.
         if (STORE && j > 1) __builtin_amdgcn_s_waitcnt(0x0F70 | NST);  // vmcnt(NST)
-        else __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the first step (and a shadow wave) stores nothing
+        else __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the first step stores nothing
         xm2 = xm1; xm1 = st; x0 = xp1; xp1 = xp2;
         if constexpr (isV) { ym2 = ym1; ym1 = y0; y0 = yp1; yp1 = yp2; um2 = um1; up1 = up2; }
         if constexpr (isC) { rw_cur = rw_nxt; rw_nxt = n_rw2; }
         o0 += rowB; o1 += rowB; o2 += rowB; q1 += rowB;
     }
     // row jm-2
-    if constexpr (!STORE) return;
-    stg(XO, o0 - rowB, xm1);
+    if (feeds_top) {
+        stg_agent(XO, o0 - rowB, xm1);
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+        if (lane == 0) __hip_atomic_store(progress, jm - 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        stg(XO, o0 - rowB, xm1);
+    }
     if constexpr (isU) {
         stg(O1, o0 - rowB, so1); stg(O2, o0 - rowB, so2); stg(O3, o0 - rowB, so3);
         stg(O4, o0 - rowB, so4); stg(O5, o0 - rowB, so5); stg(O6, o0 - rowB, so6);
@@ -392,39 +441,25 @@ __device__ __forceinline__ void sweep_role(const HydWsArgs& a, const DevConst& K
     if constexpr (isV || isW || isC) stg(O1, o0 - rowB, so1);
 }
 
-// Levels 1 .. im-2, one workgroup of five waves (one variable each) per 64 lines.  Level im-2 reads the NEW
-// salinity of level im-3 (RHS_Hyd.cpp:356-357), row by row as that level's sweep produces it.  Its workgroups
-// therefore carry three more waves that sweep level im-3's coupled variables (v, u, c - t and w do not feed back
-// into them) one step ahead in the same barrier rhythm, as shadows of the workgroup that owns level im-3: same
-// inputs (the sweep is out of place), same bits, no stores; the salinity row goes from the shadow c wave to the
-// c wave of level im-2 through LDS.  (As waves of level im-3's own workgroup - ten waves on four SIMDs - the
-// pair set the pace of the whole launch; as a launch of its own, level im-2 cost a second full sweep time.)
-__global__ __launch_bounds__(512) void k_hyd_rk3d_ws(const HydWsParams* __restrict__ P, int nlev) {
+// Levels 1 .. im-2, one workgroup of five waves (one variable each) per 64 lines.
+__global__ __launch_bounds__(320) void k_hyd_rk3d_ws(const HydWsParams* __restrict__ P, int nlev, int* __restrict__ progress,
+                                                      int* __restrict__ err) {
     const HydWsArgs& a = P->a;
     const DevConst& K = P->K;
-    __shared__ Shared sh2[2];
-    __shared__ double cfin[2][64];
-    extern __shared__ double tab2[];  // 2 x [jm][4]: cos(the), rm^2 sin(the), its reciprocal, viscous v coefficient
-    // all longitude blocks of a level on one XCD (they share cache lines; see k_rk_atm_ws.hip)
+    __shared__ Shared sh;
+    extern __shared__ double tab[];  // [jm][4]: cos(the), rm^2 sin(the), its reciprocal, viscous v coefficient
+    // all longitude blocks of a level on one XCD (they share cache lines; see k_rk_atm_ws.hip); level im-3 comes
+    // one block index before level im-2 of the same longitude block
     const int gx = (K.km - 2 + 63) / 64;
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     const int lev = xcd + 8 * (idx / gx), bx = idx % gx;
     if (lev >= nlev) return;
     const int wave = threadIdx.x >> 6;
-    const int grp = wave >= 5 ? 1 : 0;  // 1: shadow waves
-#ifdef ATOMDEV_EXP_NOPAIR  // timing experiment only: level im-2 takes a stale salinity row
-    const bool top = false;
-#else
-    const bool top = (1 + lev == K.im - 2);
-#endif
-    if (grp == 1 && !top) return;  // before any barrier: a barrier only counts the waves still running
-    const int i = 1 + lev - grp;
+    const int i = 1 + lev;
     const int jm = K.jm;
-    double* tab = tab2 + grp * 4 * jm;
     {
         const double rm = a.rad[i], rm2 = rm * rm;
-        const int first = grp ? 320 : 0, stride = grp ? 192 : 320;
-        for (int j = threadIdx.x - first; j < jm; j += stride) {
+        for (int j = threadIdx.x; j < jm; j += 320) {
             const double sinthe = a.sinthe[j], costhe = a.costhe[j];
             const double rm2sinthe = rm2 * sinthe;
             tab[4 * j + 0] = costhe;
@@ -434,31 +469,25 @@ __global__ __launch_bounds__(512) void k_hyd_rk3d_ws(const HydWsParams* __restri
         }
         __syncthreads();
     }
-    Shared& sh = sh2[grp];
-    double (*cf)[64] = top ? cfin : nullptr;
-    const int lag = top ? 1 - grp : 0, extra = top ? 1 : 0;
-    if (grp == 0) {
-        // In the workgroups of level im-2 the heavier variables get a SIMD's first slot (waves w and w + 4 share a
-        // SIMD) so that each SIMD ends up with about the same work once the shadow waves are added.
-        const int role = top ? (wave == 0 ? R_C : wave == 1 ? R_V : wave == 2 ? R_U : wave == 3 ? R_T : R_W) : wave;
-        switch (role) {
-            case R_T: sweep_role<R_T>(a, K, sh, tab, bx, i, lag, extra, cf, a.t, a.to, a.tn); break;
-            case R_V: sweep_role<R_V>(a, K, sh, tab, bx, i, lag, extra, cf, a.v, a.vo, a.vn); break;
-            case R_U: sweep_role<R_U>(a, K, sh, tab, bx, i, lag, extra, cf, a.u, a.uo, a.un); break;
-            case R_C: sweep_role<R_C>(a, K, sh, tab, bx, i, lag, extra, cf, a.c, a.co, a.cn); break;
-            default: sweep_role<R_W>(a, K, sh, tab, bx, i, lag, extra, cf, a.w, a.wo, a.wn); break;
-        }
-    } else {
-        switch (wave) {  // shadows of level im-3: u beside v, v beside u, c beside t
-            case 5: sweep_role<R_U, false>(a, K, sh, tab, bx, i, lag, extra, cf, a.u, a.uo, a.un); break;
-            case 6: sweep_role<R_V, false>(a, K, sh, tab, bx, i, lag, extra, cf, a.v, a.vo, a.vn); break;
-            default: sweep_role<R_C, false>(a, K, sh, tab, bx, i, lag, extra, cf, a.c, a.co, a.cn); break;
-        }
+#ifdef ATOMDEV_EXP_NOPAIR  // timing experiment only: level im-2 takes a stale salinity row
+    int* pw = nullptr;
+#else
+    int* pw = (i >= K.im - 3) ? progress + bx : nullptr;
+#endif
+    switch (wave) {
+        case R_T: sweep_role<R_T>(a, K, sh, tab, bx, i, pw, err, a.t, a.to, a.tn); break;
+        case R_V: sweep_role<R_V>(a, K, sh, tab, bx, i, pw, err, a.v, a.vo, a.vn); break;
+        case R_U: sweep_role<R_U>(a, K, sh, tab, bx, i, pw, err, a.u, a.uo, a.un); break;
+        case R_C: sweep_role<R_C>(a, K, sh, tab, bx, i, pw, err, a.c, a.co, a.cn); break;
+        default: sweep_role<R_W>(a, K, sh, tab, bx, i, pw, err, a.w, a.wo, a.wn); break;
     }
 }
 
 // Copies the boundary shell (i, j or k on a face) of src to dst: the sweep writes interior points only.
-__global__ void k_copy_shell(const double* const* __restrict__ src, double* const* __restrict__ dst, int im, int jm, int km) {
+__global__ void k_copy_shell(const double* const* __restrict__ src, double* const* __restrict__ dst, int im, int jm, int km,
+                             int* __restrict__ progress, int nprogress) {
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)  // the sweep that follows starts from "no row finished"
+        for (int n = threadIdx.x; n < nprogress; n += blockDim.x) progress[n] = 0;
     const double* __restrict__ s = src[blockIdx.z];
     double* __restrict__ d = dst[blockIdx.z];
     const int i = blockIdx.y;
@@ -486,9 +515,9 @@ int atomdev_hyd_rk3d_ws(atomdev* h) {
     ATOMDEV_REQUIRE(h->n3 * sizeof(double) < ((size_t)1 << 32), "hyd_rk3d: field larger than 4 GiB");
     // Two argument blocks, one per orientation of the (current, alternate) buffer pair; the sweep
     // swaps the pair, so consecutive sweeps alternate between them.
-    struct Blocks { HydWsParams p[2]; const double* src[2][5]; double* dst[2][5]; };
+    struct Blocks { HydWsParams p[2]; const double* src[2][5]; double* dst[2][5]; int progress[128]; int err; };
     if (!h->ws_params) {
-        Blocks* B = new Blocks;
+        Blocks* B = new Blocks();
         for (int o = 0; o < 2; o++) {
             HydWsArgs& a = B->p[o].a;
             double* cur[5]; double* alt[5];
@@ -512,18 +541,21 @@ int atomdev_hyd_rk3d_ws(atomdev* h) {
         h->ws_cur0 = h->f[ATOMDEV_T];
         delete B;
         ATOMDEV_TRY(e);
+        h->ws_err = &((Blocks*)h->ws_params)->err;
     }
     const int o = (h->f[ATOMDEV_T] == h->ws_cur0) ? 0 : 1;
-    const Blocks* D = (const Blocks*)h->ws_params;
+    Blocks* D = (Blocks*)h->ws_params;
     const HydWsParams* P = &D->p[o];
-    if (int rc = atomdev_prof_begin(h)) return rc;
-    hipLaunchKernelGGL(k_copy_shell, dim3(8, h->im, 5), dim3(256), 0, h->stream, &D->src[o][0], &D->dst[o][0], h->im, h->jm, h->km);
-    ATOMDEV_TRY(hipGetLastError());
     const unsigned gx = (h->km - 2 + 63) / 64;
-    const size_t lds = (size_t)h->jm * 8 * sizeof(double);
+    ATOMDEV_REQUIRE(gx <= 128, "hyd_rk3d: more than 128 longitude blocks");
     ATOMDEV_REQUIRE(h->im >= 5, "hyd_rk3d: the grid needs at least 5 levels");
-    // levels 1 .. im-2, one workgroup per 64 lines (waves 5-7 stay only in the workgroups of level im-2)
-    hipLaunchKernelGGL(k_hyd_rk3d_ws, dim3(8 * ((h->im - 2 + 7) / 8) * gx), dim3(512), lds, h->stream, P, h->im - 2);
+    if (int rc = atomdev_prof_begin(h)) return rc;
+    hipLaunchKernelGGL(k_copy_shell, dim3(8, h->im, 5), dim3(256), 0, h->stream, &D->src[o][0], &D->dst[o][0], h->im, h->jm, h->km,
+                       D->progress, (int)gx);
+    ATOMDEV_TRY(hipGetLastError());
+    const size_t lds = (size_t)h->jm * 4 * sizeof(double);
+    // levels 1 .. im-2, one workgroup per 64 lines
+    hipLaunchKernelGGL(k_hyd_rk3d_ws, dim3(8 * ((h->im - 2 + 7) / 8) * gx), dim3(320), lds, h->stream, P, h->im - 2, D->progress, &D->err);
     ATOMDEV_TRY(hipGetLastError());
     if (int rc = atomdev_prof_end(h)) return rc;
     for (int n = 0; n < 5; n++) { double* t = h->f[X[n]]; h->f[X[n]] = h->alt[X[n]]; h->alt[X[n]] = t; }

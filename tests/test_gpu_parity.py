@@ -632,6 +632,37 @@ def test_hyd_start_needs_the_one_degree_rows():
     d.close()
 
 
+def test_hyd_sweeps_of_concurrent_handles_same_bits():
+    """Volume sweeps of four hydrosphere handles enqueued side by side on their streams (the slices of a series share
+    one GPU this way): level im-2 of each waits for rows another workgroup of its own launch stores, while the
+    launches compete for the compute units.  Every handle must end with the bits a handle running alone gets, and
+    no wait may give up (sync reports that)."""
+    im, jm, km = 41, 181, 361
+    p = H.default_params(H.HYD, im, jm, km)
+    f, g = H.make_inputs(H.HYD, im, jm, km, 77, "allfluid", p)
+    f = {k: f[k] for k in H.HYD_FIELDS}
+    f["H"], g["TOPOGRAPHY"] = H.load_mask_0Ma(H.HYD)
+    models = []
+    for _ in range(4):
+        d = atom_amd.DeviceModel(H.HYD, im, jm, km, atom_amd.Params.from_buffer_copy(bytes(p)))
+        d.upload_all(f, g)
+        models.append(d)
+    for _ in range(3):
+        models[0].op("hyd_rk3d")
+    models[0].sync()
+    alone = {k: models[0].download(k) for k in ("T", "U", "V", "W", "C", "AUX_U", "SALT_BALANCE")}
+    models[0].upload_all(f, g)
+    for _ in range(3):
+        for d in models:
+            d.op("hyd_rk3d")
+    for d in models:
+        d.sync()
+    for n, d in enumerate(models):
+        for k, ref in alone.items():
+            assert H.bits_equal(d.download(k), ref), (n, k)
+        d.close()
+
+
 def test_golden_small_hyd_bitexact():
     """HIP path against the compiled reference's own outputs (tests/golden/hyd_small.npz)."""
     z = np.load(os.path.join(GOLD, "hyd_small.npz"))

@@ -206,3 +206,26 @@ def test_hyd_time_slice_device(tmp_path):
         assert e <= 1e-10, (k, e)
     print("hydrosphere time slice on the device: max rel err %.3e" % worst)
     d.close()
+
+
+@pytest.mark.gpu
+def test_hyd_time_slice_device_bitexact_after_ekman(tmp_path):
+    """The same slice with the Ekman step's v and w taken from the oracle (the only operator whose bits may differ):
+    every field of the surface loop and of the volume loop must then carry the oracle's bits - level im-2 of the volume
+    sweep included, which takes its salinity rows from another workgroup's stores while both are running."""
+    dims, p, f, g, bath, salt = _hyd_slice_inputs(tmp_path, 185, 82)
+    o = H.CpuModel("oracle", H.HYD, *dims, p, f, g)
+    d = atom_amd.DeviceModel(H.HYD, *dims, atom_amd.Params.from_buffer_copy(bytes(p)))
+    d.upload_all(f, g)
+    st = H.hyd_start(dims[0])
+    H.hyd_start_of_slice(o, st, bath, salt)
+    H.hyd_start_of_slice(d, atom_amd.HydStart.from_buffer_copy(bytes(st)), bath, salt)
+    for k in ("V", "W", "VN", "WN"):
+        d.upload(k, o.f[k])
+    for m in (o, d):
+        H.hyd_2d_loop(m)
+    _same_queries(H.hyd_3d_loop(d, 3, 2, run_data=True), H.hyd_3d_loop(o, 3, 2, run_data=True), exact=True)
+    for k in list(f) + list(g):
+        if k != "RESIDUUM":
+            assert H.bits_equal(d.download(k), o.f[k] if k in f else o.g[k]), k
+    d.close()
