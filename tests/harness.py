@@ -337,6 +337,40 @@ def write_bathymetry_file(path, jm, km, seed, L_hyd=1000.0):
                 fh.write("%d %d %.2f\n" % (k - 180, 90 - j, z[j, k]))
 
 
+def write_bathymetry_file_0Ma(path):
+    """The 0 Ma bathymetry of the golden mask file on the 1-degree grid, written back in the reference's format
+    (longitudes from -180; the reader moves them to 0..360 and repeats the first column as the last)."""
+    jm, km = 181, 361
+    _, topo = load_mask_0Ma(HYD)
+    with open(path, "w") as fh:
+        for j in range(jm):
+            row = np.concatenate([topo[j, km // 2:2 * (km // 2)], topo[j, :km // 2], topo[j, :1]])
+            for k in range(km):
+                fh.write("%d %d %.1f\n" % (k - 180, 90 - j, -row[k]))
+
+
+def make_hyd_slice_inputs_1deg(seed):
+    """A hydrosphere on the 1-degree grid as the transfer file leaves it: smooth surface winds in m/s, no dynamic
+    pressure, the ocean at rest, smooth temperature and salinity - a state the reference's 20 surface and 4 volume
+    iterations keep bounded on the 0 Ma bathymetry (rough random fields diverge within a few pressure iterations, in
+    the reference's arithmetic as much as in ours)."""
+    im, jm, km = 41, 181, 361
+    p, f, g = make_hyd_start_inputs(im, jm, km, seed)
+    rng = np.random.default_rng(seed)
+    for k in RUN_DATA_FIELDS2D:
+        g[k] = rng.uniform(-7.0, 7.0, (jm, km))
+    tj, tk = np.meshgrid(np.linspace(0.0, np.pi, jm), np.linspace(0.0, 2.0 * np.pi, km), indexing="ij")
+    for k in ("U", "V", "W", "P_DYN", "UN", "VN", "WN", "P_DYNN"):
+        f[k] = np.zeros((im, jm, km))
+    f["V"][im - 1] = 4.0 * np.sin(6.0 * tj) * (1.0 + 0.2 * np.cos(3.0 * tk))
+    f["W"][im - 1] = 7.0 * np.cos(3.0 * tj) * (1.0 + 0.2 * np.sin(2.0 * tk))
+    f["T"][:] = 1.0 + 0.09 * np.sin(tj)[None] ** 2
+    f["TN"] = f["T"].copy()
+    f["C"][:] = 1.0 + 0.02 * np.sin(tj)[None]
+    f["CN"] = f["C"].copy()
+    return (im, jm, km), p, f, g
+
+
 def write_salinity_file(path, jm, km, seed):
     """Surface salinity in the reference's format (lon lat psu, km x jm lines, j fastest; negative = no data)."""
     rng = np.random.default_rng(seed)

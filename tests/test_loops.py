@@ -229,3 +229,39 @@ def test_hyd_time_slice_device_bitexact_after_ekman(tmp_path):
         if k != "RESIDUUM":
             assert H.bits_equal(d.download(k), o.f[k] if k in f else o.g[k]), k
     d.close()
+
+
+@pytest.mark.gpu
+def test_hyd_time_slice_one_degree_reference_iteration_counts(tmp_path):
+    """The hydrosphere run at 0 Ma on the 1-degree grid: 0 Ma bathymetry, the reference's iteration counts (10 x 2
+    surface, 2 x 2 volume iterations; param.py:135-138), every operator on the device.  Every field within the stated
+    1e-10 relative after the slice (measured 1e-15), query results and their locations alike, everything finite."""
+    dims, p, f, g = H.make_hyd_slice_inputs_1deg(91)
+    bath, salt = str(tmp_path / "bath.xyz"), str(tmp_path / "salt.xyz")
+    H.write_bathymetry_file_0Ma(bath)
+    H.write_salinity_file(salt, dims[1], dims[2], 92)
+    o = H.CpuModel("oracle", H.HYD, *dims, p, f, g)
+    d = atom_amd.DeviceModel(H.HYD, *dims, atom_amd.Params.from_buffer_copy(bytes(p)))
+    d.upload_all(f, g)
+    st = H.hyd_start(dims[0])
+    logs = []
+    for m, start in ((d, atom_amd.HydStart.from_buffer_copy(bytes(st))), (o, st)):
+        H.hyd_start_of_slice(m, start, bath, salt)
+        H.hyd_2d_loop(m, 10, 2)
+        logs.append(H.hyd_3d_loop(m, 2, 2, run_data=True))
+    _same_queries(logs[0], logs[1], exact=False)
+    h_mask, _ = H.load_mask_0Ma(H.HYD)
+    # the file written from the golden bathymetry reads back as the golden mask, up to a dozen needles the first
+    # reading had removed from the solid cells but not from the depths
+    assert np.count_nonzero(o.f["H"] != h_mask) < 100
+    worst = 0.0
+    for k in list(f) + list(g):
+        if k == "RESIDUUM":
+            continue
+        ref = o.f[k] if k in f else o.g[k]
+        assert np.isfinite(ref).all(), k
+        e = H.max_rel_err(d.download(k), ref)
+        worst = max(worst, e)
+        assert e <= 1e-10, (k, e)
+    print("hydrosphere 1-degree time slice on the device: max rel err %.3e" % worst)
+    d.close()
