@@ -96,6 +96,7 @@ def load_library():
     lib.atomdev_default_hyd_start.argtypes = [C.c_int, C.POINTER(HydStart)]
     lib.atomdev_default_hyd_start.restype = None
     lib.atomdev_hyd_read_sea_ground.argtypes = [vp, C.c_char_p]
+    lib.atomdev_atm_read_mountain_surface.argtypes = [vp, C.c_char_p]
     lib.atomdev_hyd_read_surface_salinity.argtypes = [vp, C.c_char_p]
     lib.atomdev_hyd_ic_ekman_spiral.argtypes = [vp, C.c_int]
     lib.atomdev_hyd_ic_circumpolar_current.argtypes = [vp, C.c_int]
@@ -227,6 +228,10 @@ class DeviceModel:
     def op(self, name):
         """One reference operator, e.g. 'atm_rk3d', 'hyd_pressure3d'."""
         self._check(getattr(self.lib, "atomdev_" + name)(self._h))
+
+    def read_mountain_surface(self, path):
+        """BC_Bathymetry_Atmosphere::BC_MountainSurface: h and Topography from the topography file."""
+        self._check(self.lib.atomdev_atm_read_mountain_surface(self._h, os.fsencode(path)))
 
     def read_sea_ground(self, path):
         """BC_Bathymetry_Hydrosphere::BC_SeaGround: h and Bathymetry from the bathymetry file."""

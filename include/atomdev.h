@@ -225,6 +225,12 @@ int atomdev_hyd_write_plot_data(atomdev_t* h, const char* path);
 enum atomdev_section { ATOMDEV_RADIAL = 0, ATOMDEV_LONGAL = 1, ATOMDEV_ZONAL = 2 };
 int atomdev_write_vtk(atomdev_t* h, int section, int index, int Ma, const char* path);
 
+/* BC_Bathymetry_Atmosphere::BC_MountainSurface (atmosphere/BC_Bath_Atm.cpp:39-90): reads the topography file (lon lat
+ * height per line, jm x km lines, longitudes -180..180), builds h (1 = solid up to the level of the height) and
+ * Topography (metres, 0 over the sea), and moves both to 0..360.  A file with fewer than jm x km entries is an error
+ * (the reference aborts); heights above L_atm fill the column (the reference writes beyond its array there).  Host
+ * work; the result is uploaded as ATOMDEV_H and ATOMDEV_TOPOGRAPHY. */
+int atomdev_atm_read_mountain_surface(atomdev_t* h, const char* path);
 /* BC_Bathymetry_Atmosphere::vegetationDistribution (atmosphere/BC_Bath_Atm.cpp:129-142): Vegetation =
  * Precipitation / max_Precipitation on land surface cells that are not colder than t = 1, else 0. */
 int atomdev_atm_vegetation_distribution(atomdev_t* h, double max_Precipitation);

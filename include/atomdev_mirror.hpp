@@ -297,6 +297,15 @@ private:
 class BC_Bathymetry_Atmosphere {
 public:
     BC_Bathymetry_Atmosphere(int, int im, int jm, int km, double, double, double) : im_(im), jm_(jm), km_(km) {}
+    // atmosphere/BC_Bath_Atm.cpp:39-90
+    void BC_MountainSurface(std::string& topo_filename, double L_atm, Array_2D& Topography, Array& h) {
+        Device& d = Device::of(ATOMDEV_ATM);
+        d.grid(im_, jm_, km_);
+        d.params().L_atm = L_atm;
+        d.run(atomdev_atm_read_mountain_surface(d.handle(), topo_filename.c_str()), "atomdev_atm_read_mountain_surface");
+        d.pull(ATOMDEV_H, h);
+        d.pull2d(ATOMDEV_TOPOGRAPHY, Topography);
+    }
     // atmosphere/BC_Bath_Atm.cpp:94-119: only h and the seven reset fields are touched, most scalars are unused
     void BC_SolidGround(int, int, double g, double, double, double r_air, double R_Air, double t_0, double c_0, double, double,
                         double, double, double t_tropopause, double, double, double, double, double, double, double,

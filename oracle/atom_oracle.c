@@ -2073,6 +2073,32 @@ static void move_data(double* data, int len) {
     data[len - 1] = data[0];
 }
 
+/* BC_Bathymetry_Atmosphere::BC_MountainSurface, atmosphere/BC_Bath_Atm.cpp:39-90, for well-formed files of jm x km lines */
+int oracle_atm_read_mountain_surface(oracle_ctx* c, const char* path) {
+    const int im = c->im, jm = c->jm, km = c->km;
+    FILE* f = fopen(path, "r");
+    if (!f) return 1;
+    memset(c->f[ATOMDEV_H], 0, sizeof(double) * (size_t)im * jm * km);
+    for (int j = 0; j < jm; j++)
+        for (int k = 0; k < km; k++) {
+            double lon, lat, height = -999;
+            if (fscanf(f, "%lf %lf %lf", &lon, &lat, &height) != 3) { fclose(f); return 2; }
+            if (height < 0.) {
+                A3(c, ATOMDEV_H, 0, j, k) = A2(c, ATOMDEV_TOPOGRAPHY, j, k) = 0.;
+            } else {
+                int i_h = (int)floor(height / c->p.L_atm * (im - 1));
+                A2(c, ATOMDEV_TOPOGRAPHY, j, k) = height;
+                for (int i = 0; i <= i_h && i < im; i++) A3(c, ATOMDEV_H, i, j, k) = 1.;
+            }
+        }
+    fclose(f);
+    for (int j = 0; j < jm; j++) {
+        move_data(&A2(c, ATOMDEV_TOPOGRAPHY, j, 0), km);
+        for (int i = 0; i < im; i++) move_data(&A3(c, ATOMDEV_H, i, j, 0), km);
+    }
+    return 0;
+}
+
 /* BC_Bathymetry_Hydrosphere::BC_SeaGround, hydrosphere/BC_Bath_Hyd.cpp:31-114, for well-formed files of jm x km lines */
 int oracle_hyd_read_sea_ground(oracle_ctx* c, const char* path) {
     const int im = c->im, jm = c->jm, km = c->km;

@@ -387,6 +387,11 @@ int ref_hyd_read_surface_salinity(void* v, const char* path) {
     copy_out(c);
     return 0;
 }
+int ref_atm_read_mountain_surface(void* v, const char* path) {
+    copy_in((RefCtx*)v);
+    ref_read_mask(v, path);
+    return 0;
+}
 int ref_hyd_read_sea_ground(void* v, const char* path) {
     copy_in((RefCtx*)v);  // the other fields pass through unchanged
     ref_read_mask(v, path);

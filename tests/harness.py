@@ -371,6 +371,18 @@ def make_hyd_slice_inputs_1deg(seed):
     return (im, jm, km), p, f, g
 
 
+def write_topography_file(path, jm, km, seed):
+    """A topography file of the atmosphere in the reference's format: sea (negative), plains, mountains up to 9 km."""
+    rng = np.random.default_rng(seed)
+    jj, kk = np.meshgrid(np.arange(jm), np.arange(km), indexing="ij")
+    z = 3000.0 * np.sin(jj / 5.0) * np.cos(kk / 7.0) + rng.uniform(-1500.0, 1500.0, (jm, km))
+    z[rng.uniform(0, 1, (jm, km)) < 0.02] = 9000.0
+    with open(path, "w") as fh:
+        for j in range(jm):
+            for k in range(km):
+                fh.write("%d %d %.2f\n" % (k - 180, 90 - j, z[j, k]))
+
+
 def write_salinity_file(path, jm, km, seed):
     """Surface salinity in the reference's format (lon lat psu, km x jm lines, j fastest; negative = no data)."""
     rng = np.random.default_rng(seed)

@@ -622,6 +622,26 @@ def test_hyd_start_of_slice(dims, i_beg, seed, tmp_path):
     d.close()
 
 
+def test_atm_read_mountain_surface(tmp_path):
+    """BC_MountainSurface from the device library: h and Topography bit for bit the oracle's (pinned by the compiled
+    class in tests/test_oracle_vs_reference.py); a short file is an error, as the reference aborts on it."""
+    im, jm, km = 9, 21, 31
+    o, d, names = _pair(H.ATM, (im, jm, km), 83, "blobs")
+    topo = str(tmp_path / "topo.xyz")
+    H.write_topography_file(topo, jm, km, 84)
+    o.op("atm_read_mountain_surface", topo.encode()); d.read_mountain_surface(topo)
+    for k in ("H", "T", "U"):
+        assert np.array_equal(d.download(k), o.f[k]), k
+    assert np.array_equal(d.download("TOPOGRAPHY"), o.g["TOPOGRAPHY"])
+    d.op("atm_solid_ground"); H.run_op(o, "atm_solid_ground")      # the new mask is the one the operators see
+    for k in ("U", "CO2"):
+        assert H.bits_equal(d.download(k), o.f[k]), k
+    (tmp_path / "short.xyz").write_text("0 0 5\n")
+    with pytest.raises(atom_amd.AtomDevError):
+        d.read_mountain_surface(str(tmp_path / "short.xyz"))
+    d.close()
+
+
 def test_hyd_start_needs_the_one_degree_rows():
     p = H.default_params(H.HYD, 9, 21, 31)
     d = atom_amd.DeviceModel(H.HYD, 9, 21, 31, atom_amd.Params.from_buffer_copy(bytes(p)))

@@ -211,6 +211,20 @@ def test_hyd_start_of_slice(dims, i_beg, seed, tmp_path):
     _same_bits(a, b, names)
 
 
+def test_atm_read_mountain_surface(tmp_path):
+    """BC_MountainSurface: h and Topography of the oracle's reader are those of the compiled class; the other fields
+    pass through untouched."""
+    a, b, names = _pair(H.ATM, (9, 21, 31), 83, "blobs")
+    topo = str(tmp_path / "topo.xyz").encode()
+    H.write_topography_file(topo.decode(), 21, 31, 84)
+    for m in (a, b):
+        m.lib.__getattr__(m.pre + "atm_read_mountain_surface").argtypes = [C.c_void_p, C.c_char_p]
+    before = a.f["H"].copy()
+    a.op("atm_read_mountain_surface", topo); b.op("atm_read_mountain_surface", topo)
+    _same_bits(a, b, list(a.f) + list(a.g))
+    assert not np.array_equal(a.f["H"], before) and 0.2 < a.f["H"][0].mean() < 0.8 and a.f["H"][4].any()
+
+
 @pytest.mark.parametrize("max_precipitation", [7.5, 0.0])
 def test_atm_vegetation_distribution(max_precipitation):
     import ctypes as C
