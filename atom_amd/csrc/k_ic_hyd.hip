@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "atomdev_internal.h"
+#include "text_numbers.h"
 
 namespace {
 
@@ -196,21 +197,31 @@ extern "C" int atomdev_hyd_bc_temperature_salinity(atomdev_t* h, const atomdev_h
 extern "C" int atomdev_hyd_read_surface_salinity(atomdev_t* h, const char* path) {
     ATOMDEV_REQUIRE(h && path && h->model == ATOMDEV_HYD, "atomdev_hyd_read_surface_salinity: needs a hydrosphere handle and a path");
     ATOMDEV_TRY(hipSetDevice(h->device));
-    std::ifstream file(path);
-    ATOMDEV_REQUIRE(file.is_open(), std::string("could not open SurfaceSalinity_File file at ") + path);
     const int jm = h->jm, km = h->km;
-    std::vector<double> top(h->n2);
+    std::vector<double> top(h->n2), values;
     double* level = h->f[ATOMDEV_C] + (size_t)(h->im - 1) * h->n2;
     ATOMDEV_TRY(hipMemcpyAsync(top.data(), level, h->n2 * 8, hipMemcpyDeviceToHost, h->stream));
+    bool opened = false;
+    const bool fast = text_third_of_triples(path, h->n2, values, &opened);  // overlaps the download
     ATOMDEV_TRY(hipStreamSynchronize(h->stream));
-    double lon = 0., lat = 0., value = 0.;
-    for (int k = 0; k < km && !file.eof(); k++)
-        for (int j = 0; j < jm; j++) {
-            file >> lon;
-            file >> lat;
-            file >> value;
-            if (!(value < 0.)) top[(size_t)j * km + k] = value / h->p.c_0;
-        }
+    ATOMDEV_REQUIRE(opened, std::string("could not open SurfaceSalinity_File file at ") + path);
+    if (fast) {
+        for (int k = 0; k < km; k++)
+            for (int j = 0; j < jm; j++) {
+                const double value = values[(size_t)k * jm + j];
+                if (!(value < 0.)) top[(size_t)j * km + k] = value / h->p.c_0;
+            }
+    } else {  // short or malformed file: the stream's own treatment of it, as in the reference
+        std::ifstream file(path);
+        double lon = 0., lat = 0., value = 0.;
+        for (int k = 0; k < km && !file.eof(); k++)
+            for (int j = 0; j < jm; j++) {
+                file >> lon;
+                file >> lat;
+                file >> value;
+                if (!(value < 0.)) top[(size_t)j * km + k] = value / h->p.c_0;
+            }
+    }
     ATOMDEV_TRY(hipMemcpyAsync(level, top.data(), h->n2 * 8, hipMemcpyHostToDevice, h->stream));
     ATOMDEV_TRY(hipStreamSynchronize(h->stream));
     return 0;
@@ -218,28 +229,37 @@ extern "C" int atomdev_hyd_read_surface_salinity(atomdev_t* h, const char* path)
 
 extern "C" int atomdev_hyd_read_sea_ground(atomdev_t* h, const char* path) {
     ATOMDEV_REQUIRE(h && path && h->model == ATOMDEV_HYD, "atomdev_hyd_read_sea_ground: needs a hydrosphere handle and a path");
-    std::ifstream file(path);
-    ATOMDEV_REQUIRE(file.is_open(), std::string("could not open bathymetry file ") + path);
     const int im = h->im, jm = h->jm, km = h->km;
     const double L_hyd = h->p.L_hyd;
-    std::vector<double> solid(h->n3, 0.), bathymetry(h->n2, 0.);
+    std::vector<double> solid(h->n3, 0.), bathymetry(h->n2, 0.), values;
     auto H = [&](int i, int j, int k) -> double& { return solid[idx3(jm, km, i, j, k)]; };
-    int j = 0, k = 0;
-    for (j = 0; j < jm && !file.eof(); j++)
-        for (k = 0; k < km && !file.eof(); k++) {
-            double lon, lat, depth = 999;
-            file >> lon >> lat >> depth;
-            if (depth > 0.) depth = 0;
-            const int i_boden = (im - 1) + int(std::floor(depth / L_hyd * (im - 1)));
-            bathymetry[(size_t)j * km + k] = -depth;
-            for (int i = 0; i <= i_boden; i++) H(i, j, k) = 1.;
-            if (file.fail()) {  // an entry that is no number: skip the rest of its line
-                file.clear();
-                std::string rest;
-                std::getline(file, rest);
+    auto entry = [&](int j, int k, double depth) {
+        if (depth > 0.) depth = 0;
+        const int i_boden = (im - 1) + int(std::floor(depth / L_hyd * (im - 1)));
+        bathymetry[(size_t)j * km + k] = -depth;
+        for (int i = 0; i <= i_boden; i++) H(i, j, k) = 1.;
+    };
+    bool opened = false;
+    if (text_third_of_triples(path, h->n2, values, &opened)) {
+        for (int j = 0; j < jm; j++)
+            for (int k = 0; k < km; k++) entry(j, k, values[(size_t)j * km + k]);
+    } else {  // short or malformed file: the stream's own treatment of it, as in the reference
+        ATOMDEV_REQUIRE(opened, std::string("could not open bathymetry file ") + path);
+        std::ifstream file(path);
+        int j = 0, k = 0;
+        for (j = 0; j < jm && !file.eof(); j++)
+            for (k = 0; k < km && !file.eof(); k++) {
+                double lon, lat, depth = 999;
+                file >> lon >> lat >> depth;
+                entry(j, k, depth);
+                if (file.fail()) {  // an entry that is no number: skip the rest of its line
+                    file.clear();
+                    std::string rest;
+                    std::getline(file, rest);
+                }
             }
-        }
-    ATOMDEV_REQUIRE(j == jm && k == km, "wrong topography file size");
+        ATOMDEV_REQUIRE(j == jm && k == km, "wrong topography file size");
+    }
     // -180..180 -> 0..360 (lib/Utils.cpp:31-37): the halves of a row change places, the last entry repeats the first
     auto rotate = [km](double* row) {
         for (int n = 0; n < km / 2; n++) std::swap(row[n], row[km / 2 + n]);
