@@ -77,6 +77,7 @@ int atomdev_prof_end(atomdev* h);
 void atomdev_set_error(const std::string& msg);
 int atomdev_check(hipError_t e, const char* what);
 int atomdev_refresh_flags(atomdev* h);  // k_pointwise.hip
+int atomdev_upload_mask_bytes(atomdev* h, const uint8_t* solid);  // k_pointwise.hip: h from a byte mask (1 = solid)
 int atomdev_fill_theta_neumann(atomdev* h, int field);            // k_bc_pressure.hip
 int atomdev_fill_phi_seam(atomdev* h, int field, int j0, int j1);  // k_bc_pressure.hip
 int atomdev_atm_rk3d_ws(atomdev* h);    // k_rk_atm_ws.hip

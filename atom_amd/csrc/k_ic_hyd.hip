@@ -231,13 +231,14 @@ extern "C" int atomdev_hyd_read_sea_ground(atomdev_t* h, const char* path) {
     ATOMDEV_REQUIRE(h && path && h->model == ATOMDEV_HYD, "atomdev_hyd_read_sea_ground: needs a hydrosphere handle and a path");
     const int im = h->im, jm = h->jm, km = h->km;
     const double L_hyd = h->p.L_hyd;
-    std::vector<double> solid(h->n3, 0.), bathymetry(h->n2, 0.), values;
-    auto H = [&](int i, int j, int k) -> double& { return solid[idx3(jm, km, i, j, k)]; };
+    std::vector<uint8_t> solid(h->n3, 0);  // h as bytes: 1 = solid
+    std::vector<double> bathymetry(h->n2, 0.), values;
+    auto H = [&](int i, int j, int k) -> uint8_t& { return solid[idx3(jm, km, i, j, k)]; };
     auto entry = [&](int j, int k, double depth) {
         if (depth > 0.) depth = 0;
         const int i_boden = (im - 1) + int(std::floor(depth / L_hyd * (im - 1)));
         bathymetry[(size_t)j * km + k] = -depth;
-        for (int i = 0; i <= i_boden; i++) H(i, j, k) = 1.;
+        for (int i = 0; i <= i_boden; i++) H(i, j, k) = 1;
     };
     bool opened = false;
     if (text_third_of_triples(path, h->n2, values, &opened)) {
@@ -261,7 +262,7 @@ extern "C" int atomdev_hyd_read_sea_ground(atomdev_t* h, const char* path) {
         ATOMDEV_REQUIRE(j == jm && k == km, "wrong topography file size");
     }
     // -180..180 -> 0..360 (lib/Utils.cpp:31-37): the halves of a row change places, the last entry repeats the first
-    auto rotate = [km](double* row) {
+    auto rotate = [km](auto* row) {
         for (int n = 0; n < km / 2; n++) std::swap(row[n], row[km / 2 + n]);
         row[km - 1] = row[0];
     };
@@ -269,24 +270,41 @@ extern "C" int atomdev_hyd_read_sea_ground(atomdev_t* h, const char* path) {
         rotate(&bathymetry[(size_t)jj * km]);
         for (int i = 0; i < im; i++) rotate(&H(i, jj, 0));
     }
-    // needles (:88-113); `met` never goes back to 0, so every point after the first needle clears its diagonals
-    auto land = [&](int i, int jj, int kk) { return std::fabs(H(i, jj, kk) - 1) < 2.220446049250313e-16; };
-    double met = 0.;
-    for (int kk = 2; kk < km - 2; kk++)
-        for (int jj = 2; jj < jm - 2; jj++)
-            for (int i = 2; i < im - 2; i++) {
-                if (land(i, jj, kk) && !land(i, jj + 1, kk) && !land(i, jj - 1, kk) && !land(i, jj, kk + 1) && !land(i, jj, kk - 1)) {
-                    met = H(i, jj, kk);
-                    H(i, jj, kk) = 0.;
+    // Needles (:88-113): a solid cell with water on its four sides becomes water, and from the first such cell on
+    // (`h_center` is never reset) every visited point clears the diagonal neighbours that have water two cells away
+    // on both of their sides.  The reference visits the points k-outer, j, i-inner; a point reads and writes its own
+    // level only, and the one thing levels share is whether the first needle has been met yet.  So: the first needle
+    // of every level on the unsmoothed mask (nothing is modified before the first needle of all), the earliest of
+    // them in visiting order, then level by level - a plane of bytes that stays in cache - with `met` switched on
+    // from that moment of the visiting order.
+    auto needle = [&](int i, int jj, int kk) {
+        return H(i, jj, kk) && !H(i, jj + 1, kk) && !H(i, jj - 1, kk) && !H(i, jj, kk + 1) && !H(i, jj, kk - 1);
+    };
+    long first = -1;  // (k * jm + j) * im + i of the first needle
+    for (int i = 2; i < im - 2; i++)
+        for (int kk = 2; kk < km - 2; kk++) {
+            bool found = false;
+            for (int jj = 2; jj < jm - 2 && !found; jj++)
+                if (needle(i, jj, kk)) {
+                    const long at = ((long)kk * jm + jj) * im + i;
+                    if (first < 0 || at < first) first = at;
+                    found = true;
                 }
-                if (met == 1.) {
-                    const bool n2 = !land(i, jj - 2, kk), s2 = !land(i, jj + 2, kk);
-                    if (n2 && !land(i, jj, kk + 2)) H(i, jj - 1, kk + 1) = 0.;
-                    if (n2 && !land(i, jj, kk - 2)) H(i, jj - 1, kk - 1) = 0.;
-                    if (s2 && !land(i, jj, kk - 2)) H(i, jj + 1, kk - 1) = 0.;
-                    if (s2 && !land(i, jj, kk + 2)) H(i, jj + 1, kk + 1) = 0.;
+            if (found || (first >= 0 && ((long)(kk + 1) * jm) * im > first)) break;  // later columns cannot be earlier
+        }
+    if (first >= 0)
+        for (int i = 2; i < im - 2; i++)
+            for (int kk = 2; kk < km - 2; kk++)
+                for (int jj = 2; jj < jm - 2; jj++) {
+                    if (needle(i, jj, kk)) H(i, jj, kk) = 0;
+                    if (((long)kk * jm + jj) * im + i >= first) {
+                        const bool n2 = !H(i, jj - 2, kk), s2 = !H(i, jj + 2, kk);
+                        if (n2 && !H(i, jj, kk + 2)) H(i, jj - 1, kk + 1) = 0;
+                        if (n2 && !H(i, jj, kk - 2)) H(i, jj - 1, kk - 1) = 0;
+                        if (s2 && !H(i, jj, kk - 2)) H(i, jj + 1, kk - 1) = 0;
+                        if (s2 && !H(i, jj, kk + 2)) H(i, jj + 1, kk + 1) = 0;
+                    }
                 }
-            }
-    if (int rc = atomdev_upload(h, ATOMDEV_H, solid.data())) return rc;
+    if (int rc = atomdev_upload_mask_bytes(h, solid.data())) return rc;
     return atomdev_upload2d(h, ATOMDEV_TOPOGRAPHY, bathymetry.data());
 }

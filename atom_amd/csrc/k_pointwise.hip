@@ -118,6 +118,25 @@ inline unsigned blocks_for(size_t n) { return (unsigned)((n + TPB - 1) / TPB); }
 
 }  // namespace
 
+// Solid cells as bytes (1 = solid) -> the field h (1. / 0.): the readers build their masks as bytes on the host, an
+// eighth of the field to fill, rotate, smooth and send; the flags buffer stages the bytes and is derived anew afterwards.
+namespace {
+__global__ void k_expand_mask(const uint8_t* __restrict__ solid, double* __restrict__ hfield, size_t n) {
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n) hfield[q] = solid[q] ? 1. : 0.;
+}
+}  // namespace
+
+int atomdev_upload_mask_bytes(atomdev* h, const uint8_t* solid) {
+    ATOMDEV_TRY(hipSetDevice(h->device));
+    ATOMDEV_TRY(hipMemcpyAsync(h->flags, solid, h->n3, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_expand_mask, dim3(blocks_for(h->n3)), dim3(TPB), 0, h->stream, h->flags, h->f[ATOMDEV_H], h->n3);
+    ATOMDEV_TRY(hipGetLastError());
+    ATOMDEV_TRY(hipStreamSynchronize(h->stream));  // the host buffer may be reused at once
+    h->flags_dirty = true;
+    return 0;
+}
+
 int atomdev_refresh_flags(atomdev* h) {
     if (!h->flags_dirty) return 0;
     hipLaunchKernelGGL(k_derive_flags, dim3(blocks_for(h->n3)), dim3(TPB), 0, h->stream, h->f[ATOMDEV_H], h->flags,

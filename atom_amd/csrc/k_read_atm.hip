@@ -13,14 +13,16 @@ extern "C" int atomdev_atm_read_mountain_surface(atomdev_t* h, const char* path)
     ATOMDEV_REQUIRE(h && path && h->model == ATOMDEV_ATM, "atomdev_atm_read_mountain_surface: needs an atmosphere handle and a path");
     const int im = h->im, jm = h->jm, km = h->km;
     const double L_atm = h->p.L_atm;
-    std::vector<double> solid(h->n3, 0.), topography(h->n2, 0.), values;
+    std::vector<uint8_t> solid(h->n3, 0);  // h as bytes: 1 = solid
+    std::vector<double> topography(h->n2, 0.), values;
     auto entry = [&](int j, int k, double height) {
         if (height < 0.) {
-            solid[idx3(jm, km, 0, j, k)] = topography[(size_t)j * km + k] = 0.;
+            solid[idx3(jm, km, 0, j, k)] = 0;
+            topography[(size_t)j * km + k] = 0.;
         } else {
             const int i_h = std::min(int(std::floor(height / L_atm * (im - 1))), im - 1);  // the reference has no upper bound
             topography[(size_t)j * km + k] = height;
-            for (int i = 0; i <= i_h; i++) solid[idx3(jm, km, i, j, k)] = 1.;
+            for (int i = 0; i <= i_h; i++) solid[idx3(jm, km, i, j, k)] = 1;
         }
     };
     bool opened = false;
@@ -45,7 +47,7 @@ extern "C" int atomdev_atm_read_mountain_surface(atomdev_t* h, const char* path)
         ATOMDEV_REQUIRE(j == jm && k == km, "wrong topography file size");
     }
     // -180..180 -> 0..360 (lib/Utils.cpp:31-37)
-    auto rotate = [km](double* row) {
+    auto rotate = [km](auto* row) {
         for (int n = 0; n < km / 2; n++) std::swap(row[n], row[km / 2 + n]);
         row[km - 1] = row[0];
     };
@@ -53,6 +55,6 @@ extern "C" int atomdev_atm_read_mountain_surface(atomdev_t* h, const char* path)
         rotate(&topography[(size_t)jj * km]);
         for (int i = 0; i < im; i++) rotate(&solid[idx3(jm, km, i, jj, 0)]);
     }
-    if (int rc = atomdev_upload(h, ATOMDEV_H, solid.data())) return rc;
+    if (int rc = atomdev_upload_mask_bytes(h, solid.data())) return rc;
     return atomdev_upload2d(h, ATOMDEV_TOPOGRAPHY, topography.data());
 }
