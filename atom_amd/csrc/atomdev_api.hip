@@ -307,6 +307,7 @@ extern "C" int atomdev_sync(atomdev_t* h) {
     if (h->ws_err) {  // a wave of the hydrosphere sweep that waited for another workgroup and gave up
         int err = 0;
         ATOMDEV_TRY(hipMemcpy(&err, h->ws_err, sizeof(int), hipMemcpyDeviceToHost));
+        if (err) ATOMDEV_TRY(hipMemset(h->ws_err, 0, sizeof(int)));  // reported once
         ATOMDEV_REQUIRE(err == 0, "hyd_rk3d: level im-2 gave up waiting for the salinity rows of level im-3; the fields of the last sweep are not valid");
     }
     return 0;
