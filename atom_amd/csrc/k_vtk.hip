@@ -277,6 +277,143 @@ int write_vtk(atomdev* h, int kind, int index, int Ma, const char* path) {
 
 }  // namespace
 
+// ---- paraview_panorama_vts (PostProcess_Atm.cpp:120-238, dump_array :33-48; PostProcess_Hyd.cpp:269-366) ----
+// The whole grid as an ASCII .vts file, one field after the other in the writers' (k, j, i) order.  One field is on
+// the host at a time; its text goes through a large stdio buffer.
+namespace {
+
+struct VtsFile {
+    FILE* f = nullptr;
+    std::vector<char> buffer;
+    std::vector<double> field;
+    atomdev* h;
+    explicit VtsFile(atomdev* h_) : buffer(1 << 22), field(h_->n3), h(h_) {}
+    ~VtsFile() { if (f) std::fclose(f); }
+    int fetch(int id) {
+        ATOMDEV_TRY(hipMemcpyAsync(field.data(), h->f[id], h->n3 * 8, hipMemcpyDeviceToHost, h->stream));
+        ATOMDEV_TRY(hipStreamSynchronize(h->stream));
+        return 0;
+    }
+    // values of the fetched field in (k, j, i) order, `blank` after every row of levels and after every meridian
+    template <class Value>
+    void walk(const char* blank, Value value) {
+        const int im = h->im, jm = h->jm, km = h->km;
+        for (int k = 0; k < km; k++) {
+            for (int j = 0; j < jm; j++) {
+                for (int i = 0; i < im; i++) std::fprintf(f, "%.4f\n", value(field[idx3(jm, km, i, j, k)]));
+                std::fputs(blank, f);
+            }
+            std::fputs(blank, f);
+        }
+    }
+    // dump_array: single newlines between the blocks
+    int array(const char* name, int id, double multiplier) {
+        if (int rc = fetch(id)) return rc;
+        std::fprintf(f, "    <DataArray type=\"Float32\" Name=\"%s\" format=\"ascii\">\n", name);
+        walk("\n", [multiplier](double x) { return x * multiplier; });
+        std::fputs("\n    </DataArray>\n", f);
+        return 0;
+    }
+};
+
+int write_panorama(atomdev* h, const char* path) {
+    ATOMDEV_TRY(hipSetDevice(h->device));
+    const bool atm = h->model == ATOMDEV_ATM;
+    const int im = h->im, jm = h->jm, km = h->km;
+    const atomdev_params& P = h->p;
+    VtsFile out(h);
+    out.f = std::fopen(path, "w");
+    ATOMDEV_REQUIRE(out.f, std::string("could not open panorama_vts file ") + path);
+    std::setvbuf(out.f, out.buffer.data(), _IOFBF, out.buffer.size());
+    FILE* f = out.f;
+    // every line the writers end with "\n" << endl carries two newlines
+    std::fputs("<?xml version=\"1.0\"?>\n\n<VTKFile type=\"StructuredGrid\" version=\"0.1\" byte_order=\"LittleEndian\">\n\n", f);
+    std::fprintf(f, " <StructuredGrid WholeExtent=\"1 %d 1 %d 1 %d\">\n\n  <Piece Extent=\"1 %d 1 %d 1 %d\">\n\n", im, jm, km, im, jm, km);
+    std::fputs(atm ? "   <PointData Vectors=\"Velocity\" Scalars=\"Topography u-component v-component w-component Temperature "
+                     "CondensationTemp EvaporationTemp Epsilon_3D PressureDynamic PressureStatic WaterVapour CloudWater CloudIce "
+                     "CO2-Concentration Q_Latent Rain RainSuper Ice PrecipitationRain PrecipitationSnow PrecipitationConv Updraft "
+                     "Downdraft\">\n\n"
+                   : "   <PointData Vectors=\"Velocity\" Scalars=\"Topography Temperature PressureDynamic PressureStatic Salinity\">\n\n", f);
+    std::fputs("    <DataArray type=\"Float32\" NumberOfComponents=\"3\" Name=\"Velocity\" format=\"ascii\">\n\n", f);
+    {
+        std::vector<double> v(h->n3), w(h->n3);
+        ATOMDEV_TRY(hipMemcpyAsync(v.data(), h->f[ATOMDEV_V], h->n3 * 8, hipMemcpyDeviceToHost, h->stream));
+        ATOMDEV_TRY(hipMemcpyAsync(w.data(), h->f[ATOMDEV_W], h->n3 * 8, hipMemcpyDeviceToHost, h->stream));
+        if (int rc = out.fetch(ATOMDEV_U)) return rc;
+        for (int k = 0; k < km; k++) {
+            for (int j = 0; j < jm; j++) {
+                for (int i = 0; i < im; i++) {
+                    const size_t q = idx3(jm, km, i, j, k);
+                    std::fprintf(f, "%.4f %.4f %.4f\n", out.field[q], v[q], w[q]);
+                }
+                std::fputs("\n\n", f);
+            }
+            std::fputs("\n\n", f);
+        }
+        std::fputs("\n\n    </DataArray>\n\n", f);
+    }
+    struct Column { const char* name; int field; double multiplier; };
+    auto arrays = [&](std::initializer_list<Column> list) {
+        for (const Column& c : list) if (int rc = out.array(c.name, c.field, c.multiplier)) return rc;
+        return 0;
+    };
+    if (atm) {
+        if (int rc = arrays({ { "Topography", ATOMDEV_H, 1. }, { "u-component", ATOMDEV_U, 1. }, { "v-component", ATOMDEV_V, 1. },
+                              { "w-component", ATOMDEV_W, 1. } })) return rc;
+        if (int rc = out.fetch(ATOMDEV_T)) return rc;
+        std::fputs("    <DataArray type=\"Float32\" Name=\"Temperature\" format=\"ascii\">\n\n", f);
+        const double t_0 = P.t_0;
+        out.walk("\n\n", [t_0](double x) { return x * t_0 - t_0; });
+        std::fputs("\n\n    </DataArray>\n\n", f);
+        if (int rc = arrays({ { "Epsilon_3D", ATOMDEV_EPSILON_3D, 1. }, { "WaterVapour", ATOMDEV_C, 1000. }, { "CloudWater", ATOMDEV_CLOUD, 1000. },
+                              { "CloudIce", ATOMDEV_ICE, 1000. }, { "PrecipitationRain", ATOMDEV_P_RAIN, 86400. },
+                              { "PrecipitationSnow", ATOMDEV_P_SNOW, 86400. }, { "PressureDynamic", ATOMDEV_P_DYN, P.u_0 * P.u_0 * P.r_air * .01 },
+                              { "PressureStatic", ATOMDEV_P_STAT, 1. }, { "BuoyancyForce", ATOMDEV_BUOYANCY, 1. },
+                              { "CO2-Concentration", ATOMDEV_CO2, 1. }, { "Q_Latent", ATOMDEV_Q_LATENT, 1. },
+                              { "Q_Sensible", ATOMDEV_Q_SENSIBLE, 1. } })) return rc;
+    } else {
+        if (int rc = arrays({ { "Topography", ATOMDEV_H, 1. }, { "u-velocity", ATOMDEV_U, 1000. }, { "v-velocity", ATOMDEV_V, 1. },
+                              { "w-velocity", ATOMDEV_W, 1. }, { "Temperature", ATOMDEV_T, 1. },
+                              { "PressureDynamic", ATOMDEV_P_DYN, P.u_0 * P.u_0 * P.r_0_water * 1e-3 }, { "PressureStatic", ATOMDEV_P_STAT, 1. },
+                              { "Salinity", ATOMDEV_C, 1. }, { "DensityWater", ATOMDEV_R_WATER, 1. },
+                              { "DensitySaltWater", ATOMDEV_R_SALT_WATER, 1. }, { "Salt_Finger", ATOMDEV_SALT_FINGER, 1. },
+                              { "SaltDiffusion", ATOMDEV_SALT_DIFFUSION, 1. }, { "SaltBalance", ATOMDEV_SALT_BALANCE, 1. },
+                              { "BuoyancyForce", ATOMDEV_BUOYANCY, 1. } })) return rc;
+    }
+    std::fputs("   </PointData>\n\n   <Points>\n\n    <DataArray type=\"Float32\" NumberOfComponents=\"3\" format=\"ascii\">\n\n", f);
+    {   // the "cartesian" coordinates: x grows along a column except on the first meridian and the first row
+        double x = 0., y = 0., z = 0.;
+        const double dx = atm ? .1 : .025, dy = .1, dz = .1;
+        for (int k = 0; k < km; k++) {
+            for (int j = 0; j < jm; j++) {
+                for (int i = 0; i < im; i++) {
+                    if (k == 0 || j == 0) x = 0.; else x = x + dx;
+                    std::fprintf(f, "%.4f %.4f %.4f\n", x, y, z);
+                }
+                x = 0;
+                y = y + dy;
+                std::fputs("\n\n", f);
+            }
+            y = 0;
+            z = z + dz;
+            std::fputs("\n\n", f);
+        }
+    }
+    std::fputs("    </DataArray>\n\n   </Points>\n\n  </Piece>\n\n </StructuredGrid>\n\n</VTKFile>\n\n", f);
+    const bool ok = std::fflush(f) == 0 && !std::ferror(f);
+    const bool closed = std::fclose(f) == 0;
+    out.f = nullptr;
+    ATOMDEV_REQUIRE(ok && closed, std::string("write failed: ") + path);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int atomdev_write_panorama_vts(atomdev_t* h, const char* path) {
+    ATOMDEV_REQUIRE(h && path, "atomdev_write_panorama_vts: bad argument");
+    return write_panorama(h, path);
+}
+
 extern "C" int atomdev_write_vtk(atomdev_t* h, int section, int index, int Ma, const char* path) {
     ATOMDEV_REQUIRE(h && path, "atomdev_write_vtk: bad argument");
     ATOMDEV_REQUIRE(section >= ATOMDEV_RADIAL && section <= ATOMDEV_ZONAL, "atomdev_write_vtk: section is 0 (radial), 1 (longal) or 2 (zonal)");

@@ -93,6 +93,7 @@ def load_library():
     lib.atomdev_atm_vegetation_distribution.argtypes = [vp, C.c_double]
     lib.atomdev_atm_two_category_ice_scheme.argtypes = [vp, dp]
     lib.atomdev_write_vtk.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_char_p]
+    lib.atomdev_write_panorama_vts.argtypes = [vp, C.c_char_p]
     lib.atomdev_default_hyd_start.argtypes = [C.c_int, C.POINTER(HydStart)]
     lib.atomdev_default_hyd_start.restype = None
     lib.atomdev_hyd_read_sea_ground.argtypes = [vp, C.c_char_p]
@@ -270,6 +271,10 @@ class DeviceModel:
     def write_vtk(self, section, index, path, Ma=0):
         """paraview_vtk_radial / _longal / _zonal (section 0 / 1 / 2) of the handle's model at level / row / column index."""
         self._check(self.lib.atomdev_write_vtk(self._h, section, index, Ma, os.fsencode(path)))
+
+    def write_panorama_vts(self, path):
+        """paraview_panorama_vts of the handle's model: the whole grid as an ASCII .vts file."""
+        self._check(self.lib.atomdev_write_panorama_vts(self._h, os.fsencode(path)))
 
     def write_plot_data(self, path):
         """Atmosphere_PlotData / Hydrosphere_PlotData: the surface table of the slice as text."""

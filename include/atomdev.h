@@ -225,6 +225,13 @@ int atomdev_hyd_write_plot_data(atomdev_t* h, const char* path);
 enum atomdev_section { ATOMDEV_RADIAL = 0, ATOMDEV_LONGAL = 1, ATOMDEV_ZONAL = 2 };
 int atomdev_write_vtk(atomdev_t* h, int section, int index, int Ma, const char* path);
 
+/* PostProcess_Atmosphere::paraview_panorama_vts (atmosphere/PostProcess_Atm.cpp:120-238) and
+ * PostProcess_Hydrosphere::paraview_panorama_vts (hydrosphere/PostProcess_Hyd.cpp:269-366), chosen by the handle's
+ * model: the whole grid as an ASCII .vts file (the models write it only when their paraview_panorama_vts flag is set;
+ * about 150 bytes per grid point).  path is the whole file name (the reference builds it as output_path + "/[" + name +
+ * "]_Atm_panorama_" + n + ".vts"). */
+int atomdev_write_panorama_vts(atomdev_t* h, const char* path);
+
 /* BC_Bathymetry_Atmosphere::BC_MountainSurface (atmosphere/BC_Bath_Atm.cpp:39-90): reads the topography file (lon lat
  * height per line, jm x km lines, longitudes -180..180), builds h (1 = solid up to the level of the height) and
  * Topography (metres, 0 over the sea), and moves both to 0..360.  A file with fewer than jm x km entries is an error

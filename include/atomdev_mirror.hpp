@@ -448,6 +448,23 @@ public:
         const std::string path = out_ + "/[" + Name_Bathymetry_File + "]_Transfer_Atm.vw";
         d.run(atomdev_atm_write_transfer_file(d.handle(), path.c_str()), "atomdev_atm_write_transfer_file");
     }
+    // atmosphere/PostProcess_Atm.cpp:120-238
+    void paraview_panorama_vts(std::string& Name_Bathymetry_File, int n, double& u_0, double& t_0, double&, double& r_air, double&,
+                               double&, Array& h, Array& t, Array& p_dyn, Array& p_stat, Array& BuoyancyForce, Array& u, Array& v,
+                               Array& w, Array& c, Array& co2, Array& cloud, Array& ice, Array&, Array&, Array&, Array& Q_Latent,
+                               Array& Q_Sensible, Array& epsilon_3D, Array& P_rain, Array& P_snow) {
+        Device& d = Device::of(ATOMDEV_ATM);
+        d.grid(im_, jm_, km_);
+        atomdev_params& p = d.params();
+        p.u_0 = u_0; p.t_0 = t_0; p.r_air = r_air;
+        push_all(d, { { ATOMDEV_H, &h }, { ATOMDEV_T, &t }, { ATOMDEV_P_DYN, &p_dyn }, { ATOMDEV_P_STAT, &p_stat },
+                      { ATOMDEV_BUOYANCY, &BuoyancyForce }, { ATOMDEV_U, &u }, { ATOMDEV_V, &v }, { ATOMDEV_W, &w }, { ATOMDEV_C, &c },
+                      { ATOMDEV_CO2, &co2 }, { ATOMDEV_CLOUD, &cloud }, { ATOMDEV_ICE, &ice }, { ATOMDEV_Q_LATENT, &Q_Latent },
+                      { ATOMDEV_Q_SENSIBLE, &Q_Sensible }, { ATOMDEV_EPSILON_3D, &epsilon_3D }, { ATOMDEV_P_RAIN, &P_rain },
+                      { ATOMDEV_P_SNOW, &P_snow } });
+        const std::string path = out_ + "/[" + Name_Bathymetry_File + "]_Atm_panorama_" + std::to_string(n) + ".vts";
+        d.run(atomdev_write_panorama_vts(d.handle(), path.c_str()), "atomdev_write_panorama_vts");
+    }
     // atmosphere/PostProcess_Atm.cpp:240-389
     void paraview_vtk_radial(std::string& Name_Bathymetry_File, int Ma, int i_radial, int n, double& u_0, double& t_0, double&,
                              double& r_air, double&, double& co2_0, Array& h, Array& p_dyn, Array& p_stat, Array& BuoyancyForce,
@@ -780,6 +797,22 @@ public:
         d.pull2d(ATOMDEV_EVAPORATION_DALTON, Evaporation_Dalton); d.pull2d(ATOMDEV_PRECIPITATION, Precipitation);
     }
 
+    // hydrosphere/PostProcess_Hyd.cpp:269-366
+    void paraview_panorama_vts(const std::string& Name_Bathymetry_File, int n, double& u_0, double& r_0_water, Array& h, Array& t,
+                               Array& p_dyn, Array& p_stat, Array& r_water, Array& r_salt_water, Array& u, Array& v, Array& w, Array& c,
+                               Array&, Array&, Array&, Array& Salt_Finger, Array& Salt_Diffusion, Array& Buoyancy_Force,
+                               Array& Salt_Balance) {
+        Device& d = Device::of(ATOMDEV_HYD);
+        d.grid(im_, jm_, km_);
+        d.params().u_0 = u_0; d.params().r_0_water = r_0_water;
+        push_all(d, { { ATOMDEV_H, &h }, { ATOMDEV_T, &t }, { ATOMDEV_P_DYN, &p_dyn }, { ATOMDEV_P_STAT, &p_stat },
+                      { ATOMDEV_R_WATER, &r_water }, { ATOMDEV_R_SALT_WATER, &r_salt_water }, { ATOMDEV_U, &u }, { ATOMDEV_V, &v },
+                      { ATOMDEV_W, &w }, { ATOMDEV_C, &c }, { ATOMDEV_SALT_FINGER, &Salt_Finger },
+                      { ATOMDEV_SALT_DIFFUSION, &Salt_Diffusion }, { ATOMDEV_BUOYANCY, &Buoyancy_Force },
+                      { ATOMDEV_SALT_BALANCE, &Salt_Balance } });
+        const std::string path = out_ + "/[" + Name_Bathymetry_File + "]_Hyd_panorama_" + std::to_string(n) + ".vts";
+        d.run(atomdev_write_panorama_vts(d.handle(), path.c_str()), "atomdev_write_panorama_vts");
+    }
     // hydrosphere/PostProcess_Hyd.cpp:373-449, 559-636: the two sections that need no surface fields
     void paraview_vtk_longal(const std::string& Name_Bathymetry_File, int j_longal, int n, double& u_0, double& r_0_water, Array& h,
                              Array& p_dyn, Array& p_stat, Array& r_water, Array& r_salt_water, Array& t, Array& u, Array& v, Array& w,

@@ -1917,6 +1917,113 @@ static void vtk_hyd_radial(FILE* f, oracle_ctx* c, int i_radial) {
     vtk_vectors(f, c, "VECTORS v-w-Cell float", S, i_radial);
 }
 
+/* paraview_panorama_vts of both models (PostProcess_Atm.cpp:120-238 with dump_array :33-48; PostProcess_Hyd.cpp:269-366).
+ * A string the writers end with "\n" << endl carries two newlines; dump_array ends its lines with one. */
+static void vts_dump_array(FILE* f, const oracle_ctx* c, const char* name, int F, double multiplier) {
+    fprintf(f, "    <DataArray type=\"Float32\" Name=\"%s\" format=\"ascii\">\n", name);
+    for (int k = 0; k < c->km; k++) {
+        for (int j = 0; j < c->jm; j++) {
+            for (int i = 0; i < c->im; i++) fprintf(f, "%.4f\n", A3(c, F, i, j, k) * multiplier);
+            fprintf(f, "\n");
+        }
+        fprintf(f, "\n");
+    }
+    fprintf(f, "\n");
+    fprintf(f, "    </DataArray>\n");
+}
+
+int oracle_write_panorama_vts(oracle_ctx* c, const char* path) {
+    FILE* f = fopen(path, "w");
+    if (!f) return 1;
+    const int atm = c->model == ATOMDEV_ATM, im = c->im, jm = c->jm, km = c->km;
+    const atomdev_params* P = &c->p;
+    fprintf(f, "<?xml version=\"1.0\"?>\n\n");
+    fprintf(f, "<VTKFile type=\"StructuredGrid\" version=\"0.1\" byte_order=\"LittleEndian\">\n\n");
+    fprintf(f, " <StructuredGrid WholeExtent=\"%d %d %d %d %d %d\">\n\n", 1, im, 1, jm, 1, km);
+    fprintf(f, "  <Piece Extent=\"%d %d %d %d %d %d\">\n\n", 1, im, 1, jm, 1, km);
+    if (atm) fprintf(f, "   <PointData Vectors=\"Velocity\" Scalars=\"Topography u-component v-component w-component Temperature CondensationTemp EvaporationTemp Epsilon_3D PressureDynamic PressureStatic WaterVapour CloudWater CloudIce CO2-Concentration Q_Latent Rain RainSuper Ice PrecipitationRain PrecipitationSnow PrecipitationConv Updraft Downdraft\">\n\n");
+    else fprintf(f, "   <PointData Vectors=\"Velocity\" Scalars=\"Topography Temperature PressureDynamic PressureStatic Salinity\">\n\n");
+    fprintf(f, "    <DataArray type=\"Float32\" NumberOfComponents=\"3\" Name=\"Velocity\" format=\"ascii\">\n\n");
+    for (int k = 0; k < km; k++) {
+        for (int j = 0; j < jm; j++) {
+            for (int i = 0; i < im; i++)
+                fprintf(f, "%.4f %.4f %.4f\n", A3(c, ATOMDEV_U, i, j, k), A3(c, ATOMDEV_V, i, j, k), A3(c, ATOMDEV_W, i, j, k));
+            fprintf(f, "\n\n");
+        }
+        fprintf(f, "\n\n");
+    }
+    fprintf(f, "\n\n");
+    fprintf(f, "    </DataArray>\n\n");
+    if (atm) {
+        vts_dump_array(f, c, "Topography", ATOMDEV_H, 1.0);
+        vts_dump_array(f, c, "u-component", ATOMDEV_U, 1.0);
+        vts_dump_array(f, c, "v-component", ATOMDEV_V, 1.0);
+        vts_dump_array(f, c, "w-component", ATOMDEV_W, 1.0);
+        fprintf(f, "    <DataArray type=\"Float32\" Name=\"Temperature\" format=\"ascii\">\n\n");
+        for (int k = 0; k < km; k++) {
+            for (int j = 0; j < jm; j++) {
+                for (int i = 0; i < im; i++) fprintf(f, "%.4f\n", A3(c, ATOMDEV_T, i, j, k) * P->t_0 - P->t_0);
+                fprintf(f, "\n\n");
+            }
+            fprintf(f, "\n\n");
+        }
+        fprintf(f, "\n\n");
+        fprintf(f, "    </DataArray>\n\n");
+        vts_dump_array(f, c, "Epsilon_3D", ATOMDEV_EPSILON_3D, 1.0);
+        vts_dump_array(f, c, "WaterVapour", ATOMDEV_C, 1000.0);
+        vts_dump_array(f, c, "CloudWater", ATOMDEV_CLOUD, 1000.0);
+        vts_dump_array(f, c, "CloudIce", ATOMDEV_ICE, 1000.0);
+        vts_dump_array(f, c, "PrecipitationRain", ATOMDEV_P_RAIN, 86400.);
+        vts_dump_array(f, c, "PrecipitationSnow", ATOMDEV_P_SNOW, 86400.);
+        vts_dump_array(f, c, "PressureDynamic", ATOMDEV_P_DYN, P->u_0 * P->u_0 * P->r_air * .01);
+        vts_dump_array(f, c, "PressureStatic", ATOMDEV_P_STAT, 1.0);
+        vts_dump_array(f, c, "BuoyancyForce", ATOMDEV_BUOYANCY, 1.0);
+        vts_dump_array(f, c, "CO2-Concentration", ATOMDEV_CO2, 1.0);
+        vts_dump_array(f, c, "Q_Latent", ATOMDEV_Q_LATENT, 1.0);
+        vts_dump_array(f, c, "Q_Sensible", ATOMDEV_Q_SENSIBLE, 1.0);
+    } else {
+        vts_dump_array(f, c, "Topography", ATOMDEV_H, 1.0);
+        vts_dump_array(f, c, "u-velocity", ATOMDEV_U, 1000.0);
+        vts_dump_array(f, c, "v-velocity", ATOMDEV_V, 1.0);
+        vts_dump_array(f, c, "w-velocity", ATOMDEV_W, 1.0);
+        vts_dump_array(f, c, "Temperature", ATOMDEV_T, 1.0);
+        vts_dump_array(f, c, "PressureDynamic", ATOMDEV_P_DYN, P->u_0 * P->u_0 * P->r_0_water * 1e-3);
+        vts_dump_array(f, c, "PressureStatic", ATOMDEV_P_STAT, 1.0);
+        vts_dump_array(f, c, "Salinity", ATOMDEV_C, 1.0);
+        vts_dump_array(f, c, "DensityWater", ATOMDEV_R_WATER, 1.0);
+        vts_dump_array(f, c, "DensitySaltWater", ATOMDEV_R_SALT_WATER, 1.0);
+        vts_dump_array(f, c, "Salt_Finger", ATOMDEV_SALT_FINGER, 1.0);
+        vts_dump_array(f, c, "SaltDiffusion", ATOMDEV_SALT_DIFFUSION, 1.0);
+        vts_dump_array(f, c, "SaltBalance", ATOMDEV_SALT_BALANCE, 1.0);
+        vts_dump_array(f, c, "BuoyancyForce", ATOMDEV_BUOYANCY, 1.0);
+    }
+    fprintf(f, "   </PointData>\n\n");
+    fprintf(f, "   <Points>\n\n");
+    fprintf(f, "    <DataArray type=\"Float32\" NumberOfComponents=\"3\" format=\"ascii\">\n\n");
+    double x = 0., y = 0., z = 0., dx = atm ? .1 : .025, dy = .1, dz = .1;
+    for (int k = 0; k < km; k++) {
+        for (int j = 0; j < jm; j++) {
+            for (int i = 0; i < im; i++) {
+                if (k == 0 || j == 0) x = 0.;
+                else x = x + dx;
+                fprintf(f, "%.4f %.4f %.4f\n", x, y, z);
+            }
+            x = 0;
+            y = y + dy;
+            fprintf(f, "\n\n");
+        }
+        y = 0;
+        z = z + dz;
+        fprintf(f, "\n\n");
+    }
+    fprintf(f, "    </DataArray>\n\n");
+    fprintf(f, "   </Points>\n\n");
+    fprintf(f, "  </Piece>\n\n");
+    fprintf(f, " </StructuredGrid>\n\n");
+    fprintf(f, "</VTKFile>\n\n");
+    return fclose(f) != 0;
+}
+
 int oracle_write_vtk(oracle_ctx* c, int section, int index, int Ma, const char* path) {
     FILE* f = fopen(path, "w");
     if (!f) return 1;

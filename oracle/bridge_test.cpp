@@ -375,6 +375,9 @@ void atm_vtk_calls(Fields& F, const Scalars& s, std::string dir, int i_radial, i
     int Ma = 0, iter_cnt = 1;
     double u_0 = s.u_0, t_0 = s.t_0, p_0 = 1013.25, r_air = s.r_air, c_0 = s.c_0, co2_0 = 280., hp = 6.1078, ep = .623,
            R_Air = s.R_Air, g = s.g, L_atm = s.L_atm;
+    write_File.paraview_panorama_vts(bathymetry_name, iter_cnt - 1, u_0, t_0, p_0, r_air, c_0, co2_0, F["h"], F["t"], F["p_dyn"],
+        F["p_stat"], F["BuoyancyForce"], F["u"], F["v"], F["w"], F["c"], F["co2"], F["cloud"], F["ice"], F["aux_u"], F["aux_v"],
+        F["aux_w"], F["Q_Latent"], F["Q_Sensible"], F["epsilon_3D"], F["P_rain"], F["P_snow"]);
     write_File.paraview_vtk_radial(bathymetry_name, Ma, i_radial, iter_cnt - 1, u_0, t_0, p_0, r_air, c_0, co2_0, F["h"], F["p_dyn"],
         F["p_stat"], F["BuoyancyForce"], F["t"], F["u"], F["v"], F["w"], F["c"], F["co2"], F["cloud"], F["ice"], F["aux_u"], F["aux_v"],
         F["aux_w"], F["radiation_3D"], F["Q_Latent"], F["Q_Sensible"], F["epsilon_3D"], F["P_rain"], F["P_snow"],
@@ -398,6 +401,9 @@ void hyd_vtk_calls(Fields& F, const Scalars& s, const std::string& dir, int i_ra
     double u_0 = s.u_0, t_0 = s.t_0, r_0_water = s.r_0_water;
     write_File.paraview_vtk_longal(bathymetry_name, j_longal, iter_cnt - 1, u_0, r_0_water, F["h"], F["p_dyn"], F["p_stat"], F["r_water"],
         F["r_salt_water"], F["t"], F["u"], F["v"], F["w"], F["c"], F["aux_u"], F["aux_v"], F["Salt_Finger"], F["Salt_Diffusion"],
+        F["Buoyancy_Force"], F["Salt_Balance"]);
+    write_File.paraview_panorama_vts(bathymetry_name, iter_cnt - 1, u_0, r_0_water, F["h"], F["t"], F["p_dyn"], F["p_stat"], F["r_water"],
+        F["r_salt_water"], F["u"], F["v"], F["w"], F["c"], F["aux_u"], F["aux_v"], F["aux_w"], F["Salt_Finger"], F["Salt_Diffusion"],
         F["Buoyancy_Force"], F["Salt_Balance"]);
     write_File.paraview_vtk_zonal(bathymetry_name, k_zonal, iter_cnt - 1, u_0, r_0_water, F["h"], F["p_dyn"], F["p_stat"], F["r_water"],
         F["r_salt_water"], F["t"], F["u"], F["v"], F["w"], F["c"], F["Salt_Finger"], F["Salt_Diffusion"], F["Buoyancy_Force"],
@@ -586,6 +592,7 @@ int main(int argc, char** argv) {
         { Quiet q; atm_vtk_calls<RefClasses>(RA, sa, dr_, 0, 7, 11); }
         atm_vtk_calls<DevClasses>(DA, sa, dd_, 0, 7, 11);
         bad += compare(RA, DA, 0., "atmosphere, ParaView sections");
+        bad += same_file(dr_ + "/[bridge]_Atm_panorama_0.vts", dd_ + "/[bridge]_Atm_panorama_0.vts", "atmosphere, panorama file");
         bad += same_file(dr_ + "/[bridge]_Atm_radial_0_0.vtk", dd_ + "/[bridge]_Atm_radial_0_0.vtk", "atmosphere, radial section file");
         bad += same_file(dr_ + "/[bridge]_Atm_longal_7_0.vtk", dd_ + "/[bridge]_Atm_longal_7_0.vtk", "atmosphere, longitudinal section file");
         bad += same_file(dr_ + "/[bridge]_Atm_zonal_11_0.vtk", dd_ + "/[bridge]_Atm_zonal_11_0.vtk", "atmosphere, zonal section file");
@@ -603,6 +610,7 @@ int main(int argc, char** argv) {
         { Quiet q; hyd_vtk_calls<RefClasses>(R, s, dr_, im - 1, 7, 11); }
         hyd_vtk_calls<DevClasses>(D, s, dd_, im - 1, 7, 11);
         bad += compare(R, D, 0., "hydrosphere, ParaView sections");
+        bad += same_file(dr_ + "/[bridge]_Hyd_panorama_0.vts", dd_ + "/[bridge]_Hyd_panorama_0.vts", "hydrosphere, panorama file");
         bad += same_file(dr_ + "/[bridge]_Hyd_radial_8_0.vtk", dd_ + "/[bridge]_Hyd_radial_8_0.vtk", "hydrosphere, radial section file");
         bad += same_file(dr_ + "/[bridge]_Hyd_longal_7_0.vtk", dd_ + "/[bridge]_Hyd_longal_7_0.vtk", "hydrosphere, longitudinal section file");
         bad += same_file(dr_ + "/[bridge]_Hyd_zonal_11_0.vtk", dd_ + "/[bridge]_Hyd_zonal_11_0.vtk", "hydrosphere, zonal section file");

@@ -478,6 +478,25 @@ int ref_write_plot_data(void* v, const char* dir) {
     return 0;
 }
 
+/* the reference's panorama writers; the file appears as dir/[bridge]_{Atm,Hyd}_panorama_0.vts */
+int ref_write_panorama_vts(void* v, const char* dir) {
+    RefCtx* c = (RefCtx*)v; CoutSilencer s; copy_in(c);
+    std::string out(dir), name("bridge");
+    atomdev_params& P = c->p;
+    double p_0 = P.p_0, c_0 = P.c_0;
+    if (c->model == ATOMDEV_ATM) {
+        PostProcess_Atmosphere w(c->im, c->jm, c->km, out);
+        w.paraview_panorama_vts(name, 0, P.u_0, P.t_0, p_0, P.r_air, c_0, P.co2_0, A(H), A(T), A(P_DYN), A(P_STAT), A(BUOYANCY), A(U), A(V),
+                                A(W), A(C), A(CO2), A(CLOUD), A(ICE), A(AUX_U), A(AUX_V), A(AUX_W), A(Q_LATENT), A(Q_SENSIBLE),
+                                A(EPSILON_3D), A(P_RAIN), A(P_SNOW));
+    } else {
+        PostProcess_Hydrosphere w(c->im, c->jm, c->km, out);
+        w.paraview_panorama_vts(name, 0, P.u_0, P.r_0_water, A(H), A(T), A(P_DYN), A(P_STAT), A(R_WATER), A(R_SALT_WATER), A(U), A(V), A(W),
+                                A(C), A(AUX_U), A(AUX_V), A(AUX_W), A(SALT_FINGER), A(SALT_DIFFUSION), A(BUOYANCY), A(SALT_BALANCE));
+    }
+    return 0;
+}
+
 /* the reference's ParaView section writers; the file appears as dir/[bridge]_{Atm,Hyd}_{radial,longal,zonal}_<index>_0.vtk */
 int ref_write_vtk(void* v, int section, int index, int Ma, const char* dir) {
     RefCtx* c = (RefCtx*)v; CoutSilencer s; copy_in(c);

@@ -548,6 +548,26 @@ def test_vtk_section_file_bytes(model, section, index, Ma, tmp_path):
 
 
 @pytest.mark.parametrize("model", [H.ATM, H.HYD])
+def test_panorama_vts_file_bytes(model, tmp_path):
+    """paraview_panorama_vts from device-resident fields: byte for byte the oracle's file (pinned to the reference's
+    writers in tests/test_oracle_vs_reference.py)."""
+    import ctypes as C
+    im, jm, km = 7, 13, 17
+    p, f, g = H.make_vtk_inputs(model, im, jm, km, 97)
+    o = H.CpuModel("oracle", model, im, jm, km, p, f, g)
+    d = atom_amd.DeviceModel(model, im, jm, km, atom_amd.Params.from_buffer_copy(bytes(p)))
+    d.upload_all(f, g)
+    o.lib.oracle_write_panorama_vts.argtypes = [C.c_void_p, C.c_char_p]
+    assert o.lib.oracle_write_panorama_vts(o.ctx, str(tmp_path / "oracle.vts").encode()) == 0
+    d.write_panorama_vts(str(tmp_path / "device.vts"))
+    mine, theirs = (tmp_path / "device.vts").read_bytes(), (tmp_path / "oracle.vts").read_bytes()
+    assert mine == theirs, _first_difference(mine, theirs)
+    with pytest.raises(atom_amd.AtomDevError):
+        d.write_panorama_vts(str(tmp_path / "no_such_dir" / "x.vts"))
+    d.close()
+
+
+@pytest.mark.parametrize("model", [H.ATM, H.HYD])
 def test_vtk_sections_full_grid(model, tmp_path):
     """The three sections each model writes per time slice — atmosphere i = 0, j = 62, k = 87
     (cAtmosphereModel.cpp:610-626), hydrosphere j = 75, k = 185, i = 40 (cHydrosphereModel.cpp:745-759) — on the

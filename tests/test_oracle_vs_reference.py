@@ -225,6 +225,22 @@ def test_atm_read_mountain_surface(tmp_path):
     assert not np.array_equal(a.f["H"], before) and 0.2 < a.f["H"][0].mean() < 0.8 and a.f["H"][4].any()
 
 
+@pytest.mark.parametrize("model", [H.ATM, H.HYD])
+def test_panorama_vts_file(model, tmp_path):
+    """paraview_panorama_vts: the oracle's file is byte for byte the file of the reference's writer."""
+    im, jm, km = 7, 13, 17
+    p, f, g = H.make_vtk_inputs(model, im, jm, km, 97)
+    a, b = H.CpuModel("oracle", model, im, jm, km, p, f, g), H.CpuModel("ref", model, im, jm, km, p, f, g)
+    mine = tmp_path / "mine.vts"
+    a.lib.oracle_write_panorama_vts.argtypes = [C.c_void_p, C.c_char_p]
+    b.lib.ref_write_panorama_vts.argtypes = [C.c_void_p, C.c_char_p]
+    assert a.lib.oracle_write_panorama_vts(a.ctx, str(mine).encode()) == 0
+    b.lib.ref_write_panorama_vts(b.ctx, str(tmp_path).encode())
+    theirs = (tmp_path / ("[bridge]_%s_panorama_0.vts" % ("Atm" if model == H.ATM else "Hyd"))).read_bytes()
+    assert mine.read_bytes() == theirs
+    assert b"-0.0000" in theirs and theirs.count(b"<DataArray") == (19 if model == H.ATM else 16)
+
+
 @pytest.mark.parametrize("max_precipitation", [7.5, 0.0])
 def test_atm_vegetation_distribution(max_precipitation):
     import ctypes as C
