@@ -47,6 +47,13 @@ class HydStart(C.Structure):
                 ("t_average", C.c_double), ("t_cretaceous_max", C.c_double)]
 
 
+class HydSlice(C.Structure):
+    """atomdev_hyd_slice: a hydrosphere time slice as cHydrosphereModel::RunTimeSlice runs it."""
+    _fields_ = [("start", HydStart), ("velocity_iter_max_2D", C.c_int), ("pressure_iter_max_2D", C.c_int),
+                ("velocity_iter_max", C.c_int), ("pressure_iter_max", C.c_int), ("transfer_file", C.c_char_p),
+                ("bathymetry_file", C.c_char_p), ("salinity_file", C.c_char_p), ("queries", C.c_int)]
+
+
 class AtomDevError(RuntimeError):
     pass
 
@@ -97,6 +104,9 @@ def load_library():
     lib.atomdev_default_hyd_start.argtypes = [C.c_int, C.POINTER(HydStart)]
     lib.atomdev_default_hyd_start.restype = None
     lib.atomdev_hyd_read_sea_ground.argtypes = [vp, C.c_char_p]
+    lib.atomdev_default_hyd_slice.argtypes = [C.c_int, C.POINTER(HydSlice)]
+    lib.atomdev_default_hyd_slice.restype = None
+    lib.atomdev_hyd_run_time_slice.argtypes = [vp, C.POINTER(HydSlice), dp, ip]
     lib.atomdev_atm_read_mountain_surface.argtypes = [vp, C.c_char_p]
     lib.atomdev_hyd_read_surface_salinity.argtypes = [vp, C.c_char_p]
     lib.atomdev_hyd_ic_ekman_spiral.argtypes = [vp, C.c_int]
@@ -233,6 +243,25 @@ class DeviceModel:
     def read_mountain_surface(self, path):
         """BC_Bathymetry_Atmosphere::BC_MountainSurface: h and Topography from the topography file."""
         self._check(self.lib.atomdev_atm_read_mountain_surface(self._h, os.fsencode(path)))
+
+    def run_time_slice(self, bathymetry_file, salinity_file=None, transfer_file=None, queries=True, **counts):
+        """cHydrosphereModel::RunTimeSlice on the device; counts: velocity_iter_max_2D, pressure_iter_max_2D,
+        velocity_iter_max, pressure_iter_max, Ma, i_beg.  Returns (residuum before, after, location of the latter)."""
+        s = HydSlice()
+        self.lib.atomdev_default_hyd_slice(self.im, C.byref(s))
+        for k, v in counts.items():
+            if k in ("Ma", "i_beg"):
+                setattr(s.start, k, v)
+            else:
+                setattr(s, k, v)
+        s.bathymetry_file = os.fsencode(bathymetry_file)
+        s.salinity_file = os.fsencode(salinity_file) if salinity_file else None
+        s.transfer_file = os.fsencode(transfer_file) if transfer_file else None
+        s.queries = 1 if queries else 0
+        res = (C.c_double * 2)()
+        loc = (C.c_int * 3)()
+        self._check(self.lib.atomdev_hyd_run_time_slice(self._h, C.byref(s), res, loc))
+        return res[0], res[1], tuple(loc)
 
     def read_sea_ground(self, path):
         """BC_Bathymetry_Hydrosphere::BC_SeaGround: h and Bathymetry from the bathymetry file."""

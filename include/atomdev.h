@@ -291,6 +291,26 @@ int atomdev_hyd_ic_circumpolar_current(atomdev_t* h, int i_beg);
  * below 4 C, parabolic decrease of t and c with depth down to level i_beg, (ta, ca) below and on land. */
 int atomdev_hyd_bc_temperature_salinity(atomdev_t* h, const atomdev_hyd_start* s);
 
+/* cHydrosphereModel::RunTimeSlice (hydrosphere/cHydrosphereModel.cpp:234-610) without its printing and its output
+ * files: transfer file, sea ground, initial conditions, pressure_iter_max_2D x velocity_iter_max_2D surface iterations,
+ * pressure_iter_max x velocity_iter_max volume iterations with Results_Hyd::run_data, each operator the entry point
+ * above that stands for it, in the reference's order, nothing uploaded or downloaded in between.  transfer_file and
+ * salinity_file may be NULL (the surface fields are taken as they are / the salinity is not read; the reference reads
+ * it when Ma == 0).  queries != 0 runs the residuum and steady-state queries where the reference does (their results
+ * are printed only there); residuum[0], residuum[1] (may be NULL) receive the continuity residuum before and after
+ * the last velocity iteration, residuum_loc (may be NULL) the location of the latter.  Output files: atomdev_write_vtk,
+ * atomdev_write_panorama_vts, atomdev_hyd_write_plot_data afterwards. */
+typedef struct atomdev_hyd_slice {
+    atomdev_hyd_start start;
+    int velocity_iter_max_2D, pressure_iter_max_2D, velocity_iter_max, pressure_iter_max;  /* param.py:135-138: 2, 10, 2, 2 */
+    const char* transfer_file;    /* output_path/[<Ma>Ma_Golonka.xyz]_Transfer_Atm.vw */
+    const char* bathymetry_file;  /* bathymetry_path/<Ma>Ma_Golonka.xyz */
+    const char* salinity_file;    /* Name_SurfaceSalinity_File */
+    int queries;
+} atomdev_hyd_slice;
+void atomdev_default_hyd_slice(int im, atomdev_hyd_slice* s);
+int atomdev_hyd_run_time_slice(atomdev_t* h, const atomdev_hyd_slice* s, double residuum[2], int residuum_loc[3]);
+
 /* solveRungeKutta_3D_Hydrosphere + RK_RHS_3D_Hydrosphere
  * (hydrosphere/RungeKutta_Hyd.cpp:30-124, RHS_Hyd.cpp:60-447) */
 int atomdev_hyd_rk3d(atomdev_t* h);

@@ -265,3 +265,27 @@ def test_hyd_time_slice_one_degree_reference_iteration_counts(tmp_path):
         assert e <= 1e-10, (k, e)
     print("hydrosphere 1-degree time slice on the device: max rel err %.3e" % worst)
     d.close()
+
+
+@pytest.mark.gpu
+def test_hyd_run_time_slice_one_call_same_bits(tmp_path):
+    """atomdev_hyd_run_time_slice - the whole slice in one call - leaves every field with the bits of the same
+    operators called one by one (which the tests above hold against the oracle and the compiled reference), and
+    returns the last pair of residuum queries."""
+    dims, p, f, g, bath, salt = _hyd_slice_inputs(tmp_path, 185, 83)
+    a = atom_amd.DeviceModel(H.HYD, *dims, atom_amd.Params.from_buffer_copy(bytes(p)))
+    b = atom_amd.DeviceModel(H.HYD, *dims, atom_amd.Params.from_buffer_copy(bytes(p)))
+    a.upload_all(f, g); b.upload_all(f, g)
+    st = atom_amd.HydStart.from_buffer_copy(bytes(H.hyd_start(dims[0])))
+    H.hyd_start_of_slice(a, st, bath, salt)
+    H.hyd_2d_loop(a, 3, 2)
+    log = H.hyd_3d_loop(a, 2, 2, run_data=True)
+    before, after, loc = b.run_time_slice(bath, salt, pressure_iter_max_2D=3)
+    for k in list(f) + list(g):
+        x, y = a.download(k), b.download(k)
+        assert np.array_equal(x, y, equal_nan=True) and np.array_equal(np.signbit(x), np.signbit(y)), k
+    assert (before, (after, loc)) == (log[-3][0], log[-2])
+    b.run_time_slice(bath, salt, pressure_iter_max_2D=3, queries=False)
+    with pytest.raises(atom_amd.AtomDevError):
+        b.run_time_slice(str(tmp_path / "missing.xyz"))
+    a.close(); b.close()

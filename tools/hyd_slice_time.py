@@ -45,6 +45,13 @@ for rep in range(2):  # the first pass pays the lazy allocations
 print("hydrosphere time slice, 41x181x361, device: upload of the transfer-file state %.1f ms; readers + initial conditions %.1f ms; "
       "surface loop (20 sweeps) %.1f ms; volume loop (4 sweeps, queries, run_data) %.1f ms; slice %.1f ms"
       % (up, parts[0], parts[1], parts[2], sum(parts)))
+d.upload_all(f, g)
+d.sync()
+t0 = time.perf_counter()
+d.run_time_slice(bath, salt)
+print("the same slice through atomdev_hyd_run_time_slice (one call): %.1f ms" % (1e3 * (time.perf_counter() - t0)))
+d.upload_all(f, g)
+time_slice(d, dst)  # the state the comparison below expects
 if "--cpu" in sys.argv:
     o = H.CpuModel("oracle", H.HYD, im, jm, km, p, f, g)
     cp = time_slice(o, st)
