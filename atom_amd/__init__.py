@@ -6,7 +6,7 @@ importing works anywhere, but creating a device model raises if the library or
 a GPU is missing.
 """
 from .device import (ATM, HYD, F2, F3, AtomDevError, DeviceModel, HydSlice, HydStart, Params, Radiation, default_params,
-                     library_path, load_library, rk2d_batch)
+                     hyd_run_time_slices, library_path, load_library, rk2d_batch)
 
 __all__ = ["ATM", "HYD", "F2", "F3", "AtomDevError", "DeviceModel", "HydSlice", "HydStart", "Params", "Radiation", "default_params",
-           "library_path", "load_library", "rk2d_batch"]
+           "hyd_run_time_slices", "library_path", "load_library", "rk2d_batch"]

@@ -2,6 +2,8 @@
 // slice in the reference's order, every one of them an entry point of this library, fields resident throughout.
 // What the reference prints on the way (the residuum and steady-state queries, the min/max searches) is returned or
 // left to the caller; nothing here computes on the host.
+#include <vector>
+
 #include "atomdev_internal.h"
 
 extern "C" void atomdev_default_hyd_slice(int im, atomdev_hyd_slice* s) {
@@ -12,58 +14,76 @@ extern "C" void atomdev_default_hyd_slice(int im, atomdev_hyd_slice* s) {
     s->queries = 1;
 }
 
-extern "C" int atomdev_hyd_run_time_slice(atomdev_t* h, const atomdev_hyd_slice* s, double residuum[2], int residuum_loc[3]) {
-    ATOMDEV_REQUIRE(h && s && h->model == ATOMDEV_HYD, "atomdev_hyd_run_time_slice: needs a hydrosphere handle and the slice description");
-    ATOMDEV_REQUIRE(s->bathymetry_file, "atomdev_hyd_run_time_slice: no bathymetry file");
-    const int top = h->im - 1;
-#define STEP(call) do { if (int rc__ = (call)) return rc__; } while (0)
+// n slices advanced in lockstep: every operator is enqueued for all of them (each on its handle's stream, so the
+// slices overlap on the GPU) before the next one; the surface sweeps - one workgroup's worth of dependent diagonals
+// each - go into one launch for all slices.
+extern "C" int atomdev_hyd_run_time_slices(atomdev_t* const* handles, const atomdev_hyd_slice* slices, int n, double* residuum,
+                                           int* residuum_loc) {
+    ATOMDEV_REQUIRE(handles && slices && n >= 1, "atomdev_hyd_run_time_slices: bad argument");
+    const atomdev_hyd_slice& s0 = slices[0];
+    for (int m = 0; m < n; m++) {
+        ATOMDEV_REQUIRE(handles[m] && handles[m]->model == ATOMDEV_HYD, "atomdev_hyd_run_time_slices: needs hydrosphere handles");
+        ATOMDEV_REQUIRE(slices[m].bathymetry_file, "atomdev_hyd_run_time_slices: no bathymetry file");
+        ATOMDEV_REQUIRE(slices[m].velocity_iter_max_2D == s0.velocity_iter_max_2D && slices[m].pressure_iter_max_2D == s0.pressure_iter_max_2D
+                        && slices[m].velocity_iter_max == s0.velocity_iter_max && slices[m].pressure_iter_max == s0.pressure_iter_max,
+                        "atomdev_hyd_run_time_slices: the slices of one call share their iteration counts");
+    }
+#define EACH(call) do { for (int m = 0; m < n; m++) { atomdev_t* h = handles[m]; const atomdev_hyd_slice& s = slices[m]; (void)s; \
+                        if (int rc__ = (call)) return rc__; } } while (0)
     // :234-297: the atmosphere's surface, the sea ground, the initial conditions, the first old -> new copies
-    if (s->transfer_file) STEP(atomdev_hyd_read_transfer_file(h, s->transfer_file));
-    STEP(atomdev_hyd_read_sea_ground(h, s->bathymetry_file));
-    if (s->start.Ma == 0 && s->salinity_file) STEP(atomdev_hyd_read_surface_salinity(h, s->salinity_file));
-    STEP(atomdev_hyd_ic_ekman_spiral(h, s->start.i_beg));
-    if (s->start.Ma <= 41) STEP(atomdev_hyd_ic_circumpolar_current(h, s->start.i_beg));  // Drake passage
-    STEP(atomdev_hyd_bc_temperature_salinity(h, &s->start));
-    STEP(atomdev_hyd_pressure_density(h));
-    STEP(atomdev_move_data_to_new_arrays(h, -1));
-    STEP(atomdev_move_data_to_new_arrays(h, top));
+    EACH(s.transfer_file ? atomdev_hyd_read_transfer_file(h, s.transfer_file) : 0);
+    EACH(atomdev_hyd_read_sea_ground(h, s.bathymetry_file));
+    EACH(s.start.Ma == 0 && s.salinity_file ? atomdev_hyd_read_surface_salinity(h, s.salinity_file) : 0);
+    EACH(atomdev_hyd_ic_ekman_spiral(h, s.start.i_beg));
+    EACH(s.start.Ma <= 41 ? atomdev_hyd_ic_circumpolar_current(h, s.start.i_beg) : 0);  // Drake passage
+    EACH(atomdev_hyd_bc_temperature_salinity(h, &s.start));
+    EACH(atomdev_hyd_pressure_density(h));
+    EACH(atomdev_move_data_to_new_arrays(h, -1));
+    EACH(atomdev_move_data_to_new_arrays(h, h->im - 1));
     // :314-404: surface iterations (their two queries are printed only)
-    for (int p = 1; p <= s->pressure_iter_max_2D; p++) {
-        for (int v = 1; v <= s->velocity_iter_max_2D; v++) {
-            STEP(atomdev_hyd_bc_theta(h));
-            STEP(atomdev_hyd_bc_phi(h));
-            STEP(atomdev_hyd_value_limitation(h));
-            STEP(atomdev_hyd_rk2d(h));
-            STEP(atomdev_move_data_to_new_arrays(h, top));
+    for (int p = 1; p <= s0.pressure_iter_max_2D; p++) {
+        for (int v = 1; v <= s0.velocity_iter_max_2D; v++) {
+            EACH(atomdev_hyd_bc_theta(h));
+            EACH(atomdev_hyd_bc_phi(h));
+            EACH(atomdev_hyd_value_limitation(h));
+            if (n == 1) { if (int rc = atomdev_hyd_rk2d(handles[0])) return rc; }
+            else if (int rc = atomdev_rk2d_batch(handles, n)) return rc;
+            EACH(atomdev_move_data_to_new_arrays(h, h->im - 1));
         }
-        STEP(atomdev_hyd_pressure2d(h));
+        EACH(atomdev_hyd_pressure2d(h));
     }
     // :420-610: volume iterations
-    double before = 0., after = 0.;
-    int loc[3] = { 0, 0, 0 };
+    std::vector<double> before(n, 0.), after(n, 0.);
+    std::vector<int> loc(3 * (size_t)n, 0);
     double steady[6]; int steady_loc[18];
-    for (int p = 1; p <= s->pressure_iter_max; p++) {
-        for (int v = 1; v <= s->velocity_iter_max; v++) {
-            if (s->queries) { before = 0.; STEP(atomdev_hyd_residuum3d(h, &before, loc)); }
-            STEP(atomdev_hyd_bc_radius(h));
-            STEP(atomdev_hyd_bc_theta(h));
-            STEP(atomdev_hyd_bc_phi(h));
-            STEP(atomdev_hyd_pressure_density(h));
-            STEP(atomdev_hyd_value_limitation(h));
-            STEP(atomdev_hyd_rk3d(h));
-            STEP(atomdev_hyd_solid_ground(h));
-            if (s->queries) {
-                after = 0.; loc[0] = loc[1] = loc[2] = 0;
-                STEP(atomdev_hyd_residuum3d(h, &after, loc));
-                STEP(atomdev_hyd_steady3d(h, steady, steady_loc));
-            }
-            STEP(atomdev_hyd_run_data(h));
-            STEP(atomdev_move_data_to_new_arrays(h, -1));
+    for (int p = 1; p <= s0.pressure_iter_max; p++) {
+        for (int v = 1; v <= s0.velocity_iter_max; v++) {
+            EACH(s.queries ? (before[m] = 0., atomdev_hyd_residuum3d(h, &before[m], &loc[3 * m])) : 0);
+            EACH(atomdev_hyd_bc_radius(h));
+            EACH(atomdev_hyd_bc_theta(h));
+            EACH(atomdev_hyd_bc_phi(h));
+            EACH(atomdev_hyd_pressure_density(h));
+            EACH(atomdev_hyd_value_limitation(h));
+            EACH(atomdev_hyd_rk3d(h));
+            EACH(atomdev_hyd_solid_ground(h));
+            EACH(s.queries ? (after[m] = 0., loc[3 * m] = loc[3 * m + 1] = loc[3 * m + 2] = 0,
+                              atomdev_hyd_residuum3d(h, &after[m], &loc[3 * m])) : 0);
+            EACH(s.queries ? atomdev_hyd_steady3d(h, steady, steady_loc) : 0);
+            EACH(atomdev_hyd_run_data(h));
+            EACH(atomdev_move_data_to_new_arrays(h, -1));
         }
-        STEP(atomdev_hyd_pressure3d(h));
+        EACH(atomdev_hyd_pressure3d(h));
     }
-#undef STEP
-    if (residuum) { residuum[0] = before; residuum[1] = after; }
-    if (residuum_loc) { residuum_loc[0] = loc[0]; residuum_loc[1] = loc[1]; residuum_loc[2] = loc[2]; }
-    return atomdev_sync(h);
+    for (int m = 0; m < n; m++) {
+        if (residuum) { residuum[2 * m] = before[m]; residuum[2 * m + 1] = after[m]; }
+        if (residuum_loc) for (int q = 0; q < 3; q++) residuum_loc[3 * m + q] = loc[3 * m + q];
+    }
+    EACH(atomdev_sync(h));
+#undef EACH
+    return 0;
+}
+
+extern "C" int atomdev_hyd_run_time_slice(atomdev_t* h, const atomdev_hyd_slice* s, double residuum[2], int residuum_loc[3]) {
+    ATOMDEV_REQUIRE(h && s, "atomdev_hyd_run_time_slice: needs a hydrosphere handle and the slice description");
+    return atomdev_hyd_run_time_slices(&h, s, 1, residuum, residuum_loc);
 }

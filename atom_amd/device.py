@@ -107,6 +107,7 @@ def load_library():
     lib.atomdev_default_hyd_slice.argtypes = [C.c_int, C.POINTER(HydSlice)]
     lib.atomdev_default_hyd_slice.restype = None
     lib.atomdev_hyd_run_time_slice.argtypes = [vp, C.POINTER(HydSlice), dp, ip]
+    lib.atomdev_hyd_run_time_slices.argtypes = [C.POINTER(vp), C.POINTER(HydSlice), C.c_int, dp, ip]
     lib.atomdev_atm_read_mountain_surface.argtypes = [vp, C.c_char_p]
     lib.atomdev_hyd_read_surface_salinity.argtypes = [vp, C.c_char_p]
     lib.atomdev_hyd_ic_ekman_spiral.argtypes = [vp, C.c_int]
@@ -148,6 +149,28 @@ def default_params(model, im=41, jm=181, km=361):
         p.dthe = np.pi / (jm - 1)
         p.dphi = p.dthe
     return p
+
+
+def hyd_run_time_slices(models, files, queries=True, **counts):
+    """atomdev_hyd_run_time_slices: the time slices of several hydrosphere handles in lockstep.  files: one
+    (bathymetry_file, salinity_file or None, transfer_file or None, Ma) per model; counts as in run_time_slice."""
+    n = len(models)
+    lib = models[0].lib
+    slices = (HydSlice * n)()
+    keep = []
+    for m, (bath, salt, transfer, Ma) in enumerate(files):
+        lib.atomdev_default_hyd_slice(models[m].im, C.byref(slices[m]))
+        for k, v in counts.items():
+            setattr(slices[m], k, v)
+        slices[m].start.Ma = Ma
+        keep += [os.fsencode(bath), os.fsencode(salt) if salt else None, os.fsencode(transfer) if transfer else None]
+        slices[m].bathymetry_file, slices[m].salinity_file, slices[m].transfer_file = keep[-3:]
+        slices[m].queries = 1 if queries else 0
+    hs = (C.c_void_p * n)(*[m._h for m in models])
+    res = (C.c_double * (2 * n))()
+    loc = (C.c_int * (3 * n))()
+    models[0]._check(lib.atomdev_hyd_run_time_slices(hs, slices, n, res, loc))
+    return [(res[2 * m], res[2 * m + 1], tuple(loc[3 * m:3 * m + 3])) for m in range(n)]
 
 
 def rk2d_batch(models):

@@ -310,6 +310,13 @@ typedef struct atomdev_hyd_slice {
 } atomdev_hyd_slice;
 void atomdev_default_hyd_slice(int im, atomdev_hyd_slice* s);
 int atomdev_hyd_run_time_slice(atomdev_t* h, const atomdev_hyd_slice* s, double residuum[2], int residuum_loc[3]);
+/* The same for n independent time slices (the slices of a paleo series, each its own handle on one device, same grid
+ * and iteration counts) advanced in lockstep: every operator is enqueued for all slices, each on its handle's stream,
+ * and the surface sweeps of all slices share one launch (atomdev_rk2d_batch).  residuum: 2 n values, residuum_loc:
+ * 3 n (both may be NULL).  No counterpart in the reference, which runs one slice after the other; every slice ends with
+ * the bits of a call of its own. */
+int atomdev_hyd_run_time_slices(atomdev_t* const* handles, const atomdev_hyd_slice* slices, int n, double* residuum,
+                                int* residuum_loc);
 
 /* solveRungeKutta_3D_Hydrosphere + RK_RHS_3D_Hydrosphere
  * (hydrosphere/RungeKutta_Hyd.cpp:30-124, RHS_Hyd.cpp:60-447) */

@@ -289,3 +289,31 @@ def test_hyd_run_time_slice_one_call_same_bits(tmp_path):
     with pytest.raises(atom_amd.AtomDevError):
         b.run_time_slice(str(tmp_path / "missing.xyz"))
     a.close(); b.close()
+
+
+@pytest.mark.gpu
+def test_hyd_run_time_slices_lockstep_same_bits(tmp_path):
+    """Three time slices (different fields, bathymetries and Ma) advanced in lockstep by one call - their surface sweeps
+    share a launch, their other operators overlap on their streams - end with the bits of three calls of their own."""
+    runs = []
+    for n, (seed, Ma) in enumerate(((84, 0), (85, 30), (86, 60))):
+        sub = tmp_path / str(n)
+        sub.mkdir()
+        dims, p, f, g, bath, salt = _hyd_slice_inputs(sub, 185, seed)
+        runs.append((dims, p, f, g, bath, salt, Ma))
+    def models():
+        out = []
+        for dims, p, f, g, *_ in runs:
+            d = atom_amd.DeviceModel(H.HYD, *dims, atom_amd.Params.from_buffer_copy(bytes(p)))
+            d.upload_all(f, g)
+            out.append(d)
+        return out
+    alone, together = models(), models()
+    single = [d.run_time_slice(r[4], r[5], Ma=r[6], pressure_iter_max_2D=2) for d, r in zip(alone, runs)]
+    batch = atom_amd.hyd_run_time_slices(together, [(r[4], r[5], None, r[6]) for r in runs], pressure_iter_max_2D=2)
+    assert [tuple(x) for x in batch] == [tuple(x) for x in single]
+    for a, b, r in zip(alone, together, runs):
+        for k in list(r[2]) + list(r[3]):
+            x, y = a.download(k), b.download(k)
+            assert np.array_equal(x, y, equal_nan=True) and np.array_equal(np.signbit(x), np.signbit(y)), k
+        a.close(); b.close()
