@@ -2,6 +2,8 @@
 // slice in the reference's order, every one of them an entry point of this library, fields resident throughout.
 // What the reference prints on the way (the residuum and steady-state queries, the min/max searches) is returned or
 // left to the caller; nothing here computes on the host.
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "atomdev_internal.h"
@@ -31,9 +33,32 @@ extern "C" int atomdev_hyd_run_time_slices(atomdev_t* const* handles, const atom
 #define EACH(call) do { for (int m = 0; m < n; m++) { atomdev_t* h = handles[m]; const atomdev_hyd_slice& s = slices[m]; (void)s; \
                         if (int rc__ = (call)) return rc__; } } while (0)
     // :234-297: the atmosphere's surface, the sea ground, the initial conditions, the first old -> new copies
-    EACH(s.transfer_file ? atomdev_hyd_read_transfer_file(h, s.transfer_file) : 0);
-    EACH(atomdev_hyd_read_sea_ground(h, s.bathymetry_file));
-    EACH(s.start.Ma == 0 && s.salinity_file ? atomdev_hyd_read_surface_salinity(h, s.salinity_file) : 0);
+    // the readers are host work (text files, the needle smoothing): one host thread per slice, at most 16 at a time
+    auto read_files = [&](int m) -> int {
+        atomdev_t* h = handles[m];
+        const atomdev_hyd_slice& s = slices[m];
+        if (s.transfer_file) if (int rc = atomdev_hyd_read_transfer_file(h, s.transfer_file)) return rc;
+        if (int rc = atomdev_hyd_read_sea_ground(h, s.bathymetry_file)) return rc;
+        if (s.start.Ma == 0 && s.salinity_file) if (int rc = atomdev_hyd_read_surface_salinity(h, s.salinity_file)) return rc;
+        return 0;
+    };
+    if (n == 1) {
+        if (int rc = read_files(0)) return rc;
+    } else {
+        std::vector<int> status(n, 0);
+        std::vector<std::string> message(n);
+        for (int first = 0; first < n; first += 16) {
+            std::vector<std::thread> readers;
+            for (int m = first; m < n && m < first + 16; m++)
+                readers.emplace_back([&, m]() {
+                    status[m] = read_files(m);
+                    if (status[m]) message[m] = atomdev_last_error();  // the error text is kept per thread
+                });
+            for (std::thread& t : readers) t.join();
+        }
+        for (int m = 0; m < n; m++)
+            if (status[m]) { atomdev_set_error(message[m]); return status[m]; }
+    }
     EACH(atomdev_hyd_ic_ekman_spiral(h, s.start.i_beg));
     EACH(s.start.Ma <= 41 ? atomdev_hyd_ic_circumpolar_current(h, s.start.i_beg) : 0);  // Drake passage
     EACH(atomdev_hyd_bc_temperature_salinity(h, &s.start));
