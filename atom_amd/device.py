@@ -54,6 +54,18 @@ class HydSlice(C.Structure):
                 ("bathymetry_file", C.c_char_p), ("salinity_file", C.c_char_p), ("queries", C.c_int)]
 
 
+class AtmLoop(C.Structure):
+    """atomdev_atm_loop: the iteration loops of cAtmosphereModel (run_2D_loop, run_3D_loop)."""
+    _fields_ = [("velocity_iter_max_2D", C.c_int), ("pressure_iter_max_2D", C.c_int), ("velocity_iter_max", C.c_int),
+                ("pressure_iter_max", C.c_int), ("column_physics", C.c_int), ("RadiationModel", C.c_int),
+                ("radiation", Radiation), ("i_trop", C.POINTER(C.c_int)), ("queries", C.c_int)]
+
+
+class AtmLoopState(C.Structure):
+    _fields_ = [("q_v_hyp", C.c_double), ("S_nuc", C.c_double), ("S_i_dep", C.c_double), ("residuum", C.c_double * 2),
+                ("residuum_loc", C.c_int * 3)]
+
+
 class AtomDevError(RuntimeError):
     pass
 
@@ -104,6 +116,10 @@ def load_library():
     lib.atomdev_default_hyd_start.argtypes = [C.c_int, C.POINTER(HydStart)]
     lib.atomdev_default_hyd_start.restype = None
     lib.atomdev_hyd_read_sea_ground.argtypes = [vp, C.c_char_p]
+    lib.atomdev_default_atm_loop.argtypes = [C.POINTER(AtmLoop)]
+    lib.atomdev_default_atm_loop.restype = None
+    lib.atomdev_atm_run_2d_loop.argtypes = [vp, C.POINTER(AtmLoop)]
+    lib.atomdev_atm_run_3d_loop.argtypes = [vp, C.POINTER(AtmLoop), C.POINTER(AtmLoopState)]
     lib.atomdev_default_hyd_slice.argtypes = [C.c_int, C.POINTER(HydSlice)]
     lib.atomdev_default_hyd_slice.restype = None
     lib.atomdev_hyd_run_time_slice.argtypes = [vp, C.POINTER(HydSlice), dp, ip]
@@ -262,6 +278,33 @@ class DeviceModel:
     def op(self, name):
         """One reference operator, e.g. 'atm_rk3d', 'hyd_pressure3d'."""
         self._check(getattr(self.lib, "atomdev_" + name)(self._h))
+
+    def atm_loop(self, i_trop=None, radiation=None, queries=True, **counts):
+        """An atomdev_atm_loop with the reference's defaults; counts: velocity_iter_max[_2D], pressure_iter_max[_2D]."""
+        L = AtmLoop()
+        self.lib.atomdev_default_atm_loop(C.byref(L))
+        for k, v in counts.items():
+            setattr(L, k, v)
+        if radiation is not None:
+            L.radiation = radiation
+        if i_trop is not None:
+            self._i_trop = np.ascontiguousarray(i_trop, dtype=np.int32)
+            if self._i_trop.size != self.jm:
+                raise AtomDevError("i_trop must have jm entries")
+            L.i_trop = self._i_trop.ctypes.data_as(C.POINTER(C.c_int))
+            L.column_physics = 1
+        L.queries = 1 if queries else 0
+        return L
+
+    def run_2d_loop(self, loop):
+        """cAtmosphereModel::run_2D_loop on the device."""
+        self._check(self.lib.atomdev_atm_run_2d_loop(self._h, C.byref(loop)))
+
+    def run_3d_loop(self, loop, state=None):
+        """cAtmosphereModel::run_3D_loop on the device; returns the carried state (AtmLoopState)."""
+        state = state or AtmLoopState()
+        self._check(self.lib.atomdev_atm_run_3d_loop(self._h, C.byref(loop), C.byref(state)))
+        return state
 
     def read_mountain_surface(self, path):
         """BC_Bathymetry_Atmosphere::BC_MountainSurface: h and Topography from the topography file."""

@@ -238,6 +238,30 @@ int atomdev_write_panorama_vts(atomdev_t* h, const char* path);
  * (the reference aborts); heights above L_atm fill the column (the reference writes beyond its array there).  Host
  * work; the result is uploaded as ATOMDEV_H and ATOMDEV_TOPOGRAPHY. */
 int atomdev_atm_read_mountain_surface(atomdev_t* h, const char* path);
+/* cAtmosphereModel::run_2D_loop / run_3D_loop (atmosphere/cAtmosphereModel.cpp:660-735, 743-898) without their printing,
+ * as one call each: the entry points above in the reference's order, nothing uploaded or downloaded in between.
+ * column_physics != 0 adds BC_Thermo's Ice_Water_Saturation_Adjustment and Two_Category_Ice_Scheme (every second
+ * velocity iteration), BC_Radiation_multi_layer, Latent_Heat and the vegetation distribution where run_3D_loop calls
+ * them; the class members these carry from call to call travel in atomdev_atm_loop_state, zero at the start of a time
+ * slice.  queries != 0 runs the residuum and steady-state queries where the reference does; the state receives the
+ * last pair of residuum values (one Accuracy_Atm object: the second query starts from the first one's result). */
+typedef struct atomdev_atm_loop {
+    int velocity_iter_max_2D, pressure_iter_max_2D, velocity_iter_max, pressure_iter_max;  /* param.py:33-36: 2, 10, 2, 2 */
+    int column_physics;
+    int RadiationModel;            /* argument of run_MSL_data (1) */
+    atomdev_radiation radiation;   /* constants of BC_Radiation_multi_layer */
+    const int* i_trop;             /* jm tropopause levels (cAtmosphereModel::get_tropopause), needed with column_physics */
+    int queries;
+} atomdev_atm_loop;
+typedef struct atomdev_atm_loop_state {
+    double q_v_hyp, S_nuc, S_i_dep;   /* members of BC_Thermo carried between its calls */
+    double residuum[2];               /* continuity residuum before and after the last velocity iteration */
+    int residuum_loc[3];
+} atomdev_atm_loop_state;
+void atomdev_default_atm_loop(atomdev_atm_loop* L);
+int atomdev_atm_run_2d_loop(atomdev_t* h, const atomdev_atm_loop* L);
+int atomdev_atm_run_3d_loop(atomdev_t* h, const atomdev_atm_loop* L, atomdev_atm_loop_state* state);
+
 /* BC_Bathymetry_Atmosphere::vegetationDistribution (atmosphere/BC_Bath_Atm.cpp:129-142): Vegetation =
  * Precipitation / max_Precipitation on land surface cells that are not colder than t = 1, else 0. */
 int atomdev_atm_vegetation_distribution(atomdev_t* h, double max_Precipitation);

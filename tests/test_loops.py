@@ -317,3 +317,38 @@ def test_hyd_run_time_slices_lockstep_same_bits(tmp_path):
             x, y = a.download(k), b.download(k)
             assert np.array_equal(x, y, equal_nan=True) and np.array_equal(np.signbit(x), np.signbit(y)), k
         a.close(); b.close()
+
+
+@pytest.mark.gpu
+def test_atm_run_loops_one_call_same_bits():
+    """atomdev_atm_run_2d_loop and atomdev_atm_run_3d_loop (column physics included) leave every field with the bits of
+    the same operators called one by one, which the tests above hold against the oracle; the carried members of
+    BC_Thermo and the last residuum pair come back in the state."""
+    im, jm, km = 12, 21, 34
+    p, f, g, i_trop = physics_loop_inputs(im, jm, km, 76)
+    a = atom_amd.DeviceModel(H.ATM, im, jm, km, atom_amd.Params.from_buffer_copy(bytes(p)))
+    b = atom_amd.DeviceModel(H.ATM, im, jm, km, atom_amd.Params.from_buffer_copy(bytes(p)))
+    a.upload_all(f, g); b.upload_all(f, g)
+    # surface loop, operator by operator (cAtmosphereModel.cpp:685-728)
+    for _ in range(2):
+        for _ in range(2):
+            a.op("atm_bc_theta"); a.op("atm_bc_phi")
+            first = a.residuum("atm_residuum2d")
+            for op in ("atm_value_limitation", "atm_solid_ground", "atm_rk2d"):
+                a.op(op)
+            a.residuum("atm_residuum2d", *first)
+            a.steady("atm_steady2d", 3)
+            a.move_data_to_new_arrays(0)
+        a.op("atm_pressure2d")
+    log = H.atm_3d_loop(a, 1, 2, physics=True, i_trop=i_trop)
+    r = atom_amd.Radiation(albedo_pole=.7, albedo_equator=.15, epsilon_pole=.59, epsilon_equator=.594, epsilon_tropopause=.001,
+                           rad_pole=40., rad_equator=230., co2_coeff=.98 * (330. / 320.), sigma=5.670280e-8)
+    L = b.atm_loop(i_trop, r, pressure_iter_max_2D=2, pressure_iter_max=1)
+    b.run_2d_loop(L)
+    st = b.run_3d_loop(L)
+    for k in list(f) + list(g):
+        x, y = a.download(k), b.download(k)
+        assert np.array_equal(x, y, equal_nan=True) and np.array_equal(np.signbit(x), np.signbit(y)), k
+    assert (st.q_v_hyp, st.S_nuc, st.S_i_dep) == (log[-3][0], log[-2][0], log[-1][0])
+    assert (st.residuum[1], tuple(st.residuum_loc)) == log[-5]
+    a.close(); b.close()

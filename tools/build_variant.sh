@@ -4,7 +4,7 @@ set -e
 name=$1; shift
 cd "$(dirname "$0")/../atom_amd/csrc"
 mkdir -p ../../variants/$name
-for f in atomdev_api k_pointwise k_rk_atm k_rk_atm_ws k_rk_hyd k_bc_pressure k_rk2d k_accuracy k_columns k_transfer k_ice_scheme k_results_hyd k_vtk k_ic_hyd k_read_atm k_slice_hyd; do
+for f in atomdev_api k_pointwise k_rk_atm k_rk_atm_ws k_rk_hyd k_bc_pressure k_rk2d k_accuracy k_columns k_transfer k_ice_scheme k_results_hyd k_vtk k_ic_hyd k_read_atm k_slice_hyd k_slice_atm; do
   [ -f $f.hip ] || continue
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -I../../include -I. "$@" -c $f.hip -o ../../variants/$name/$f.o &
 done
