@@ -1,6 +1,8 @@
 // cAtmosphereModel::run_2D_loop and run_3D_loop (atmosphere/cAtmosphereModel.cpp:660-735, 743-898) as one call each:
 // the operators of the loops in the reference's order, every one of them an entry point of this library, fields
 // resident throughout.  What the reference prints on the way is returned (the last residuum queries) or left out.
+#include <vector>
+
 #include "atomdev_internal.h"
 
 extern "C" void atomdev_default_atm_loop(atomdev_atm_loop* L) {
@@ -14,26 +16,39 @@ extern "C" void atomdev_default_atm_loop(atomdev_atm_loop* L) {
 
 #define STEP(call) do { if (int rc__ = (call)) return rc__; } while (0)
 
-extern "C" int atomdev_atm_run_2d_loop(atomdev_t* h, const atomdev_atm_loop* L) {
-    ATOMDEV_REQUIRE(h && L && h->model == ATOMDEV_ATM, "atomdev_atm_run_2d_loop: needs an atmosphere handle and the loop description");
-    double res = 0., st[3]; int loc[3] = { 0, 0, 0 }, st_loc[9];
+// The surface loops of n independent time slices in lockstep: each operator enqueued for all slices on their own
+// streams, the surface sweeps - one workgroup's worth of dependent diagonals each - in one launch.
+extern "C" int atomdev_atm_run_2d_loops(atomdev_t* const* handles, int n, const atomdev_atm_loop* L) {
+    ATOMDEV_REQUIRE(handles && n >= 1 && L, "atomdev_atm_run_2d_loops: bad argument");
+    for (int m = 0; m < n; m++)
+        ATOMDEV_REQUIRE(handles[m] && handles[m]->model == ATOMDEV_ATM, "atomdev_atm_run_2d_loops: needs atmosphere handles");
+#define EACH(call) do { for (int m = 0; m < n; m++) { atomdev_t* h = handles[m]; if (int rc__ = (call)) return rc__; } } while (0)
+    std::vector<double> res(n, 0.);
+    std::vector<int> loc(3 * (size_t)n, 0);
+    double st[3]; int st_loc[9];
     for (int p = 1; p <= L->pressure_iter_max_2D; p++) {
         for (int v = 1; v <= L->velocity_iter_max_2D; v++) {
-            STEP(atomdev_atm_bc_theta(h));
-            STEP(atomdev_atm_bc_phi(h));
-            if (L->queries) { res = 0.; loc[0] = loc[1] = loc[2] = 0; STEP(atomdev_atm_residuum2d(h, &res, loc)); }
-            STEP(atomdev_atm_value_limitation(h));
-            STEP(atomdev_atm_solid_ground(h));
-            STEP(atomdev_atm_rk2d(h));
+            EACH(atomdev_atm_bc_theta(h));
+            EACH(atomdev_atm_bc_phi(h));
+            if (L->queries) EACH((res[m] = 0., loc[3 * m] = loc[3 * m + 1] = loc[3 * m + 2] = 0, atomdev_atm_residuum2d(h, &res[m], &loc[3 * m])));
+            EACH(atomdev_atm_value_limitation(h));
+            EACH(atomdev_atm_solid_ground(h));
+            if (n == 1) STEP(atomdev_atm_rk2d(handles[0])); else STEP(atomdev_rk2d_batch(handles, n));
             if (L->queries) {  // the same Accuracy_Atm object as before the sweep: its state is carried (:688-712)
-                STEP(atomdev_atm_residuum2d(h, &res, loc));
-                STEP(atomdev_atm_steady2d(h, st, st_loc));
+                EACH(atomdev_atm_residuum2d(h, &res[m], &loc[3 * m]));
+                EACH(atomdev_atm_steady2d(h, st, st_loc));
             }
-            STEP(atomdev_move_data_to_new_arrays(h, 0));
+            EACH(atomdev_move_data_to_new_arrays(h, 0));
         }
-        STEP(atomdev_atm_pressure2d(h));
+        EACH(atomdev_atm_pressure2d(h));
     }
+#undef EACH
     return 0;
+}
+
+extern "C" int atomdev_atm_run_2d_loop(atomdev_t* h, const atomdev_atm_loop* L) {
+    ATOMDEV_REQUIRE(h && L, "atomdev_atm_run_2d_loop: needs an atmosphere handle and the loop description");
+    return atomdev_atm_run_2d_loops(&h, 1, L);
 }
 
 extern "C" int atomdev_atm_run_3d_loop(atomdev_t* h, const atomdev_atm_loop* L, atomdev_atm_loop_state* S) {

@@ -119,6 +119,7 @@ def load_library():
     lib.atomdev_default_atm_loop.argtypes = [C.POINTER(AtmLoop)]
     lib.atomdev_default_atm_loop.restype = None
     lib.atomdev_atm_run_2d_loop.argtypes = [vp, C.POINTER(AtmLoop)]
+    lib.atomdev_atm_run_2d_loops.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(AtmLoop)]
     lib.atomdev_atm_run_3d_loop.argtypes = [vp, C.POINTER(AtmLoop), C.POINTER(AtmLoopState)]
     lib.atomdev_default_hyd_slice.argtypes = [C.c_int, C.POINTER(HydSlice)]
     lib.atomdev_default_hyd_slice.restype = None
@@ -165,6 +166,12 @@ def default_params(model, im=41, jm=181, km=361):
         p.dthe = np.pi / (jm - 1)
         p.dphi = p.dthe
     return p
+
+
+def atm_run_2d_loops(models, loop):
+    """atomdev_atm_run_2d_loops: the surface loops of several atmosphere handles in lockstep."""
+    hs = (C.c_void_p * len(models))(*[m._h for m in models])
+    models[0]._check(models[0].lib.atomdev_atm_run_2d_loops(hs, len(models), C.byref(loop)))
 
 
 def hyd_run_time_slices(models, files, queries=True, **counts):

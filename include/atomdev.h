@@ -260,6 +260,9 @@ typedef struct atomdev_atm_loop_state {
 } atomdev_atm_loop_state;
 void atomdev_default_atm_loop(atomdev_atm_loop* L);
 int atomdev_atm_run_2d_loop(atomdev_t* h, const atomdev_atm_loop* L);
+/* The surface loops of n independent time slices (one atmosphere handle each, same surface size) in lockstep, their
+ * sweeps sharing one launch (atomdev_rk2d_batch).  No counterpart in the reference; same bits as calls of their own. */
+int atomdev_atm_run_2d_loops(atomdev_t* const* handles, int n, const atomdev_atm_loop* L);
 int atomdev_atm_run_3d_loop(atomdev_t* h, const atomdev_atm_loop* L, atomdev_atm_loop_state* state);
 
 /* BC_Bathymetry_Atmosphere::vegetationDistribution (atmosphere/BC_Bath_Atm.cpp:129-142): Vegetation =

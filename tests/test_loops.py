@@ -352,3 +352,28 @@ def test_atm_run_loops_one_call_same_bits():
     assert (st.q_v_hyp, st.S_nuc, st.S_i_dep) == (log[-3][0], log[-2][0], log[-1][0])
     assert (st.residuum[1], tuple(st.residuum_loc)) == log[-5]
     a.close(); b.close()
+
+
+@pytest.mark.gpu
+def test_atm_run_2d_loops_lockstep_same_bits():
+    """The surface loops of three atmosphere slices in lockstep (one launch per sweep for all of them): the bits of
+    three loops of their own."""
+    im, jm, km = 9, 21, 70
+    alone, together = [], []
+    for seed in (77, 78, 79):
+        p = H.default_params(H.ATM, im, jm, km)
+        f, g = H.make_msl_inputs(im, jm, km, seed, p)
+        for group in (alone, together):
+            d = atom_amd.DeviceModel(H.ATM, im, jm, km, atom_amd.Params.from_buffer_copy(bytes(p)))
+            d.upload_all(f, g)
+            group.append(d)
+    L = alone[0].atm_loop(pressure_iter_max_2D=3)
+    for d in alone:
+        d.run_2d_loop(L)
+    atom_amd.atm_run_2d_loops(together, L)
+    for a, b in zip(alone, together):
+        a.sync(); b.sync()
+        for k in ("V", "W", "P_DYN", "VN", "WN", "P_DYNN", "AUX_V", "AUX_W", "T", "C"):
+            x, y = a.download(k), b.download(k)
+            assert np.array_equal(x, y, equal_nan=True) and np.array_equal(np.signbit(x), np.signbit(y)), k
+        a.close(); b.close()
