@@ -172,7 +172,12 @@ def main():
         th = time.perf_counter() - th
         hms, hn = hyd.profile_read()
         hyd.close()
-        hyd_info = {"updates_per_s": UPDATES * nh / th, "ms_per_step": 1e3 * th / nh,
+        hyd_traffic = None
+        try:
+            hyd_traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_hyd_rk3d.json"))).get("hbm_bytes_per_launch")
+        except Exception:
+            pass
+        hyd_info = {"updates_per_s": UPDATES * nh / th, "ms_per_step": 1e3 * th / nh, "rk_traffic": hyd_traffic,
                     "rk_sweep_ms": hms / hn,
                     "rk_hbm_frac": UPDATES * HYD_BYTES_PER_UPDATE / (hms / hn * 1e-3) / 1e9 / HBM_PEAK_GBS}
 

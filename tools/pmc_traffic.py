@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """HBM traffic per launch of a kernel from the FETCH_SIZE / WRITE_SIZE passes of tools/pmc.sh, calibrated
 against the streaming copy kernel (k_copy_lists: 9 fields read and 9 written, 8 bytes per lane like the sweeps)
-that ran in the same pass:  pmc_traffic.py <tag> <kernel-substring> <im> <jm> <km> > profiles/pmc_<...>.json"""
+that ran in the same pass:  pmc_traffic.py <tag> <kernel-substring> <im> <jm> <km> [fields copied: 9 atm, 6 hyd] > profiles/pmc_<...>.json"""
 import collections, csv, glob, json, sys
 tag, sub = sys.argv[1], sys.argv[2]
 n3 = int(sys.argv[3]) * int(sys.argv[4]) * int(sys.argv[5])
-copy_bytes = 9 * n3 * 8  # each way
+copy_bytes = (int(sys.argv[6]) if len(sys.argv) > 6 else 9) * n3 * 8  # each way
 def avg(passname, counter, sub):
     vals = collections.defaultdict(float)
     for f in glob.glob("gpurun_out/pmc_%s_%s/*counter_collection.csv" % (tag, passname)):
