@@ -177,7 +177,7 @@ void atomdev_default_radiation(atomdev_radiation* r);
  * topography and the tropopause.  i_trop[j] (jm entries, host memory) is the tropopause level of row j as the
  * function computes it: im_tropopause[j] + GetTropopauseHightAdd(t_cretaceous / t_0) (:226, :3299-3303).
  * Reads p_stat, h; changes t, c, cloud, ice (zero clamps below the tropopause), epsilon_3D, radiation_3D and
- * the 2-D fields albedo, epsilon, radiation_surface.  Parity unpinned, like atomdev_atm_latent_heat. */
+ * the 2-D fields albedo, epsilon, radiation_surface. */
 int atomdev_atm_radiation_multi_layer(atomdev_t* h, const atomdev_radiation* r, const int* i_trop);
 /* BC_Thermo::Two_Category_Ice_Scheme (atmosphere/BC_Thermo.cpp:2803-3143): rain and snow by the two-category
  * ice scheme - one preparatory and five full passes over the grid, each integrating P_rain and P_snow down
@@ -185,7 +185,7 @@ int atomdev_atm_radiation_multi_layer(atomdev_t* h, const atomdev_radiation* r, 
  * clamps c, cloud, ice at zero and zeroes S_c_c inside the ground.  The reference keeps S_nuc and S_i_dep as
  * class members that are assigned only under conditions, so a grid point may inherit them from the point
  * visited before it (k outer, j, i downwards), from the previous pass or from the previous call:
- * state = {S_nuc, S_i_dep} carries the two members in and out.  Parity unpinned, like atomdev_atm_latent_heat. */
+ * state = {S_nuc, S_i_dep} carries the two members in and out. */
 int atomdev_atm_two_category_ice_scheme(atomdev_t* h, double state[2]);
 
 /* BC_Thermo::Ice_Water_Saturation_Adjustment (atmosphere/BC_Thermo.cpp:2509-2796): water vapour, cloud water and
@@ -196,8 +196,8 @@ int atomdev_atm_two_category_ice_scheme(atomdev_t* h, double state[2]);
 int atomdev_atm_ice_water_saturation_adjustment(atomdev_t* h, double* q_v_hyp);
 /* BC_Thermo::Latent_Heat (atmosphere/BC_Thermo.cpp:2418-2502): Q_Latent and Q_Sensible from the radial
  * gradients of c, ice and t, one-sided at the top of the topography (i_topography, :128-139), central above it
- * up to level im-3.  Reads t, c, ice, p_stat, h.  BC_Thermo.cpp cannot be compiled outside the reference's own
- * build (generated headers), so this operator is checked against a restatement only: parity unpinned. */
+ * up to level im-3.  Reads t, c, ice, p_stat, h.  A column whose topography reaches level im-2 is left as it is
+ * (the reference reads level im, outside its arrays, there). */
 int atomdev_atm_latent_heat(atomdev_t* h);
 /* Results_Hyd::run_data (hydrosphere/Results_Hyd.cpp:102-320) without its printout: Ekman-layer integrals of v and w
  * (Simpson's rule over the array as the reference indexes it: entries 0..i_max-i_Ekman of a buffer that is filled at

@@ -1017,8 +1017,8 @@ void oracle_atm_msl_data(oracle_ctx* c, int RadiationModel) {
 }
 
 /* BC_Thermo::Latent_Heat, atmosphere/BC_Thermo.cpp:2418-2502, with i_topography as the constructor builds it
- * (:128-139: the highest land level at or below im-2, else 0).  PARITY UNPINNED: BC_Thermo.cpp needs the
- * reference's generated headers and cannot be compiled here, so this follows the source text only.  The
+ * (:128-139: the highest land level at or below im-2, else 0).  Pinned bit for bit by the compiled class
+ * (tests/test_oracle_vs_reference.py, tests/golden/bc_thermo.npz).  The
  * saturation pressures the function evaluates (:2450-2453, :2488-2491) are never used and are left out; the
  * bottom formula divides by R_WaterVapour (:2455), the column formula by r_water_vapour (:2493).  A column
  * whose topography reaches level im-2 would read level im (outside the array) and is skipped. */
@@ -1065,8 +1065,8 @@ void oracle_atm_latent_heat(oracle_ctx* c) {
 /* lib/Utils.h:79-81 */
 static double exp_func(double T_K, double co_1, double co_2) { return exp(co_1 * (T_K - 273.15) / (T_K - co_2)); }
 
-/* BC_Thermo::Two_Category_Ice_Scheme, atmosphere/BC_Thermo.cpp:2803-3143.  PARITY UNPINNED (BC_Thermo.cpp cannot be
- * compiled here): a statement-by-statement restatement of the source text in the reference's traversal order.
+/* BC_Thermo::Two_Category_Ice_Scheme, atmosphere/BC_Thermo.cpp:2803-3143, pinned bit for bit by the compiled class
+ * (tests/test_oracle_vs_reference.py, tests/golden/bc_thermo.npz): a statement-by-statement restatement of the source text in the reference's traversal order.
  * S_nuc and S_i_dep are class members there, assigned only under conditions (:2923-2931, :2995-3016), so their
  * values travel from grid point to grid point, pass to pass and call to call: state[0], state[1].  N_i (member)
  * and m_i (local) are carried too but are only read where they have just been assigned.  dt_snow_dim = 417,
@@ -1231,8 +1231,8 @@ void oracle_atm_two_category_ice_scheme(oracle_ctx* c, double state[2]) {
 #undef F_
 }
 
-/* BC_Thermo::Ice_Water_Saturation_Adjustment, atmosphere/BC_Thermo.cpp:2509-2796.  PARITY UNPINNED (BC_Thermo.cpp
- * cannot be compiled here): a statement-by-statement restatement of the source text in the reference's traversal
+/* BC_Thermo::Ice_Water_Saturation_Adjustment, atmosphere/BC_Thermo.cpp:2509-2796, pinned bit for bit by the compiled
+ * class (tests/test_oracle_vs_reference.py, tests/golden/bc_thermo.npz): a statement-by-statement restatement of the source text in the reference's traversal
  * order (k outer, j, i upwards; a column's sea-level pressure uses t(0), which the column's first point has just
  * changed).  q_v_hyp is a class member assigned only under conditions (:2658-2661; none holds where cloud water or
  * cloud ice comes in negative), so it travels from grid point to grid point and call to call: *q_v_hyp_state. */
@@ -1351,8 +1351,8 @@ void oracle_atm_ice_water_saturation_adjustment(oracle_ctx* c, double* q_v_hyp_s
 #undef F_
 }
 
-/* BC_Thermo::BC_Radiation_multi_layer, atmosphere/BC_Thermo.cpp:166-424.  PARITY UNPINNED (BC_Thermo.cpp cannot
- * be compiled here): a statement-by-statement restatement of the source text, including the transmission
+/* BC_Thermo::BC_Radiation_multi_layer, atmosphere/BC_Thermo.cpp:166-424, pinned bit for bit by the compiled class
+ * (tests/test_oracle_vs_reference.py, tests/golden/bc_thermo.npz): a statement-by-statement restatement, including the transmission
  * matrix CC whose recurrence starts from an element that is never set (so all of it stays 0, :341-344) and the
  * sums CCC / DDD that are not reset inside the level loop (:312, :357-362). */
 static double parabola(double x) { return x * x - 2 * x; } /* lib/Utils.h:41-43 */

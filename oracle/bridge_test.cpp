@@ -219,8 +219,8 @@ void land_calls(Fields& F, const Scalars& s) {
 }
 
 // ---- the BC_Thermo members of the iteration loop (cAtmosphereModel.cpp:788-865) ----
-// BC_Thermo.cpp cannot be compiled outside the reference's own build, so the mirror class is checked for its
-// plumbing instead: the same calls through the C-ABI with all fields resident must give the same bits.
+// This program links the reference's operator classes without its model classes (BC_Thermo needs a cAtmosphereModel
+// object), so the mirror of BC_Thermo is checked for its plumbing: the same calls through the C-ABI with all fields resident must give the same bits.
 struct LoopModel {  // the public members BC_Thermo's constructor reads (BC_Thermo.cpp:38-94)
     double L_atm = 16000., dt = 0.00001, dr, dthe, dphi, g = 9.8066, ep = .623, hp = 6.1078, u_0 = 8., p_0 = 1013.25,
            t_0 = 273.15, sigma = 5.670280e-8, albedo_equator = .15, albedo_pole = .7, gam = .65, lv = 2.52e6, ls = 2.83e6,

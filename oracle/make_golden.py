@@ -158,6 +158,14 @@ def transfer_case():
     print("transfer_small.npz", len(out), "entries")
 
 
+def thermo_case():
+    """BC_Thermo's in-loop functions (atmosphere/BC_Thermo.cpp:166-424, 2418-3143, 3235-3275) through the compiled class:
+    SHA-256 of every field each call changed, the members carried between calls, one slice per field."""
+    out = H.thermo_golden_run("ref")
+    np.savez_compressed(os.path.join(GOLD, "bc_thermo.npz"), **out)
+    print("bc_thermo.npz", len(out), "entries")
+
+
 if __name__ == "__main__":
     assert H.have_ref(), "build oracle/_ref first: make -C oracle ref"
     os.makedirs(GOLD, exist_ok=True)
@@ -170,3 +178,4 @@ if __name__ == "__main__":
     full_case(H.HYD, "hyd")
     msl_case()
     transfer_case()
+    thermo_case()

@@ -1,0 +1,185 @@
+/*
+ * ref_model_shim.cpp - flat-array C entry points around the reference's BC_Thermo and model classes.
+ *
+ * TEST INFRASTRUCTURE ONLY (see ref_shim.cpp): our own code, linked against atmosphere/BC_Thermo.cpp,
+ * atmosphere/cAtmosphereModel.cpp, hydrosphere/cHydrosphereModel.cpp, lib/Config.cpp, tinyxml2 and
+ * cli/DefaultStream.cpp compiled where they lie, plus the pieces the reference's own param.py generates
+ * (oracle/gen_ref_headers.py).  BC_Thermo takes its constants from a cAtmosphereModel object and from the
+ * globals of namespace AtmParameters, which only cAtmosphereModel::LoadConfig fills
+ * (AtmosphereLoadConfig.cpp.inc): one model object is created here, given a config file without
+ * parameters (every element keeps its default) through LoadConfig, and then receives the scalars of
+ * the caller's atomdev_params in both places.
+ *
+ * The reference keeps these classes' state private; this translation unit reads and writes it (the
+ * members BC_Thermo carries between calls, the model's time list and tropopause table) by including
+ * the class definitions with `private` spelled `public`.  Access specifiers do not change the layout
+ * the compiler gives these classes, and the reference's own objects are compiled untouched.
+ */
+#include <algorithm>
+#include <cmath>
+#include <csignal>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <limits>
+#include <map>
+#include <set>
+#include <sstream>
+#include <string>
+#include <tuple>
+#include <vector>
+#include <unistd.h>
+
+#define private public
+#include "cAtmosphereModel.h"
+#include "BC_Thermo.h"
+#undef private
+#include "AtmParameters.h"
+
+#include "ref_shim.h"
+
+#ifndef ATOM_REF_DIR
+#define ATOM_REF_DIR "/root/reference"
+#endif
+
+namespace {
+
+cAtmosphereModel* g_model = nullptr;
+
+// Sets a parameter where the reference keeps it twice: the model's member and the AtmParameters global.
+#define SETP(name, value) do { g_model->name = (value); AtmParameters::name = (value); } while (0)
+
+cAtmosphereModel* model() {
+    if (g_model) return g_model;
+    CoutSilencer quiet;
+    void (*old_int)(int) = std::signal(SIGINT, SIG_DFL);   // the constructor installs exit() on SIGINT
+    g_model = new cAtmosphereModel();
+    std::signal(SIGINT, old_int);
+    char path[] = "/tmp/atomref_cfg_XXXXXX";
+    int fd = mkstemp(path);
+    const char* xml = "<atom><common></common><atmosphere></atmosphere></atom>";
+    if (fd < 0 || write(fd, xml, std::strlen(xml)) < 0) std::abort();
+    close(fd);
+    g_model->LoadConfig(path);
+    unlink(path);
+    // the constructor looked for the temperature curve relative to the working directory (param.py:24)
+    g_model->temperature_curve_file = std::string(ATOM_REF_DIR) + "/data/Lenton_etal_COPSE_time_temp.txt";
+    AtmParameters::temperature_curve_file = g_model->temperature_curve_file;
+    g_model->m_temperature_curve.clear();
+    g_model->load_temperature_curve();
+    return g_model;
+}
+
+void set_scalars(const atomdev_params& p) {
+    model();
+    SETP(L_atm, p.L_atm); SETP(g, p.g); SETP(ep, p.ep); SETP(hp, p.hp); SETP(u_0, p.u_0); SETP(p_0, p.p_0);
+    SETP(t_0, p.t_0); SETP(c_0, p.c_0); SETP(co2_0, p.co2_0); SETP(cp_l, p.cp_l); SETP(r_air, p.r_air);
+    SETP(R_Air, p.R_Air); SETP(r_water_vapour, p.r_water_vapour); SETP(R_WaterVapour, p.R_WaterVapour);
+    SETP(lv, p.lv); SETP(ls, p.ls); SETP(gam, p.gam); SETP(t_tropopause, p.t_tropopause);
+    SETP(re, p.re); SETP(pr, p.pr); SETP(sc_WaterVapour, p.sc_WaterVapour); SETP(sc_CO2, p.sc_CO2);
+    SETP(Buoyancy, p.Buoyancy);
+}
+
+void set_time(int Ma) {
+    cAtmosphereModel* m = model();
+    m->m_time_list.clear();
+    m->m_current_time = m->m_time_list.insert(float(Ma)).first;
+}
+
+// A BC_Thermo object on the context's grid.  The constructor copies dt, dr, dthe, dphi from the model's
+// compile-time constants of the 1-degree grid (BC_Thermo.cpp:41-44) and derives dt_dim and dr_dim from
+// them (:121-123); on another grid they are replaced by the context's step sizes, as a model built for
+// that grid would have passed them.
+struct Thermo {
+    RefCtx* c;
+    std::vector<int> trop;
+    int* old_trop;
+    BC_Thermo* circ;
+    Thermo(RefCtx* c_, int Ma = 0, const int* im_tropopause = nullptr) : c(c_), trop(c_->jm, 0) {
+        set_scalars(c->p);
+        set_time(Ma);
+        cAtmosphereModel* m = model();
+        if (im_tropopause) std::copy(im_tropopause, im_tropopause + c->jm, trop.begin());
+        old_trop = m->im_tropopause;
+        m->im_tropopause = trop.data();
+        copy_in(c);
+        circ = new BC_Thermo(m, c->im, c->jm, c->km, *c->a[ATOMDEV_H]);
+        circ->dt = c->p.dt; circ->dr = c->p.dr; circ->dthe = c->p.dthe; circ->dphi = c->p.dphi;
+        circ->dt_dim = circ->L_atm / circ->u_0 * circ->dt;
+        circ->dr_dim = circ->dr * circ->L_atm;
+    }
+    ~Thermo() {
+        delete circ;
+        model()->im_tropopause = old_trop;
+        copy_out(c);
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+/* BC_Thermo::Value_Limitation_Atm (atmosphere/BC_Thermo.cpp:3235-3275) */
+void ref_atm_value_limitation(void* v) {
+    RefCtx* c = (RefCtx*)v;
+    CoutSilencer quiet;
+    Thermo th(c);
+    th.circ->Value_Limitation_Atm(A(H), A(U), A(V), A(W), A(P_DYN), A(T), A(C), A(CLOUD), A(ICE), A(CO2));
+}
+
+/* BC_Thermo::Latent_Heat (atmosphere/BC_Thermo.cpp:2418-2502), called as cAtmosphereModel.cpp:844-845 does */
+void ref_atm_latent_heat(void* v) {
+    RefCtx* c = (RefCtx*)v;
+    CoutSilencer quiet;
+    Thermo th(c);
+    th.circ->Latent_Heat(c->rad, c->the, c->phi, A(H), A(T), A(TN), A(U), A(V), A(W), A(P_DYN), A(P_STAT), A(C), A(ICE),
+                         A(Q_LATENT), A(Q_SENSIBLE), A(RADIATION_3D), B(Q_RADIATION), B(Q_LATENT_2D), B(Q_SENSIBLE_2D),
+                         B(Q_BOTTOM));
+}
+
+/* BC_Thermo::Two_Category_Ice_Scheme (atmosphere/BC_Thermo.cpp:2803-3143); state = the members S_nuc, S_i_dep */
+void ref_atm_two_category_ice_scheme(void* v, double state[2]) {
+    RefCtx* c = (RefCtx*)v;
+    CoutSilencer quiet;
+    Thermo th(c);
+    th.circ->S_nuc = state[0]; th.circ->S_i_dep = state[1];
+    th.circ->Two_Category_Ice_Scheme(A(H), A(C), A(T), A(P_STAT), A(CLOUD), A(ICE), A(P_RAIN), A(P_SNOW), A(S_V), A(S_C),
+                                     A(S_I), A(S_R), A(S_S), A(S_C_C));
+    state[0] = th.circ->S_nuc; state[1] = th.circ->S_i_dep;
+}
+
+/* BC_Thermo::Ice_Water_Saturation_Adjustment (atmosphere/BC_Thermo.cpp:2509-2796); *q_v_hyp = the member of that name */
+void ref_atm_ice_water_saturation_adjustment(void* v, double* q_v_hyp) {
+    RefCtx* c = (RefCtx*)v;
+    CoutSilencer quiet;
+    Thermo th(c);
+    th.circ->q_v_hyp = *q_v_hyp;
+    th.circ->Ice_Water_Saturation_Adjustment(A(H), A(C), A(CN), A(CLOUD), A(CLOUDN), A(ICE), A(ICEN), A(T), A(P_STAT),
+                                             A(S_C_C));
+    *q_v_hyp = th.circ->q_v_hyp;
+}
+
+/* BC_Thermo::BC_Radiation_multi_layer (atmosphere/BC_Thermo.cpp:166-424) at Ma = 0, where the tropopause level of a
+ * row is im_tropopause[j] itself (:226 adds GetTropopauseHightAdd(0) = 0).  Returns non-zero if co2_coeff is neither
+ * of the two values the function can derive (:251-256). */
+int ref_atm_radiation_multi_layer(void* v, const atomdev_radiation* R, const int* i_trop) {
+    RefCtx* c = (RefCtx*)v;
+    CoutSilencer quiet;
+    cAtmosphereModel* m = model();
+    SETP(albedo_pole, R->albedo_pole); SETP(albedo_equator, R->albedo_equator);
+    SETP(epsilon_pole, R->epsilon_pole); SETP(epsilon_equator, R->epsilon_equator);
+    SETP(epsilon_tropopause, R->epsilon_tropopause); SETP(rad_pole, R->rad_pole); SETP(rad_equator, R->rad_equator);
+    SETP(sigma, R->sigma);
+    if (R->co2_coeff == 1.) SETP(CO2, 0.);
+    else if (R->co2_coeff == m->co2_factor * (m->co2_equator / m->co2_tropopause)) SETP(CO2, 1.);
+    else return 1;
+    Thermo th(c, 0, i_trop);
+    th.circ->BC_Radiation_multi_layer(B(ALBEDO), B(EPSILON), B(RADIATION_SURFACE), A(P_STAT), A(T), A(C), A(H),
+                                      A(EPSILON_3D), A(RADIATION_3D), A(CLOUD), A(ICE), A(CO2));
+    return 0;
+}
+
+}  // extern "C"

@@ -252,6 +252,86 @@ def make_msl_inputs(im, jm, km, seed, params):
     return f, g
 
 
+
+def make_latent_heat_inputs(im, jm, km, seed):
+    """Inputs of BC_Thermo::Latent_Heat: make_msl_inputs plus topography up to level im-2 in some columns, where the
+    bottom formula is skipped."""
+    p = default_params(ATM, im, jm, km)
+    f, g = make_msl_inputs(im, jm, km, seed, p)
+    f["H"][im - 2, ::3, ::4] = 1.0
+    return p, f, g
+
+
+def make_radiation_inputs(im, jm, km, seed, trop):
+    """Inputs of BC_Thermo::BC_Radiation_multi_layer and the tropopause level of every row (trop, one less in every
+    fifth row); a low trop puts mountains above the tropopause."""
+    p = default_params(ATM, im, jm, km)
+    f, g = make_msl_inputs(im, jm, km, seed, p)
+    rng = np.random.default_rng(seed)
+    f["EPSILON_3D"] = rng.uniform(0.3, 1.3, (im, jm, km))
+    for k in ("ALBEDO", "EPSILON", "RADIATION_SURFACE"):
+        g[k] = rng.uniform(0.0, 1.0, (jm, km))
+    i_trop = np.full(jm, trop, dtype=np.int32)
+    i_trop[::5] -= 1
+    return p, f, g, i_trop
+
+
+def make_ice_scheme_inputs(im, jm, km, seed, first):
+    """Inputs of BC_Thermo::Two_Category_Ice_Scheme.  The first columns of the visiting order assign nothing to one of
+    the carried members ("warm": S_nuc, "icy": S_i_dep); returns the generator for what the caller changes between
+    two calls."""
+    p = default_params(ATM, im, jm, km)
+    f, g = make_msl_inputs(im, jm, km, seed, p)
+    rng = np.random.default_rng(seed)
+    shp = (im, jm, km)
+    lev = np.arange(im).reshape(im, 1, 1) / (im - 1)
+    f["T"] = 1.07 - 0.25 * lev + rng.uniform(-0.03, 0.03, shp)          # 295 K at the ground to 224 K at the top
+    f["C"] = rng.uniform(-1e-4, 2e-2, shp) * (1.0 - 0.95 * lev)
+    f["CLOUD"] = np.where(rng.random(shp) < 0.5, 0.0, rng.uniform(-1e-5, 1e-3, shp))
+    f["ICE"] = np.where(rng.random(shp) < 0.5, 0.0, rng.uniform(-1e-5, 2e-3, shp))
+    f["S_C_C"] = rng.uniform(-1e-7, 1e-7, shp)
+    f["H"][im - 2, ::3, ::4] = 1.0
+    f["H"][im - 3, ::3, ::4] = 1.0
+    if first == "warm":   # no ice, above t_nuc: S_nuc is not assigned
+        f["T"][:, :4, 0] = 1.05; f["ICE"][:, :4, 0] = 0.0
+    else:                 # cold, dry, more ice than the deficit: S_i_dep is not assigned
+        f["T"][:, :4, 0] = 0.9; f["C"][:, :4, 0] = 0.0; f["ICE"][:, :4, 0] = 0.01
+    f["T"][:, 5:8, 2:4] = 1.05; f["ICE"][:, 5:8, 2:4] = 0.0               # more columns without an S_nuc of their own
+    return p, f, g, rng
+
+
+def make_adjustment_inputs(im, jm, km, seed):
+    """Inputs of BC_Thermo::Ice_Water_Saturation_Adjustment: points that inherit the member q_v_hyp (cloud water or ice
+    negative on entry), whole columns that start with one, columns without a cold point, warm points below, at and
+    above saturation; returns the generator for what the caller changes between two calls."""
+    p = default_params(ATM, im, jm, km)
+    f, g = make_msl_inputs(im, jm, km, seed, p)
+    rng = np.random.default_rng(seed)
+    shp = (im, jm, km)
+    lev = np.arange(im).reshape(im, 1, 1) / (im - 1)
+    f["T"] = 1.07 - 0.25 * lev + rng.uniform(-0.03, 0.03, shp)
+    f["T"][:, 7, 3] = 1.06                                   # a column without a cold point
+    f["T"][0, ::4, ::5] = 1.0                                # exactly 0 degrees Celsius counts as warm
+    cold_all = [(0, 0), (2, 1), (3, 1), (4, 1), (jm - 1, km - 1)]   # (j, k): columns cold from the ground up ...
+    for j, k in cold_all:
+        f["T"][:, j, k] = np.minimum(f["T"][:, j, k], 0.97)
+    # water vapour between 20 % and 115 % of saturation over water (far above it the reference's iteration diverges)
+    t_u = f["T"] * p.t_0
+    p_h = ((t_u - p.gam * lev * p.L_atm * 1e-2) / t_u) ** (p.g / (1e-2 * p.gam * p.R_Air)) * .01 * p.r_air * p.R_Air * t_u[0]
+    e_rain = p.hp * np.exp(17.2694 * (t_u - 273.15) / (t_u - 35.86))
+    f["C"] = p.ep * e_rain / (p_h - e_rain) * rng.uniform(0.2, 1.15, shp)
+    f["C"] = np.minimum(f["C"], 0.02)
+    f["C"][rng.random(shp) < 0.02] = -1e-5
+    f["CLOUD"] = np.where(rng.random(shp) < 0.4, 0.0, rng.uniform(-1e-4, 1e-3, shp))
+    f["ICE"] = np.where(rng.random(shp) < 0.4, 0.0, rng.uniform(-1e-4, 1e-3, shp))
+    f["CN"] = f["C"] + rng.uniform(-1e-5, 1e-5, shp)
+    f["S_C_C"] = rng.uniform(-1e-7, 1e-7, shp)
+    for j, k in cold_all:
+        f["ICE"][0, j, k] = -1e-4                            # ... whose first point cannot assign q_v_hyp itself
+    f["CLOUD"][0, 3, 1] = -2e-4; f["ICE"][0, 3, 1] = 3e-4
+    return p, f, g, rng
+
+
 RUN_DATA_FIELDS2D = ["UPWELLING", "DOWNWELLING", "BOTTOM_WATER", "SALT_FINGER_2D", "SALT_DIFFUSION_2D",
                      "BUOYANCY_FORCE_2D", "SALT_TOTAL"]
 
@@ -673,3 +753,85 @@ def atm_3d_loop(m, pressure_iters=2, velocity_iters=2, physics=False, i_trop=Non
         log.append((ice_state[0], (0, 0, 0)))
         log.append((ice_state[1], (0, 0, 0)))
     return log
+
+
+# --------------------------------------------------------------------------
+# BC_Thermo: the run behind tests/golden/bc_thermo.npz (oracle/make_golden.py with the compiled reference,
+# tests/test_oracle_golden.py with the oracle)
+# --------------------------------------------------------------------------
+
+def default_radiation():
+    """Constants of BC_Radiation_multi_layer at their defaults (param.py:60-70, 123-130) with CO2 = 1."""
+    import atom_amd
+    return atom_amd.Radiation(albedo_pole=.7, albedo_equator=.15, epsilon_pole=.59, epsilon_equator=.594,
+                              epsilon_tropopause=.001, rad_pole=40., rad_equator=230., co2_coeff=.98 * (330. / 320.),
+                              sigma=5.670280e-8)
+
+
+def thermo_golden_run(kind):
+    """Runs Value_Limitation_Atm, Latent_Heat, BC_Radiation_multi_layer (twice), Two_Category_Ice_Scheme (twice, state
+    handed on) and Ice_Water_Saturation_Adjustment (twice) of ``kind`` ("ref" or "oracle") on seeded inputs.  Returns
+    {key: SHA-256 of a changed field | carried state | sample slice}."""
+    import hashlib
+    out = {}
+    dp = C.POINTER(C.c_double)
+
+    def record(tag, m, f, g):
+        for k in sorted(f):
+            if not np.array_equal(m.f[k], f[k]):
+                out["%s/%s/sha256" % (tag, k)] = np.array(hashlib.sha256(m.f[k].tobytes()).hexdigest())
+                out["%s/%s/j5" % (tag, k)] = m.f[k][:, 5, :].copy()
+        for k in sorted(g):
+            if not np.array_equal(m.g[k], g[k]):
+                out["%s/%s/sha256" % (tag, k)] = np.array(hashlib.sha256(m.g[k].tobytes()).hexdigest())
+
+    pre = "oracle_" if kind == "oracle" else "ref_"
+    dims = (12, 13, 17)
+    # limiter
+    p = default_params(ATM, *dims)
+    f, g = make_inputs(ATM, *dims, 5, "blobs", p)
+    f = {k: f[k] for k in ATM_FIELDS}
+    rng = np.random.default_rng(5)
+    for k in ["U", "V", "W", "T", "C", "CLOUD", "ICE", "CO2"]:
+        f[k] = f[k] + rng.normal(0, 2.0 * np.abs(f[k]).max(), f[k].shape)
+    m = CpuModel(kind, ATM, *dims, p, f, g)
+    m.op("atm_value_limitation")
+    record("limit", m, f, g)
+    # latent heat (no topography on level im-2: the reference would read outside its arrays)
+    p, f, g = make_latent_heat_inputs(*dims, 58)
+    f["H"][dims[0] - 2] = 0.0
+    m = CpuModel(kind, ATM, *dims, p, f, g)
+    m.op("atm_latent_heat")
+    record("latent", m, f, g)
+    # radiation, two calls
+    p, f, g, i_trop = make_radiation_inputs(*dims, 60, 8)
+    m = CpuModel(kind, ATM, *dims, p, f, g)
+    r = default_radiation()
+    fn = getattr(m.lib, pre + "atm_radiation_multi_layer")
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+    for call in range(2):
+        fn(m.ctx, C.byref(r), i_trop.ctypes.data_as(C.POINTER(C.c_int)))
+        record("radiation%d" % call, m, f, g)
+    # ice scheme, two calls
+    p, f, g, rng = make_ice_scheme_inputs(*dims, 63, "icy")
+    m = CpuModel(kind, ATM, *dims, p, f, g)
+    fn = getattr(m.lib, pre + "atm_two_category_ice_scheme"); fn.argtypes = [C.c_void_p, dp]
+    st = (C.c_double * 2)(3.0e-7, -2.0e-7)
+    for call in range(2):
+        fn(m.ctx, st)
+        record("ice%d" % call, m, f, g)
+        out["ice%d/state" % call] = np.array([st[0], st[1]])
+        for k in ("C", "ICE"):
+            m.f[k][...] = m.f[k] * rng.uniform(0.5, 1.5, dims)
+    # saturation adjustment, two calls
+    p, f, g, rng = make_adjustment_inputs(*dims, 66)
+    m = CpuModel(kind, ATM, *dims, p, f, g)
+    fn = getattr(m.lib, pre + "atm_ice_water_saturation_adjustment"); fn.argtypes = [C.c_void_p, dp]
+    q = C.c_double(4.0e-3)
+    for call in range(2):
+        fn(m.ctx, C.byref(q))
+        record("adjust%d" % call, m, f, g)
+        out["adjust%d/state" % call] = np.array([q.value])
+        for k, lo, hi in (("C", 0.7, 1.02), ("CLOUD", 0.5, 1.5), ("ICE", 0.5, 1.5)):
+            m.f[k][...] = m.f[k] * rng.uniform(lo, hi, dims) - 2e-5
+    return out

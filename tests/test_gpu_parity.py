@@ -288,12 +288,10 @@ def test_rk2d_batch_same_bits():
 
 @pytest.mark.parametrize("dims,seed", [((9, 21, 70), 57), ((7, 13, 17), 58)])
 def test_atm_latent_heat_bitexact(dims, seed):
-    """BC_Thermo::Latent_Heat: +, -, *, / only, so bit-exact against the oracle's restatement - which itself is
-    PARITY UNPINNED (BC_Thermo.cpp cannot be compiled outside the reference's own build; no fixture exists)."""
+    """BC_Thermo::Latent_Heat: +, -, *, / only, so bit-exact against the oracle's restatement (itself pinned bit
+    for bit by the compiled BC_Thermo class: test_oracle_vs_reference.py, golden/bc_thermo.npz)."""
     im, jm, km = dims
-    p = H.default_params(H.ATM, im, jm, km)
-    f, g = H.make_msl_inputs(im, jm, km, seed, p)
-    f["H"][im - 2, ::3, ::4] = 1.0   # topography up to level im-2: the bottom formula is skipped there
+    p, f, g = H.make_latent_heat_inputs(im, jm, km, seed)
     o = H.CpuModel("oracle", H.ATM, im, jm, km, p, f, g)
     d = atom_amd.DeviceModel(H.ATM, im, jm, km, atom_amd.Params.from_buffer_copy(bytes(p)))
     d.upload_all(f, g)
@@ -308,19 +306,12 @@ def test_atm_latent_heat_bitexact(dims, seed):
                                             ((41, 37, 45), 76, 12), ((60, 9, 11), 77, 40)])   # 60 levels: one thread per column
 def test_atm_radiation_multi_layer(dims, seed, trop):
     """BC_Thermo::BC_Radiation_multi_layer against the oracle's statement-by-statement restatement (which builds
-    the reference's full transmission matrix): pow() and sqrt() on both sides, 1e-10 per field.  PARITY UNPINNED
-    against the reference itself (BC_Thermo.cpp cannot be compiled outside its own build).  trop = 3 puts
+    the reference's full transmission matrix): pow() and sqrt() on both sides, 1e-10 per field; the oracle is pinned bit
+    for bit by the compiled BC_Thermo class (test_oracle_vs_reference.py, golden/bc_thermo.npz).  trop = 3 puts
     mountains above the tropopause."""
     import ctypes as C
     im, jm, km = dims
-    p = H.default_params(H.ATM, im, jm, km)
-    f, g = H.make_msl_inputs(im, jm, km, seed, p)
-    rng = np.random.default_rng(seed)
-    f["EPSILON_3D"] = rng.uniform(0.3, 1.3, (im, jm, km))
-    for k in ("ALBEDO", "EPSILON", "RADIATION_SURFACE"):
-        g[k] = rng.uniform(0.0, 1.0, (jm, km))
-    i_trop = np.full(jm, trop, dtype=np.int32)
-    i_trop[::5] -= 1
+    p, f, g, i_trop = H.make_radiation_inputs(im, jm, km, seed, trop)
     o = H.CpuModel("oracle", H.ATM, im, jm, km, p, f, g)
     d = atom_amd.DeviceModel(H.ATM, im, jm, km, atom_amd.Params.from_buffer_copy(bytes(p)))
     d.upload_all(f, g)
@@ -345,31 +336,16 @@ def test_atm_radiation_multi_layer(dims, seed, trop):
                                              ((130, 7, 9), 70, "icy")])   # 130 levels: the one-thread-per-column kernels
 def test_atm_two_category_ice_scheme(dims, seed, first):
     """BC_Thermo::Two_Category_Ice_Scheme against the oracle's restatement in the reference's serial visiting
-    order (exp() and pow() on both sides, 1e-10 per field), PARITY UNPINNED against the reference itself
-    (BC_Thermo.cpp cannot be compiled outside its own build).  S_nuc and S_i_dep are assigned only under
+    order (exp() and pow() on both sides, 1e-10 per field); the oracle is pinned bit for bit by the compiled
+    BC_Thermo class (test_oracle_vs_reference.py, golden/bc_thermo.npz).  S_nuc and S_i_dep are assigned only under
     conditions and otherwise keep the value of the grid point visited before - across columns, passes and calls:
     the first columns of the visiting order are built so that they assign nothing ("warm": S_nuc, "icy":
     S_i_dep), which makes them work with the caller's state in the first pass and with the grid's last
     assignment afterwards; two calls in a row hand the state on."""
     import ctypes as C
     im, jm, km = dims
-    p = H.default_params(H.ATM, im, jm, km)
-    f, g = H.make_msl_inputs(im, jm, km, seed, p)
-    rng = np.random.default_rng(seed)
+    p, f, g, rng = H.make_ice_scheme_inputs(im, jm, km, seed, first)
     shp = (im, jm, km)
-    lev = np.arange(im).reshape(im, 1, 1) / (im - 1)
-    f["T"] = 1.07 - 0.25 * lev + rng.uniform(-0.03, 0.03, shp)          # 295 K at the ground to 224 K at the top
-    f["C"] = rng.uniform(-1e-4, 2e-2, shp) * (1.0 - 0.95 * lev)
-    f["CLOUD"] = np.where(rng.random(shp) < 0.5, 0.0, rng.uniform(-1e-5, 1e-3, shp))
-    f["ICE"] = np.where(rng.random(shp) < 0.5, 0.0, rng.uniform(-1e-5, 2e-3, shp))
-    f["S_C_C"] = rng.uniform(-1e-7, 1e-7, shp)
-    f["H"][im - 2, ::3, ::4] = 1.0
-    f["H"][im - 3, ::3, ::4] = 1.0
-    if first == "warm":   # no ice, above t_nuc: S_nuc is not assigned
-        f["T"][:, :4, 0] = 1.05; f["ICE"][:, :4, 0] = 0.0
-    else:                 # cold, dry, more ice than the deficit: S_i_dep is not assigned
-        f["T"][:, :4, 0] = 0.9; f["C"][:, :4, 0] = 0.0; f["ICE"][:, :4, 0] = 0.01
-    f["T"][:, 5:8, 2:4] = 1.05; f["ICE"][:, 5:8, 2:4] = 0.0               # more columns without an S_nuc of their own
     o = H.CpuModel("oracle", H.ATM, im, jm, km, p, f, g)
     d = atom_amd.DeviceModel(H.ATM, im, jm, km, atom_amd.Params.from_buffer_copy(bytes(p)))
     d.upload_all(f, g)
@@ -402,38 +378,15 @@ def test_atm_two_category_ice_scheme(dims, seed, first):
                                        ((130, 9, 9), 71)])   # 130 levels: the one-thread-per-column kernel
 def test_atm_ice_water_saturation_adjustment(dims, seed):
     """BC_Thermo::Ice_Water_Saturation_Adjustment against the oracle's restatement in the reference's serial
-    visiting order (exp() and pow() inside an iteration with a 1e-5 exit test; 1e-10 per field), PARITY UNPINNED
-    against the reference itself (BC_Thermo.cpp cannot be compiled outside its own build).  The member q_v_hyp
+    visiting order (exp() and pow() inside an iteration with a 1e-5 exit test; 1e-10 per field); the oracle is
+    pinned bit for bit by the compiled BC_Thermo class (test_oracle_vs_reference.py, golden/bc_thermo.npz).  The member q_v_hyp
     is inherited by cold points whose cloud water or ice comes in negative: the inputs hold such points, whole
     columns that start with one (three of them in a row in visiting order, and the very first column, which
     takes the caller's value), columns without a cold point, and warm points below, at and above saturation."""
     import ctypes as C
     im, jm, km = dims
-    p = H.default_params(H.ATM, im, jm, km)
-    f, g = H.make_msl_inputs(im, jm, km, seed, p)
-    rng = np.random.default_rng(seed)
+    p, f, g, rng = H.make_adjustment_inputs(im, jm, km, seed)
     shp = (im, jm, km)
-    lev = np.arange(im).reshape(im, 1, 1) / (im - 1)
-    f["T"] = 1.07 - 0.25 * lev + rng.uniform(-0.03, 0.03, shp)
-    f["T"][:, 7, 3] = 1.06                                   # a column without a cold point
-    f["T"][0, ::4, ::5] = 1.0                                # exactly 0 degrees Celsius counts as warm
-    cold_all = [(0, 0), (2, 1), (3, 1), (4, 1), (jm - 1, km - 1)]   # (j, k): columns cold from the ground up ...
-    for j, k in cold_all:
-        f["T"][:, j, k] = np.minimum(f["T"][:, j, k], 0.97)
-    # water vapour between 20 % and 115 % of saturation over water (far above it the reference's iteration diverges)
-    t_u = f["T"] * p.t_0
-    p_h = ((t_u - p.gam * lev * p.L_atm * 1e-2) / t_u) ** (p.g / (1e-2 * p.gam * p.R_Air)) * .01 * p.r_air * p.R_Air * t_u[0]
-    e_rain = p.hp * np.exp(17.2694 * (t_u - 273.15) / (t_u - 35.86))
-    f["C"] = p.ep * e_rain / (p_h - e_rain) * rng.uniform(0.2, 1.15, shp)
-    f["C"] = np.minimum(f["C"], 0.02)
-    f["C"][rng.random(shp) < 0.02] = -1e-5
-    f["CLOUD"] = np.where(rng.random(shp) < 0.4, 0.0, rng.uniform(-1e-4, 1e-3, shp))
-    f["ICE"] = np.where(rng.random(shp) < 0.4, 0.0, rng.uniform(-1e-4, 1e-3, shp))
-    f["CN"] = f["C"] + rng.uniform(-1e-5, 1e-5, shp)
-    f["S_C_C"] = rng.uniform(-1e-7, 1e-7, shp)
-    for j, k in cold_all:
-        f["ICE"][0, j, k] = -1e-4                            # ... whose first point cannot assign q_v_hyp itself
-    f["CLOUD"][0, 3, 1] = -2e-4; f["ICE"][0, 3, 1] = 3e-4
     o = H.CpuModel("oracle", H.ATM, im, jm, km, p, f, g)
     d = atom_amd.DeviceModel(H.ATM, im, jm, km, atom_amd.Params.from_buffer_copy(bytes(p)))
     d.upload_all(f, g)

@@ -117,8 +117,8 @@ def physics_loop_inputs(im, jm, km, seed):
 @pytest.mark.gpu
 def test_atm_loop_with_column_physics_device():
     """The whole velocity iteration of cAtmosphereModel.cpp:756-874 on the device, the BC_Thermo column physics
-    included (saturation adjustment, radiation, latent heat, vegetation, ice scheme; PARITY UNPINNED pieces, compared
-    with the oracle's restatements): no operator of the loop is left to the host.  One pressure iteration of two
+    included (saturation adjustment, radiation, latent heat, vegetation, ice scheme, compared with the oracle's
+    restatements, which the compiled BC_Thermo class pins bit for bit): no operator of the loop is left to the host.  One pressure iteration of two
     velocity iterations (each operator at least once), 1e-10 per field, on a state the physics keeps bounded.
     Longer loops are not held to 1e-10: the saturation adjustment iterates to a 1e-5 exit test and, on the oracle
     itself, returns a 1e-12 relative change of t as 2.5e-10 in c - every further call multiplies what the
