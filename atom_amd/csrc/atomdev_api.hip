@@ -152,6 +152,7 @@ extern "C" int atomdev_create(int model, int im, int jm, int km, const atomdev_p
     h->ws_params = nullptr; h->ws_err = nullptr; h->surf = nullptr; h->xfer = nullptr; h->batch = nullptr; h->batch_bytes = 0;
     if (const char* e = getenv("ATOMDEV_RK_VARIANT")) h->rk_variant = atoi(e);
     h->rad = h->sinthe = h->costhe = h->plane = nullptr; h->red = nullptr;
+    h->static_scratch = nullptr; h->static_scratch_bytes = 0; h->pinned = nullptr;
     fill_constants(h);
 
     int rc = 0;
@@ -178,6 +179,8 @@ extern "C" int atomdev_create(int model, int im, int jm, int km, const atomdev_p
     h->red_bytes = 1 << 20;
     if ((rc = atomdev_check(hipMalloc(&h->red, h->red_bytes), "hipMalloc(red)"))) return fail(rc);
 
+    if ((rc = atomdev_check(hipHostMalloc(&h->pinned, 256, hipHostMallocDefault), "hipHostMalloc(pinned)"))) return fail(rc);
+    if ((rc = atomdev_static_scratch_init(h))) return fail(rc);
     if ((rc = upload_tables(h))) return fail(rc);
     for (int n = 0; n < 2; n++)
         if ((rc = atomdev_check(hipMalloc(&h->scr[n], h->n3 * sizeof(double)), "hipMalloc(scr)"))) return fail(rc);
@@ -208,6 +211,7 @@ extern "C" int atomdev_destroy(atomdev_t* h) {
     if (h->flags) (void)hipFree(h->flags);
     if (h->plane) (void)hipFree(h->plane);
     if (h->red) (void)hipFree(h->red);
+    if (h->pinned) (void)hipHostFree(h->pinned);
     if (h->rad) (void)hipFree(h->rad);
     if (h->sinthe) (void)hipFree(h->sinthe);
     if (h->costhe) (void)hipFree(h->costhe);

@@ -64,6 +64,9 @@ struct atomdev {
     void* ws_params;                // device copy of the wave-specialised sweep's argument block(s) (lazy)
     const double* ws_cur0;          // hyd: f[T] at the time the blocks were built (tells the buffer orientation)
     int* ws_err;                    // hyd: device word the sweep sets when a wait between workgroups gave up (lazy)
+    void* static_scratch;           // this GPU's copy of the library's static scratch array (k_accuracy.hip)
+    size_t static_scratch_bytes;
+    void* pinned;                   // 256 bytes of page-locked host memory for results read back without staging
     int rk_variant;                 // 0: wave-specialised sweep (default), 1: one thread per theta line
     bool profile_rk;                // bracket RK sweep kernels with events
     std::vector<hipEvent_t> prof_ev;  // pairs (start, stop), prof_used of them recorded
@@ -80,6 +83,7 @@ int atomdev_refresh_flags(atomdev* h);  // k_pointwise.hip
 int atomdev_upload_mask_bytes(atomdev* h, const uint8_t* solid);  // k_pointwise.hip: h from a byte mask (1 = solid)
 int atomdev_fill_theta_neumann(atomdev* h, int field);            // k_bc_pressure.hip
 int atomdev_fill_phi_seam(atomdev* h, int field, int j0, int j1);  // k_bc_pressure.hip
+int atomdev_static_scratch_init(atomdev* h);  // k_accuracy.hip
 int atomdev_atm_rk3d_ws(atomdev* h);    // k_rk_atm_ws.hip
 int atomdev_hyd_rk3d_ws(atomdev* h);    // k_rk_hyd_ws.hip
 

@@ -208,23 +208,47 @@ __global__ void k_steady_final(const Best* __restrict__ part, int nblocks, int n
     (void)nf;
 }
 
-int residuum(atomdev* h, bool three_d, bool ge, double* min, int loc[3]) {
+// Scratch of the residuum query that no call allocates: one array per GPU in the library's own device
+// image, for callers that must not allocate (atomdev_atm_residuum3d_noalloc).  It holds the compact
+// residuum sequence, the per-chunk summaries and the two result words of one query of up to
+// STATIC_SEQ_MAX interior points (the 41 x 181 x 361 grid has 2 506 179).  Every query writes what it
+// reads before it reads it, so nothing has to start at zero; two queries that overlap in time on one
+// GPU would share the array and race.
+constexpr size_t STATIC_SEQ_MAX = 2621440;   // 20 MiB of doubles
+constexpr size_t STATIC_SCRATCH_BYTES = STATIC_SEQ_MAX * sizeof(double) + (STATIC_SEQ_MAX / CHUNK + 1) * sizeof(ChunkSum) + 256;
+static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
+
+// where a query keeps its intermediate results: the handle's reduction buffer (grown on demand) or the static array
+struct ResScratch { void* base; size_t bytes; double* host_result; };
+
+int residuum(atomdev* h, bool three_d, bool ge, double* min, int loc[3], const ResScratch* fixed = nullptr) {
     const int im = h->im, jm = h->jm, km = h->km;
     const size_t n = three_d ? (size_t)(im - 2) * (jm - 2) * (km - 2) : (size_t)(jm - 2) * (km - 2);
     const int nchunks = (int)((n + CHUNK - 1) / CHUNK);
     // scratch: seq | chunk functions | result
-    const size_t need = n * sizeof(double) + (size_t)nchunks * sizeof(ChunkSum) + 128;
-    if (need > h->red_bytes) {
-        ATOMDEV_TRY(hipStreamSynchronize(h->stream));
-        ATOMDEV_TRY(hipFree(h->red));
-        h->red = nullptr; h->red_bytes = 0;
-        ATOMDEV_TRY(hipMalloc(&h->red, need));
-        h->red_bytes = need;
+    const size_t need = ((n * sizeof(double) + 63) / 64) * 64 + (size_t)nchunks * sizeof(ChunkSum) + 128;
+    void* base; size_t bytes;
+    if (fixed) {
+        base = fixed->base; bytes = fixed->bytes;
+        if (need > bytes) {
+            atomdev_set_error("residuum query without allocation: the grid has " + std::to_string(n) +
+                              " interior points, the static scratch holds at most " + std::to_string(STATIC_SEQ_MAX));
+            return 1;
+        }
+    } else {
+        if (need > h->red_bytes) {
+            ATOMDEV_TRY(hipStreamSynchronize(h->stream));
+            ATOMDEV_TRY(hipFree(h->red));
+            h->red = nullptr; h->red_bytes = 0;
+            ATOMDEV_TRY(hipMalloc(&h->red, need));
+            h->red_bytes = need;
+        }
+        base = h->red; bytes = h->red_bytes;
     }
-    double* seq = (double*)h->red;
-    ChunkSum* fn = (ChunkSum*)((char*)h->red + ((n * sizeof(double) + 63) / 64) * 64);
+    double* seq = (double*)base;
+    ChunkSum* fn = (ChunkSum*)((char*)base + ((n * sizeof(double) + 63) / 64) * 64);
     double* out = (double*)((char*)fn + (size_t)nchunks * sizeof(ChunkSum));
-    if ((char*)(out + 2) > (char*)h->red + h->red_bytes) { atomdev_set_error("residuum: scratch layout"); return 1; }
+    if ((char*)(out + 2) > (char*)base + bytes) { atomdev_set_error("residuum: scratch layout"); return 1; }
     if (three_d) {
         dim3 grid((km - 2 + 127) / 128, jm - 2, im - 2);
         hipLaunchKernelGGL(k_residuum3d, grid, dim3(128), 0, h->stream, h->f[ATOMDEV_U], h->f[ATOMDEV_V], h->f[ATOMDEV_W],
@@ -240,8 +264,9 @@ int residuum(atomdev* h, bool three_d, bool ge, double* min, int loc[3]) {
     if (ge) hipLaunchKernelGGL(k_scan_jumps<true>, dim3(1), dim3(TPB), 0, h->stream, seq, n, fn, nchunks, m_in, out);
     else hipLaunchKernelGGL(k_scan_jumps<false>, dim3(1), dim3(TPB), 0, h->stream, seq, n, fn, nchunks, m_in, out);
     ATOMDEV_TRY(hipGetLastError());
-    double res[2];
-    ATOMDEV_TRY(hipMemcpyAsync(res, out, sizeof(res), hipMemcpyDeviceToHost, h->stream));
+    double stack_res[2];
+    double* res = fixed ? fixed->host_result : stack_res;   // pinned memory of the handle / pageable
+    ATOMDEV_TRY(hipMemcpyAsync(res, out, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     ATOMDEV_TRY(hipStreamSynchronize(h->stream));
     *min = res[0];
     long pos = (long)res[1];
@@ -388,6 +413,25 @@ extern "C" int atomdev_atm_residuum3d(atomdev_t* h, double* min, int loc[3]) {
     ATOMDEV_TRY(hipSetDevice(h->device));
     return residuum(h, true, false, min, loc);
 }
+// The address of this GPU's copy of the static scratch, looked up once per handle at set-up with the handle's
+// device current (atomdev_create).  Host code must use this pointer: the array's name is a host-side stand-in.
+int atomdev_static_scratch_init(atomdev* h) {
+    void* p = nullptr;
+    ATOMDEV_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    ATOMDEV_REQUIRE(p != nullptr, "atomdev_create: the static scratch of this device has no address");
+    h->static_scratch = p;
+    h->static_scratch_bytes = STATIC_SCRATCH_BYTES;
+    return 0;
+}
+
+extern "C" int atomdev_atm_residuum3d_noalloc(atomdev_t* h, double* min, int loc[3]) {
+    ATOMDEV_REQUIRE(h && h->model == ATOMDEV_ATM && min && loc, "atomdev_atm_residuum3d_noalloc: bad argument");
+    ATOMDEV_REQUIRE(h->static_scratch && h->pinned, "atomdev_atm_residuum3d_noalloc: the handle has no static scratch");
+    ATOMDEV_TRY(hipSetDevice(h->device));
+    const ResScratch fixed = { h->static_scratch, h->static_scratch_bytes, (double*)h->pinned };
+    return residuum(h, true, false, min, loc, &fixed);
+}
+
 extern "C" int atomdev_atm_residuum2d(atomdev_t* h, double* min, int loc[3]) {
     ATOMDEV_REQUIRE(h && h->model == ATOMDEV_ATM && min && loc, "atomdev_atm_residuum2d: bad argument");
     ATOMDEV_TRY(hipSetDevice(h->device));

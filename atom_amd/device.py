@@ -142,7 +142,7 @@ def load_library():
     lib.atomdev_hyd_read_transfer_file.argtypes = [vp, C.c_char_p]
     for op in _OPS:
         getattr(lib, "atomdev_" + op).argtypes = [vp]
-    for name in ("atomdev_atm_residuum3d", "atomdev_atm_residuum2d", "atomdev_hyd_residuum3d"):
+    for name in ("atomdev_atm_residuum3d", "atomdev_atm_residuum3d_noalloc", "atomdev_atm_residuum2d", "atomdev_hyd_residuum3d"):
         getattr(lib, name).argtypes = [vp, dp, ip]
     for name in ("atomdev_atm_steady3d", "atomdev_atm_steady2d", "atomdev_hyd_steady3d"):
         getattr(lib, name).argtypes = [vp, dp, ip]

@@ -150,6 +150,17 @@ int atomdev_atm_pressure2d(atomdev_t* h);
  * field is left in ATOMDEV_RESIDUUM. loc = {i, j, k} ({0, j, k} for 2-D). */
 int atomdev_atm_residuum3d(atomdev_t* h, double* min, int loc[3]);
 int atomdev_atm_residuum2d(atomdev_t* h, double* min, int loc[3]);
+/* atomdev_atm_residuum3d for callers that must not allocate device memory while they run (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  The query's
+ * intermediate results (the compact residuum sequence, its per-chunk summaries, the result words) live in a
+ * static array of the library's device image, 20 MiB per GPU for as long as the process lives, instead of the
+ * handle's reduction buffer that atomdev_atm_residuum3d grows on demand; the result comes back through page-locked
+ * memory the handle received at atomdev_create.  The call allocates and frees nothing.  Grids with more than
+ * 2 621 440 interior points ((im-2)(jm-2)(km-2); the 41 x 181 x 361 grid has 2 506 179) are refused with an error.
+ * Same kernels, same results as atomdev_atm_residuum3d.  All handles of one GPU share the array: calls that
+ * overlap in time on one GPU (two host threads with a handle each) race; calls one after the other do not,
+ * whatever the earlier call left in the array. */
+int atomdev_atm_residuum3d_noalloc(atomdev_t* h, double* min, int loc[3]);
 /* Accuracy_Atm::steadyQuery_3D (atmosphere/Accuracy_Atm.cpp:192-337): max |x - xn|
  * and its first location, order u v w t c cloud ice co2 p_dyn; loc = 9 x {i,j,k}. */
 int atomdev_atm_steady3d(atomdev_t* h, double out[9], int loc[27]);
