@@ -61,6 +61,8 @@ struct atomdev {
     size_t batch_bytes;
     double* xfer;                   // six surface planes of the atmosphere -> hydrosphere transfer (lazy)
     void* surf;                     // skewed copy of the surface fields for the 2-D sweep (lazy)
+    double* vstage;                 // atm, split sweep: the four stage values of v of every point (lazy)
+    bool ws_params_split;           // the argument block on the device knows vstage
     void* ws_params;                // device copy of the wave-specialised sweep's argument block(s) (lazy)
     const double* ws_cur0;          // hyd: f[T] at the time the blocks were built (tells the buffer orientation)
     int* ws_err;                    // hyd: device word the sweep sets when a wait between workgroups gave up (lazy)
@@ -85,6 +87,7 @@ int atomdev_fill_theta_neumann(atomdev* h, int field);            // k_bc_pressu
 int atomdev_fill_phi_seam(atomdev* h, int field, int j0, int j1);  // k_bc_pressure.hip
 int atomdev_static_scratch_init(atomdev* h);  // k_accuracy.hip
 int atomdev_atm_rk3d_ws(atomdev* h);    // k_rk_atm_ws.hip
+int atomdev_atm_rk3d_ws_fast(atomdev* h);  // k_rk_atm_ws.hip compiled with -DATOMDEV_RK_FAST
 int atomdev_hyd_rk3d_ws(atomdev* h);    // k_rk_hyd_ws.hip
 
 #define ATOMDEV_TRY(expr)                                   \

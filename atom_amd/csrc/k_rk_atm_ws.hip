@@ -37,6 +37,21 @@
 // range scaling, which holds for densities and mixing ratios.
 #include "atomdev_internal.h"
 
+// This file is compiled twice.  As it stands: every quotient carries the bits of the reference's division
+// (div_by, no contraction).  With -DATOMDEV_RK_FAST -ffp-contract=fast: division by a loop-invariant divisor
+// is one multiplication by its reciprocal and products feeding sums fuse, which costs up to one unit in the
+// last place per operation (the sweep then agrees with the reference to about 1e-13 instead of bit for bit
+// plus pow) and removes a third of the instructions of every RK stage.
+#ifdef ATOMDEV_RK_FAST
+#define ATM_WS_ENTRY atomdev_atm_rk3d_ws_fast
+#define k_atm_rk3d_ws k_atm_rk3d_wsf
+#define k_atm_prep k_atm_prepf
+#define DIVC(a, b, rb) ((a) * (rb))
+#else
+#define ATM_WS_ENTRY atomdev_atm_rk3d_ws
+#define DIVC(a, b, rb) div_by(a, b, rb)
+#endif
+
 namespace {
 
 enum Role { R_V = 0, R_T = 1, R_U = 2, R_C = 3, R_W = 4, R_CO2 = 5, R_ICE = 6, R_CLOUD = 7 };
@@ -52,6 +67,7 @@ struct AtmWsArgs {
     const double *ph100, *h0i;                 // k_atm_prep outputs (3-D)
     const double *rad, *costhe;
     const double *tab_rm2sin, *tab_irm2sin, *tab_coefv;   // [i*jm + j]
+    double* vs[4];   // split form: the value of v every stage of every point worked with (3-D each)
 };
 
 // Arguments live in device memory, not in the kernel-argument segment: a role then reads the dozen
@@ -107,7 +123,7 @@ __global__ void k_atm_prep(const double* __restrict__ t, const double* __restric
 #define STAMP(n)                                                                                      \
     do {                                                                                              \
         if (j == 60 && bx == 2 && i == 11 && lane == 0)                                           \
-            a.aux_w[(threadIdx.x >> 6) * 16 + (n)] = (double)(long long)__builtin_readcyclecounter(); \
+            a.aux_w[ROLE * 16 + (n)] = (double)(long long)__builtin_readcyclecounter(); \
     } while (0)
 #else
 #define STAMP(n) do {} while (0)
@@ -140,23 +156,37 @@ __device__ __forceinline__ double rcp_refined(double b) {
 }
 // a / b for operands that need no range scaling (finite, normal, quotient far from overflow and
 // underflow): the compiler's own sequence without its scaling and fix-up instructions.
-__device__ __forceinline__ double fdiv_normal(double a, double b) { return div_by(a, b, rcp_refined(b)); }
+__device__ __forceinline__ double fdiv_normal(double a, double b) { return DIVC(a, b, rcp_refined(b)); }
 
 struct ThetaK { double dthe, i_dthe, two_dthe, i_two_dthe, dthe2, i_dthe2; };
 
-// theta derivative pair (RHS_Atm.cpp:162-170, 192-199, 245-312); see k_rk_atm.hip
-__device__ __forceinline__ void dtheta(int mode, double hdj, double xm2, double xm1, double x0, double xp1,
-                                       const ThetaK& K, double& d1, double& d2) {
-    if (mode == 0) {
-        d1 = div_by(hdj * (xp1 - xm1), K.two_dthe, K.i_two_dthe);
-        d2 = div_by(hdj * (xp1 - 2. * x0 + xm1), K.dthe2, K.i_dthe2);
-    } else if (mode == 1) {
-        d1 = div_by(hdj * (x0 - xm1), K.dthe, K.i_dthe);
-        d2 = 0.;
-    } else {
-        d1 = div_by(hdj * (-3. * x0 + 4. * xm1 - xm2), K.two_dthe, K.i_two_dthe);
-        d2 = div_by(hdj * (2 * x0 - 2. * xm1 + xm2), K.dthe2, K.i_dthe2);
-    }
+// Theta derivatives (RHS_Atm.cpp:162-170, 192-199, 245-312).  The reference's cascade of branches leaves one
+// of three forms standing at a point (see k_rk_atm.hip):
+//   0, outside the index window:        d1 = hdj (x[j+1] - x[j-1]) / 2dthe         d2 = hdj (x[j+1] - 2 x + x[j-1]) / dthe2
+//   1, inside it:                       d1 = hdj (x - x[j-1]) / dthe               d2 = 0
+//   2, land cell, fluid at j-1 and j-2: d1 = hdj (-3 x + 4 x[j-1] - x[j-2]) / 2dthe  d2 = hdj (2 x - 2 x[j-1] + x[j-2]) / dthe2
+// All three are  hdj ((a x + B) + C) / D  with per-point a, B, C, D fixed for the four stages of a row, evaluated
+// with the reference's roundings: a x is exact or the reference's own product (-3 x), B and C are neighbour
+// values times 1, -1, 4 or -2 (exact), and the two additions are the reference's two.  So every lane runs the
+// same instructions whatever its form is.
+struct ThetaForm {
+    double a, e;          // factors of the stage value in d1 and d2
+    double D1, iD1;       // divisor of d1 and its reciprocal
+};
+__device__ __forceinline__ ThetaForm theta_form(int mode, const ThetaK& K) {
+    ThetaForm f;
+    f.a = mode == 0 ? 0. : (mode == 1 ? 1. : -3.);
+    f.e = mode == 0 ? -2. : (mode == 1 ? 0. : 2.);
+    f.D1 = mode == 1 ? K.dthe : K.two_dthe;
+    f.iD1 = mode == 1 ? K.i_dthe : K.i_two_dthe;
+    return f;
+}
+// B, C of d1 and F, G of d2 for one variable's neighbour rows
+__device__ __forceinline__ void theta_terms(int mode, double xm2, double xm1, double xp1, double& B, double& C, double& F, double& G) {
+    B = mode == 0 ? xp1 : (mode == 1 ? -xm1 : 4. * xm1);
+    C = mode == 0 ? -xm1 : (mode == 1 ? 0. : -xm2);
+    F = mode == 0 ? xp1 : (mode == 1 ? 0. : -2. * xm1);
+    G = mode == 0 ? xm1 : (mode == 1 ? 0. : xm2);
 }
 
 // The whole sweep of one wave.  ROLE is a template parameter so that every wave runs
@@ -166,17 +196,29 @@ __device__ __forceinline__ void dtheta(int mode, double hdj, double xm2, double 
 // Memory schedule of a step (row j): every load (xn, flags and source terms of row j+1, row j+2 of the
 // own variable) is issued at the top, the stores of row j-1's results in stage 2, the geometry table
 // of row j+1 is read from LDS in stage 4.  Nothing loaded in a step is used before the next step.
-template <int ROLE>
+//
+// SPLIT = 0: all eight roles in one workgroup, v handed on through LDS.  SPLIT = 1: the sweep as two
+// kernels.  Only v, t, u and c depend on each other; w, co2, ice and cloud only listen to v.  The first
+// kernel runs the four coupled roles (one wave per SIMD, four-wave stage barriers) and its v wave
+// leaves the four stage values of v of every point in a[].vs; the second kernel runs the four
+// listening roles from those values without any barrier or LDS exchange, every wave on its own.
+template <int ROLE, int SPLIT>
 __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K, Shared& sh, const double* tab,
                                            int bx, int i, double* __restrict__ X, const double* __restrict__ XN) {
     constexpr bool isV = ROLE == R_V, isU = ROLE == R_U, isT = ROLE == R_T, isC = ROLE == R_C, isW = ROLE == R_W;
     constexpr bool hasH0I = ROLE == R_U || ROLE == R_CO2 || ROLE == R_ICE || ROLE == R_CLOUD;
+    constexpr bool passive = ROLE >= R_W;
+    constexpr bool listen_mem = SPLIT && passive;   // v comes from memory, no barriers
+    constexpr bool tell_mem = SPLIT && isV;         // v also goes to memory
+#ifdef ATOMDEV_EXP_PRIO
+    if constexpr (SPLIT) { if constexpr (passive) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3); }
+#endif
     const int jm = K.jm, km = K.km;
     const int lane = threadIdx.x & 63;
     const int kk = 1 + bx * 64 + lane;
     const int k = kk <= km - 2 ? kk : km - 2;  // idle lanes shadow the last line and reproduce its bits
     const bool lvl1 = isC && (i == 1);
-    constexpr int NST = isU ? 3 : (isV || isW) ? 2 : 1;  // stores per step
+    constexpr int NST = (isU ? 3 : (isV || isW) ? 2 : 1) + (tell_mem ? 4 : 0);  // stores per step
 
     // ---- constants of the dependent chain, in vector registers ----
     ThetaK TK = { K.dthe, K.i_dthe, K.two_dthe, K.i_two_dthe, K.dthe2, K.i_dthe2 };
@@ -235,12 +277,14 @@ __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K
     // raw inputs of the next step, loaded during this one
     double n_xn, n_r1 = 0., n_r2 = 0., n_r3 = 0., n_r4 = 0., n_r5 = 0.;
     double n_cos, n_rm2sin, n_irm2sin, n_coefv = 0.;
+    double n_v0 = 0., n_v1 = 0., n_v2 = 0., n_v3 = 0.;   // listening roles of the split form: v of the four stages
     uint8_t n_fl;
     auto load_top = [&](unsigned o) {  // xn, flags
         n_xn = ldg(XN, o);
         n_fl = ldg_u8(FL, o >> 3);
     };
     auto load_sources = [&](unsigned o, unsigned q) {
+        if constexpr (listen_mem) { n_v0 = ldg(a.vs[0], o); n_v1 = ldg(a.vs[1], o); n_v2 = ldg(a.vs[2], o); n_v3 = ldg(a.vs[3], o); }
         if constexpr (isT) { n_r2 = ldg(E2, o); n_r3 = ldg(E3, o); n_r4 = ldg(E4, o); n_r5 = ldg(E5, o); }
         if constexpr (hasH0I) n_r1 = ldg(E1, o);
         if constexpr (ROLE == R_ICE || ROLE == R_CLOUD || isC) n_r2 = ldg(E2, o);
@@ -266,11 +310,14 @@ __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K
         sh.rdry[buf][lane] = r_dry;
         sh.yr[buf][lane] = rcp_refined(r_dry);
     };
+    double c_opc = 0., c_cb = 0., c_cy = 0.;   // c wave: what it published for the value it is working with
     auto publish_c = [&](int buf, double cval) {
-        const double b = 1. + k1 * cval;
-        sh.opc[buf][lane] = 1. + cval;
-        sh.cb[buf][lane] = b;
-        sh.cy[buf][lane] = rcp_refined(b);
+        c_cb = 1. + k1 * cval;
+        c_opc = 1. + cval;
+        c_cy = rcp_refined(c_cb);
+        sh.opc[buf][lane] = c_opc;
+        sh.cb[buf][lane] = c_cb;
+        sh.cy[buf][lane] = c_cy;
     };
 
     // stage-1 values of row 1
@@ -278,7 +325,7 @@ __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K
     if constexpr (isU) sh.u[0][lane] = x0;
     if constexpr (isC) publish_c(0, x0);
     if constexpr (isT) publish_t(0, x0, ph_cur);
-    lds_barrier();
+    if constexpr (!listen_mem) lds_barrier();
 
     // Everything loaded so far has arrived before the loop starts, so that the only vector-memory
     // wait inside the loop is the one at the end of a step.
@@ -292,7 +339,8 @@ __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K
         const double xn = n_xn;
         const uint8_t fl = n_fl;
         const double costhe = n_cos, rm2sin = n_rm2sin, i_rm2sin = n_irm2sin, coef_v = n_coefv;
-        double e_a = n_r1, e_b = 0., e_c = 0., c_lvl0 = 0., c_lvl3 = 0.;
+        double e_a = n_r1, e_b = 0., e_c = 0., c_lvl0 = 0., c_lvl3 = 0., m3c0 = 0., om2c0 = 0.;
+        const double vst[4] = { n_v0, n_v1, n_v2, n_v3 };
         if constexpr (isT) e_a = ph_cur;
         if constexpr (isT) { e_b = k3 * (n_r2 + n_r3); e_c = k3 * (n_r4 + n_r5); }
         if constexpr (ROLE == R_ICE || ROLE == R_CLOUD || isC) e_b = n_r2 * k2;
@@ -302,6 +350,7 @@ __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K
                 if (ep >= 6.) ep = 6.;
                 if (ep <= -6.) ep = -6.;
                 e_a = ep; c_lvl0 = n_r4; c_lvl3 = n_r5;
+                m3c0 = -3. * c_lvl0; om2c0 = 1. - 2. * c_lvl0;
             }
         }
 #ifdef ATOMDEV_EXP_NOMEM  // timing experiment only (results are wrong): bit 0 no loads, bit 1 no stores inside the loop
@@ -317,20 +366,26 @@ __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K
             if constexpr (isV) { yp2 = ldg(E1, o2); up2 = ldg(E2, o2); }
         }
         if (exp_mem) load_sources(o1, q1);
+        if constexpr (tell_mem) stg(a.vs[0], o0, x0);   // stage 1 works with the old v
         STAMP(1);
         const bool land = fl & FL_LAND;
         const double h_d_j = ((fl & FL_H0J) && (fl & FL_H0K)) ? 0. : 1.;  // RHS_Atm.cpp:129-149
         const bool window = (j >= 2) && (j < jm - 3);
         const int mode = !window ? 0 : ((fl & FL_ONESIDED_S) ? 2 : 1);
         const bool all_bw = __all(mode == 1);  // whole wave on the two-point backward form: d2 == 0
+        const ThetaForm TF = theta_form(mode, TK);
+        double xB = 0., xC = 0., xF = 0., xG = 0., uB = 0., uC = 0.;
+        if (!all_bw) theta_terms(mode, xm2, xm1, xp1, xB, xC, xF, xG);
 
         double pg_v = 0., h_0 = 0.;
         if constexpr (isV) {
             h_0 = (fl & FL_H0J) ? 1. : 0.;
             if (j > 1) um1 = sh.ufin[lane];  // updated u of row j-1 (row 0 is a boundary row)
-            double dpdthe, d2p;
-            dtheta(mode, h_d_j, ym2, ym1, y0, yp1, TK, dpdthe, d2p);
-            pg_v = div_by(div_by(h_d_j * dpdthe, rm, i_rm), k1, k2);  // h_d_j*dpdthe/rm/r_air
+            double pB, pC, pF, pG;
+            theta_terms(mode, ym2, ym1, yp1, pB, pC, pF, pG);
+            const double dpdthe = DIVC(h_d_j * ((TF.a * y0 + pB) + pC), TF.D1, TF.iD1);
+            pg_v = DIVC(DIVC(h_d_j * dpdthe, rm, i_rm), k1, k2);  // h_d_j*dpdthe/rm/r_air
+            theta_terms(mode, um2, um1, up1, uB, uC, pF, pG);
         }
         if constexpr (isW) h_0 = (fl & FL_H0K) ? 1. : 0.;
         if constexpr (hasH0I) h_0 = e_a;  // h_0_i
@@ -346,44 +401,44 @@ __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K
             }
             if (s == 3) load_table(j + 1);
             double v;
-            if constexpr (isV) v = st; else v = sh.v[rb][lane];
+            if constexpr (isV) v = st; else if constexpr (listen_mem) v = vst[s]; else v = sh.v[rb][lane];
             double d1, d2 = 0., brk;
             if (all_bw) {
-                d1 = div_by(h_d_j * (st - xm1), TK.dthe, TK.i_dthe);
-                if constexpr (isV || isW) brk = div_by(d1, rm2sin, i_rm2sin) * costhe;
-                else brk = div_by(d1 * costhe, rm2sin, i_rm2sin);
+                d1 = DIVC(h_d_j * (st - xm1), TK.dthe, TK.i_dthe);
+                if constexpr (isV || isW) brk = DIVC(d1, rm2sin, i_rm2sin) * costhe;
+                else brk = DIVC(d1 * costhe, rm2sin, i_rm2sin);
             } else {
-                dtheta(mode, h_d_j, xm2, xm1, st, xp1, TK, d1, d2);
-                if constexpr (isV || isW) brk = div_by(d2, rm2, i_rm2) + div_by(d1, rm2sin, i_rm2sin) * costhe;
-                else brk = div_by(d2, rm2, i_rm2) + div_by(d1 * costhe, rm2sin, i_rm2sin);
+                d1 = DIVC(h_d_j * ((TF.a * st + xB) + xC), TF.D1, TF.iD1);
+                d2 = DIVC(h_d_j * ((TF.e * st + xF) + xG), TK.dthe2, TK.i_dthe2);
+                if constexpr (isV || isW) brk = DIVC(d2, rm2, i_rm2) + DIVC(d1, rm2sin, i_rm2sin) * costhe;
+                else brk = DIVC(d2, rm2, i_rm2) + DIVC(d1 * costhe, rm2sin, i_rm2sin);
             }
-            const double adv = div_by(v * d1, rm, i_rm);
+            const double adv = DIVC(v * d1, rm, i_rm);
 
             if constexpr (isT) {
-                rhs = -adv + div_by(brk, dv, i_dv) + e_b + e_c;
+                rhs = -adv + DIVC(brk, dv, i_dv) + e_b + e_c;
             } else if constexpr (isU) {
                 // buoyancy, RHS_Atm.cpp:390-404, from the current-stage dry density and vapour
                 const double r_dry = sh.rdry[rb][lane];
-                const double r_humid = div_by(r_dry * sh.opc[rb][lane], sh.cb[rb][lane], sh.cy[rb][lane]);
-                RS = div_by(k2 * (r_humid - r_dry), r_dry, sh.yr[rb][lane]) * k3;
-                rhs = -adv + div_by(brk, dv, i_dv) - RS - div_by(h_0 * st, dm, i_dm);
+                const double r_humid = DIVC(r_dry * sh.opc[rb][lane], sh.cb[rb][lane], sh.cy[rb][lane]);
+                RS = DIVC(k2 * (r_humid - r_dry), r_dry, sh.yr[rb][lane]) * k3;
+                rhs = -adv + DIVC(brk, dv, i_dv) - RS - DIVC(h_0 * st, dm, i_dm);
             } else if constexpr (isV) {
-                double d1u, d2u;
-                dtheta(mode, h_d_j, um2, um1, sh.u[rb][lane], up1, TK, d1u, d2u);
+                const double d1u = DIVC(h_d_j * ((TF.a * sh.u[rb][lane] + uB) + uC), TF.D1, TF.iD1);
                 rhs = -adv + -pg_v
-                      + div_by(brk - coef_v * h_d_j * v + div_by(2. * d1u, rm2, i_rm2), dv, i_dv)
-                      - div_by(h_0 * v, dm, i_dm);
+                      + DIVC(brk - coef_v * h_d_j * v + DIVC(2. * d1u, rm2, i_rm2), dv, i_dv)
+                      - DIVC(h_0 * v, dm, i_dm);
             } else if constexpr (isW || ROLE == R_CO2) {
-                rhs = -adv + div_by(brk, dv, i_dv) - div_by(h_0 * st, dm, i_dm);
+                rhs = -adv + DIVC(brk, dv, i_dv) - DIVC(h_0 * st, dm, i_dm);
             } else if constexpr (ROLE == R_ICE || ROLE == R_CLOUD) {
-                rhs = -adv + div_by(brk, dv, i_dv) + e_b - div_by(h_0 * st, dm, i_dm);
+                rhs = -adv + DIVC(brk, dv, i_dv) + e_b - DIVC(h_0 * st, dm, i_dm);
             } else {  // R_C
-                rhs = -adv + div_by(brk, dv, i_dv) + e_b;
+                rhs = -adv + DIVC(brk, dv, i_dv) + e_b;
                 if (lvl1) {  // RHS_Atm.cpp:412-430: surface evaporation source, c at levels 0, 1 (own), 3
+                    // 1 + c, 1 + k c and the refined reciprocal of the latter are what this wave published for st
                     const double r_dry = sh.rdry[rb][lane];
-                    const double r_humid = fdiv_normal(r_dry * (1. + st), 1. + k1 * st);
-                    double vapour_surface = div_by(r_humid * (-3. * c_lvl0 + 4. * st - c_lvl3), k4, i_k4)
-                                            * (1. - 2. * c_lvl0) * e_a;
+                    const double r_humid = DIVC(r_dry * c_opc, c_cb, c_cy);
+                    double vapour_surface = DIVC(r_humid * (m3c0 + 4. * st - c_lvl3), k4, i_k4) * om2c0 * e_a;
                     double vapour_evaporation = k3 * vapour_surface;
                     if (land) vapour_evaporation = 0.;
                     rhs = rhs + vapour_evaporation;
@@ -394,16 +449,17 @@ __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K
             if (s == 0) { acc = rhs; st = xn + rhs * hdt; }
             else if (s == 1) { acc = __builtin_fma(2., rhs, acc); st = xn + rhs * hdt; }
             else if (s == 2) { acc = __builtin_fma(2., rhs, acc); st = xn + rhs * dt; }
-            else st = xn + div_by(dt * (acc + rhs), six, i_six);
+            else st = xn + DIVC(dt * (acc + rhs), six, i_six);
 
             // publish: the next stage's value, or (after the last stage) stage 1 of the next row
             const double pub = (s < 3) ? st : xp1;
             if constexpr (isV) sh.v[wb][lane] = pub;
+            if constexpr (tell_mem) { if (s < 3) stg(a.vs[s + 1], o0, st); }
             if constexpr (isU) { sh.u[wb][lane] = pub; if (s == 3) sh.ufin[lane] = st; }
             if constexpr (isC) publish_c(wb, pub);
             if constexpr (isT) publish_t(wb, pub, (s < 3) ? ph_cur : ph_nxt);
             STAMP(2 + 2 * s);
-            lds_barrier();
+            if constexpr (!listen_mem) lds_barrier();
             STAMP(3 + 2 * s);
         }
 
@@ -428,7 +484,9 @@ __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K
     if constexpr (isV || isW) stg(O1, o0 - rowB, so1);
 }
 
-__global__ __launch_bounds__(512) void k_atm_rk3d_ws(const AtmWsParams* __restrict__ P) {
+// SPLIT = 0: 512 threads, all roles.  SPLIT = 1: 256 threads, roles first_role .. first_role + 3.
+template <int SPLIT>
+__global__ __launch_bounds__(SPLIT ? 256 : 512) void k_atm_rk3d_ws(const AtmWsParams* __restrict__ P, int first_role) {
     const AtmWsArgs& a = P->a;
     const DevConst& K = P->K;
     __shared__ Shared sh;
@@ -441,6 +499,9 @@ __global__ __launch_bounds__(512) void k_atm_rk3d_ws(const AtmWsParams* __restri
     const int lev = xcd + 8 * (idx / gx), bx = idx % gx;
     if (lev >= K.im - 2) return;  // padding workgroups of the last round of levels
     const int i = 1 + lev;
+#ifdef ATOMDEV_EXP_WGTIME  // timing experiment only: duration of every workgroup goes to level 0 of aux_u
+    const long long wg_t0 = __builtin_readcyclecounter();
+#endif
     {
         const int jm = K.jm;
         for (int j = threadIdx.x; j < jm; j += blockDim.x) {
@@ -451,21 +512,25 @@ __global__ __launch_bounds__(512) void k_atm_rk3d_ws(const AtmWsParams* __restri
         }
         __syncthreads();
     }
-    switch (threadIdx.x >> 6) {
-        case R_U: sweep_role<R_U>(a, K, sh, tab, bx, i, a.u, a.un); break;
-        case R_V: sweep_role<R_V>(a, K, sh, tab, bx, i, a.v, a.vn); break;
-        case R_T: sweep_role<R_T>(a, K, sh, tab, bx, i, a.t, a.tn); break;
-        case R_W: sweep_role<R_W>(a, K, sh, tab, bx, i, a.w, a.wn); break;
-        case R_CO2: sweep_role<R_CO2>(a, K, sh, tab, bx, i, a.co2, a.co2n); break;
-        case R_ICE: sweep_role<R_ICE>(a, K, sh, tab, bx, i, a.ice, a.icen); break;
-        case R_CLOUD: sweep_role<R_CLOUD>(a, K, sh, tab, bx, i, a.cloud, a.cloudn); break;
-        default: sweep_role<R_C>(a, K, sh, tab, bx, i, a.c, a.cn); break;
+    switch ((int)(threadIdx.x >> 6) + first_role) {
+        case R_U: sweep_role<R_U, SPLIT>(a, K, sh, tab, bx, i, a.u, a.un); break;
+        case R_V: sweep_role<R_V, SPLIT>(a, K, sh, tab, bx, i, a.v, a.vn); break;
+        case R_T: sweep_role<R_T, SPLIT>(a, K, sh, tab, bx, i, a.t, a.tn); break;
+        case R_W: sweep_role<R_W, SPLIT>(a, K, sh, tab, bx, i, a.w, a.wn); break;
+        case R_CO2: sweep_role<R_CO2, SPLIT>(a, K, sh, tab, bx, i, a.co2, a.co2n); break;
+        case R_ICE: sweep_role<R_ICE, SPLIT>(a, K, sh, tab, bx, i, a.ice, a.icen); break;
+        case R_CLOUD: sweep_role<R_CLOUD, SPLIT>(a, K, sh, tab, bx, i, a.cloud, a.cloudn); break;
+        default: sweep_role<R_C, SPLIT>(a, K, sh, tab, bx, i, a.c, a.cn); break;
     }
+#ifdef ATOMDEV_EXP_WGTIME
+    if ((threadIdx.x & 63) == 0)
+        a.aux_u[(first_role ? 16384 : 0) + (lev * gx + bx) * 8 + (threadIdx.x >> 6)] = (double)(__builtin_readcyclecounter() - wg_t0);
+#endif
 }
 
 }  // namespace
 
-int atomdev_atm_rk3d_ws(atomdev* h) {
+int ATM_WS_ENTRY(atomdev* h) {
     AtmWsParams P;
     AtmWsArgs& a = P.a;
     a.t = h->f[ATOMDEV_T]; a.u = h->f[ATOMDEV_U]; a.v = h->f[ATOMDEV_V]; a.w = h->f[ATOMDEV_W];
@@ -482,8 +547,20 @@ int atomdev_atm_rk3d_ws(atomdev* h) {
     a.rad = h->rad; a.costhe = h->costhe;
     a.tab_rm2sin = h->tab_rm2sin; a.tab_irm2sin = h->tab_irm2sin; a.tab_coefv = h->tab_coefv;
     P.K = h->k;
+#ifdef ATOMDEV_RK_FAST
+    const bool split = false;
+#else
+    const bool split = h->rk_variant == 2;
+#endif
+    if (split && !h->vstage) ATOMDEV_TRY(hipMalloc(&h->vstage, 4 * h->n3 * sizeof(double)));
+    for (int s = 0; s < 4; s++) a.vs[s] = h->vstage ? h->vstage + (size_t)s * h->n3 : nullptr;
+    if (h->ws_params && split && !h->ws_params_split) {   // the block on the device predates the stage buffers
+        ATOMDEV_TRY(hipStreamSynchronize(h->stream));
+        ATOMDEV_TRY(hipFree(h->ws_params)); h->ws_params = nullptr;
+    }
     // field pointers of the atmosphere never change after creation: one upload per handle
     if (!h->ws_params) {
+        h->ws_params_split = split;
         ATOMDEV_TRY(hipMalloc(&h->ws_params, sizeof(P)));
         ATOMDEV_TRY(hipMemcpy(h->ws_params, &P, sizeof(P), hipMemcpyHostToDevice));
     }
@@ -500,13 +577,21 @@ int atomdev_atm_rk3d_ws(atomdev* h) {
     const unsigned gx = (h->km - 2 + 63) / 64, rounds = (h->im - 2 + 7) / 8;
     dim3 grid(8 * rounds * gx);
     ATOMDEV_REQUIRE(h->n3 * sizeof(double) < ((size_t)1 << 32), "atm_rk3d: field larger than 4 GiB");
-#ifdef ATOMDEV_EXP_COREONLY  // timing experiment only: the four coupled roles alone (w, co2, ice, cloud not advanced)
-    hipLaunchKernelGGL(k_atm_rk3d_ws, grid, dim3(256), (size_t)h->jm * 4 * sizeof(double), h->stream,
-                       (const AtmWsParams*)h->ws_params);
-    if (0)
+    const size_t tab_bytes = (size_t)h->jm * 4 * sizeof(double);
+    if (split) {
+        hipLaunchKernelGGL(k_atm_rk3d_ws<1>, grid, dim3(256), tab_bytes, h->stream, (const AtmWsParams*)h->ws_params, (int)R_V);
+#ifdef ATOMDEV_EXP_CONCURRENT  // timing experiment only (results are wrong): the two kernels side by side
+        static hipStream_t s2 = nullptr; static hipEvent_t e2 = nullptr;
+        if (!s2) { ATOMDEV_TRY(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking)); ATOMDEV_TRY(hipEventCreate(&e2)); }
+        hipLaunchKernelGGL(k_atm_rk3d_ws<1>, grid, dim3(256), tab_bytes, s2, (const AtmWsParams*)h->ws_params, (int)R_W);
+        ATOMDEV_TRY(hipEventRecord(e2, s2));
+        ATOMDEV_TRY(hipStreamWaitEvent(h->stream, e2, 0));
+#else
+        hipLaunchKernelGGL(k_atm_rk3d_ws<1>, grid, dim3(256), tab_bytes, h->stream, (const AtmWsParams*)h->ws_params, (int)R_W);
 #endif
-    hipLaunchKernelGGL(k_atm_rk3d_ws, grid, dim3(512), (size_t)h->jm * 4 * sizeof(double), h->stream,
-                       (const AtmWsParams*)h->ws_params);
+    } else {
+        hipLaunchKernelGGL(k_atm_rk3d_ws<0>, grid, dim3(512), tab_bytes, h->stream, (const AtmWsParams*)h->ws_params, 0);
+    }
     ATOMDEV_TRY(hipGetLastError());
     if (int rc = atomdev_prof_end(h)) return rc;
     return 0;

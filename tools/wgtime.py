@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Prints per-workgroup durations a -DATOMDEV_EXP_WGTIME build leaves in level 0 of aux_u (cycles), by level."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import atom_amd, harness as H
+im, jm, km = 41, 181, 361
+p = H.default_params(H.ATM, im, jm, km)
+f, g = H.make_inputs(H.ATM, im, jm, km, 1234, "allfluid", p)
+f = {k: f[k] for k in H.ATM_FIELDS}
+if len(sys.argv) < 2 or sys.argv[1] != "allfluid":
+    f["H"], g["TOPOGRAPHY"] = H.load_mask_0Ma(H.ATM)
+d = atom_amd.DeviceModel(H.ATM, im, jm, km, atom_amd.Params.from_buffer_copy(bytes(p)))
+d.upload_all(f, g)
+for _ in range(3):
+    d.op("atm_rk3d")
+a = d.download("AUX_U").reshape(-1)
+gx = 6
+for base, tag in ((0, "first kernel"), (16384, "second kernel")):
+    t = a[base:base + 39 * gx * 8].reshape(39, gx, 8)
+    if t.max() <= 0: continue
+    print(tag, "max over waves per workgroup, kilo-cycles; rows = level 1..39, columns = longitude block")
+    for lev in range(39):
+        print("%2d " % (lev + 1) + " ".join("%6.0f" % (t[lev, b].max() / 1e3) for b in range(gx)))
+d.close()
