@@ -149,7 +149,7 @@ extern "C" int atomdev_create(int model, int im, int jm, int km, const atomdev_p
     h->profile_rk = false; h->prof_used = 0;
     h->scr[0] = h->scr[1] = nullptr; h->tab_rm2sin = h->tab_irm2sin = h->tab_coefv = nullptr;
     h->rk_variant = 0;
-    h->ws_params = nullptr; h->vstage = nullptr; h->ws_params_split = false; h->ws_err = nullptr; h->surf = nullptr; h->xfer = nullptr; h->batch = nullptr; h->batch_bytes = 0;
+    h->ws_params = nullptr; h->ws_err = nullptr; h->surf = nullptr; h->xfer = nullptr; h->batch = nullptr; h->batch_bytes = 0;
     if (const char* e = getenv("ATOMDEV_RK_VARIANT")) h->rk_variant = atoi(e);
     h->rad = h->sinthe = h->costhe = h->plane = nullptr; h->red = nullptr;
     h->static_scratch = nullptr; h->static_scratch_bytes = 0; h->pinned = nullptr;
@@ -219,7 +219,6 @@ extern "C" int atomdev_destroy(atomdev_t* h) {
     if (h->tab_irm2sin) (void)hipFree(h->tab_irm2sin);
     if (h->tab_coefv) (void)hipFree(h->tab_coefv);
     if (h->ws_params) (void)hipFree(h->ws_params);
-    if (h->vstage) (void)hipFree(h->vstage);
     if (h->surf) (void)hipFree(h->surf);
     if (h->xfer) (void)hipFree(h->xfer);
     if (h->batch) (void)hipFree(h->batch);
@@ -375,7 +374,7 @@ extern "C" int atomdev_profile_read(atomdev_t* h, float* total_ms, int* sweeps) 
 
 extern "C" int atomdev_set_rk_variant(atomdev_t* h, int variant) {
     ATOMDEV_REQUIRE(h != nullptr, "atomdev_set_rk_variant: null handle");
-    ATOMDEV_REQUIRE(variant >= 0 && variant <= 3, "atomdev_set_rk_variant: variant must be 0, 1, 2 or 3");
+    ATOMDEV_REQUIRE(variant >= 0 && variant <= 2, "atomdev_set_rk_variant: variant must be 0, 1 or 2");
     h->rk_variant = variant;
     return 0;
 }

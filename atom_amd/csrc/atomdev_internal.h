@@ -61,15 +61,13 @@ struct atomdev {
     size_t batch_bytes;
     double* xfer;                   // six surface planes of the atmosphere -> hydrosphere transfer (lazy)
     void* surf;                     // skewed copy of the surface fields for the 2-D sweep (lazy)
-    double* vstage;                 // atm, split sweep: the four stage values of v of every point (lazy)
-    bool ws_params_split;           // the argument block on the device knows vstage
     void* ws_params;                // device copy of the wave-specialised sweep's argument block(s) (lazy)
     const double* ws_cur0;          // hyd: f[T] at the time the blocks were built (tells the buffer orientation)
     int* ws_err;                    // hyd: device word the sweep sets when a wait between workgroups gave up (lazy)
     void* static_scratch;           // this GPU's copy of the library's static scratch array (k_accuracy.hip)
     size_t static_scratch_bytes;
     void* pinned;                   // 256 bytes of page-locked host memory for results read back without staging
-    int rk_variant;                 // 0: wave-specialised sweep (default), 1: one thread per theta line
+    int rk_variant;                 // 0: wave-specialised sweep (default), 1: one thread per theta line, 2: 0 in its tolerance form
     bool profile_rk;                // bracket RK sweep kernels with events
     std::vector<hipEvent_t> prof_ev;  // pairs (start, stop), prof_used of them recorded
     size_t prof_used;
@@ -89,6 +87,7 @@ int atomdev_static_scratch_init(atomdev* h);  // k_accuracy.hip
 int atomdev_atm_rk3d_ws(atomdev* h);    // k_rk_atm_ws.hip
 int atomdev_atm_rk3d_ws_fast(atomdev* h);  // k_rk_atm_ws.hip compiled with -DATOMDEV_RK_FAST
 int atomdev_hyd_rk3d_ws(atomdev* h);    // k_rk_hyd_ws.hip
+int atomdev_hyd_rk3d_ws_fast(atomdev* h);  // k_rk_hyd_ws.hip compiled with -DATOMDEV_RK_FAST
 
 #define ATOMDEV_TRY(expr)                                   \
     do {                                                    \

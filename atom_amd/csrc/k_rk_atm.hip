@@ -223,8 +223,8 @@ extern "C" int atomdev_atm_rk3d(atomdev_t* h) {
     if (int rc = atomdev_refresh_flags(h)) return rc;
     // c at level 3 as the level-1 points must see it: before the sweep touches it
     ATOMDEV_TRY(hipMemcpyAsync(h->plane, h->f[ATOMDEV_C] + 3 * h->n2, h->n2 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    if (h->rk_variant == 3) return atomdev_atm_rk3d_ws_fast(h);
-    if (h->rk_variant != 1) return atomdev_atm_rk3d_ws(h);
+    if (h->rk_variant == 2) return atomdev_atm_rk3d_ws_fast(h);
+    if (h->rk_variant == 0) return atomdev_atm_rk3d_ws(h);
     AtmRkArgs a;
     a.t = h->f[ATOMDEV_T]; a.u = h->f[ATOMDEV_U]; a.v = h->f[ATOMDEV_V]; a.w = h->f[ATOMDEV_W];
     a.c = h->f[ATOMDEV_C]; a.cloud = h->f[ATOMDEV_CLOUD]; a.ice = h->f[ATOMDEV_ICE]; a.co2 = h->f[ATOMDEV_CO2];

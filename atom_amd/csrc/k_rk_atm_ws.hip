@@ -67,7 +67,6 @@ struct AtmWsArgs {
     const double *ph100, *h0i;                 // k_atm_prep outputs (3-D)
     const double *rad, *costhe;
     const double *tab_rm2sin, *tab_irm2sin, *tab_coefv;   // [i*jm + j]
-    double* vs[4];   // split form: the value of v every stage of every point worked with (3-D each)
 };
 
 // Arguments live in device memory, not in the kernel-argument segment: a role then reads the dozen
@@ -122,7 +121,7 @@ __global__ void k_atm_prep(const double* __restrict__ t, const double* __restric
 #ifdef ATOMDEV_EXP_STAMP  // timing experiment only: cycle stamps of step 60 of one workgroup go to level 0 of aux_w
 #define STAMP(n)                                                                                      \
     do {                                                                                              \
-        if (j == 60 && bx == 2 && i == 11 && lane == 0)                                           \
+        if (j == 60 && bx == 2 && i == ATOMDEV_EXP_STAMP && lane == 0)                                           \
             a.aux_w[ROLE * 16 + (n)] = (double)(long long)__builtin_readcyclecounter(); \
     } while (0)
 #else
@@ -196,29 +195,17 @@ __device__ __forceinline__ void theta_terms(int mode, double xm2, double xm1, do
 // Memory schedule of a step (row j): every load (xn, flags and source terms of row j+1, row j+2 of the
 // own variable) is issued at the top, the stores of row j-1's results in stage 2, the geometry table
 // of row j+1 is read from LDS in stage 4.  Nothing loaded in a step is used before the next step.
-//
-// SPLIT = 0: all eight roles in one workgroup, v handed on through LDS.  SPLIT = 1: the sweep as two
-// kernels.  Only v, t, u and c depend on each other; w, co2, ice and cloud only listen to v.  The first
-// kernel runs the four coupled roles (one wave per SIMD, four-wave stage barriers) and its v wave
-// leaves the four stage values of v of every point in a[].vs; the second kernel runs the four
-// listening roles from those values without any barrier or LDS exchange, every wave on its own.
-template <int ROLE, int SPLIT>
+template <int ROLE>
 __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K, Shared& sh, const double* tab,
                                            int bx, int i, double* __restrict__ X, const double* __restrict__ XN) {
     constexpr bool isV = ROLE == R_V, isU = ROLE == R_U, isT = ROLE == R_T, isC = ROLE == R_C, isW = ROLE == R_W;
     constexpr bool hasH0I = ROLE == R_U || ROLE == R_CO2 || ROLE == R_ICE || ROLE == R_CLOUD;
-    constexpr bool passive = ROLE >= R_W;
-    constexpr bool listen_mem = SPLIT && passive;   // v comes from memory, no barriers
-    constexpr bool tell_mem = SPLIT && isV;         // v also goes to memory
-#ifdef ATOMDEV_EXP_PRIO
-    if constexpr (SPLIT) { if constexpr (passive) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3); }
-#endif
     const int jm = K.jm, km = K.km;
     const int lane = threadIdx.x & 63;
     const int kk = 1 + bx * 64 + lane;
     const int k = kk <= km - 2 ? kk : km - 2;  // idle lanes shadow the last line and reproduce its bits
     const bool lvl1 = isC && (i == 1);
-    constexpr int NST = (isU ? 3 : (isV || isW) ? 2 : 1) + (tell_mem ? 4 : 0);  // stores per step
+    constexpr int NST = isU ? 3 : (isV || isW) ? 2 : 1;  // stores per step
 
     // ---- constants of the dependent chain, in vector registers ----
     ThetaK TK = { K.dthe, K.i_dthe, K.two_dthe, K.i_two_dthe, K.dthe2, K.i_dthe2 };
@@ -277,14 +264,12 @@ __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K
     // raw inputs of the next step, loaded during this one
     double n_xn, n_r1 = 0., n_r2 = 0., n_r3 = 0., n_r4 = 0., n_r5 = 0.;
     double n_cos, n_rm2sin, n_irm2sin, n_coefv = 0.;
-    double n_v0 = 0., n_v1 = 0., n_v2 = 0., n_v3 = 0.;   // listening roles of the split form: v of the four stages
     uint8_t n_fl;
     auto load_top = [&](unsigned o) {  // xn, flags
         n_xn = ldg(XN, o);
         n_fl = ldg_u8(FL, o >> 3);
     };
     auto load_sources = [&](unsigned o, unsigned q) {
-        if constexpr (listen_mem) { n_v0 = ldg(a.vs[0], o); n_v1 = ldg(a.vs[1], o); n_v2 = ldg(a.vs[2], o); n_v3 = ldg(a.vs[3], o); }
         if constexpr (isT) { n_r2 = ldg(E2, o); n_r3 = ldg(E3, o); n_r4 = ldg(E4, o); n_r5 = ldg(E5, o); }
         if constexpr (hasH0I) n_r1 = ldg(E1, o);
         if constexpr (ROLE == R_ICE || ROLE == R_CLOUD || isC) n_r2 = ldg(E2, o);
@@ -325,7 +310,7 @@ __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K
     if constexpr (isU) sh.u[0][lane] = x0;
     if constexpr (isC) publish_c(0, x0);
     if constexpr (isT) publish_t(0, x0, ph_cur);
-    if constexpr (!listen_mem) lds_barrier();
+    lds_barrier();
 
     // Everything loaded so far has arrived before the loop starts, so that the only vector-memory
     // wait inside the loop is the one at the end of a step.
@@ -340,7 +325,6 @@ __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K
         const uint8_t fl = n_fl;
         const double costhe = n_cos, rm2sin = n_rm2sin, i_rm2sin = n_irm2sin, coef_v = n_coefv;
         double e_a = n_r1, e_b = 0., e_c = 0., c_lvl0 = 0., c_lvl3 = 0., m3c0 = 0., om2c0 = 0.;
-        const double vst[4] = { n_v0, n_v1, n_v2, n_v3 };
         if constexpr (isT) e_a = ph_cur;
         if constexpr (isT) { e_b = k3 * (n_r2 + n_r3); e_c = k3 * (n_r4 + n_r5); }
         if constexpr (ROLE == R_ICE || ROLE == R_CLOUD || isC) e_b = n_r2 * k2;
@@ -366,7 +350,6 @@ __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K
             if constexpr (isV) { yp2 = ldg(E1, o2); up2 = ldg(E2, o2); }
         }
         if (exp_mem) load_sources(o1, q1);
-        if constexpr (tell_mem) stg(a.vs[0], o0, x0);   // stage 1 works with the old v
         STAMP(1);
         const bool land = fl & FL_LAND;
         const double h_d_j = ((fl & FL_H0J) && (fl & FL_H0K)) ? 0. : 1.;  // RHS_Atm.cpp:129-149
@@ -401,7 +384,7 @@ __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K
             }
             if (s == 3) load_table(j + 1);
             double v;
-            if constexpr (isV) v = st; else if constexpr (listen_mem) v = vst[s]; else v = sh.v[rb][lane];
+            if constexpr (isV) v = st; else v = sh.v[rb][lane];
             double d1, d2 = 0., brk;
             if (all_bw) {
                 d1 = DIVC(h_d_j * (st - xm1), TK.dthe, TK.i_dthe);
@@ -454,12 +437,11 @@ __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K
             // publish: the next stage's value, or (after the last stage) stage 1 of the next row
             const double pub = (s < 3) ? st : xp1;
             if constexpr (isV) sh.v[wb][lane] = pub;
-            if constexpr (tell_mem) { if (s < 3) stg(a.vs[s + 1], o0, st); }
             if constexpr (isU) { sh.u[wb][lane] = pub; if (s == 3) sh.ufin[lane] = st; }
             if constexpr (isC) publish_c(wb, pub);
             if constexpr (isT) publish_t(wb, pub, (s < 3) ? ph_cur : ph_nxt);
             STAMP(2 + 2 * s);
-            if constexpr (!listen_mem) lds_barrier();
+            lds_barrier();
             STAMP(3 + 2 * s);
         }
 
@@ -484,9 +466,7 @@ __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K
     if constexpr (isV || isW) stg(O1, o0 - rowB, so1);
 }
 
-// SPLIT = 0: 512 threads, all roles.  SPLIT = 1: 256 threads, roles first_role .. first_role + 3.
-template <int SPLIT>
-__global__ __launch_bounds__(SPLIT ? 256 : 512) void k_atm_rk3d_ws(const AtmWsParams* __restrict__ P, int first_role) {
+__global__ __launch_bounds__(512) void k_atm_rk3d_ws(const AtmWsParams* __restrict__ P) {
     const AtmWsArgs& a = P->a;
     const DevConst& K = P->K;
     __shared__ Shared sh;
@@ -512,19 +492,18 @@ __global__ __launch_bounds__(SPLIT ? 256 : 512) void k_atm_rk3d_ws(const AtmWsPa
         }
         __syncthreads();
     }
-    switch ((int)(threadIdx.x >> 6) + first_role) {
-        case R_U: sweep_role<R_U, SPLIT>(a, K, sh, tab, bx, i, a.u, a.un); break;
-        case R_V: sweep_role<R_V, SPLIT>(a, K, sh, tab, bx, i, a.v, a.vn); break;
-        case R_T: sweep_role<R_T, SPLIT>(a, K, sh, tab, bx, i, a.t, a.tn); break;
-        case R_W: sweep_role<R_W, SPLIT>(a, K, sh, tab, bx, i, a.w, a.wn); break;
-        case R_CO2: sweep_role<R_CO2, SPLIT>(a, K, sh, tab, bx, i, a.co2, a.co2n); break;
-        case R_ICE: sweep_role<R_ICE, SPLIT>(a, K, sh, tab, bx, i, a.ice, a.icen); break;
-        case R_CLOUD: sweep_role<R_CLOUD, SPLIT>(a, K, sh, tab, bx, i, a.cloud, a.cloudn); break;
-        default: sweep_role<R_C, SPLIT>(a, K, sh, tab, bx, i, a.c, a.cn); break;
+    switch (threadIdx.x >> 6) {
+        case R_U: sweep_role<R_U>(a, K, sh, tab, bx, i, a.u, a.un); break;
+        case R_V: sweep_role<R_V>(a, K, sh, tab, bx, i, a.v, a.vn); break;
+        case R_T: sweep_role<R_T>(a, K, sh, tab, bx, i, a.t, a.tn); break;
+        case R_W: sweep_role<R_W>(a, K, sh, tab, bx, i, a.w, a.wn); break;
+        case R_CO2: sweep_role<R_CO2>(a, K, sh, tab, bx, i, a.co2, a.co2n); break;
+        case R_ICE: sweep_role<R_ICE>(a, K, sh, tab, bx, i, a.ice, a.icen); break;
+        case R_CLOUD: sweep_role<R_CLOUD>(a, K, sh, tab, bx, i, a.cloud, a.cloudn); break;
+        default: sweep_role<R_C>(a, K, sh, tab, bx, i, a.c, a.cn); break;
     }
 #ifdef ATOMDEV_EXP_WGTIME
-    if ((threadIdx.x & 63) == 0)
-        a.aux_u[(first_role ? 16384 : 0) + (lev * gx + bx) * 8 + (threadIdx.x >> 6)] = (double)(__builtin_readcyclecounter() - wg_t0);
+    if ((threadIdx.x & 63) == 0) a.aux_u[(lev * gx + bx) * 8 + (threadIdx.x >> 6)] = (double)(__builtin_readcyclecounter() - wg_t0);
 #endif
 }
 
@@ -547,20 +526,8 @@ int ATM_WS_ENTRY(atomdev* h) {
     a.rad = h->rad; a.costhe = h->costhe;
     a.tab_rm2sin = h->tab_rm2sin; a.tab_irm2sin = h->tab_irm2sin; a.tab_coefv = h->tab_coefv;
     P.K = h->k;
-#ifdef ATOMDEV_RK_FAST
-    const bool split = false;
-#else
-    const bool split = h->rk_variant == 2;
-#endif
-    if (split && !h->vstage) ATOMDEV_TRY(hipMalloc(&h->vstage, 4 * h->n3 * sizeof(double)));
-    for (int s = 0; s < 4; s++) a.vs[s] = h->vstage ? h->vstage + (size_t)s * h->n3 : nullptr;
-    if (h->ws_params && split && !h->ws_params_split) {   // the block on the device predates the stage buffers
-        ATOMDEV_TRY(hipStreamSynchronize(h->stream));
-        ATOMDEV_TRY(hipFree(h->ws_params)); h->ws_params = nullptr;
-    }
     // field pointers of the atmosphere never change after creation: one upload per handle
     if (!h->ws_params) {
-        h->ws_params_split = split;
         ATOMDEV_TRY(hipMalloc(&h->ws_params, sizeof(P)));
         ATOMDEV_TRY(hipMemcpy(h->ws_params, &P, sizeof(P), hipMemcpyHostToDevice));
     }
@@ -578,20 +545,7 @@ int ATM_WS_ENTRY(atomdev* h) {
     dim3 grid(8 * rounds * gx);
     ATOMDEV_REQUIRE(h->n3 * sizeof(double) < ((size_t)1 << 32), "atm_rk3d: field larger than 4 GiB");
     const size_t tab_bytes = (size_t)h->jm * 4 * sizeof(double);
-    if (split) {
-        hipLaunchKernelGGL(k_atm_rk3d_ws<1>, grid, dim3(256), tab_bytes, h->stream, (const AtmWsParams*)h->ws_params, (int)R_V);
-#ifdef ATOMDEV_EXP_CONCURRENT  // timing experiment only (results are wrong): the two kernels side by side
-        static hipStream_t s2 = nullptr; static hipEvent_t e2 = nullptr;
-        if (!s2) { ATOMDEV_TRY(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking)); ATOMDEV_TRY(hipEventCreate(&e2)); }
-        hipLaunchKernelGGL(k_atm_rk3d_ws<1>, grid, dim3(256), tab_bytes, s2, (const AtmWsParams*)h->ws_params, (int)R_W);
-        ATOMDEV_TRY(hipEventRecord(e2, s2));
-        ATOMDEV_TRY(hipStreamWaitEvent(h->stream, e2, 0));
-#else
-        hipLaunchKernelGGL(k_atm_rk3d_ws<1>, grid, dim3(256), tab_bytes, h->stream, (const AtmWsParams*)h->ws_params, (int)R_W);
-#endif
-    } else {
-        hipLaunchKernelGGL(k_atm_rk3d_ws<0>, grid, dim3(512), tab_bytes, h->stream, (const AtmWsParams*)h->ws_params, 0);
-    }
+    hipLaunchKernelGGL(k_atm_rk3d_ws, grid, dim3(512), tab_bytes, h->stream, (const AtmWsParams*)h->ws_params);
     ATOMDEV_TRY(hipGetLastError());
     if (int rc = atomdev_prof_end(h)) return rc;
     return 0;

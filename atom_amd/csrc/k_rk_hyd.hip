@@ -222,7 +222,8 @@ extern "C" int atomdev_hyd_rk3d(atomdev_t* h) {
     ATOMDEV_REQUIRE(h && h->model == ATOMDEV_HYD, "atomdev_hyd_rk3d: not a hydrosphere handle");
     ATOMDEV_TRY(hipSetDevice(h->device));
     if (int rc = atomdev_refresh_flags(h)) return rc;
-    if (h->rk_variant != 1) return atomdev_hyd_rk3d_ws(h);
+    if (h->rk_variant == 2) return atomdev_hyd_rk3d_ws_fast(h);
+    if (h->rk_variant == 0) return atomdev_hyd_rk3d_ws(h);
     static const int X[5] = { ATOMDEV_T, ATOMDEV_U, ATOMDEV_V, ATOMDEV_W, ATOMDEV_C };
     // the sweep only writes interior points: carry the boundary values over first
     for (int n = 0; n < 5; n++)

@@ -30,6 +30,19 @@
 // alternate set, whose boundary shell is refreshed beforehand by k_copy_shell.
 #include "atomdev_internal.h"
 
+// Compiled twice, like k_rk_atm_ws.hip: as it stands every quotient carries the bits of the reference's division;
+// with -DATOMDEV_RK_FAST -ffp-contract=fast divisions by loop-invariant divisors become multiplications by the
+// reciprocal and products feeding sums fuse (tolerance form, about 1e-13 from the exact form).
+#ifdef ATOMDEV_RK_FAST
+#define HYD_WS_ENTRY atomdev_hyd_rk3d_ws_fast
+#define k_hyd_rk3d_ws k_hyd_rk3d_wsf
+#define k_copy_shell k_copy_shellf
+#define DIVC(a, b, rb) ((a) * (rb))
+#else
+#define HYD_WS_ENTRY atomdev_hyd_rk3d_ws
+#define DIVC(a, b, rb) div_by(a, b, rb)
+#endif
+
 namespace {
 
 enum Role { R_T = 0, R_V = 1, R_U = 2, R_C = 3, R_W = 4 };
@@ -60,6 +73,16 @@ struct Shared {
 };
 
 #define PIN(x) asm volatile("" : "+v"(x))
+
+#ifdef ATOMDEV_EXP_STAMP  // timing experiment only: cycle stamps of step 60 of one workgroup go to level 0 of aux_w
+#define STAMP(n)                                                                                      \
+    do {                                                                                              \
+        if (j == 60 && bx == 2 && i == ATOMDEV_EXP_STAMP && lane == 0)                                \
+            a.aux_w[ROLE * 16 + (n)] = (double)(long long)__builtin_readcyclecounter();               \
+    } while (0)
+#else
+#define STAMP(n) do {} while (0)
+#endif
 
 typedef const __attribute__((address_space(1))) char* gcchar_t;
 typedef __attribute__((address_space(1))) char* gchar_t;
@@ -109,19 +132,27 @@ __device__ __forceinline__ double rcp_refined(double b) {
 
 struct ThetaK { double dthe, i_dthe, two_dthe, i_two_dthe, dthe2, i_dthe2; };
 
-// theta derivative pair (RHS_Hyd.cpp:156-161, 177-181, 250-276)
-__device__ __forceinline__ void dtheta(int mode, double hdj, double xm2, double xm1, double x0, double xp1,
-                                       const ThetaK& K, double& d1, double& d2) {
-    if (mode == 0) {
-        d1 = div_by(hdj * (xp1 - xm1), K.two_dthe, K.i_two_dthe);
-        d2 = div_by(hdj * (xp1 - 2. * x0 + xm1), K.dthe2, K.i_dthe2);
-    } else if (mode == 1) {
-        d1 = div_by(hdj * (x0 - xm1), K.dthe, K.i_dthe);
-        d2 = 0.;
-    } else {
-        d1 = div_by(hdj * (-3. * x0 + 4. * xm1 - xm2), K.two_dthe, K.i_two_dthe);
-        d2 = div_by(hdj * (2 * x0 - 2. * xm1 + xm2), K.dthe2, K.i_dthe2);
-    }
+// Theta derivatives (RHS_Hyd.cpp:156-161, 177-181, 250-276) in the one form  hdj ((a x + B) + C) / D  that covers the
+// three forms the reference's cascade of branches leaves standing (see k_rk_atm_ws.hip: same coefficients, same
+// roundings); a lane whose second derivative the phi block zeroes (RHS_Hyd.cpp:296-300, 326-330) gets e = F = G = 0.
+struct ThetaForm {
+    double a, e;          // factors of the stage value in d1 and d2
+    double D1, iD1;       // divisor of d1 and its reciprocal
+};
+__device__ __forceinline__ ThetaForm theta_form(int mode, bool d2zero, const ThetaK& K) {
+    ThetaForm f;
+    f.a = mode == 0 ? 0. : (mode == 1 ? 1. : -3.);
+    f.e = d2zero ? 0. : (mode == 0 ? -2. : (mode == 1 ? 0. : 2.));
+    f.D1 = mode == 1 ? K.dthe : K.two_dthe;
+    f.iD1 = mode == 1 ? K.i_dthe : K.i_two_dthe;
+    return f;
+}
+__device__ __forceinline__ void theta_terms(int mode, bool d2zero, double xm2, double xm1, double xp1, double& B, double& C,
+                                            double& F, double& G) {
+    B = mode == 0 ? xp1 : (mode == 1 ? -xm1 : 4. * xm1);
+    C = mode == 0 ? -xm1 : (mode == 1 ? 0. : -xm2);
+    F = d2zero ? 0. : (mode == 0 ? xp1 : (mode == 1 ? 0. : -2. * xm1));
+    G = d2zero ? 0. : (mode == 0 ? xm1 : (mode == 1 ? 0. : xm2));
 }
 
 // The whole sweep of one wave.  All roles execute the same number of barriers (one before the
@@ -263,6 +294,7 @@ __device__ __forceinline__ void sweep_role(const HydWsArgs& a, const DevConst& K
             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
             if (lane == 0) __hip_atomic_store(progress, j - 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        STAMP(0);
         // ---- take over the prefetched inputs of this step, start loading the next step's ----
         const double xn = n_xn, xa_raw = n_xa;
         const uint8_t fl = n_fl;
@@ -283,6 +315,7 @@ __device__ __forceinline__ void sweep_role(const HydWsArgs& a, const DevConst& K
             if constexpr (isC) n_rw2 = ldg(E1, o2);
             if constexpr (isV) { yp2 = ldg(E1, o2); up2 = ldg(E2, o2); }
         }
+        STAMP(1);
 
         const bool land = fl & FL_LAND;
         const double h_d_j = ((fl & FL_H0J) && (fl & FL_H0K)) ? 0. : 1.;  // RHS_Hyd.cpp:117-139
@@ -292,6 +325,9 @@ __device__ __forceinline__ void sweep_role(const HydWsArgs& a, const DevConst& K
         const bool d2zero = kwin && (fl & FL_D2ZERO);            // RHS_Hyd.cpp:296-300, 326-330
         const bool rlive = (i < im - 2) && !(fl & FL_RDEAD);     // RHS_Hyd.cpp:191-214
         const double xa = rlive ? xa_raw : 0.;
+        const ThetaForm TF = theta_form(mode, d2zero, TK);
+        double xB = 0., xC = 0., xF = 0., xG = 0., uB = 0., uC = 0.;
+        if (!all_bw) theta_terms(mode, d2zero, xm2, xm1, xp1, xB, xC, xF, xG);
 
         double h_0 = 0.;
         if constexpr (hasH0I) {  // h_0_i, RHS_Hyd.cpp:96-111
@@ -307,9 +343,11 @@ __device__ __forceinline__ void sweep_role(const HydWsArgs& a, const DevConst& K
         double pg_num = 0.;
         if constexpr (isV) {
             if (j > 1) um1 = sh.ufin[lane];  // updated u of row j-1 (row 0 is a boundary row)
-            double dpdthe, d2p;
-            dtheta(mode, h_d_j, ym2, ym1, y0, yp1, TK, dpdthe, d2p);
-            pg_num = div_by(h_d_j * dpdthe, rm, i_rm);  // h_d_j*dpdthe/rm, then / salt_water_ref per stage
+            double pB, pC, pF, pG;
+            theta_terms(mode, true, ym2, ym1, yp1, pB, pC, pF, pG);
+            const double dpdthe = DIVC(h_d_j * ((TF.a * y0 + pB) + pC), TF.D1, TF.iD1);
+            pg_num = DIVC(h_d_j * dpdthe, rm, i_rm);  // h_d_j*dpdthe/rm, then / salt_water_ref per stage
+            theta_terms(mode, true, um2, um1, up1, uB, uC, pF, pG);
         }
         double rsw = rsw_in;  // u wave: r_salt_water, overwritten on land after the first evaluation
         double rw = rw_cur;   // c wave: r_water, likewise
@@ -333,24 +371,24 @@ __device__ __forceinline__ void sweep_role(const HydWsArgs& a, const DevConst& K
 
             double d1, d2 = 0.;
             if (all_bw) {
-                d1 = div_by(h_d_j * (st - xm1), TK.dthe, TK.i_dthe);
+                d1 = DIVC(h_d_j * (st - xm1), TK.dthe, TK.i_dthe);
             } else {
-                dtheta(mode, h_d_j, xm2, xm1, st, xp1, TK, d1, d2);
-                if (d2zero) d2 = 0.;
+                d1 = DIVC(h_d_j * ((TF.a * st + xB) + xC), TF.D1, TF.iD1);
+                d2 = DIVC(h_d_j * ((TF.e * st + xF) + xG), TK.dthe2, TK.i_dthe2);
             }
-            const double dr1 = rlive ? div_by(xa - st, dr, i_dr) : 0.;  // RHS_Hyd.cpp:206-211
-            const double adv = u * dr1 + div_by(v * d1, rm, i_rm);
+            const double dr1 = rlive ? DIVC(xa - st, dr, i_dr) : 0.;  // RHS_Hyd.cpp:206-211
+            const double adv = u * dr1 + DIVC(v * d1, rm, i_rm);
 
             // RHS_Hyd.cpp:406-437 with the exact-zero terms removed
             if constexpr (isT || isC) {
                 double brk;
-                if (all_bw) brk = div_by(dr1 * 2., rm, i_rm) + div_by(d1 * costhe, rm2sin, i_rm2sin);
-                else brk = div_by(dr1 * 2., rm, i_rm) + div_by(d2, rm2, i_rm2) + div_by(d1 * costhe, rm2sin, i_rm2sin);
-                rhs = -adv + div_by(brk, dv, i_dv);
+                if (all_bw) brk = DIVC(dr1 * 2., rm, i_rm) + DIVC(d1 * costhe, rm2sin, i_rm2sin);
+                else brk = DIVC(dr1 * 2., rm, i_rm) + DIVC(d2, rm2, i_rm2) + DIVC(d1 * costhe, rm2sin, i_rm2sin);
+                rhs = -adv + DIVC(brk, dv, i_dv);
                 if constexpr (isC) {
                     if (top) {  // RHS_Hyd.cpp:355-372
                         const double swr = rw + .7 * st * k1;
-                        double salinity_surface = div_by(swr * (-3. * c_top + 4. * st - c_below), k3, k4)
+                        double salinity_surface = DIVC(swr * (-3. * c_top + 4. * st - c_below), k3, k4)
                                                   * (1. - 2. * c_top) * ep;
                         double salinity_evaporation = k2 * salinity_surface;
                         if (land) salinity_evaporation = 0.;
@@ -360,31 +398,30 @@ __device__ __forceinline__ void sweep_role(const HydWsArgs& a, const DevConst& K
                     }
                     if (land) rw = 1007.;  // seen by the following stages (RHS_Hyd.cpp:395-402)
                 }
-                rhs = rhs - div_by(h_0 * st, dm, i_dm);
+                rhs = rhs - DIVC(h_0 * st, dm, i_dm);
             } else if constexpr (isU) {
                 double brk;
-                if (all_bw) brk = div_by(4. * dr1, rm, i_rm) + div_by(d1 * costhe, rm2sin, i_rm2sin);
-                else brk = div_by(d2, rm2, i_rm2) + div_by(4. * dr1, rm, i_rm) + div_by(d1 * costhe, rm2sin, i_rm2sin);
+                if (all_bw) brk = DIVC(4. * dr1, rm, i_rm) + DIVC(d1 * costhe, rm2sin, i_rm2sin);
+                else brk = DIVC(d2, rm2, i_rm2) + DIVC(4. * dr1, rm, i_rm) + DIVC(d1 * costhe, rm2sin, i_rm2sin);
                 const double swr = sh.swr[rb][lane];
-                RS = div_by(k1 * (rsw - swr), swr, sh.yswr[rb][lane]);  // RHS_Hyd.cpp:374
+                RS = DIVC(k1 * (rsw - swr), swr, sh.yswr[rb][lane]);  // RHS_Hyd.cpp:374
                 sb = swr - rsw;
                 if (land) rsw = 1032.;
-                rhs = -adv + div_by(brk, dv, i_dv) + RS - div_by(h_0 * u, dm, i_dm);
+                rhs = -adv + DIVC(brk, dv, i_dv) + RS - DIVC(h_0 * u, dm, i_dm);
             } else if constexpr (isV) {
-                double d1u, d2u;
-                dtheta(mode, h_d_j, um2, um1, u, up1, TK, d1u, d2u);
-                pg_v = div_by(pg_num, sh.swr[rb][lane], sh.yswr[rb][lane]);
+                const double d1u = DIVC(h_d_j * ((TF.a * u + uB) + uC), TF.D1, TF.iD1);
+                pg_v = DIVC(pg_num, sh.swr[rb][lane], sh.yswr[rb][lane]);
                 double brk;
-                if (all_bw) brk = div_by(dr1 * 2., rm, i_rm) + div_by(d1, rm2sin, i_rm2sin) * costhe;
-                else brk = div_by(dr1 * 2., rm, i_rm) + div_by(d2, rm2, i_rm2) + div_by(d1, rm2sin, i_rm2sin) * costhe;
+                if (all_bw) brk = DIVC(dr1 * 2., rm, i_rm) + DIVC(d1, rm2sin, i_rm2sin) * costhe;
+                else brk = DIVC(dr1 * 2., rm, i_rm) + DIVC(d2, rm2, i_rm2) + DIVC(d1, rm2sin, i_rm2sin) * costhe;
                 rhs = -adv - pg_v
-                      + div_by(brk - coef_v * h_d_j * v + div_by(2. * d1u, rm2, i_rm2), dv, i_dv)
-                      - div_by(h_0 * v, dm, i_dm);
+                      + DIVC(brk - coef_v * h_d_j * v + DIVC(2. * d1u, rm2, i_rm2), dv, i_dv)
+                      - DIVC(h_0 * v, dm, i_dm);
             } else {  // R_W
                 double brk;
-                if (all_bw) brk = div_by(dr1 * 2., rm, i_rm) + div_by(d1, rm2sin, i_rm2sin) * costhe;
-                else brk = div_by(dr1 * 2., rm, i_rm) + div_by(d2, rm2, i_rm2) + div_by(d1, rm2sin, i_rm2sin) * costhe;
-                rhs = -adv + div_by(brk, dv, i_dv) - div_by(h_0 * st, dm, i_dm);
+                if (all_bw) brk = DIVC(dr1 * 2., rm, i_rm) + DIVC(d1, rm2sin, i_rm2sin) * costhe;
+                else brk = DIVC(dr1 * 2., rm, i_rm) + DIVC(d2, rm2, i_rm2) + DIVC(d1, rm2sin, i_rm2sin) * costhe;
+                rhs = -adv + DIVC(brk, dv, i_dv) - DIVC(h_0 * st, dm, i_dm);
             }
 
             // RungeKutta_Hyd.cpp:56-120 (stage 3 advances w from its stage-2 value, :101)
@@ -393,7 +430,7 @@ __device__ __forceinline__ void sweep_role(const HydWsArgs& a, const DevConst& K
             if (s == 0) { acc = rhs; st = xn + rhs * hdt; }
             else if (s == 1) { acc = __builtin_fma(2., rhs, acc); st = xn + rhs * hdt; }
             else if (s == 2) { acc = __builtin_fma(2., rhs, acc); st = (isW ? st : xn) + rhs * dt; }
-            else st = xn + div_by(dt * (acc + rhs), six, i_six);
+            else st = xn + DIVC(dt * (acc + rhs), six, i_six);
 
             // publish: the next stage's value, or (after the last stage) stage 1 of the next row
             const double pub = (s < 3) ? st : xp1;
@@ -402,7 +439,9 @@ __device__ __forceinline__ void sweep_role(const HydWsArgs& a, const DevConst& K
             if constexpr (isC) {
                 publish_c(wb, pub, (s < 3) ? rw : rw_nxt);
             }
+            STAMP(2 + 2 * s);
             lds_barrier();
+            STAMP(3 + 2 * s);
         }
 
         // ---- side outputs of the 4th evaluation (RHS_Hyd.cpp:379-402, 440-446) ----
@@ -421,6 +460,7 @@ __device__ __forceinline__ void sweep_role(const HydWsArgs& a, const DevConst& K
         // be outstanding completes its loads without waiting for the write acknowledgements.
         if (STORE && j > 1) __builtin_amdgcn_s_waitcnt(0x0F70 | NST);  // vmcnt(NST)
         else __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the first step stores nothing
+        STAMP(10);
         xm2 = xm1; xm1 = st; x0 = xp1; xp1 = xp2;
         if constexpr (isV) { ym2 = ym1; ym1 = y0; y0 = yp1; yp1 = yp2; um2 = um1; up1 = up2; }
         if constexpr (isC) { rw_cur = rw_nxt; rw_nxt = n_rw2; }
@@ -510,7 +550,7 @@ __global__ void k_copy_shell(const double* const* __restrict__ src, double* cons
 
 }  // namespace
 
-int atomdev_hyd_rk3d_ws(atomdev* h) {
+int HYD_WS_ENTRY(atomdev* h) {
     static const int X[5] = { ATOMDEV_T, ATOMDEV_U, ATOMDEV_V, ATOMDEV_W, ATOMDEV_C };
     ATOMDEV_REQUIRE(h->n3 * sizeof(double) < ((size_t)1 << 32), "hyd_rk3d: field larger than 4 GiB");
     // Two argument blocks, one per orientation of the (current, alternate) buffer pair; the sweep
