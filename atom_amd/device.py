@@ -54,6 +54,17 @@ class HydSlice(C.Structure):
                 ("bathymetry_file", C.c_char_p), ("salinity_file", C.c_char_p), ("queries", C.c_int)]
 
 
+class AtmStart(C.Structure):
+    """atomdev_atm_start: what BC_Thermo's constructor receives beyond Params."""
+    _fields_ = ([(n, C.c_int) for n in ("Ma", "first_time_slice", "Ma_previous", "sun", "RadiationModel", "NASATemperature",
+                                        "declination", "sun_position_lat", "sun_position_lon")] +
+                [(n, C.c_double) for n in ("t_cretaceous", "t_cretaceous_add", "t_average", "t_equator", "t_pole", "t_land",
+                                           "c_tropopause", "c_ocean", "c_land", "co2_average", "co2_equator",
+                                           "co2_tropopause", "co2_pole", "co2_cretaceous", "co2_vegetation", "co2_ocean",
+                                           "co2_land")] +
+                [("im_tropopause", C.POINTER(C.c_int))])
+
+
 class AtmLoop(C.Structure):
     """atomdev_atm_loop: the iteration loops of cAtmosphereModel (run_2D_loop, run_3D_loop)."""
     _fields_ = [("velocity_iter_max_2D", C.c_int), ("pressure_iter_max_2D", C.c_int), ("velocity_iter_max", C.c_int),

@@ -2543,3 +2543,493 @@ void oracle_default_params(int model, atomdev_params* p) {
     p->R_WaterVapour = 461.6; p->L_atm = 16000.; p->cp_l = 1005.; p->t_tropopause = .798;
     p->sc = 1.7329; p->L_hyd = 1000.; p->r_0_water = 1000.; p->ta = 1.01464; p->pa = 0.; p->ca = 1.;
 }
+
+/* ------------------------------------------------------------------------- */
+/* The atmosphere's start of a time slice (atmosphere/cAtmosphereModel.cpp:220-302)  */
+/* ------------------------------------------------------------------------- */
+
+/* BC_Thermo's i_topography (atmosphere/BC_Thermo.cpp:128-139): the highest land level at or below im-2, else 0 */
+static int topography_level(const oracle_ctx* c, int j, int k) {
+    for (int i = c->im - 2; i >= 0; i--) if (is_land(c, i, j, k)) return i;
+    return 0;
+}
+
+/* BC_Thermo::GetTropopauseHightAdd, atmosphere/BC_Thermo.cpp:3298-3302, called with t_cretaceous / t_0 */
+static int tropopause_add(double t_cretaceous, double t_0) { return (int)round(((t_cretaceous / t_0) * t_0) / 2.6); }
+
+/* BC_Thermo::IC_CellStructure, atmosphere/BC_Thermo.cpp:934-2307.  The reference's loops never combine different
+ * longitudes, so the statements run here for one longitude after the other, each in the reference's order. */
+static void cell_rows_u(oracle_ctx* c, int k, int j0, int j1, double ua, const int* trop) { /* e.g. :1014-1024 */
+    for (int j = j0; j <= j1; j++) {
+        const int i_max = trop[j], i_half = trop[j] / 2;
+        const double d_i_half = (double)i_half;
+        for (int i = 0; i <= i_max; i++) {
+            const double d_i = (double)i;
+            A3(c, ATOMDEV_U, i, j, k) = -ua * (d_i * d_i / (d_i_half * d_i_half) - 2. * d_i / d_i_half);
+        }
+    }
+}
+/* below the tropopause (e.g. :1082-1094); F = ATOMDEV_V or ATOMDEV_W */
+static void cell_rows_low(oracle_ctx* c, int F, int k, int j0, int j1, double x_trop, double x_sl, const int* trop) {
+    for (int j = j0; j <= j1; j++) {
+        const int i_max = trop[j];
+        const double d_i_max = (double)i_max;
+        for (int i = 0; i < i_max; i++) {
+            const double d_i = (double)i;
+            A3(c, F, i, j, k) = (x_trop - x_sl) * d_i / d_i_max + x_sl;
+        }
+    }
+}
+/* from the tropopause up (e.g. :1095-1106); guard: 0 none (:1330-1340), 1 "d_i_max == 0." (:1098), 2 "i_max == 40" (:1044) */
+static void cell_rows_high(oracle_ctx* c, int F, int k, int j0, int j1, double x_trop, int guard, const int* trop) {
+    const int im = c->im;
+    for (int j = j0; j <= j1; j++) {
+        const int i_max = trop[j];
+        double d_i_max = (double)(i_max - (im - 1));
+        if (guard == 1 && d_i_max == 0.) d_i_max = 1.e-6;
+        if (guard == 2 && i_max == 40) d_i_max = 1.e-6;
+        for (int i = i_max; i < im; i++) {
+            const double d_i = (double)(i - (im - 1));
+            A3(c, F, i, j, k) = x_trop * d_i / d_i_max;
+        }
+    }
+}
+/* x[j] = (x[ja] - x[jb]) * (j - jb) / (ja - jb) + x[jb] for j from j0 to j1 in steps of dir, in place (e.g. :1472-1484) */
+static void cell_interpolate(oracle_ctx* c, int F, int k, int j0, int j1, int dir, int ja, int jb) {
+    const double d_b = (double)jb, d_diff = (double)ja - (double)jb;
+    for (int j = j0; dir > 0 ? j <= j1 : j >= j1; j += dir) {
+        const double d_j = (double)j;
+        for (int i = 0; i < c->im; i++)
+            A3(c, F, i, j, k) = (A3(c, F, i, ja, k) - A3(c, F, i, jb, k)) * (d_j - d_b) / d_diff + A3(c, F, i, jb, k);
+    }
+}
+/* seven rows around a cell border (e.g. :2144-2157) */
+static void cell_smooth(oracle_ctx* c, int k, int jc) {
+    static const int F[3] = { ATOMDEV_U, ATOMDEV_V, ATOMDEV_W };
+    const int j_s = jc - 3, j_n = jc + 3;
+    for (int i = 0; i < c->im; i++)
+        for (int j = j_s; j <= j_n; j++)
+            for (int n = 0; n < 3; n++)
+                A3(c, F[n], i, j, k) = (A3(c, F[n], i, j_n, k) - A3(c, F[n], i, j_s, k)) / ((int)(j_n - j_s)) * (int)(j - j_s) + A3(c, F[n], i, j_s, k);
+}
+
+int oracle_atm_ic_cell_structure(oracle_ctx* c, const int* trop) {
+    if (c->jm != 181) return 1;   /* the cell borders are rows of the 1-degree grid (:987-999) */
+    const int im = c->im, jm = c->jm, km = c->km, V = ATOMDEV_V, W = ATOMDEV_W;
+    /* :944-984 */
+    const double ua_00 = 1., va_equator_SL = 0.000, va_equator_Tropopause = 0.000, wa_equator_SL = -1., wa_equator_Tropopause = -7.5;
+    const double ua_30 = -1., va_Hadley_SL = .25, va_Hadley_Tropopause = -1., va_Hadley_SL_15 = 1., va_Hadley_Tropopause_15 = -1.,
+                 wa_Hadley_SL = 1., wa_Hadley_Tropopause = 30.;
+    const double ua_60 = 0.5, va_Ferrel_SL = 0.5, va_Ferrel_Tropopause = 1., va_Ferrel_SL_45 = -.1, va_Ferrel_Tropopause_45 = 1.,
+                 wa_Ferrel_SL = -.2, wa_Ferrel_Tropopause = 10.;
+    const double ua_90 = -0.5, va_Polar_SL = 0., va_Polar_Tropopause = 0., va_Polar_SL_75 = .5, va_Polar_Tropopause_75 = -1.,
+                 wa_Polar_SL = -0.01, wa_Polar_Tropopause = 0.;
+    const int j_aeq = 90, j_pol_n = 0, j_pol_s = jm - 1, j_pol_v_n = 15, j_pol_v_s = 165, j_fer_n = 30, j_fer_s = 150,
+              j_fer_v_n = 45, j_fer_v_s = 135, j_had_n = 60, j_had_s = 120, j_had_v_n = 75, j_had_v_s = 105;
+    for (int k = 0; k < km; k++) {
+        /* equator, :1014-1052 */
+        cell_rows_u(c, k, j_aeq, j_aeq, ua_00, trop);
+        cell_rows_low(c, V, k, j_aeq, j_aeq, va_equator_Tropopause, va_equator_SL, trop);
+        cell_rows_low(c, W, k, j_aeq, j_aeq, wa_equator_Tropopause, wa_equator_SL, trop);
+        cell_rows_high(c, V, k, j_aeq, j_aeq, va_equator_Tropopause, 2, trop);
+        cell_rows_high(c, W, k, j_aeq, j_aeq, wa_equator_Tropopause, 2, trop);
+        /* northern polar cell, :1068-1133 */
+        cell_rows_u(c, k, 0, j_pol_n, ua_90, trop);
+        cell_rows_low(c, V, k, j_pol_n, j_fer_n, va_Polar_Tropopause, va_Polar_SL, trop);
+        cell_rows_low(c, W, k, j_pol_n, j_fer_n, wa_Polar_Tropopause, wa_Polar_SL, trop);
+        cell_rows_high(c, V, k, j_pol_n, j_fer_n, va_Polar_Tropopause, 1, trop);
+        cell_rows_high(c, W, k, j_pol_n, j_fer_n, wa_Polar_Tropopause, 1, trop);
+        cell_rows_low(c, V, k, j_pol_v_n, j_pol_v_n, va_Polar_Tropopause_75, va_Polar_SL_75, trop);
+        cell_rows_high(c, V, k, j_pol_v_n, j_pol_v_n, va_Polar_Tropopause_75, 1, trop);
+        /* northern Ferrel cell, :1143-1209 */
+        cell_rows_u(c, k, j_fer_n, j_fer_n, ua_60, trop);
+        cell_rows_low(c, V, k, j_fer_n, j_fer_n, va_Ferrel_Tropopause, va_Ferrel_SL, trop);
+        cell_rows_low(c, W, k, j_fer_n, j_fer_n, wa_Ferrel_Tropopause, wa_Ferrel_SL, trop);
+        cell_rows_high(c, V, k, j_fer_n, j_fer_n, va_Ferrel_Tropopause, 1, trop);
+        cell_rows_high(c, W, k, j_fer_n, j_fer_n, wa_Ferrel_Tropopause, 1, trop);
+        cell_rows_low(c, V, k, j_fer_v_n, j_fer_v_n, va_Ferrel_Tropopause_45, va_Ferrel_SL_45, trop);
+        cell_rows_high(c, V, k, j_fer_v_n, j_fer_v_n, va_Ferrel_Tropopause_45, 1, trop);
+        /* northern Hadley cell, :1218-1283 */
+        cell_rows_u(c, k, j_had_n, j_had_n, ua_30, trop);
+        cell_rows_low(c, V, k, j_had_n, j_had_n, va_Hadley_Tropopause, va_Hadley_SL, trop);
+        cell_rows_low(c, W, k, j_had_n, j_had_n, wa_Hadley_Tropopause, wa_Hadley_SL, trop);
+        cell_rows_high(c, V, k, j_had_n, j_had_n, va_Hadley_Tropopause, 1, trop);
+        cell_rows_high(c, W, k, j_had_n, j_had_n, wa_Hadley_Tropopause, 1, trop);
+        cell_rows_low(c, V, k, j_had_v_n, j_had_v_n, va_Hadley_Tropopause_15, va_Hadley_SL_15, trop);
+        cell_rows_high(c, V, k, j_had_v_n, j_had_v_n, va_Hadley_Tropopause_15, 1, trop);
+        /* southern Hadley cell, :1302-1366 (no guard at 30 S) */
+        cell_rows_u(c, k, j_had_s, j_had_s, ua_30, trop);
+        cell_rows_low(c, V, k, j_had_s, j_had_s, va_Hadley_Tropopause, va_Hadley_SL, trop);
+        cell_rows_low(c, W, k, j_had_s, j_had_s, wa_Hadley_Tropopause, wa_Hadley_SL, trop);
+        cell_rows_high(c, V, k, j_had_s, j_had_s, va_Hadley_Tropopause, 0, trop);
+        cell_rows_high(c, W, k, j_had_s, j_had_s, wa_Hadley_Tropopause, 0, trop);
+        cell_rows_low(c, V, k, j_had_v_s, j_had_v_s, va_Hadley_Tropopause_15, va_Hadley_SL_15, trop);
+        cell_rows_high(c, V, k, j_had_v_s, j_had_v_s, va_Hadley_Tropopause_15, 1, trop);
+        /* southern Ferrel cell (no guard at 60 S) */
+        cell_rows_u(c, k, j_fer_s, j_fer_s, ua_60, trop);
+        cell_rows_low(c, V, k, j_fer_s, j_fer_s, va_Ferrel_Tropopause, va_Ferrel_SL, trop);
+        cell_rows_low(c, W, k, j_fer_s, j_fer_s, wa_Ferrel_Tropopause, wa_Ferrel_SL, trop);
+        cell_rows_high(c, V, k, j_fer_s, j_fer_s, va_Ferrel_Tropopause, 0, trop);
+        cell_rows_high(c, W, k, j_fer_s, j_fer_s, wa_Ferrel_Tropopause, 0, trop);
+        cell_rows_low(c, V, k, j_fer_v_s, j_fer_v_s, va_Ferrel_Tropopause_45, va_Ferrel_SL_45, trop);
+        cell_rows_high(c, V, k, j_fer_v_s, j_fer_v_s, va_Ferrel_Tropopause_45, 1, trop);
+        /* southern polar cell (no guard between 60 S and the pole) */
+        cell_rows_u(c, k, j_pol_s, jm - 1, ua_90, trop);
+        cell_rows_low(c, V, k, j_fer_s + 1, j_pol_s, va_Polar_Tropopause, va_Polar_SL, trop);
+        cell_rows_low(c, W, k, j_fer_s + 1, j_pol_s, wa_Polar_Tropopause, wa_Polar_SL, trop);
+        cell_rows_high(c, V, k, j_fer_s + 1, j_pol_s, va_Polar_Tropopause, 0, trop);
+        cell_rows_high(c, W, k, j_fer_s + 1, j_pol_s, wa_Polar_Tropopause, 0, trop);
+        cell_rows_low(c, V, k, j_pol_v_s, j_pol_v_s, va_Polar_Tropopause_75, va_Polar_SL_75, trop);
+        cell_rows_high(c, V, k, j_pol_v_s, j_pol_v_s, va_Polar_Tropopause_75, 1, trop);
+        /* linear connections between the rows, :1468-1700, in the reference's order.  u and w of one loop are independent. */
+        cell_interpolate(c, ATOMDEV_U, k, j_pol_n, j_fer_n, 1, j_fer_n, j_pol_n);
+        cell_interpolate(c, W, k, j_pol_n, j_fer_n, 1, j_fer_n, j_pol_n);
+        cell_interpolate(c, V, k, j_pol_n, j_pol_v_n, 1, j_pol_v_n, j_pol_n);
+        cell_interpolate(c, V, k, j_pol_v_n, j_fer_n, 1, j_fer_n, j_pol_v_n);
+        cell_interpolate(c, ATOMDEV_U, k, j_fer_n + 1, j_had_n, 1, j_had_n, j_fer_n);
+        cell_interpolate(c, W, k, j_fer_n + 1, j_had_n, 1, j_had_n, j_fer_n);
+        cell_interpolate(c, V, k, j_fer_n, j_fer_v_n, 1, j_fer_v_n, j_fer_n);
+        cell_interpolate(c, V, k, j_fer_v_n, j_had_n, 1, j_had_n, j_fer_v_n);
+        cell_interpolate(c, V, k, j_fer_v_s, j_had_s, -1, j_fer_v_s, j_had_s);
+        cell_interpolate(c, ATOMDEV_U, k, j_had_n, j_aeq, 1, j_aeq, j_had_n);
+        cell_interpolate(c, W, k, j_had_n, j_aeq, 1, j_aeq, j_had_n);
+        cell_interpolate(c, V, k, j_had_v_n, j_aeq, 1, j_aeq, j_had_v_n);
+        cell_interpolate(c, V, k, j_had_n, j_had_v_n, 1, j_had_v_n, j_had_n);
+        cell_interpolate(c, ATOMDEV_U, k, j_fer_s, j_pol_s, 1, j_fer_s, j_pol_s);
+        cell_interpolate(c, W, k, j_fer_s, j_pol_s, 1, j_fer_s, j_pol_s);
+        cell_interpolate(c, V, k, j_pol_s, j_pol_v_s, -1, j_pol_s, j_pol_v_s);
+        cell_interpolate(c, V, k, j_pol_v_s, j_fer_s, -1, j_pol_v_s, j_fer_s);
+        cell_interpolate(c, ATOMDEV_U, k, j_had_s, j_fer_s, 1, j_had_s, j_fer_s);
+        cell_interpolate(c, W, k, j_had_s, j_fer_s, 1, j_had_s, j_fer_s);
+        cell_interpolate(c, V, k, j_fer_s, j_fer_v_s, -1, j_fer_s, j_fer_v_s);
+        cell_interpolate(c, ATOMDEV_U, k, j_aeq, j_had_s, 1, j_aeq, j_had_s);
+        cell_interpolate(c, W, k, j_aeq, j_had_s, 1, j_aeq, j_had_s);
+        cell_interpolate(c, V, k, j_had_s, j_had_v_s, -1, j_had_s, j_had_v_s);
+        cell_interpolate(c, V, k, j_had_v_s, j_aeq, -1, j_had_v_s, j_aeq);
+        /* change in sign of the v-component in the southern hemisphere */
+        for (int i = 0; i < im; i++)
+            for (int j = j_aeq + 1; j < jm; j++) A3(c, V, i, j, k) = -A3(c, V, i, j, k);
+        /* smoothing around the cell borders, :2144-2283 */
+        cell_smooth(c, k, j_had_n); cell_smooth(c, k, j_fer_n); cell_smooth(c, k, j_had_v_n); cell_smooth(c, k, j_fer_v_n);
+        cell_smooth(c, k, j_aeq); cell_smooth(c, k, j_had_s); cell_smooth(c, k, j_fer_s); cell_smooth(c, k, j_had_v_s);
+        cell_smooth(c, k, j_fer_v_s);
+        /* :2288-2303 */
+        for (int i = 0; i < im; i++)
+            for (int j = 0; j < jm; j++) {
+                A3(c, ATOMDEV_U, i, j, k) = A3(c, ATOMDEV_U, i, j, k) / c->p.u_0;
+                A3(c, V, i, j, k) = A3(c, V, i, j, k) / c->p.u_0;
+                A3(c, W, i, j, k) = A3(c, W, i, j, k) / c->p.u_0;
+                if (is_land(c, i, j, k)) A3(c, ATOMDEV_U, i, j, k) = A3(c, V, i, j, k) = A3(c, W, i, j, k) = 0.;
+            }
+    }
+    return 0;
+}
+
+/* BC_Thermo::BC_Surface_Temperature_NASA, atmosphere/BC_Thermo.cpp:2310-2350, for files whose entries are all numbers */
+int oracle_atm_read_surface_temperature(oracle_ctx* c, const char* path) {
+    FILE* f = fopen(path, "r");
+    if (!f) return 1;
+    const int jm = c->jm, km = c->km, k_half = (km - 1) / 2;
+    for (int k = 0; k < km && !feof(f); k++)
+        for (int j = 0; j < jm; j++) {
+            double lat, lon, temperature = 0.;
+            if (fscanf(f, "%lf %lf %lf", &lat, &lon, &temperature) != 3) { /* the stream has failed: the value stays */ }
+            A3(c, ATOMDEV_T, 0, j, k) = A2(c, ATOMDEV_TEMPERATURE_NASA, j, k) = (temperature + c->p.t_0) / c->p.t_0;
+        }
+    fclose(f);
+    for (int j = 0; j < jm; j++) {
+        A3(c, ATOMDEV_T, 0, j, k_half) = (A3(c, ATOMDEV_T, 0, j, k_half + 1) + A3(c, ATOMDEV_T, 0, j, k_half - 1)) / 2.;
+        A2(c, ATOMDEV_TEMPERATURE_NASA, j, k_half) = (A2(c, ATOMDEV_TEMPERATURE_NASA, j, k_half + 1) + A2(c, ATOMDEV_TEMPERATURE_NASA, j, k_half - 1)) / 2.;
+    }
+    return 0;
+}
+
+/* BC_Thermo::BC_Surface_Precipitation_NASA, atmosphere/BC_Thermo.cpp:2352-2385 */
+int oracle_atm_read_surface_precipitation(oracle_ctx* c, const char* path) {
+    FILE* f = fopen(path, "r");
+    if (!f) return 1;
+    for (int k = 0; k < c->km && !feof(f); k++)
+        for (int j = 0; j < c->jm; j++) {
+            double lat, lon, precipitation = 0.;
+            if (fscanf(f, "%lf %lf %lf", &lat, &lon, &precipitation) != 3) { }
+            A2(c, ATOMDEV_PRECIPITATION_NASA, j, k) = precipitation;
+        }
+    fclose(f);
+    return 0;
+}
+
+/* BC_Thermo::GetPoleTemperature, atmosphere/BC_Thermo.cpp:3305-3332, with the table of :544-561 */
+static double pole_temperature(int Ma) {
+    static const int M[16] = { 0, 40, 45, 50, 55, 60, 70, 80, 90, 100, 120, 130, 140, 150, 160, 340 };
+    static const double T[16] = { 0., 22., 23.5, 24.1, 24.3, 22.4, 24.2, 23.7, 22.8, 21.8, 19., 17.8, 16.9, 16.4, 16., 16. };
+    if (Ma <= M[0]) return T[0];
+    if (Ma > M[15]) return T[15];
+    int up = 0, bottom = 1;
+    for (int n = 0; n < 16; n++) {
+        if (M[n] >= Ma) { bottom = n; break; }
+        up = n;
+    }
+    return (T[bottom] - T[up]) / (double)(M[bottom] - M[up]) * (double)(Ma - M[up]) + T[up];
+}
+
+/* BC_Thermo::BC_Temperature, atmosphere/BC_Thermo.cpp:427-676 */
+void oracle_atm_bc_temperature(oracle_ctx* c, const atomdev_atm_start* s) {
+    const int im = c->im, jm = c->jm, km = c->km, Ma = s->Ma;
+    const double t_0 = c->p.t_0, t_cretaceous_add = s->t_cretaceous_add;
+    if (Ma > 0 && s->sun == 1) {   /* :485-536, temperature distribution at a prescribed sun position */
+        int j_par = s->sun_position_lat;
+        j_par = j_par + s->declination;
+        const int j_pol = jm - 1;
+        const double j_par_f = (double)j_par, j_pol_f = (double)j_pol;
+        double aa = (s->t_equator - s->t_pole) / (((j_par_f * j_par_f) - (j_pol_f * j_pol_f)) - 2. * j_par_f * (j_par_f - j_pol_f));
+        double bb = -2. * aa * j_par_f;
+        double cc = s->t_equator + aa * j_par_f * j_par_f;
+        const double j_d = sqrt((cc - s->t_pole) / aa);
+        const double dd = 2. * aa * j_d + bb;
+        const double e = s->t_pole;
+        for (int k = 0; k < km; k++)
+            for (int j = 0; j < jm; j++) {
+                const double d_j = (double)j;
+                if (d_j <= j_d) A3(c, ATOMDEV_T, 0, j, k) = dd * d_j + e + t_cretaceous_add;
+                if (d_j > j_d) A3(c, ATOMDEV_T, 0, j, k) = aa * d_j * d_j + bb * d_j + cc + t_cretaceous_add;
+            }
+        const int k_par = s->sun_position_lon, k_pol = km - 1;
+        const double t_360 = (t_0 + 5.) / t_0;
+        for (int j = 0; j < jm; j++) {
+            const double jm_temp_asym = A3(c, ATOMDEV_T, 0, j, 20);
+            for (int k = 0; k < km; k++) {
+                const double k_par_f = (double)k_par, k_pol_f = (double)k_pol, d_k = (double)k;
+                aa = (jm_temp_asym - t_360) / (((k_par_f * k_par_f) - (k_pol_f * k_pol_f)) - 2. * k_par_f * (k_par_f - k_pol_f));
+                bb = -2. * aa * k_par_f;
+                cc = jm_temp_asym + aa * k_par_f * k_par_f;
+                A3(c, ATOMDEV_T, 0, j, k) = aa * d_k * d_k + bb * d_k + cc;
+            }
+        }
+    }
+    const double d_j_half = (double)(jm - 1) / 2.0;
+    if (s->RadiationModel == 1) {   /* :568-633 */
+        double t_pole_diff_ocean = 0.;
+        if (!s->first_time_slice) t_pole_diff_ocean = pole_temperature(Ma) - pole_temperature(s->Ma_previous);
+        const double t_pole_diff_land = pole_temperature(Ma);
+        const double t_eff = s->t_pole - s->t_equator;
+        for (int k = 0; k < km; k++)
+            for (int j = 0; j < jm; j++) {
+                const int i_mount = topography_level(c, j, k);
+                const double d_j = (double)j;
+                if (s->NASATemperature == 0) {
+                    A3(c, ATOMDEV_T, i_mount, j, k) = t_eff * parabola(d_j / d_j_half) + s->t_pole + t_cretaceous_add;
+                    if (is_land(c, 0, j, k))
+                        A3(c, ATOMDEV_T, i_mount, j, k) = t_eff * parabola(d_j / d_j_half) + s->t_pole + t_cretaceous_add + s->t_land;
+                } else {
+                    if (is_land(c, 0, j, k)) {
+                        A3(c, ATOMDEV_T, i_mount, j, k) = t_eff * parabola(d_j / d_j_half) + s->t_pole + t_cretaceous_add + s->t_land;
+                        A3(c, ATOMDEV_T, i_mount, j, k) += t_pole_diff_land * fabs(parabola(d_j / d_j_half) + 1.) / t_0;
+                    } else if (Ma > 0) {
+                        A3(c, ATOMDEV_T, 0, j, k) += t_cretaceous_add + t_pole_diff_ocean * fabs(parabola(d_j / d_j_half) + 1.) / t_0;
+                    }
+                }
+            }
+    }
+    /* :635-664, up to the tropopause and above */
+    double t_tropopause_pole = -4.;
+    t_tropopause_pole = c->p.t_tropopause + t_tropopause_pole / t_0;
+    const double t_eff_tropo = t_tropopause_pole - c->p.t_tropopause;
+    for (int j = 0; j < jm; j++) {
+        const int i_trop = s->im_tropopause[j] + tropopause_add(s->t_cretaceous, t_0);
+        const double temp_tropopause = t_eff_tropo * parabola(j / ((jm - 1) / 2.0)) + t_tropopause_pole + t_cretaceous_add;
+        for (int k = 0; k < km; k++) {
+            const int i_mount = topography_level(c, j, k);
+            double tmp = A3(c, ATOMDEV_T, i_mount, j, k);
+            tmp = (temp_tropopause - tmp) * ((double)i_mount / i_trop) + tmp;
+            for (int i = 0; i < im; i++) {
+                if (i < i_trop + 1) {
+                    if (i > i_mount) A3(c, ATOMDEV_T, i, j, k) = (temp_tropopause - tmp) * ((double)(i - i_mount) / i_trop) + tmp;
+                    else A3(c, ATOMDEV_T, i, j, k) = tmp;
+                } else {
+                    A3(c, ATOMDEV_T, i, j, k) = temp_tropopause;
+                }
+            }
+        }
+    }
+}
+
+/* BC_Thermo::IC_Temperature_WestEastCoast, atmosphere/BC_Thermo.cpp:3151-3233 */
+void oracle_atm_ic_temperature_west_east_coast(oracle_ctx* c) {
+    const int jm = c->jm, km = c->km, j_grad = 7, k_grad = 7;
+#define T0_(j, k) A3(c, ATOMDEV_T, 0, j, k)
+    int j_air = 0, flip = 0, ll;
+    for (int k = 1; k < km - 1; k++) {   /* north coasts */
+        for (int j = j_grad; j < jm - 1; j++) {
+            if (is_fluid(c, 0, j, k)) { j_air = 0; flip = 0; }
+            else j_air = 1;
+            if (flip == 0 && j_air == 1) {
+                ll = j - j_grad;
+                for (int l = ll; l < j; l++) T0_(l, k) = T0_(ll, k);
+                flip = 1;
+            }
+        }
+        flip = 0;
+    }
+    j_air = 0;
+    int j_sequel = 1;
+    for (int k = 1; k < km - 1; k++) {   /* south coasts */
+        for (int j = 0; j < jm - j_grad; j++) {
+            if (is_land(c, 0, j, k)) j_sequel = 0;
+            if (is_fluid(c, 0, j, k) && j_sequel == 0) j_air = 0;
+            else j_air = 1;
+            if (is_fluid(c, 0, j, k) && j_air == 0) {
+                ll = j + j_grad;
+                for (int l = ll; l > j; l--) T0_(l, k) = T0_(ll, k);
+                j_sequel = 1;
+            }
+        }
+        j_air = 0;
+    }
+    int k_air = 0, k_sequel = 1;
+    for (int j = 1; j < jm - 1; j++) {   /* east coasts */
+        for (int k = k_grad; k < km - k_grad; k++) {
+            if (is_land(c, 0, j, k)) k_sequel = 0;
+            if (is_fluid(c, 0, j, k) && k_sequel == 0) k_air = 0;
+            else k_air = 1;
+            if (is_fluid(c, 0, j, k) && k_air == 0) {
+                ll = k + k_grad;
+                for (int l = ll; l > k; l--) T0_(j, l) = T0_(j, ll);
+                k_sequel = 1;
+            }
+        }
+        k_air = 0;
+    }
+    k_air = 0; flip = 0;
+    for (int j = 1; j < jm - 1; j++) {   /* west coasts */
+        for (int k = k_grad; k < km - 1; k++) {
+            if (is_fluid(c, 0, j, k)) { k_air = 0; flip = 0; }
+            else k_air = 1;
+            if (flip == 0 && k_air == 1) {
+                ll = k - k_grad;
+                for (int l = ll; l < k; l++) T0_(j, l) = T0_(j, ll);
+                flip = 1;
+            }
+        }
+        flip = 0;
+    }
+#undef T0_
+}
+
+/* BC_Thermo::BC_Pressure, atmosphere/BC_Thermo.cpp:2387-2407 */
+void oracle_atm_bc_pressure(oracle_ctx* c) {
+    const atomdev_params* P = &c->p;
+    const int im = c->im, jm = c->jm, km = c->km;
+    const double exp_pressure = P->g / (1.e-2 * P->gam * P->R_Air);
+    for (int k = 0; k < km; k++)
+        for (int j = 0; j < jm; j++) A3(c, ATOMDEV_P_STAT, 0, j, k) = .01 * (P->r_air * P->R_Air * A3(c, ATOMDEV_T, 0, j, k) * P->t_0);
+    for (int k = 0; k < km; k++)
+        for (int j = 0; j < jm; j++)
+            for (int i = 1; i < im; i++) {
+                const double hight = (double)i * (P->L_atm / (double)(im - 1));
+                A3(c, ATOMDEV_P_STAT, i, j, k) = pow(((A3(c, ATOMDEV_T, 0, j, k) * P->t_0 - P->gam * hight * 1.e-2) /
+                                                      (A3(c, ATOMDEV_T, 0, j, k) * P->t_0)), exp_pressure) * A3(c, ATOMDEV_P_STAT, 0, j, k);
+            }
+}
+
+/* BC_Thermo::BC_WaterVapour, atmosphere/BC_Thermo.cpp:679-780.  Dalton_Evaporation is computed over the ocean only; a land
+ * column adds what the ocean column visited before it (k outer, j inner) left in that variable (:744). */
+void oracle_atm_bc_water_vapour(oracle_ctx* c, const atomdev_atm_start* s) {
+    const atomdev_params* P = &c->p;
+    const int im = c->im, jm = c->jm, km = c->km;
+    const double t_0 = P->t_0, hp = P->hp, ep = P->ep, r_air = P->r_air, R_Air = P->R_Air;
+    const double dt_dim = P->L_atm / P->u_0 * P->dt, dr_dim = P->dr * P->L_atm;   /* :121-123 */
+    double Dalton_Evaporation = 0;
+#define C_(i) A3(c, ATOMDEV_C, i, j, k)
+#define T_(i) A3(c, ATOMDEV_T, i, j, k)
+    for (int k = 0; k < km; k++)
+        for (int j = 0; j < jm; j++) {
+            const int i_mount = topography_level(c, j, k);
+            if (is_fluid(c, 0, j, k)) {
+                C_(i_mount) = hp * ep * exp(17.0809 * (T_(i_mount) * t_0 - t_0) / (234.175 + (T_(i_mount) * t_0 - t_0))) /
+                              ((r_air * R_Air * T_(i_mount) * t_0) * .01);
+                C_(i_mount) = s->c_ocean * C_(i_mount);
+                A3(c, ATOMDEV_P_STAT, i_mount, j, k) = (r_air * R_Air * T_(i_mount) * t_0) * .01;
+                const double p_stat = A3(c, ATOMDEV_P_STAT, i_mount, j, k);
+                const double t_u = T_(i_mount) * t_0;
+                const double r_dry = 100. * p_stat / (R_Air * T_(i_mount) * t_0);
+                const double r_humid = r_dry / (1. + (P->R_WaterVapour / R_Air - 1.) * C_(i_mount));
+                const double e = C_(i_mount) * p_stat / ep;
+                const double E = hp * exp_func(t_u, 17.2694, 35.86);
+                const double sat_difference = (E - e);
+                Dalton_Evaporation = 8.46e-4 * C_Dalton(P->u_0, A3(c, ATOMDEV_V, i_mount, j, k), A3(c, ATOMDEV_W, i_mount, j, k)) *
+                                     sat_difference * dt_dim / (r_humid * dr_dim) * 24.;
+                C_(i_mount) = Dalton_Evaporation + C_(i_mount);
+            }
+            if (is_land(c, 0, j, k)) {
+                C_(i_mount) = hp * ep * exp(17.0809 * (T_(i_mount) * t_0 - t_0) / (234.175 + (T_(i_mount) * t_0 - t_0))) /
+                              ((r_air * R_Air * T_(i_mount) * t_0) * .01);
+                C_(i_mount) = s->c_land * C_(i_mount);
+                C_(i_mount) = Dalton_Evaporation + C_(i_mount);
+            }
+        }
+    for (int j = 0; j < jm; j++) {
+        const int i_trop = s->im_tropopause[j] + tropopause_add(s->t_cretaceous, t_0);
+        const double d_i_max = (double)i_trop;
+        for (int k = 0; k < km; k++) {
+            const int i_mount = topography_level(c, j, k);
+            for (int i = 0; i < im; i++) {
+                if (i < i_trop) {
+                    const double d_i = (double)i;
+                    C_(i) = C_(i_mount) - (s->c_tropopause - C_(i_mount)) * (d_i / d_i_max * (d_i / d_i_max - 2.));
+                } else {
+                    C_(i) = s->c_tropopause;
+                }
+            }
+        }
+    }
+#undef C_
+#undef T_
+}
+
+/* BC_Thermo::BC_CO2, atmosphere/BC_Thermo.cpp:788-881 */
+void oracle_atm_bc_co2(oracle_ctx* c, const atomdev_atm_start* s) {
+    const int im = c->im, jm = c->jm, km = c->km;
+    const double co2_0 = c->p.co2_0, t_0 = c->p.t_0;
+    const int j_max = jm - 1, j_half = j_max / 2;
+    double co2_cretaceous = 3.2886 * pow((s->t_cretaceous + s->t_average), 2) - 32.8859 * (s->t_cretaceous + s->t_average) + 102.2148;
+    const double co2_average = 3.2886 * pow(s->t_average, 2) - 32.8859 * s->t_average + 102.2148;
+    co2_cretaceous = co2_cretaceous - co2_average;
+    const double d_j_half = (double)j_half;
+    const double co2_equator = s->co2_equator / co2_0, co2_pole = s->co2_pole / co2_0;
+    co2_cretaceous = co2_cretaceous / co2_0;
+    const double co2_land = s->co2_land / co2_0, co2_ocean = s->co2_ocean / co2_0, co2_vegetation = s->co2_vegetation / co2_0,
+                 co2_tropopause = s->co2_tropopause / co2_0;
+    const double co2_eff = co2_pole - co2_equator;
+#define CO2_(i) A3(c, ATOMDEV_CO2, i, j, k)
+    for (int k = 0; k < km; k++)
+        for (int j = 0; j < jm; j++) {
+            const int i_mount = topography_level(c, j, k);
+            if (is_fluid(c, i_mount, j, k)) {
+                const double d_j = (double)j;
+                CO2_(i_mount) = co2_eff * (d_j * d_j / (d_j_half * d_j_half) - 2. * d_j / d_j_half) + co2_pole + co2_cretaceous + co2_ocean;
+            }
+            if (is_land(c, i_mount, j, k)) {
+                const double d_j = (double)j;
+                CO2_(i_mount) = co2_eff * (d_j * d_j / (d_j_half * d_j_half) - 2. * d_j / d_j_half) + co2_pole + co2_cretaceous + co2_land -
+                                co2_vegetation * A2(c, ATOMDEV_VEGETATION, j, k);
+            }
+        }
+    for (int j = 0; j < jm; j++) {
+        const int i_trop = s->im_tropopause[j] + tropopause_add(s->t_cretaceous, t_0);
+        const double d_i_max = (double)i_trop;
+        for (int k = 0; k < km; k++) {
+            const int i_mount = topography_level(c, j, k);
+            for (int i = 1; i <= im - 1; i++) {
+                if (i <= i_trop) {
+                    const double d_i = (double)i;
+                    CO2_(i) = CO2_(i_mount) - (co2_tropopause - CO2_(i_mount)) * (d_i / d_i_max * (d_i / d_i_max - 2.));
+                } else {
+                    CO2_(i) = co2_tropopause;
+                }
+            }
+            for (int i = i_trop - 1; i >= 0; i--)
+                if (is_land(c, i, j, k) != (is_land(c, i, j, k) && is_fluid(c, i + 1, j, k))) CO2_(i) = CO2_(i_mount);
+        }
+    }
+#undef CO2_
+}

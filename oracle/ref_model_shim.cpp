@@ -89,6 +89,21 @@ void set_time(int Ma) {
     m->m_current_time = m->m_time_list.insert(float(Ma)).first;
 }
 
+// The model's members and time list as a time slice described by atomdev_atm_start would have them.
+void set_start(const atomdev_atm_start* s) {
+    cAtmosphereModel* m = model();
+    SETP(sun, s->sun); SETP(RadiationModel, s->RadiationModel); SETP(NASATemperature, s->NASATemperature);
+    SETP(declination, s->declination); SETP(sun_position_lat, s->sun_position_lat); SETP(sun_position_lon, s->sun_position_lon);
+    SETP(t_average, s->t_average); SETP(t_equator, s->t_equator); SETP(t_pole, s->t_pole); SETP(t_land, s->t_land);
+    SETP(c_tropopause, s->c_tropopause); SETP(c_ocean, s->c_ocean); SETP(c_land, s->c_land);
+    SETP(co2_average, s->co2_average); SETP(co2_equator, s->co2_equator); SETP(co2_tropopause, s->co2_tropopause);
+    SETP(co2_pole, s->co2_pole); SETP(co2_cretaceous, s->co2_cretaceous); SETP(co2_vegetation, s->co2_vegetation);
+    SETP(co2_ocean, s->co2_ocean); SETP(co2_land, s->co2_land);
+    m->m_time_list.clear();
+    if (!s->first_time_slice) m->m_time_list.insert(float(s->Ma_previous));
+    m->m_current_time = m->m_time_list.insert(float(s->Ma)).first;
+}
+
 // A BC_Thermo object on the context's grid.  The constructor copies dt, dr, dthe, dphi from the model's
 // compile-time constants of the 1-degree grid (BC_Thermo.cpp:41-44) and derives dt_dim and dr_dim from
 // them (:121-123); on another grid they are replaced by the context's step sizes, as a model built for
@@ -98,9 +113,11 @@ struct Thermo {
     std::vector<int> trop;
     int* old_trop;
     BC_Thermo* circ;
-    Thermo(RefCtx* c_, int Ma = 0, const int* im_tropopause = nullptr) : c(c_), trop(c_->jm, 0) {
+    Thermo(RefCtx* c_, int Ma = 0, const int* im_tropopause = nullptr, const atomdev_atm_start* start = nullptr)
+        : c(c_), trop(c_->jm, 0) {
         set_scalars(c->p);
-        set_time(Ma);
+        if (start) { set_start(start); im_tropopause = start->im_tropopause; }
+        else set_time(Ma);
         cAtmosphereModel* m = model();
         if (im_tropopause) std::copy(im_tropopause, im_tropopause + c->jm, trop.begin());
         old_trop = m->im_tropopause;
@@ -180,6 +197,63 @@ int ref_atm_radiation_multi_layer(void* v, const atomdev_radiation* R, const int
     th.circ->BC_Radiation_multi_layer(B(ALBEDO), B(EPSILON), B(RADIATION_SURFACE), A(P_STAT), A(T), A(C), A(H),
                                       A(EPSILON_3D), A(RADIATION_3D), A(CLOUD), A(ICE), A(CO2));
     return 0;
+}
+
+/* ---- the atmosphere's start of a time slice (cAtmosphereModel.cpp:260-292), member by member ---- */
+
+/* cAtmosphereModel::get_mean_temperature_from_curve (cAtmosphereModel.cpp:924-946), in float like the reference */
+float ref_atm_mean_temperature_from_curve(float time) { CoutSilencer quiet; return model()->get_mean_temperature_from_curve(time); }
+
+int ref_atm_ic_cell_structure(void* v, const int* im_tropopause) {
+    RefCtx* c = (RefCtx*)v;
+    CoutSilencer quiet;
+    Thermo th(c, 0, im_tropopause);
+    th.circ->IC_CellStructure(A(H), A(U), A(V), A(W));
+    return 0;
+}
+int ref_atm_read_surface_temperature(void* v, const char* path) {
+    RefCtx* c = (RefCtx*)v;
+    CoutSilencer quiet;
+    Thermo th(c);
+    th.circ->BC_Surface_Temperature_NASA(path, B(TEMPERATURE_NASA), A(T));
+    return 0;
+}
+int ref_atm_read_surface_precipitation(void* v, const char* path) {
+    RefCtx* c = (RefCtx*)v;
+    CoutSilencer quiet;
+    Thermo th(c);
+    th.circ->BC_Surface_Precipitation_NASA(path, B(PRECIPITATION_NASA));
+    return 0;
+}
+void ref_atm_bc_temperature(void* v, const atomdev_atm_start* s) {
+    RefCtx* c = (RefCtx*)v;
+    CoutSilencer quiet;
+    Thermo th(c, 0, nullptr, s);
+    th.circ->BC_Temperature(B(TEMPERATURE_NASA), A(H), A(T), A(TN), A(P_DYN), A(P_STAT));
+}
+void ref_atm_ic_temperature_west_east_coast(void* v) {
+    RefCtx* c = (RefCtx*)v;
+    CoutSilencer quiet;
+    Thermo th(c);
+    th.circ->IC_Temperature_WestEastCoast(A(H), A(T));
+}
+void ref_atm_bc_pressure(void* v) {
+    RefCtx* c = (RefCtx*)v;
+    CoutSilencer quiet;
+    Thermo th(c);
+    th.circ->BC_Pressure(A(P_STAT), A(P_DYN), A(T), A(H));
+}
+void ref_atm_bc_water_vapour(void* v, const atomdev_atm_start* s) {
+    RefCtx* c = (RefCtx*)v;
+    CoutSilencer quiet;
+    Thermo th(c, 0, nullptr, s);
+    th.circ->BC_WaterVapour(A(H), A(P_STAT), A(T), A(C), A(V), A(W));
+}
+void ref_atm_bc_co2(void* v, const atomdev_atm_start* s) {
+    RefCtx* c = (RefCtx*)v;
+    CoutSilencer quiet;
+    Thermo th(c, 0, nullptr, s);
+    th.circ->BC_CO2(B(VEGETATION), A(H), A(T), A(P_DYN), A(CO2));
 }
 
 }  // extern "C"

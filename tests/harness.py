@@ -835,3 +835,72 @@ def thermo_golden_run(kind):
         for k, lo, hi in (("C", 0.7, 1.02), ("CLOUD", 0.5, 1.5), ("ICE", 0.5, 1.5)):
             m.f[k][...] = m.f[k] * rng.uniform(lo, hi, dims) - 2e-5
     return out
+
+
+# --------------------------------------------------------------------------
+# the atmosphere's start of a time slice (BC_Thermo's initial conditions)
+# --------------------------------------------------------------------------
+
+def atm_start(jm, trop=30, **kw):
+    """atomdev_atm_start with param.py's defaults (:45-58, 108-129), the tropopause at level ``trop`` in every row (an
+    array of jm levels is taken as it is), and whatever ``kw`` overrides.  Returns (struct, the array it points to)."""
+    import atom_amd
+    s = atom_amd.AtmStart(Ma=0, first_time_slice=1, Ma_previous=0, sun=0, RadiationModel=1, NASATemperature=1, declination=0,
+                          sun_position_lat=60, sun_position_lon=180, t_cretaceous=0., t_cretaceous_add=0., t_average=15.,
+                          t_equator=1.0842, t_pole=.945, t_land=0., c_tropopause=.001, c_ocean=.58, c_land=.64,
+                          co2_average=280., co2_equator=330., co2_tropopause=320., co2_pole=320., co2_cretaceous=330.,
+                          co2_vegetation=3., co2_ocean=0., co2_land=0.)
+    for k, v in kw.items():
+        setattr(s, k, v)
+    i_trop = np.ascontiguousarray(np.broadcast_to(np.asarray(trop, dtype=np.int32), (jm,)))
+    s.im_tropopause = i_trop.ctypes.data_as(C.POINTER(C.c_int))
+    return s, i_trop
+
+
+def set_paleo_time(s, Ma, Ma_previous, curve, t_0=273.15):
+    """Fills Ma, first_time_slice, Ma_previous, t_cretaceous and t_cretaceous_add of an atomdev_atm_start the way
+    BC_Thermo derives them (BC_Thermo.cpp:93-94, 446-451); ``curve(Ma)`` is the mean temperature of the model's curve, a
+    float like the reference's.  Ma_previous None: the first slice."""
+    f32 = np.float32
+    s.Ma = Ma
+    s.first_time_slice = 1 if Ma_previous is None else 0
+    s.Ma_previous = 0 if Ma_previous is None else Ma_previous
+    s.t_cretaceous = float(f32(curve(Ma)) - f32(curve(0)))
+    s.t_cretaceous_add = 0. if Ma_previous is None else float(f32(curve(Ma)) - f32(curve(Ma_previous))) / t_0
+
+
+def write_lat_lon_value_file(path, values_jk, fmt="%.4f"):
+    """A file in the layout of the NASA surface files: one 'lat lon value' line per cell, longitude outer, latitude
+    inner (BC_Thermo.cpp:2329-2341)."""
+    jm, km = values_jk.shape
+    with open(path, "w") as fh:
+        for k in range(km):
+            for j in range(jm):
+                fh.write(("%d %d " + fmt + "\n") % (90 - j, k - 180, values_jk[j, k]))
+
+
+ATM_START_FIELDS2D = ["VEGETATION", "TEMPERATURE_NASA", "PRECIPITATION_NASA"]
+
+
+def make_atm_start_inputs(im, jm, km, seed):
+    """Atmosphere fields as reset_arrays leaves them (cAtmosphereModel.cpp:384-472: t, c, co2 at their initial values, no
+    wind) with a seeded topography (none on the top level), surface wind for Dalton's evaporation, vegetation, and a
+    temperature file's content in t level 0 / temperature_NASA."""
+    p = default_params(ATM, im, jm, km)
+    rng = np.random.default_rng(seed)
+    h, topo = synthetic_mask(ATM, im, jm, km, p.L_atm, rng, "blobs")
+    h[im - 1] = 0.0
+    shp = (im, jm, km)
+    f = {k: np.zeros(shp) for k in ATM_FIELDS + ["P_STAT"]}
+    f["H"] = h
+    f["T"][...] = 1.0; f["TN"][...] = 1.0
+    f["CO2"][...] = 1.0; f["CO2N"][...] = 1.0
+    f["V"] = rng.uniform(-0.02, 0.02, shp); f["W"] = rng.uniform(-0.05, 0.05, shp)
+    g = {k: np.zeros((jm, km)) for k in FIELDS2D + ATM_START_FIELDS2D}
+    g["TOPOGRAPHY"] = topo
+    g["VEGETATION"] = rng.uniform(0.0, 1.0, (jm, km)) * (h[0] > 0)
+    lat = np.cos(np.linspace(-np.pi / 2, np.pi / 2, jm)).reshape(jm, 1)
+    celsius = np.round(-20. + 48. * lat + rng.uniform(-3., 3., (jm, km)), 2)
+    g["TEMPERATURE_NASA"] = (celsius + p.t_0) / p.t_0
+    f["T"][0] = g["TEMPERATURE_NASA"]
+    return p, f, g

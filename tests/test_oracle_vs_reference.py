@@ -393,3 +393,127 @@ def test_atm_ice_water_saturation_adjustment(dims, seed):
             x = a.f[k] * rng.uniform(lo, hi, dims) - 2e-5
             a.f[k][...] = x; b.f[k][...] = x
     assert not np.array_equal(a.f["T"], f["T"])
+
+
+# ---- the atmosphere's start of a time slice ----
+
+def _ref_curve():
+    fn = H.load_ref().ref_atm_mean_temperature_from_curve
+    fn.restype = C.c_float
+    fn.argtypes = [C.c_float]
+    return lambda Ma: fn(float(Ma))
+
+
+def _start_pair(dims, seed):
+    p, f, g = H.make_atm_start_inputs(*dims, seed)
+    return p, f, g, _thermo_pair(dims, p, f, g)
+
+
+def _call(m, name, *args):
+    fn = getattr(m.lib, m.pre + name)
+    fn.restype = C.c_int
+    return fn(m.ctx, *args)
+
+
+@pytest.mark.parametrize("dims,seed,trop", [((41, 181, 5), 91, 30), ((41, 181, 3), 92, 24), ((17, 181, 4), 93, 12)])
+def test_atm_ic_cell_structure(dims, seed, trop):
+    im, jm, km = dims
+    p, f, g, (o, r) = _start_pair(dims, seed)
+    i_trop = np.full(jm, trop, dtype=np.int32)
+    i_trop[60:120] = min(trop + 3, im - 2)      # a higher tropopause between the tropics
+    for m in (o, r):
+        # the reference's caller passes the reset values (no wind); wind on entry shows what is overwritten and what is kept
+        assert _call(m, "atm_ic_cell_structure", i_trop.ctypes.data_as(C.POINTER(C.c_int))) == 0
+    _all_same_bits(o, r, "IC_CellStructure")
+    assert np.abs(o.f["U"]).max() > 0 and np.abs(o.f["V"]).max() > 0 and np.abs(o.f["W"]).max() > 0
+
+
+def test_atm_surface_files(tmp_path):
+    dims = (9, 21, 31)
+    p, f, g, (o, r) = _start_pair(dims, 94)
+    rng = np.random.default_rng(94)
+    temp, prec = tmp_path / "t.xyz", tmp_path / "p.xyz"
+    H.write_lat_lon_value_file(str(temp), rng.uniform(-40., 32., dims[1:]), "%.2f")
+    H.write_lat_lon_value_file(str(prec), rng.uniform(0., 12., dims[1:]), "%.3f")
+    for m in (o, r):
+        assert _call(m, "atm_read_surface_temperature", str(temp).encode()) == 0
+        assert _call(m, "atm_read_surface_precipitation", str(prec).encode()) == 0
+    _all_same_bits(o, r, "NASA files")
+    assert not np.array_equal(o.g["PRECIPITATION_NASA"], g["PRECIPITATION_NASA"])
+
+
+def test_atm_surface_files_of_the_reference():
+    """The reference's own 1-degree files."""
+    dims = (3, 181, 361)
+    p, f, g, (o, r) = _start_pair(dims, 95)
+    for m in (o, r):
+        assert _call(m, "atm_read_surface_temperature", b"/root/reference/data/SurfaceTemperature_NASA.xyz") == 0
+        assert _call(m, "atm_read_surface_precipitation", b"/root/reference/data/SurfacePrecipitation_NASA.xyz") == 0
+    _all_same_bits(o, r, "NASA files")
+    assert o.g["TEMPERATURE_NASA"].min() > 0.7 and o.g["PRECIPITATION_NASA"].max() > 1.0
+
+
+START_CASES = [dict(Ma=0, prev=None), dict(Ma=10, prev=0), dict(Ma=10, prev=0, NASATemperature=0),
+               dict(Ma=50, prev=40, sun=1), dict(Ma=100, prev=90, RadiationModel=0), dict(Ma=140, prev=130, t_land=0.003661),
+               dict(Ma=0, prev=None, NASATemperature=0, t_land=0.003661)]
+
+
+def _start_struct(case, jm, trop):
+    kw = {k: v for k, v in case.items() if k not in ("Ma", "prev")}
+    s, keep = H.atm_start(jm, trop, **kw)
+    H.set_paleo_time(s, case["Ma"], case["prev"], _ref_curve())
+    return s, keep
+
+
+@pytest.mark.parametrize("case", START_CASES)
+@pytest.mark.parametrize("dims,seed,trop", [((41, 19, 25), 96, 30), ((12, 13, 27), 97, 8)])
+def test_atm_bc_temperature(dims, seed, trop, case):
+    p, f, g, (o, r) = _start_pair(dims, seed)
+    i_trop = np.full(dims[1], trop, dtype=np.int32)
+    i_trop[::4] -= 2
+    s, keep = _start_struct(case, dims[1], i_trop)
+    for m in (o, r):
+        m.op("atm_bc_temperature", C.byref(s))
+    _all_same_bits(o, r, "BC_Temperature %r" % (case,))
+    assert not np.array_equal(o.f["T"], f["T"])
+
+
+@pytest.mark.parametrize("dims,seed", [((5, 19, 25), 98), ((4, 33, 41), 99)])
+def test_atm_ic_temperature_west_east_coast(dims, seed):
+    p, f, g, (o, r) = _start_pair(dims, seed)
+    for m in (o, r):
+        m.op("atm_ic_temperature_west_east_coast")
+    _all_same_bits(o, r, "IC_Temperature_WestEastCoast")
+    assert not np.array_equal(o.f["T"], f["T"])
+
+
+@pytest.mark.parametrize("dims,seed", [((41, 19, 25), 100), ((12, 13, 27), 101)])
+def test_atm_bc_pressure(dims, seed):
+    p, f, g, (o, r) = _start_pair(dims, seed)
+    for m in (o, r):
+        m.op("atm_bc_pressure")
+    _all_same_bits(o, r, "BC_Pressure")
+    assert o.f["P_STAT"].min() > 50.
+
+
+@pytest.mark.parametrize("case", [dict(Ma=0, prev=None), dict(Ma=100, prev=90), dict(Ma=140, prev=130, c_ocean=.78, c_land=.84)])
+@pytest.mark.parametrize("dims,seed,trop", [((41, 19, 25), 102, 30), ((12, 13, 27), 103, 8)])
+def test_atm_bc_water_vapour(dims, seed, trop, case):
+    p, f, g, (o, r) = _start_pair(dims, seed)
+    s, keep = _start_struct(case, dims[1], trop)
+    for m in (o, r):
+        m.op("atm_bc_temperature", C.byref(s))
+        m.op("atm_bc_water_vapour", C.byref(s))
+    _all_same_bits(o, r, "BC_WaterVapour %r" % (case,))
+    assert o.f["C"].max() > 0.003
+
+
+@pytest.mark.parametrize("case", [dict(Ma=0, prev=None), dict(Ma=100, prev=90), dict(Ma=140, prev=130, co2_ocean=2., co2_land=1.)])
+@pytest.mark.parametrize("dims,seed,trop", [((41, 19, 25), 104, 30), ((12, 13, 27), 105, 8)])
+def test_atm_bc_co2(dims, seed, trop, case):
+    p, f, g, (o, r) = _start_pair(dims, seed)
+    s, keep = _start_struct(case, dims[1], trop)
+    for m in (o, r):
+        m.op("atm_bc_co2", C.byref(s))
+    _all_same_bits(o, r, "BC_CO2 %r" % (case,))
+    assert o.f["CO2"].max() > 1.1
