@@ -481,6 +481,7 @@ __global__ __launch_bounds__(512) void k_atm_rk3d_ws(const AtmWsParams* __restri
     const int i = 1 + lev;
 #ifdef ATOMDEV_EXP_WGTIME  // timing experiment only: duration of every workgroup goes to level 0 of aux_u
     const long long wg_t0 = __builtin_readcyclecounter();
+    const long long wg_w0 = wall_clock64();
 #endif
     {
         const int jm = K.jm;
@@ -503,7 +504,10 @@ __global__ __launch_bounds__(512) void k_atm_rk3d_ws(const AtmWsParams* __restri
         default: sweep_role<R_C>(a, K, sh, tab, bx, i, a.c, a.cn); break;
     }
 #ifdef ATOMDEV_EXP_WGTIME
-    if ((threadIdx.x & 63) == 0) a.aux_u[(lev * gx + bx) * 8 + (threadIdx.x >> 6)] = (double)(__builtin_readcyclecounter() - wg_t0);
+    if ((threadIdx.x & 63) == 0) {
+        a.aux_u[(lev * gx + bx) * 8 + (threadIdx.x >> 6)] = (double)(__builtin_readcyclecounter() - wg_t0);
+        if (threadIdx.x == 0) { a.aux_u[16384 + lev * gx + bx] = (double)wg_w0; a.aux_u[32768 + lev * gx + bx] = (double)wall_clock64(); }
+    }
 #endif
 }
 

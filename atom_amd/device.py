@@ -137,6 +137,17 @@ def load_library():
     lib.atomdev_hyd_run_time_slice.argtypes = [vp, C.POINTER(HydSlice), dp, ip]
     lib.atomdev_hyd_run_time_slices.argtypes = [C.POINTER(vp), C.POINTER(HydSlice), C.c_int, dp, ip]
     lib.atomdev_atm_read_mountain_surface.argtypes = [vp, C.c_char_p]
+    lib.atomdev_default_atm_start.argtypes = [C.POINTER(AtmStart)]
+    lib.atomdev_default_atm_start.restype = None
+    lib.atomdev_atm_co2_coeff.argtypes = [C.c_double] * 5
+    lib.atomdev_atm_co2_coeff.restype = C.c_double
+    lib.atomdev_atm_ic_cell_structure.argtypes = [vp, ip]
+    lib.atomdev_atm_read_surface_temperature.argtypes = [vp, C.c_char_p]
+    lib.atomdev_atm_read_surface_precipitation.argtypes = [vp, C.c_char_p]
+    for name in ("atomdev_atm_bc_temperature", "atomdev_atm_bc_water_vapour", "atomdev_atm_bc_co2"):
+        getattr(lib, name).argtypes = [vp, C.POINTER(AtmStart)]
+    lib.atomdev_atm_ic_temperature_west_east_coast.argtypes = [vp]
+    lib.atomdev_atm_bc_pressure.argtypes = [vp]
     lib.atomdev_hyd_read_surface_salinity.argtypes = [vp, C.c_char_p]
     lib.atomdev_hyd_ic_ekman_spiral.argtypes = [vp, C.c_int]
     lib.atomdev_hyd_ic_circumpolar_current.argtypes = [vp, C.c_int]
@@ -327,6 +338,37 @@ class DeviceModel:
     def read_mountain_surface(self, path):
         """BC_Bathymetry_Atmosphere::BC_MountainSurface: h and Topography from the topography file."""
         self._check(self.lib.atomdev_atm_read_mountain_surface(self._h, os.fsencode(path)))
+
+    def ic_cell_structure(self, im_tropopause):
+        """BC_Thermo::IC_CellStructure; im_tropopause: tropopause level of every row (jm ints)."""
+        it = np.ascontiguousarray(im_tropopause, dtype=np.int32)
+        if it.shape != (self.jm,):
+            raise AtomDevError("im_tropopause must have jm entries")
+        self._check(self.lib.atomdev_atm_ic_cell_structure(self._h, it.ctypes.data_as(C.POINTER(C.c_int))))
+
+    def read_surface_temperature(self, path):
+        """BC_Thermo::BC_Surface_Temperature_NASA: t at the sea level and temperature_NASA from the file."""
+        self._check(self.lib.atomdev_atm_read_surface_temperature(self._h, os.fsencode(path)))
+
+    def read_surface_precipitation(self, path):
+        """BC_Thermo::BC_Surface_Precipitation_NASA: precipitation_NASA from the file."""
+        self._check(self.lib.atomdev_atm_read_surface_precipitation(self._h, os.fsencode(path)))
+
+    def bc_temperature(self, start):
+        """BC_Thermo::BC_Temperature; start: AtmStart with im_tropopause set."""
+        self._check(self.lib.atomdev_atm_bc_temperature(self._h, C.byref(start)))
+
+    def ic_temperature_west_east_coast(self):
+        self._check(self.lib.atomdev_atm_ic_temperature_west_east_coast(self._h))
+
+    def bc_pressure(self):
+        self._check(self.lib.atomdev_atm_bc_pressure(self._h))
+
+    def bc_water_vapour(self, start):
+        self._check(self.lib.atomdev_atm_bc_water_vapour(self._h, C.byref(start)))
+
+    def bc_co2(self, start):
+        self._check(self.lib.atomdev_atm_bc_co2(self._h, C.byref(start)))
 
     def run_time_slice(self, bathymetry_file, salinity_file=None, transfer_file=None, queries=True, **counts):
         """cHydrosphereModel::RunTimeSlice on the device; counts: velocity_iter_max_2D, pressure_iter_max_2D,

@@ -280,6 +280,58 @@ int atomdev_atm_run_3d_loop(atomdev_t* h, const atomdev_atm_loop* L, atomdev_atm
  * Precipitation / max_Precipitation on land surface cells that are not colder than t = 1, else 0. */
 int atomdev_atm_vegetation_distribution(atomdev_t* h, double max_Precipitation);
 
+/* ---- the atmosphere's start of a time slice (atmosphere/cAtmosphereModel.cpp:220-302) ---- */
+
+/* What BC_Thermo's constructor takes from the model beyond the scalars of struct atomdev_params - atmosphere/BC_Thermo.cpp:38-94,
+ * defaults param.py:45-58, 108-130 - and what it derives from the model's time list and temperature curve. */
+typedef struct atomdev_atm_start {
+    int Ma;                          /* time slice in million years */
+    int first_time_slice;            /* cAtmosphereModel::is_first_time_slice() */
+    int Ma_previous;                 /* the time slice before this one (read unless first_time_slice) */
+    int sun, RadiationModel, NASATemperature, declination, sun_position_lat, sun_position_lon;
+    double t_cretaceous;             /* mean temperature (Ma) - mean temperature (0) of the curve, in C (:93-94) */
+    double t_cretaceous_add;         /* (mean temperature (Ma) - mean temperature (previous Ma)) / t_0; 0 on the first slice (:446-451) */
+    double t_average, t_equator, t_pole, t_land;
+    double c_tropopause, c_ocean, c_land;
+    double co2_average, co2_equator, co2_tropopause, co2_pole, co2_cretaceous, co2_vegetation, co2_ocean, co2_land;
+    const int* im_tropopause;        /* jm tropopause levels (BC_Thermo::TropopauseLocation, :884-932: tropopause_equator everywhere) */
+} atomdev_atm_start;
+/* Defaults of param.py for the first slice at Ma = 0; im_tropopause is left NULL. */
+void atomdev_default_atm_start(atomdev_atm_start* s);
+
+/* BC_Thermo::IC_CellStructure (atmosphere/BC_Thermo.cpp:934-2307): u, v, w of the Hadley, Ferrel and polar cells - vertical
+ * profiles on thirteen rows of the 1-degree grid (jm must be 181), linear interpolation between them in the reference's
+ * order (the interpolation loops rewrite their own end rows, later loops read the rewritten values), seven-row smoothing
+ * around the cell borders, division by u_0, zero on land.  Works in place on whatever u, v, w hold, like the reference
+ * (its caller passes the reset values ua, va, wa). */
+int atomdev_atm_ic_cell_structure(atomdev_t* h, const int* im_tropopause);
+/* BC_Thermo::BC_Surface_Temperature_NASA (:2310-2350): surface temperature in C (lat lon value per line, km x jm lines,
+ * j fastest) into t at level 0 and into temperature_NASA as (value + t_0) / t_0; the column k = (km-1)/2 is replaced by the
+ * mean of its neighbours.  BC_Surface_Precipitation_NASA (:2352-2385): the same file layout into precipitation_NASA. */
+int atomdev_atm_read_surface_temperature(atomdev_t* h, const char* path);
+int atomdev_atm_read_surface_precipitation(atomdev_t* h, const char* path);
+/* BC_Thermo::BC_Temperature (:427-676): surface temperature on the topography (parabola from pole to pole on land, the
+ * file's values over the ocean, both with the increments of a paleo time slice), linear decay up to the tropopause,
+ * constant above. */
+int atomdev_atm_bc_temperature(atomdev_t* h, const atomdev_atm_start* s);
+/* BC_Thermo::IC_Temperature_WestEastCoast (:3151-3233): surface temperature held constant over seven cells off every
+ * coast, four order-dependent scans.  The model calls it when NASATemperature == 1, Ma > 0 and the plate reconstruction
+ * is off (cAtmosphereModel.cpp:276-279). */
+int atomdev_atm_ic_temperature_west_east_coast(atomdev_t* h);
+/* BC_Thermo::BC_Pressure (:2387-2407): p_stat from the surface temperature by the polytropic formula. */
+int atomdev_atm_bc_pressure(atomdev_t* h);
+/* BC_Thermo::BC_WaterVapour (:679-780): saturation vapour on the topography reduced by c_ocean / c_land plus Dalton's
+ * evaporation over the ocean (on land the value the last ocean point visited before, in (k, j) order, left behind),
+ * parabolic decrease up to the tropopause. */
+int atomdev_atm_bc_water_vapour(atomdev_t* h, const atomdev_atm_start* s);
+/* BC_Thermo::BC_CO2 (:788-881): CO2 on the topography from the pole-to-pole parabola, vegetation and the paleo increment,
+ * parabolic decrease up to the tropopause.  The reference divides its members co2_equator, co2_tropopause, ... by co2_0 in
+ * this call and its radiation model later works with the divided values: see atomdev_atm_co2_coeff. */
+int atomdev_atm_bc_co2(atomdev_t* h, const atomdev_atm_start* s);
+/* co2_coeff of atomdev_radiation as BC_Radiation_multi_layer derives it (:251-256) after BC_CO2 has run on the same
+ * BC_Thermo object: co2_factor * ((co2_equator / co2_0) / (co2_tropopause / co2_0)) if CO2 == 1, else 1. */
+double atomdev_atm_co2_coeff(double CO2, double co2_factor, double co2_equator, double co2_tropopause, double co2_0);
+
 /* ---- hydrosphere ---- */
 /* BC_Hydrosphere::RB_radius / RB_theta / RB_phi (hydrosphere/BC_Hyd.cpp:38-158) */
 int atomdev_hyd_bc_radius(atomdev_t* h);

@@ -34,6 +34,18 @@ def test_default_params_match_reference_defaults():
         assert getattr(p, name) == getattr(o, name), name
 
 
+def test_default_atm_start_matches_reference_defaults():
+    lib = atom_amd.load_library()
+    s = atom_amd.AtmStart()
+    lib.atomdev_default_atm_start(C.byref(s))
+    ref, keep = H.atm_start(181)
+    for name, _ in atom_amd.AtmStart._fields_[:-1]:
+        assert getattr(s, name) == getattr(ref, name), name
+    assert not s.im_tropopause
+    assert lib.atomdev_atm_co2_coeff(1., .98, 330., 320., 280.) == .98 * ((330. / 280.) / (320. / 280.))
+    assert lib.atomdev_atm_co2_coeff(0., .98, 330., 320., 280.) == 1.
+
+
 def test_bad_arguments_are_reported_not_crashed():
     lib = atom_amd.load_library()
     h = C.c_void_p()

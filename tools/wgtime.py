@@ -23,4 +23,9 @@ for base, tag in ((0, "first kernel"), (16384, "second kernel")):
     print(tag, "max over waves per workgroup, kilo-cycles; rows = level 1..39, columns = longitude block")
     for lev in range(39):
         print("%2d " % (lev + 1) + " ".join("%6.0f" % (t[lev, b].max() / 1e3) for b in range(gx)))
+t0 = a[16384:16384 + 39 * gx]; t1 = a[32768:32768 + 39 * gx]
+if t0.max() > 0:
+    base = t0.min()
+    print("start of workgroups after the first one, kilo-ticks: min %.1f median %.1f max %.1f" % (0, np.median(t0 - base) / 1e3, (t0 - base).max() / 1e3))
+    print("end: min %.1f median %.1f max %.1f; ticks are 10 ns" % ((t1 - base).min() / 1e3, np.median(t1 - base) / 1e3, (t1 - base).max() / 1e3))
 d.close()
