@@ -35,7 +35,8 @@ extern "C" void atomdev_default_params(int model, atomdev_params* p) {
     else { p->re = 10.; p->pr = 6.957; p->u_0 = .25; p->c_0 = 34.6; }
     p->sc_WaterVapour = .61; p->sc_CO2 = .96; p->gam = .65; p->r_air = 1.2041; p->R_Air = 287.1;
     p->R_WaterVapour = 461.6; p->L_atm = 16000.; p->cp_l = 1005.; p->t_tropopause = .798;
-    p->sc = 1.7329; p->L_hyd = 1000.; p->r_0_water = 1000.; p->ta = 1.01464; p->pa = 0.; p->ca = 1.;
+    p->sc = 1.7329; p->L_hyd = 1000.; p->r_0_water = 1000.; p->pa = 0.; p->ca = 1.;
+    p->ta = model == ATOMDEV_ATM ? 1. : 1.01464;  // param.py:102, 163
 }
 
 static bool field_used(int model, int f) {

@@ -625,6 +625,40 @@ extern "C" int atomdev_atm_ic_temperature_west_east_coast(atomdev_t* h) {
     return 0;
 }
 
+__global__ void k_restrain_temperature(double* __restrict__ t, size_t n2, double shift, double cap) {
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n2) return;
+    double v = t[q] - shift;
+    if (v > cap) v = cap;
+    t[q] = v;
+}
+
+extern "C" int atomdev_atm_restrain_temperature(atomdev_t* h, double mean_temperature) {
+    ATOMDEV_REQUIRE(h && h->model == ATOMDEV_ATM, "atomdev_atm_restrain_temperature: needs an atmosphere handle");
+    ATOMDEV_TRY(hipSetDevice(h->device));
+    const int jm = h->jm, km = h->km;
+    std::vector<double> sea(h->n2);
+    ATOMDEV_TRY(hipMemcpyAsync(sea.data(), h->f[ATOMDEV_T], h->n2 * 8, hipMemcpyDeviceToHost, h->stream));
+    ATOMDEV_TRY(hipStreamSynchronize(h->stream));
+    // calculate_mean_temperature with the weights of calculate_node_weights (:952-988): one running sum in the reference's
+    // order, the result a float
+    double ret = 0., weight = 0.;
+    for (int j = 0; j < jm; j++) {
+        const double w = j <= 90 ? std::cos((90 - j) * M_PI / 180.0) : std::cos((j - 90) * M_PI / 180.0);
+        for (int k = 0; k < km; k++) {
+            ret += sea[(size_t)j * km + k] * w;
+            weight += w;
+        }
+    }
+    const double t_0 = h->p.t_0;
+    const double tmp_2 = (float)((ret / weight - 1) * t_0);
+    const double diff = tmp_2 - mean_temperature;
+    hipLaunchKernelGGL(k_restrain_temperature, dim3((unsigned)((h->n2 + 255) / 256)), dim3(256), 0, h->stream, h->f[ATOMDEV_T], h->n2, diff / t_0,
+                       1 + 40 / t_0);
+    ATOMDEV_TRY(hipGetLastError());
+    return 0;
+}
+
 extern "C" int atomdev_atm_bc_pressure(atomdev_t* h) {
     ATOMDEV_REQUIRE(h && h->model == ATOMDEV_ATM, "atomdev_atm_bc_pressure: needs an atmosphere handle");
     ATOMDEV_TRY(hipSetDevice(h->device));

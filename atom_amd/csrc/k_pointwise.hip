@@ -156,6 +156,14 @@ extern "C" int atomdev_fill(atomdev_t* h, int field, double value) {
     return 0;
 }
 
+extern "C" int atomdev_fill2d(atomdev_t* h, int field, double value) {
+    ATOMDEV_REQUIRE(h && field >= 0 && field < ATOMDEV_N2D && h->g[field], "atomdev_fill2d: bad field");
+    ATOMDEV_TRY(hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_fill, dim3(blocks_for(h->n2)), dim3(TPB), 0, h->stream, h->g[field], value, h->n2);
+    ATOMDEV_TRY(hipGetLastError());
+    return 0;
+}
+
 extern "C" int atomdev_move_data_to_new_arrays(atomdev_t* h, int level) {
     ATOMDEV_REQUIRE(h != nullptr, "atomdev_move_data_to_new_arrays: null handle");
     ATOMDEV_REQUIRE(level < h->im, "atomdev_move_data_to_new_arrays: level out of range");

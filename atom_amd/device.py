@@ -69,12 +69,22 @@ class AtmLoop(C.Structure):
     """atomdev_atm_loop: the iteration loops of cAtmosphereModel (run_2D_loop, run_3D_loop)."""
     _fields_ = [("velocity_iter_max_2D", C.c_int), ("pressure_iter_max_2D", C.c_int), ("velocity_iter_max", C.c_int),
                 ("pressure_iter_max", C.c_int), ("column_physics", C.c_int), ("RadiationModel", C.c_int),
-                ("radiation", Radiation), ("i_trop", C.POINTER(C.c_int)), ("queries", C.c_int)]
+                ("radiation", Radiation), ("i_trop", C.POINTER(C.c_int)), ("queries", C.c_int), ("nm", C.c_int)]
 
 
 class AtmLoopState(C.Structure):
+    """atomdev_atm_loop_state"""
     _fields_ = [("q_v_hyp", C.c_double), ("S_nuc", C.c_double), ("S_i_dep", C.c_double), ("residuum", C.c_double * 2),
                 ("residuum_loc", C.c_int * 3)]
+
+
+class AtmSlice(C.Structure):
+    """atomdev_atm_slice: an atmosphere time slice as cAtmosphereModel::RunTimeSlice runs it."""
+    _fields_ = [("start", AtmStart), ("loop", AtmLoop), ("tropopause_equator", C.c_int), ("coast_correction", C.c_int),
+                ("checkpoint", C.c_int), ("CO2", C.c_double), ("co2_factor", C.c_double), ("ua", C.c_double), ("va", C.c_double),
+                ("wa", C.c_double), ("coa", C.c_double), ("mean_temperature", C.c_double), ("bathymetry_file", C.c_char_p),
+                ("temperature_file", C.c_char_p), ("precipitation_file", C.c_char_p), ("output_path", C.c_char_p),
+                ("bathymetry_name", C.c_char_p)]
 
 
 class AtomDevError(RuntimeError):
@@ -147,6 +157,11 @@ def load_library():
     for name in ("atomdev_atm_bc_temperature", "atomdev_atm_bc_water_vapour", "atomdev_atm_bc_co2"):
         getattr(lib, name).argtypes = [vp, C.POINTER(AtmStart)]
     lib.atomdev_atm_ic_temperature_west_east_coast.argtypes = [vp]
+    lib.atomdev_atm_restrain_temperature.argtypes = [vp, C.c_double]
+    lib.atomdev_default_atm_slice.argtypes = [C.POINTER(AtmSlice)]
+    lib.atomdev_default_atm_slice.restype = None
+    lib.atomdev_atm_run_time_slice.argtypes = [vp, C.POINTER(AtmSlice), C.POINTER(AtmLoopState)]
+    lib.atomdev_fill2d.argtypes = [vp, C.c_int, C.c_double]
     lib.atomdev_atm_bc_pressure.argtypes = [vp]
     lib.atomdev_hyd_read_surface_salinity.argtypes = [vp, C.c_char_p]
     lib.atomdev_hyd_ic_ekman_spiral.argtypes = [vp, C.c_int]
@@ -369,6 +384,38 @@ class DeviceModel:
 
     def bc_co2(self, start):
         self._check(self.lib.atomdev_atm_bc_co2(self._h, C.byref(start)))
+
+    def restrain_temperature(self, mean_temperature):
+        """cAtmosphereModel::restrain_temperature; mean_temperature: the curve's value for the time slice in C."""
+        self._check(self.lib.atomdev_atm_restrain_temperature(self._h, mean_temperature))
+
+    def atm_slice(self, bathymetry_file, temperature_file, precipitation_file, output_path=None, bathymetry_name=None, **values):
+        """An AtmSlice at the reference's defaults; values: fields of the slice, of its start (Ma, t_cretaceous, ...) or of
+        its loop (velocity_iter_max, ...) by name."""
+        s = AtmSlice()
+        self.lib.atomdev_default_atm_slice(C.byref(s))
+        top, start, loop = {n for n, _ in AtmSlice._fields_}, {n for n, _ in AtmStart._fields_}, {n for n, _ in AtmLoop._fields_}
+        for k, v in values.items():
+            if k in top:
+                setattr(s, k, v)
+            elif k in start:
+                setattr(s.start, k, v)
+            elif k in loop:
+                setattr(s.loop, k, v)
+            else:
+                raise AtomDevError("atm_slice: unknown value " + k)
+        s.bathymetry_file = os.fsencode(bathymetry_file)
+        s.temperature_file = os.fsencode(temperature_file)
+        s.precipitation_file = os.fsencode(precipitation_file)
+        s.output_path = os.fsencode(output_path) if output_path else None
+        s.bathymetry_name = os.fsencode(bathymetry_name) if bathymetry_name else None
+        return s
+
+    def atm_run_time_slice(self, slice_):
+        """cAtmosphereModel::RunTimeSlice on the device; returns the carried state (AtmLoopState)."""
+        state = AtmLoopState()
+        self._check(self.lib.atomdev_atm_run_time_slice(self._h, C.byref(slice_), C.byref(state)))
+        return state
 
     def run_time_slice(self, bathymetry_file, salinity_file=None, transfer_file=None, queries=True, **counts):
         """cHydrosphereModel::RunTimeSlice on the device; counts: velocity_iter_max_2D, pressure_iter_max_2D,

@@ -112,6 +112,7 @@ int atomdev_download(atomdev_t* h, int field3d, double* host);
 int atomdev_upload2d(atomdev_t* h, int field2d, const double* host);
 int atomdev_download2d(atomdev_t* h, int field2d, double* host);
 int atomdev_fill(atomdev_t* h, int field3d, double value); /* Array::initArray */
+int atomdev_fill2d(atomdev_t* h, int field2d, double value); /* Array_2D::initArray_2D */
 /* Columns k0 .. k0+nk-1 (all i, j) of a 3-D field to / from a dense buffer of im*jm rows of nk
  * doubles, in host or device memory.  This is the halo transfer of a phi-slab decomposition
  * (one slab of longitudes per GPU); the reference is single-domain and has no counterpart, the
@@ -252,9 +253,10 @@ int atomdev_atm_read_mountain_surface(atomdev_t* h, const char* path);
 /* cAtmosphereModel::run_2D_loop / run_3D_loop (atmosphere/cAtmosphereModel.cpp:660-735, 743-898) without their printing,
  * as one call each: the entry points above in the reference's order, nothing uploaded or downloaded in between.
  * column_physics != 0 adds BC_Thermo's Ice_Water_Saturation_Adjustment and Two_Category_Ice_Scheme (every second
- * velocity iteration), BC_Radiation_multi_layer, Latent_Heat and the vegetation distribution where run_3D_loop calls
- * them; the class members these carry from call to call travel in atomdev_atm_loop_state, zero at the start of a time
- * slice.  queries != 0 runs the residuum and steady-state queries where the reference does; the state receives the
+ * velocity iteration), BC_Radiation_multi_layer (when RadiationModel == 1, :828-831), Latent_Heat and the vegetation
+ * distribution where run_3D_loop calls them - with it the loop is the reference's; without it, the flow solver alone.
+ * The class members these carry from call to call travel in atomdev_atm_loop_state, zero at the start of a time slice.
+ * Both loops end after the pressure iteration that takes the count of velocity iterations beyond nm (:731-735, 891-895).  queries != 0 runs the residuum and steady-state queries where the reference does; the state receives the
  * last pair of residuum values (one Accuracy_Atm object: the second query starts from the first one's result). */
 typedef struct atomdev_atm_loop {
     int velocity_iter_max_2D, pressure_iter_max_2D, velocity_iter_max, pressure_iter_max;  /* param.py:33-36: 2, 10, 2, 2 */
@@ -263,6 +265,7 @@ typedef struct atomdev_atm_loop {
     atomdev_radiation radiation;   /* constants of BC_Radiation_multi_layer */
     const int* i_trop;             /* jm tropopause levels (cAtmosphereModel::get_tropopause), needed with column_physics */
     int queries;
+    int nm;                        /* most velocity iterations of a loop (cAtmosphereModel.h:123: 200) */
 } atomdev_atm_loop;
 typedef struct atomdev_atm_loop_state {
     double q_v_hyp, S_nuc, S_i_dep;   /* members of BC_Thermo carried between its calls */
@@ -331,6 +334,37 @@ int atomdev_atm_bc_co2(atomdev_t* h, const atomdev_atm_start* s);
 /* co2_coeff of atomdev_radiation as BC_Radiation_multi_layer derives it (:251-256) after BC_CO2 has run on the same
  * BC_Thermo object: co2_factor * ((co2_equator / co2_0) / (co2_tropopause / co2_0)) if CO2 == 1, else 1. */
 double atomdev_atm_co2_coeff(double CO2, double co2_factor, double co2_equator, double co2_tropopause, double co2_0);
+
+/* cAtmosphereModel::restrain_temperature (atmosphere/cAtmosphereModel.cpp:952-1006): the sea-level temperature shifted so
+ * that its mean, weighted with the cosine of the latitude of the 1-degree rows and rounded to float like the reference's,
+ * meets mean_temperature (get_mean_temperature_from_curve of the time slice, in C), then capped at 40 C.  The mean is
+ * summed on the host in the reference's order. */
+int atomdev_atm_restrain_temperature(atomdev_t* h, double mean_temperature);
+
+/* cAtmosphereModel::RunTimeSlice (atmosphere/cAtmosphereModel.cpp:140-341) without its printing and without the plate
+ * reconstruction script (:177-189; the caller names the surface files): reset_arrays, the topography, the initial
+ * conditions above in the reference's order, BC_Radiation_multi_layer when RadiationModel == 1, the surface loop, the
+ * volume loop with BC_Thermo's column physics, restrain_temperature, the output files - every step the entry point that
+ * stands for it, nothing uploaded or downloaded in between. */
+typedef struct atomdev_atm_slice {
+    atomdev_atm_start start;         /* im_tropopause NULL: tropopause_equator on every row (BC_Thermo::TropopauseLocation) */
+    atomdev_atm_loop loop;           /* i_trop, radiation.co2_coeff and column_physics are not read: the slice derives the
+                                      * first two (levels + the paleo shift of :226; atomdev_atm_co2_coeff) and runs the physics */
+    int tropopause_equator;          /* param.py:58 */
+    int coast_correction;            /* IC_Temperature_WestEastCoast; the model: NASATemperature == 1 && Ma > 0 && no plate reconstruction (:276) */
+    int checkpoint;                  /* output files also after every checkpoint-th pressure iteration (:886-888, param.py:37); 0: never */
+    double CO2, co2_factor;          /* param.py:41, 130 */
+    double ua, va, wa, coa;          /* reset values beyond ta, pa, ca of struct atomdev_params - param.py:97-103 */
+    double mean_temperature;         /* mean temperature (Ma) of the model's curve in C, for restrain_temperature */
+    const char* bathymetry_file;     /* bathymetry_path + "/" + bathymetry_name */
+    const char* temperature_file;
+    const char* precipitation_file;
+    const char* output_path;         /* NULL: no output files */
+    const char* bathymetry_name;     /* "<Ma>Ma_Golonka.xyz": part of every output file's name (write_file, :599-652) */
+} atomdev_atm_slice;
+/* Defaults of param.py for the first slice at Ma = 0; the five strings are left NULL. */
+void atomdev_default_atm_slice(atomdev_atm_slice* s);
+int atomdev_atm_run_time_slice(atomdev_t* h, const atomdev_atm_slice* s, atomdev_atm_loop_state* state);
 
 /* ---- hydrosphere ---- */
 /* BC_Hydrosphere::RB_radius / RB_theta / RB_phi (hydrosphere/BC_Hyd.cpp:38-158) */

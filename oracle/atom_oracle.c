@@ -2541,7 +2541,8 @@ void oracle_default_params(int model, atomdev_params* p) {
     }
     p->sc_WaterVapour = .61; p->sc_CO2 = .96; p->gam = .65; p->r_air = 1.2041; p->R_Air = 287.1;
     p->R_WaterVapour = 461.6; p->L_atm = 16000.; p->cp_l = 1005.; p->t_tropopause = .798;
-    p->sc = 1.7329; p->L_hyd = 1000.; p->r_0_water = 1000.; p->ta = 1.01464; p->pa = 0.; p->ca = 1.;
+    p->sc = 1.7329; p->L_hyd = 1000.; p->r_0_water = 1000.; p->pa = 0.; p->ca = 1.;
+    p->ta = model == ATOMDEV_ATM ? 1. : 1.01464; /* param.py:102, 163 */
 }
 
 /* ------------------------------------------------------------------------- */
@@ -3032,4 +3033,41 @@ void oracle_atm_bc_co2(oracle_ctx* c, const atomdev_atm_start* s) {
         }
     }
 #undef CO2_
+}
+
+/* cAtmosphereModel::restrain_temperature with calculate_mean_temperature and calculate_node_weights
+ * (atmosphere/cAtmosphereModel.cpp:952-1006).  mean_temperature_curve: get_mean_temperature_from_curve(Ma), the float
+ * the reference gets, widened.  The weighted mean passes through float like the reference's return value. */
+void oracle_atm_restrain_temperature(oracle_ctx* c, double mean_temperature_curve) {
+    const int jm = c->jm, km = c->km;
+    const double t_0 = c->p.t_0;
+    double ret = 0., weight = 0.;
+    for (int j = 0; j < jm; j++) {
+        const double w = j <= 90 ? cos((90 - j) * M_PI / 180.0) : cos((j - 90) * M_PI / 180.0);
+        for (int k = 0; k < km; k++) {
+            ret += A3(c, ATOMDEV_T, 0, j, k) * w;
+            weight += w;
+        }
+    }
+    const double tmp_1 = mean_temperature_curve;
+    const double tmp_2 = (float)((ret / weight - 1) * t_0);
+    const double diff = tmp_2 - tmp_1;
+    for (int j = 0; j < jm; j++)
+        for (int k = 0; k < km; k++) {
+            A3(c, ATOMDEV_T, 0, j, k) -= diff / t_0;
+            if (A3(c, ATOMDEV_T, 0, j, k) > (1 + 40 / t_0)) A3(c, ATOMDEV_T, 0, j, k) = 1 + 40 / t_0;
+        }
+}
+
+/* PostProcess_Atmosphere::Atmosphere_v_w_Transfer (atmosphere/PostProcess_Atm.cpp:98-118): "%.4f" is what an ofstream
+ * with precision(4) and ios::fixed prints */
+int oracle_atm_write_transfer_file(oracle_ctx* c, const char* path) {
+    FILE* f = fopen(path, "w");
+    if (!f) return 1;
+    for (int j = 0; j < c->jm; j++)
+        for (int k = 0; k < c->km; k++)
+            fprintf(f, "%.4f %.4f %.4f %.4f %.4f %.4f\n", A3(c, ATOMDEV_V, 0, j, k) * c->p.u_0, A3(c, ATOMDEV_W, 0, j, k) * c->p.u_0,
+                    A3(c, ATOMDEV_T, 0, j, k), A3(c, ATOMDEV_P_DYN, 0, j, k), A2(c, ATOMDEV_EVAPORATION_DALTON, j, k),
+                    A2(c, ATOMDEV_PRECIPITATION, j, k));
+    return fclose(f) != 0;
 }

@@ -13,6 +13,7 @@ import sys
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import harness as H  # noqa: E402
 
@@ -166,9 +167,67 @@ def thermo_case():
     print("bc_thermo.npz", len(out), "entries")
 
 
+def atm_slice_inputs():
+    """The reference's own input files of the atmosphere as compact arrays (tests/harness.py writes them back digit for
+    digit): the two 1-degree surface files in hundredths, the Golonka topography of the golden time slices (the doubles
+    their text stands for), and the mean temperatures the model's curve gives for the time slices involved."""
+    import ctypes as C
+    data = "/root/reference/data"
+    out = {}
+    for key, name in (("temperature_c100", "SurfaceTemperature_NASA.xyz"), ("precipitation_c100", "SurfacePrecipitation_NASA.xyz")):
+        v = np.loadtxt(os.path.join(data, name))[:, 2]
+        c = np.round(v * 100.).astype(np.int64)
+        assert np.abs(c).max() < 32768 and np.array_equal(c / 100., v)
+        out[key] = c.astype(np.int16)
+    for Ma in sorted({m for case in H.ATM_SLICE_CASES for m in case[:1]}):
+        v = np.loadtxt(os.path.join(data, "Paleotopography_bathymetry/Golonka_rev210/%dMa_Golonka.xyz" % Ma))[:, 2]
+        out["topography_%d" % Ma] = v
+    fn = H.load_ref().ref_atm_mean_temperature_from_curve
+    fn.restype = C.c_float; fn.argtypes = [C.c_float]
+    times = sorted({m for case in H.ATM_SLICE_CASES for m in case if m is not None} | {0})
+    out["curve_Ma"] = np.array(times, dtype=np.int32)
+    out["curve_temperature"] = np.array([fn(float(m)) for m in times], dtype=np.float32)
+    np.savez_compressed(H.ATM_SLICE_INPUTS, **out)
+    print("atm_slice_inputs.npz", len(out), "entries")
+    # the files written back are the reference's, byte for byte
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        H.write_atm_slice_inputs(tmp)
+        for name, ref in [("SurfaceTemperature_NASA.xyz", "SurfaceTemperature_NASA.xyz"), ("SurfacePrecipitation_NASA.xyz", "SurfacePrecipitation_NASA.xyz")] + \
+                         [("%dMa_Golonka.xyz" % m, "Paleotopography_bathymetry/Golonka_rev210/%dMa_Golonka.xyz" % m) for m, _ in H.ATM_SLICE_CASES]:
+            a, b = open(os.path.join(tmp, name), "rb").read(), open(os.path.join(data, ref), "rb").read()
+            print("  %s: %s" % (name, "same bytes" if a == b else "same values" if np.array_equal(np.loadtxt(os.path.join(tmp, name))[:, 2], np.loadtxt(os.path.join(data, ref))[:, 2]) else "DIFFERENT"))
+
+
+def atm_slice_case():
+    """cAtmosphereModel::RunTimeSlice of the compiled reference (plate reconstruction off) for the golden time slices at the
+    reference's iteration counts, from the input files as tests/harness.py writes them back."""
+    import tempfile
+    out = {}
+    dims = (41, 181, 361)
+    with tempfile.TemporaryDirectory() as tmp:
+        _, _, curve = H.write_atm_slice_inputs(tmp)
+        for Ma, prev in H.ATM_SLICE_CASES:
+            p = H.default_params(H.ATM)
+            f, g = H.atm_reset_arrays(dims, p)
+            r = H.CpuModel("ref", H.ATM, *dims, p, f, g)
+            s, keep = H.atm_slice_start(Ma, prev, curve)
+            outdir = os.path.join(tmp, "out_%d" % Ma)
+            os.makedirs(outdir)
+            H.run_ref_atm_slice(r, s, (2, 10, 2, 2), tmp, outdir)
+            out.update(H.atm_slice_record(r, outdir, "Ma%d" % Ma))
+            print("  Ma", Ma, "done")
+    np.savez_compressed(H.ATM_SLICE_GOLDEN, **out)
+    print("atm_time_slice.npz", len(out), "entries")
+
+
 if __name__ == "__main__":
     assert H.have_ref(), "build oracle/_ref first: make -C oracle ref"
     os.makedirs(GOLD, exist_ok=True)
+    if len(sys.argv) > 1:   # single cases by name
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
     masks()
     small_case(H.ATM, (7, 13, 17), H.ATM_SEQ, 11, "atm_small.npz")
     small_case(H.HYD, (7, 13, 17), H.HYD_SEQ, 12, "hyd_small.npz")
@@ -179,3 +238,5 @@ if __name__ == "__main__":
     msl_case()
     transfer_case()
     thermo_case()
+    atm_slice_inputs()
+    atm_slice_case()

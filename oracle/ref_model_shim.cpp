@@ -256,4 +256,74 @@ void ref_atm_bc_co2(void* v, const atomdev_atm_start* s) {
     th.circ->BC_CO2(B(VEGETATION), A(H), A(T), A(P_DYN), A(CO2));
 }
 
+/* ---- cAtmosphereModel::RunTimeSlice (cAtmosphereModel.cpp:140-341) as a whole ---- */
+
+struct ref_atm_slice_files {
+    const char* bathymetry_path;     /* directory of the <Ma>Ma_Golonka.xyz files */
+    const char* temperature_file;
+    const char* precipitation_file;
+    const char* output_path;
+};
+
+/* Runs the model object's own RunTimeSlice on its own arrays (the context must have the model's compile-time grid,
+ * 41 x 181 x 361) and copies every bound field out afterwards.  The plate reconstruction is switched off (its script
+ * needs pygplates): Ma > 0 reads the same surface files and runs IC_Temperature_WestEastCoast.  Returns 1 on a grid
+ * mismatch. */
+int ref_atm_run_time_slice(void* v, const atomdev_atm_start* s, const atomdev_atm_loop* L, const ref_atm_slice_files* files) {
+    RefCtx* c = (RefCtx*)v;
+    if (c->im != 41 || c->jm != 181 || c->km != 361) return 1;
+    CoutSilencer quiet;
+    cAtmosphereModel* m = model();
+    set_scalars(c->p);
+    set_start(s);
+    const atomdev_radiation* R = &L->radiation;
+    SETP(albedo_pole, R->albedo_pole); SETP(albedo_equator, R->albedo_equator);
+    SETP(epsilon_pole, R->epsilon_pole); SETP(epsilon_equator, R->epsilon_equator);
+    SETP(epsilon_tropopause, R->epsilon_tropopause); SETP(rad_pole, R->rad_pole); SETP(rad_equator, R->rad_equator);
+    SETP(sigma, R->sigma);
+    SETP(CO2, 1.);
+    SETP(velocity_iter_max_2D, L->velocity_iter_max_2D); SETP(pressure_iter_max_2D, L->pressure_iter_max_2D);
+    SETP(velocity_iter_max, L->velocity_iter_max); SETP(pressure_iter_max, L->pressure_iter_max);
+    SETP(use_earthbyte_reconstruction, false);
+    SETP(verbose, false); SETP(paraview_panorama_vts, false); SETP(debug, false);
+    SETP(bathymetry_path, std::string(files->bathymetry_path));
+    SETP(temperature_file, std::string(files->temperature_file));
+    SETP(precipitation_file, std::string(files->precipitation_file));
+    SETP(output_path, std::string(files->output_path));
+    // the time list as the slices before this one left it; RunTimeSlice inserts Ma itself (:149)
+    m->m_time_list.clear();
+    if (!s->first_time_slice) m->m_time_list.insert(float(s->Ma_previous));
+    m->m_current_time = m->m_time_list.begin();
+    m->RunTimeSlice(s->Ma);
+    struct { int id; Array* a; } f3[] = {
+        { ATOMDEV_T, &m->t }, { ATOMDEV_U, &m->u }, { ATOMDEV_V, &m->v }, { ATOMDEV_W, &m->w }, { ATOMDEV_P_DYN, &m->p_dyn },
+        { ATOMDEV_C, &m->c }, { ATOMDEV_CLOUD, &m->cloud }, { ATOMDEV_ICE, &m->ice }, { ATOMDEV_CO2, &m->co2 },
+        { ATOMDEV_TN, &m->tn }, { ATOMDEV_UN, &m->un }, { ATOMDEV_VN, &m->vn }, { ATOMDEV_WN, &m->wn },
+        { ATOMDEV_P_DYNN, &m->p_dynn }, { ATOMDEV_CN, &m->cn }, { ATOMDEV_CLOUDN, &m->cloudn }, { ATOMDEV_ICEN, &m->icen },
+        { ATOMDEV_CO2N, &m->co2n }, { ATOMDEV_H, &m->h }, { ATOMDEV_AUX_U, &m->aux_u }, { ATOMDEV_AUX_V, &m->aux_v },
+        { ATOMDEV_AUX_W, &m->aux_w }, { ATOMDEV_BUOYANCY, &m->BuoyancyForce }, { ATOMDEV_S_V, &m->S_v }, { ATOMDEV_S_C, &m->S_c },
+        { ATOMDEV_S_I, &m->S_i }, { ATOMDEV_S_R, &m->S_r }, { ATOMDEV_S_S, &m->S_s }, { ATOMDEV_P_STAT, &m->p_stat },
+        { ATOMDEV_Q_LATENT, &m->Q_Latent }, { ATOMDEV_Q_SENSIBLE, &m->Q_Sensible }, { ATOMDEV_RADIATION_3D, &m->radiation_3D },
+        { ATOMDEV_P_RAIN, &m->P_rain }, { ATOMDEV_P_SNOW, &m->P_snow }, { ATOMDEV_EPSILON_3D, &m->epsilon_3D },
+        { ATOMDEV_S_C_C, &m->S_c_c } };
+    for (auto& e : f3)
+        if (c->f[e.id])
+            for (int i = 0; i < c->im; i++)
+                for (int j = 0; j < c->jm; j++)
+                    std::memcpy(c->f[e.id] + ((size_t)i * c->jm + j) * c->km, e.a->x[i][j], sizeof(double) * c->km);
+    struct { int id; Array_2D* a; } f2[] = {
+        { ATOMDEV_TOPOGRAPHY, &m->Topography }, { ATOMDEV_EVAPORATION_DALTON, &m->Evaporation_Dalton },
+        { ATOMDEV_PRECIPITATION, &m->Precipitation }, { ATOMDEV_Q_RADIATION, &m->Q_radiation },
+        { ATOMDEV_PRECIPITABLE_WATER, &m->precipitable_water }, { ATOMDEV_EVAPORATION_PENMAN, &m->Evaporation_Penman },
+        { ATOMDEV_Q_EVAPORATION, &m->Q_Evaporation }, { ATOMDEV_Q_LATENT_2D, &m->Q_latent }, { ATOMDEV_Q_SENSIBLE_2D, &m->Q_sensible },
+        { ATOMDEV_Q_BOTTOM, &m->Q_bottom }, { ATOMDEV_CO2_TOTAL, &m->co2_total }, { ATOMDEV_VEGETATION, &m->Vegetation },
+        { ATOMDEV_ALBEDO, &m->albedo }, { ATOMDEV_EPSILON, &m->epsilon }, { ATOMDEV_RADIATION_SURFACE, &m->radiation_surface },
+        { ATOMDEV_TEMPERATURE_NASA, &m->temperature_NASA }, { ATOMDEV_PRECIPITATION_NASA, &m->precipitation_NASA },
+        { ATOMDEV_TEMP_NASA_CELSIUS, &m->temp_NASA } };
+    for (auto& e : f2)
+        if (c->g[e.id])
+            for (int j = 0; j < c->jm; j++) std::memcpy(c->g[e.id] + (size_t)j * c->km, e.a->y[j], sizeof(double) * c->km);
+    return 0;
+}
+
 }  // extern "C"

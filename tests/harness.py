@@ -663,7 +663,7 @@ def _is_device(m):
     return not hasattr(m, "ctx")
 
 
-def _atm_physics(m):
+def _atm_physics(m, radiation_constants=None):
     """The BC_Thermo column physics and the two searches between them, the same calls for the oracle and the device."""
     import atom_amd
     dev = _is_device(m)
@@ -686,9 +686,9 @@ def _atm_physics(m):
         return (st[0], st[1])
 
     def radiation(i_trop):
-        r = atom_amd.Radiation(albedo_pole=.7, albedo_equator=.15, epsilon_pole=.59, epsilon_equator=.594,
-                               epsilon_tropopause=.001, rad_pole=40., rad_equator=230., co2_coeff=.98 * (330. / 320.),
-                               sigma=5.670280e-8)   # param.py:60-70, 123-130
+        r = radiation_constants or atom_amd.Radiation(
+            albedo_pole=.7, albedo_equator=.15, epsilon_pole=.59, epsilon_equator=.594, epsilon_tropopause=.001, rad_pole=40.,
+            rad_equator=230., co2_coeff=.98 * (330. / 320.), sigma=5.670280e-8)   # param.py:60-70, 123-130
         if dev:
             m.radiation_multi_layer(i_trop, r)
         else:
@@ -713,17 +713,18 @@ def _atm_physics(m):
     return adjust, ice_scheme, radiation, max_precipitation, vegetation
 
 
-def atm_3d_loop(m, pressure_iters=2, velocity_iters=2, physics=False, i_trop=None):
+def atm_3d_loop(m, pressure_iters=2, velocity_iters=2, physics=False, i_trop=None, radiation_constants=None, radiation_model=1,
+                after_pressure=None):
     """cAtmosphereModel.cpp:756-874 with the operators of this library: returns the queries' results in call order.
     physics=True adds the BC_Thermo column physics where the reference calls it (:787-789, :828-831, :844-866;
     the saturation adjustment and the ice scheme on even velocity iterations) with the carried class members
     kept across the iterations as the reference's circulation object keeps them."""
     log = []
     if physics:
-        adjust, ice_scheme, radiation, max_precipitation, vegetation = _atm_physics(m)
+        adjust, ice_scheme, radiation, max_precipitation, vegetation = _atm_physics(m, radiation_constants)
         q_v_hyp, ice_state = 0.0, (0.0, 0.0)
     _move3d(m)
-    for _ in range(pressure_iters):
+    for pressure_iter in range(1, pressure_iters + 1):
         for velocity_iter in range(1, velocity_iters + 1):
             mn, loc = m.residuum("atm_residuum3d")
             log.append((mn, loc))
@@ -733,7 +734,7 @@ def atm_3d_loop(m, pressure_iters=2, velocity_iters=2, physics=False, i_trop=Non
                 q_v_hyp = adjust(q_v_hyp)
             for op in ("atm_value_limitation", "atm_solid_ground", "atm_rk3d", "atm_value_limitation"):
                 m.op(op)
-            if physics:
+            if physics and radiation_model == 1:
                 radiation(i_trop)
             log.append(m.residuum("atm_residuum3d", mn, loc))  # same Accuracy_Atm object: state carried
             log.append(m.steady("atm_steady3d", 9))
@@ -741,13 +742,15 @@ def atm_3d_loop(m, pressure_iters=2, velocity_iters=2, physics=False, i_trop=Non
                 m.op("atm_latent_heat")
                 vegetation(max_precipitation())
             if hasattr(m, "msl_data"):
-                m.msl_data(1)
+                m.msl_data(radiation_model)
             else:
-                m.op("atm_msl_data", C.c_int(1))
+                m.op("atm_msl_data", C.c_int(radiation_model))
             if physics and velocity_iter % 2 == 0:
                 ice_state = ice_scheme(ice_state)
             _move3d(m)
         m.op("atm_pressure3d")
+        if after_pressure:
+            after_pressure(pressure_iter)
     if physics:
         log.append((q_v_hyp, (0, 0, 0)))
         log.append((ice_state[0], (0, 0, 0)))
@@ -904,3 +907,185 @@ def make_atm_start_inputs(im, jm, km, seed):
     g["TEMPERATURE_NASA"] = (celsius + p.t_0) / p.t_0
     f["T"][0] = g["TEMPERATURE_NASA"]
     return p, f, g
+
+
+# --------------------------------------------------------------------------
+# cAtmosphereModel::RunTimeSlice (cAtmosphereModel.cpp:140-341) composed of this library's operators
+# --------------------------------------------------------------------------
+
+ATM_SLICE_FIELDS3D = ATM_FIELDS + ["P_STAT", "Q_LATENT", "Q_SENSIBLE", "RADIATION_3D", "P_RAIN", "P_SNOW", "EPSILON_3D", "S_C_C"]
+ATM_SLICE_FIELDS2D = ["TOPOGRAPHY", "EVAPORATION_DALTON", "PRECIPITATION", "Q_RADIATION", "PRECIPITABLE_WATER", "EVAPORATION_PENMAN",
+                      "Q_EVAPORATION", "Q_LATENT_2D", "Q_SENSIBLE_2D", "Q_BOTTOM", "CO2_TOTAL", "VEGETATION", "ALBEDO", "EPSILON",
+                      "RADIATION_SURFACE", "TEMPERATURE_NASA", "PRECIPITATION_NASA", "TEMP_NASA_CELSIUS"]
+
+
+def atm_reset_arrays(dims, p):
+    """reset_arrays (cAtmosphereModel.cpp:384-472): t, c, co2 and their new-level twins at ta, ca, coa (param.py:97-103),
+    everything else 0."""
+    f = {k: np.zeros(dims) for k in ATM_SLICE_FIELDS3D}
+    for k, v in (("T", p.ta), ("C", p.ca), ("CO2", 1.0)):
+        f[k][...] = v; f[k + "N"][...] = v
+    for k in ("P_DYN", "P_DYNN", "P_STAT"):
+        f[k][...] = p.pa
+    g = {k: np.zeros(dims[1:]) for k in ATM_SLICE_FIELDS2D}
+    return f, g
+
+
+def atm_2d_loop(m, pressure_iters=10, velocity_iters=2):
+    """cAtmosphereModel.cpp:667-736 without its printing."""
+    for _ in range(pressure_iters):
+        for _ in range(velocity_iters):
+            m.op("atm_bc_theta"); m.op("atm_bc_phi")
+            first = m.residuum("atm_residuum2d")
+            for op in ("atm_value_limitation", "atm_solid_ground", "atm_rk2d"):
+                m.op(op)
+            m.residuum("atm_residuum2d", *first)
+            m.steady("atm_steady2d", 3)
+            _move2d(m)
+        m.op("atm_pressure2d")
+
+
+def slice_radiation(s, co2_0=280., CO2=1., co2_factor=.98):
+    """The radiation constants of a time slice: param.py:60-70 with co2_coeff as BC_Radiation_multi_layer derives it after
+    BC_CO2 has divided the members by co2_0 (BC_Thermo.cpp:251-256, 806-812)."""
+    import atom_amd
+    coeff = co2_factor * ((s.co2_equator / co2_0) / (s.co2_tropopause / co2_0)) if CO2 == 1. else 1.
+    return atom_amd.Radiation(albedo_pole=.7, albedo_equator=.15, epsilon_pole=.59, epsilon_equator=.594, epsilon_tropopause=.001,
+                              rad_pole=40., rad_equator=230., co2_coeff=coeff, sigma=5.670280e-8)
+
+
+def tropopause_add(t_cretaceous, t_0=273.15):
+    """BC_Thermo::GetTropopauseHightAdd as its callers use it (BC_Thermo.cpp:3298-3302); C's round()."""
+    x = ((t_cretaceous / t_0) * t_0) / 2.6
+    return int(np.floor(abs(x) + 0.5) * np.sign(x))
+
+
+def atm_time_slice(m, s, i_trop, files, counts, mean_temperature, coast_correction, checkpoint=2):
+    """cAtmosphereModel::RunTimeSlice on a CPU model whose fields atm_reset_arrays made.  files: bathymetry, temperature,
+    precipitation inputs, then the output directory and the bathymetry name that goes into the output files' names; counts:
+    (velocity_iter_max_2D, pressure_iter_max_2D, velocity_iter_max, pressure_iter_max).  Returns the 3-D loop's log."""
+    bathymetry, temperature, precipitation, output_path, bathymetry_name = files
+    ip = C.POINTER(C.c_int)
+
+    def write_files(n, final):   # cAtmosphereModel::write_file (:599-652)
+        stem = "%s/[%s]" % (output_path, bathymetry_name)
+        for section, index, tag in ((0, 0, "radial"), (1, 62, "longal"), (2, 87, "zonal")):
+            fn = m.lib.oracle_write_vtk; fn.restype = C.c_int
+            assert fn(m.ctx, section, index, s.Ma, ("%s_Atm_%s_%d_%d.vtk" % (stem, tag, index, n)).encode()) == 0
+        call("atm_write_transfer_file", (stem + "_Transfer_Atm.vw").encode())
+        fn = m.lib.oracle_write_plot_data; fn.restype = C.c_int
+        assert fn(m.ctx, (stem + "_PlotData_Atm" + ("" if final else "_%d" % n) + ".xyz").encode()) == 0
+
+    def call(name, *args):
+        fn = getattr(m.lib, m.pre + name)
+        fn.restype = C.c_int
+        assert fn(m.ctx, *args) == 0, name
+
+    call("atm_read_mountain_surface", bathymetry.encode())
+    call("atm_ic_cell_structure", i_trop.ctypes.data_as(ip))
+    call("atm_read_surface_temperature", temperature.encode())
+    call("atm_read_surface_precipitation", precipitation.encode())
+    m.op("atm_bc_temperature", C.byref(s))
+    if coast_correction:
+        m.op("atm_ic_temperature_west_east_coast")
+    m.op("atm_bc_pressure")
+    m.op("atm_bc_water_vapour", C.byref(s))
+    m.op("atm_bc_co2", C.byref(s))
+    r = slice_radiation(s, m.params.co2_0)
+    levels = (i_trop + tropopause_add(s.t_cretaceous, m.params.t_0)).astype(np.int32)
+    if s.RadiationModel == 1:
+        fn = m.lib.oracle_atm_radiation_multi_layer
+        fn.argtypes = [C.c_void_p, C.c_void_p, ip]; fn.restype = None
+        fn(m.ctx, C.byref(r), levels.ctypes.data_as(ip))
+    _move3d(m)
+    _move2d(m)
+    atm_2d_loop(m, counts[1], counts[0])
+    def after_pressure(pressure_iter):   # :886-888
+        if checkpoint and pressure_iter % checkpoint == 0:
+            write_files(pressure_iter * counts[2], False)
+
+    log = atm_3d_loop(m, counts[3], counts[2], physics=True, i_trop=levels, radiation_constants=r, radiation_model=s.RadiationModel,
+                      after_pressure=after_pressure)
+    m.op("atm_restrain_temperature", C.c_double(mean_temperature))
+    write_files(counts[3] * counts[2], True)
+    return log
+
+
+# ---- the whole atmosphere time slice: inputs that travel, the reference's run, the golden record ----
+
+ATM_SLICE_INPUTS = os.path.join(ROOT, "tests", "golden", "atm_slice_inputs.npz")
+ATM_SLICE_GOLDEN = os.path.join(ROOT, "tests", "golden", "atm_time_slice.npz")
+ATM_SLICE_CASES = [(0, None), (40, 30), (140, 130)]     # (Ma, the slice before it)
+
+
+def write_atm_slice_inputs(directory):
+    """Writes the reference's input files of the atmosphere (the 1-degree surface temperature and precipitation, the
+    Golonka topography of the golden cases' time slices) from tests/golden/atm_slice_inputs.npz, in the reference's text
+    formats (the surface files digit for digit, the topography as numbers that read back to the same doubles).  Returns (temperature file, precipitation file, {Ma: mean temperature of the curve})."""
+    z = np.load(ATM_SLICE_INPUTS)
+    jm, km = 181, 361
+    for name, key in (("SurfaceTemperature_NASA.xyz", "temperature_c100"), ("SurfacePrecipitation_NASA.xyz", "precipitation_c100")):
+        v = z[key].astype(np.int64)
+        with open(os.path.join(directory, name), "w") as fh:
+            n = 0
+            for k in range(km):
+                for j in range(jm):
+                    c = int(v[n]); n += 1
+                    fh.write("%.2f %.2f %s%d.%02d\n" % (k, 90 - j, "-" if c < 0 else "", abs(c) // 100, abs(c) % 100))
+    for key in z.files:
+        if key.startswith("topography_"):
+            Ma = int(key.split("_")[1])
+            v = z[key].astype(np.float64)
+            with open(os.path.join(directory, "%dMa_Golonka.xyz" % Ma), "w") as fh:
+                n = 0
+                for j in range(jm):
+                    for k in range(km):
+                        fh.write("%d\t%d\t%r\n" % (k - 180, 90 - j, float(v[n]))); n += 1   # shortest text that reads back as v[n]
+    curve = {int(a): float(b) for a, b in zip(z["curve_Ma"], z["curve_temperature"])}
+    return (os.path.join(directory, "SurfaceTemperature_NASA.xyz"), os.path.join(directory, "SurfacePrecipitation_NASA.xyz"), curve)
+
+
+class RefSliceFiles(C.Structure):
+    _fields_ = [(n, C.c_char_p) for n in ("bathymetry_path", "temperature_file", "precipitation_file", "output_path")]
+
+
+def atm_slice_start(Ma, prev, curve):
+    """atomdev_atm_start of a golden time slice; curve: {Ma: mean temperature} or a callable."""
+    s, i_trop = atm_start(181, 30)
+    set_paleo_time(s, Ma, prev, curve if callable(curve) else (lambda a: curve[int(a)]))
+    return s, i_trop
+
+
+def run_ref_atm_slice(r, s, counts, inputs_dir, output_path):
+    """cAtmosphereModel::RunTimeSlice of the compiled reference on the CpuModel r (fields bound for copying out)."""
+    import atom_amd
+    lib = load_ref()
+    fl = RefSliceFiles(inputs_dir.encode(), os.path.join(inputs_dir, "SurfaceTemperature_NASA.xyz").encode(),
+                       os.path.join(inputs_dir, "SurfacePrecipitation_NASA.xyz").encode(), output_path.encode())
+    L = atom_amd.AtmLoop(velocity_iter_max_2D=counts[0], pressure_iter_max_2D=counts[1], velocity_iter_max=counts[2],
+                         pressure_iter_max=counts[3], column_physics=1, RadiationModel=s.RadiationModel,
+                         radiation=slice_radiation(s), queries=1, nm=200)
+    assert lib.ref_atm_run_time_slice(r.ctx, C.byref(s), C.byref(L), C.byref(fl)) == 0
+
+
+def run_oracle_atm_slice(o, s, i_trop, counts, inputs_dir, output_path, curve):
+    name = "%dMa_Golonka.xyz" % s.Ma
+    value = curve(s.Ma) if callable(curve) else curve[int(s.Ma)]
+    return atm_time_slice(o, s, i_trop, (os.path.join(inputs_dir, name), os.path.join(inputs_dir, "SurfaceTemperature_NASA.xyz"),
+                                         os.path.join(inputs_dir, "SurfacePrecipitation_NASA.xyz"), output_path, name),
+                          counts, float(np.float32(value)), coast_correction=(s.Ma > 0 and s.NASATemperature == 1))
+
+
+def atm_slice_record(m, output_path, tag):
+    """What the golden file keeps of a finished slice: SHA-256 and a sample of every field, SHA-256 of every output file."""
+    import hashlib
+    out = {}
+    for k in sorted(list(m.f) + list(m.g)):
+        if k == "RESIDUUM":
+            continue
+        a = m.f[k] if k in m.f else m.g[k]
+        out["%s/%s/sha256" % (tag, k)] = np.array(hashlib.sha256(a.tobytes()).hexdigest())
+        out["%s/%s/sample" % (tag, k)] = a[::4, 62, ::8].copy() if a.ndim == 3 else a[62, ::8].copy()
+    for fn in sorted(os.listdir(output_path)):
+        out["%s/file/%s" % (tag, fn)] = np.array(hashlib.sha256(open(os.path.join(output_path, fn), "rb").read()).hexdigest())
+    return out

@@ -1,0 +1,137 @@
+"""cAtmosphereModel::RunTimeSlice (atmosphere/cAtmosphereModel.cpp:140-341) as a whole, on the 1-degree grid with the
+reference's own input files (tests/golden/atm_slice_inputs.npz writes them back), the plate reconstruction off.
+
+* the oracle's operators composed in the reference's order against the compiled model object's own RunTimeSlice: every
+  field bit for bit, every output file byte for byte (CPU, where the reference is);
+* the oracle against the golden record of three time slices (0, 40 and 140 Ma) at the reference's iteration counts
+  (tests/golden/atm_time_slice.npz, made by oracle/make_golden.py from the compiled reference);
+* the device's atomdev_atm_run_time_slice against the oracle and against that record.
+
+Bars.  The slice runs pow/exp in the sweep and in the column physics, and the saturation adjustment iterates to a 1e-5
+exit test: last-place differences of libm grow with every call (tests/test_loops.py measures it).  The device is held to
+DEVICE_TOL per field (max |a-b| / max |b|) after the reference's full iteration set; the error of every field is printed.
+"""
+import ctypes as C
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import atom_amd
+import harness as H
+
+DIMS = (41, 181, 361)
+DEFAULT_COUNTS = (2, 10, 2, 2)      # param.py:33-36
+DEVICE_TOL = 2e-10      # measured: 1.06e-10 (c at 140 Ma), 4.4e-11 (S_c at 140 Ma), 3.7e-11 (S_c at 0 Ma)
+
+
+def _oracle_slice(tmp_path, Ma, prev, counts, curve):
+    p = H.default_params(H.ATM)
+    f, g = H.atm_reset_arrays(DIMS, p)
+    o = H.CpuModel("oracle", H.ATM, *DIMS, p, f, g)
+    s, i_trop = H.atm_slice_start(Ma, prev, curve)
+    out = str(tmp_path / ("oracle_%d" % Ma))
+    os.makedirs(out)
+    H.run_oracle_atm_slice(o, s, i_trop, counts, str(tmp_path), out, curve)
+    return p, o, s, out
+
+
+def test_slice_inputs_are_written_back(tmp_path):
+    temp, prec, curve = H.write_atm_slice_inputs(str(tmp_path))
+    t = np.loadtxt(temp)
+    assert t.shape == (181 * 361, 3) and t[0].tolist() == [0., 90., -14.89]
+    assert sorted(curve) == [0, 30, 40, 130, 140]
+    for Ma, _ in H.ATM_SLICE_CASES:
+        assert np.loadtxt(str(tmp_path / ("%dMa_Golonka.xyz" % Ma))).shape == (181 * 361, 3)
+
+
+@pytest.mark.skipif(not H.have_ref(), reason="oracle/_ref/libatomref.so not built")
+def test_atm_time_slice_oracle_vs_reference(tmp_path):
+    """A paleo slice (40 Ma after 30 Ma: the coast correction, the paleo increments) with 2 x 2 surface and 1 x 2 volume
+    iterations (the saturation adjustment and the ice scheme run once, the checkpoint files are written)."""
+    counts = (2, 2, 2, 1)
+    _, _, curve = H.write_atm_slice_inputs(str(tmp_path))
+    p, o, s, out_o = _oracle_slice(tmp_path, 40, 30, counts, curve)
+    f, g = H.atm_reset_arrays(DIMS, p)
+    r = H.CpuModel("ref", H.ATM, *DIMS, p, f, g)
+    out_r = str(tmp_path / "ref_40")
+    os.makedirs(out_r)
+    H.run_ref_atm_slice(r, s, counts, str(tmp_path), out_r)
+    for k in list(o.f) + list(o.g):
+        if k == "RESIDUUM":
+            continue
+        a, b = (o.f[k], r.f[k]) if k in o.f else (o.g[k], r.g[k])
+        assert H.bits_equal(a, b), (k, H.max_rel_err(a, b))
+    for k in ("T", "U", "V", "W", "C", "CLOUD", "ICE", "CO2", "P_DYN", "P_RAIN", "S_C_C", "Q_LATENT", "RADIATION_3D"):
+        assert not np.array_equal(o.f[k], f[k]), k
+    names = sorted(os.listdir(out_r))
+    assert len(names) == 5 and names == sorted(os.listdir(out_o))     # 1 pressure iteration: no checkpoint at 2
+    for fn in names:
+        assert open(os.path.join(out_r, fn), "rb").read() == open(os.path.join(out_o, fn), "rb").read(), fn
+
+
+def _check_against_record(m, out, tag, z):
+    rec = H.atm_slice_record(m, out, tag)
+    keys = [k for k in z.files if k.startswith(tag + "/")]
+    assert sorted(keys) == sorted(rec)
+    for k in keys:
+        if k.endswith("/sha256") or "/file/" in k:
+            assert str(rec[k]) == str(z[k]), k
+
+
+def test_atm_time_slice_oracle_golden(tmp_path):
+    """The oracle's slice at 0 Ma with the reference's iteration counts: SHA-256 of every field and of the six output files
+    as the compiled reference left them."""
+    _, _, curve = H.write_atm_slice_inputs(str(tmp_path))
+    p, o, s, out = _oracle_slice(tmp_path, 0, None, DEFAULT_COUNTS, curve)
+    _check_against_record(o, out, "Ma0", np.load(H.ATM_SLICE_GOLDEN))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Ma,prev", H.ATM_SLICE_CASES)
+def test_atm_time_slice_device(Ma, prev, tmp_path):
+    """atomdev_atm_run_time_slice with the reference's iteration counts (2 x 10 surface, 2 x 2 volume iterations, the
+    saturation adjustment and the ice scheme twice each, the checkpoint files) against the oracle's slice, which is
+    checked against the golden record here as well; the output files against the oracle's and the record."""
+    _, _, curve = H.write_atm_slice_inputs(str(tmp_path))
+    z = np.load(H.ATM_SLICE_GOLDEN)
+    tag = "Ma%d" % Ma
+    p, o, s, out_o = _oracle_slice(tmp_path, Ma, prev, DEFAULT_COUNTS, curve)
+    _check_against_record(o, out_o, tag, z)
+    d = atom_amd.DeviceModel(H.ATM, *DIMS, atom_amd.Params.from_buffer_copy(bytes(p)))
+    out_d = str(tmp_path / ("device_%d" % Ma))
+    os.makedirs(out_d)
+    name = "%dMa_Golonka.xyz" % Ma
+    sl = d.atm_slice(str(tmp_path / name), str(tmp_path / "SurfaceTemperature_NASA.xyz"), str(tmp_path / "SurfacePrecipitation_NASA.xyz"),
+                     out_d, name, coast_correction=1 if Ma > 0 else 0, mean_temperature=float(np.float32(curve[Ma])))
+    for fld, _ in atom_amd.AtmStart._fields_[:-1]:
+        setattr(sl.start, fld, getattr(s, fld))
+    state = d.atm_run_time_slice(sl)
+    errs = {}
+    for k in list(o.f) + list(o.g):
+        if k == "RESIDUUM":
+            continue
+        ref = o.f[k] if k in o.f else o.g[k]
+        assert np.isfinite(ref).all(), k
+        errs[k] = H.max_rel_err(d.download(k), ref)
+    print("\n%d Ma, device against oracle, max |a-b| / max |b| per field:" % Ma)
+    for k, e in sorted(errs.items(), key=lambda kv: -kv[1]):
+        print("  %-20s %.3e" % (k, e))
+    for k, e in errs.items():
+        assert e <= DEVICE_TOL, (k, e)
+    # samples of the compiled reference's own fields
+    for k in errs:
+        a = d.download(k)
+        sample = a[::4, 62, ::8] if a.ndim == 3 else a[62, ::8]
+        scale = max(np.abs(o.f[k] if k in o.f else o.g[k]).max(), 1e-300)
+        assert np.abs(sample - z["%s/%s/sample" % (tag, k)]).max() / scale <= DEVICE_TOL, k
+    # output files: the reference's names and bytes (the values are printed with 4 to 6 decimals)
+    names = sorted(os.listdir(out_o))
+    assert names == sorted(os.listdir(out_d)) and len(names) == 6
+    for fn in names:
+        digest = hashlib.sha256(open(os.path.join(out_d, fn), "rb").read()).hexdigest()
+        assert digest == str(z["%s/file/%s" % (tag, fn)]), fn
+    print("  the six output files carry the reference's bytes; carried members: q_v_hyp %.6e S_nuc %.6e S_i_dep %.6e"
+          % (state.q_v_hyp, state.S_nuc, state.S_i_dep))
+    d.close()
