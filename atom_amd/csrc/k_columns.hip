@@ -1,6 +1,7 @@
 // Operators that walk each (theta, phi) column level by level: a thread owns one column, a
 // wavefront covers 64 neighbouring longitudes, so every level is one coalesced row segment.
 #include "atomdev_internal.h"
+#include "cr_math.h"
 
 namespace {
 
@@ -113,12 +114,12 @@ __global__ void k_atm_msl_columns(MslArgs a) {
             const double t = a.t[id], cc = a.c[id];
             double ps;
             if (i == 0) { ps = (a.r_air * a.R_Air * t * a.t_0) * .01; ps0 = ps; }
-            else ps = exp(-a.g * (double)i * step / (a.R_Air * t * a.t_0)) * ps0;
+            else ps = cr_exp(-a.g * (double)i * step / (a.R_Air * t * a.t_0)) * ps0;
             a.p_stat[id] = ps;
             const double t_Celsius = t * a.t_0 - a.t_0;
             const double e = cc * ps / a.ep;
             const double t_denom = t_Celsius + 234.175;
-            const double E = a.hp * exp(17.0809 * t_Celsius / t_denom);
+            const double E = a.hp * cr_exp(17.0809 * t_Celsius / t_denom);
             const double Delta = 4000. * E / (t_denom * t_denom);
             const double sat_deficit = (E - e);
             const double gamma = ps0 * a.cp_l / (a.ep * a.lv);
@@ -241,11 +242,10 @@ struct RadArgs {
 };
 
 __device__ __forceinline__ double parabola(double x) { return x * x - 2 * x; }  // lib/Utils.h:41-43
-// The reference writes pow(x, 4.) and pow(y, 1. / 4.) (:262, :380, :387 ...).  Two squarings and two square roots
-// stay within 2 units in the last place of those (each step is correctly rounded), far inside the 1e-10 the
-// operator is held to, and cost a hundredth of the general pow().
-__device__ __forceinline__ double pow4(double x) { const double x2 = x * x; return x2 * x2; }
-__device__ __forceinline__ double root4(double y) { return sqrt(sqrt(y)); }
+// The reference writes pow(x, 4.) and pow(y, 1. / 4.) (:262, :380, :387 ...): the correctly rounded values from a few
+// fused operations (cr_math.h), a hundredth of the cost of the general function.
+__device__ __forceinline__ double pow4(double x) { return cr_pow4(x); }
+__device__ __forceinline__ double root4(double y) { return cr_root4(y); }
 
 __global__ void k_atm_radiation(RadArgs a) {
     const size_t n2 = (size_t)a.jm * a.km;

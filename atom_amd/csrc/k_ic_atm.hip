@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "atomdev_internal.h"
+#include "cr_math.h"
 #include "text_numbers.h"
 
 namespace {
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(256) void k_atm_bc_pressure(double* __restrict__ p_
     p_stat[q] = p0;
     for (int i = 1; i < im; i++) {
         const double hight = (double)i * (L_atm / (double)(im - 1));
-        p_stat[(size_t)i * n2 + q] = pow(((t0 * t_0 - gam * hight * 1.e-2) / (t0 * t_0)), exp_pressure) * p0;
+        p_stat[(size_t)i * n2 + q] = cr_pow(((t0 * t_0 - gam * hight * 1.e-2) / (t0 * t_0)), exp_pressure) * p0;
     }
 }
 
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(256) void k_vapour_surface(double* __restrict__ c, 
     if (q >= n2) return;
     const size_t p = (size_t)topography_level(flags, n2, q, im) * n2 + q;
     const double t_m = t[p], t_0 = S.t_0;
-    double cm = S.hp * S.ep * exp(17.0809 * (t_m * t_0 - t_0) / (234.175 + (t_m * t_0 - t_0))) / ((S.r_air * S.R_Air * t_m * t_0) * .01);
+    double cm = S.hp * S.ep * cr_exp(17.0809 * (t_m * t_0 - t_0) / (234.175 + (t_m * t_0 - t_0))) / ((S.r_air * S.R_Air * t_m * t_0) * .01);
     if (!(flags[q] & FL_LAND)) {
         cm = S.c_ocean * cm;
         const double ps = (S.r_air * S.R_Air * t_m * t_0) * .01;
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(256) void k_vapour_surface(double* __restrict__ c, 
         const double r_dry = 100. * ps / (S.R_Air * t_m * t_0);
         const double r_humid = r_dry / (1. + (S.R_WaterVapour / S.R_Air - 1.) * cm);
         const double e = cm * ps / S.ep;
-        const double E = S.hp * exp(17.2694 * (t_u - 273.15) / (t_u - 35.86));
+        const double E = S.hp * cr_exp(17.2694 * (t_u - 273.15) / (t_u - 35.86));
         const double sat_difference = (E - e);
         const double ev = 8.46e-4 * c_dalton(S.u_0, v[p], w[p]) * sat_difference * S.dt_dim / (r_humid * S.dr_dim) * 24.;
         dalton[q] = ev;

@@ -11,6 +11,7 @@
 // from the columns before it, and the last assignment of the whole grid, which is what the first columns
 // inherit from the previous pass; (3) every column runs the preparatory and the five full passes on its own.
 #include "atomdev_internal.h"
+#include "cr_math.h"
 
 namespace {
 
@@ -33,7 +34,7 @@ struct IceArgs {
 };
 
 // lib/Utils.h:79-81
-__device__ __forceinline__ double exp_func(double T_K, double co_1, double co_2) { return exp(co_1 * (T_K - 273.15) / (T_K - co_2)); }
+__device__ __forceinline__ double exp_func(double T_K, double co_1, double co_2) { return cr_exp(co_1 * (T_K - 273.15) / (T_K - co_2)); }
 
 constexpr double N_i_0 = 1.e2, m_i_0 = 1.e-12, m_i_max = 1.e-9, m_s_0 = 3.e-9;
 constexpr double c_i_dep = 1.3e-5, c_c_au = 4.e-4, c_i_au = 1.e-3, c_ac = .24, c_rim = 18.6, c_agg = 10.3, c_i_cri = .24,
@@ -58,7 +59,7 @@ __device__ __forceinline__ Local local_terms(const IceArgs& a, int i, double t, 
     const double p_SL = .01 * (a.r_air * a.R_Air * t_surface * t_0);
     const double hight = (double)i * (a.L_atm / (double)(a.im - 1));
     double p_h;
-    if (i != 0) p_h = pow(((L.t_u - a.gam * hight * 1.e-2) / (L.t_u)), exp_pressure) * p_SL;
+    if (i != 0) p_h = cr_pow(((L.t_u - a.gam * hight * 1.e-2) / (L.t_u)), exp_pressure) * p_SL;
     else p_h = p_SL;
     const double r_dry = 100. * p_h / (a.R_Air * L.t_u);
     L.r_humid = r_dry * (1. + cc) / (1. + a.R_WaterVapour / a.R_Air * cc);
@@ -69,7 +70,7 @@ __device__ __forceinline__ Local local_terms(const IceArgs& a, int i, double t, 
     L.cold = L.t_u <= t_0;
     L.N_i = 0.; L.m_i = m_i_max;
     if (L.cold) {  // :2985-2992 (where t_u > t_0 neither is read)
-        L.N_i = N_i_0 * exp(.2 * (t_0 - L.t_u));
+        L.N_i = N_i_0 * cr_exp(.2 * (t_0 - L.t_u));
         L.m_i = L.r_humid * ic / L.N_i;
         if (L.m_i > m_i_max) L.m_i = m_i_max;
         if (L.m_i < m_i_0) L.m_i = m_i_0;
@@ -84,7 +85,7 @@ __device__ __forceinline__ Local local_terms(const IceArgs& a, int i, double t, 
     // S_i_dep, :3008-3016 (t_Celsius = t_u - t_0 <= 0 exactly where t_u <= t_0)
     L.dep_def = false; L.dep_val = 0.;
     if (L.cold) {
-        if (cc > L.q_Ice) { L.dep_def = true; L.dep_val = c_i_dep * L.N_i * pow(L.m_i, (1. / 3.)) * (cc - L.q_Ice); }
+        if (cc > L.q_Ice) { L.dep_def = true; L.dep_val = c_i_dep * L.N_i * cr_pow(L.m_i, (1. / 3.)) * (cc - L.q_Ice); }
         if ((cc < L.q_Ice) && (-ic / dt_snow_dim > (cc - L.q_Ice) / dt_snow_dim)) { L.dep_def = true; L.dep_val = -ic / dt_snow_dim; }
     } else { L.dep_def = true; L.dep_val = 0.; }
     return L;
@@ -228,31 +229,31 @@ __global__ void k_ice_column_passes(IceArgs a) {
             const double S_c_frz = ((t_u < t_hn) && (cl > 0.)) ? cl / dt_rain_dim : 0.;
             const double S_c_au = ((t_u >= t_0) && (cl > 0.)) ? c_c_au * cl : 0.;
             const double S_i_au = ((t_u <= t_0) && (ic > 0.)) ? c_i_au * ic : 0.;
-            const double S_d_au = (t_u <= t_0) ? S_i_dep / (1.5 * (pow((m_s_0 / L.m_i), (2. / 3.)) - 1.)) : 0.;
-            const double S_ac = (t_u > t_0) ? c_ac * cl * pow(pr0, (7. / 9.)) : 0.;
+            const double S_d_au = (t_u <= t_0) ? S_i_dep / (1.5 * (cr_pow((m_s_0 / L.m_i), (2. / 3.)) - 1.)) : 0.;
+            const double S_ac = (t_u > t_0) ? c_ac * cl * cr_pow(pr0, (7. / 9.)) : 0.;
             const double S_rim = (t_u < t_0) ? c_rim * cl * ps0 : 0.;
             const double S_shed = (t_u >= t_0) ? c_rim * cl * ps0 : 0.;
             double S_agg = 0., S_i_cri = 0., S_r_cri = 0.;
             if (t_u <= t_0) {
                 S_agg = c_agg * ic * ps0;
-                S_i_cri = c_i_cri * ic * pow(pr0, (7. / 9.));
-                S_r_cri = c_r_cri * ic / L.m_i * pow(pr0, (13. / 9.));
+                S_i_cri = c_i_cri * ic * cr_pow(pr0, (7. / 9.));
+                S_r_cri = c_r_cri * ic / L.m_i * cr_pow(pr0, (13. / 9.));
             }
-            const double S_ev = (t_u >= t_0) ? a_ev * (1. + b_ev * pow(pr0, (1. / 6.))) * (L.q_Rain - cc) * pow(pr0, (4. / 9.)) : 0.;
-            const double S_s_dep = (t_u < t_0) ? c_s_dep * (1. + b_s_dep * pow(ps0, (5. / 26.))) * (cc - L.q_Ice) * pow(ps0, (8. / 13.)) : 0.;
+            const double S_ev = (t_u >= t_0) ? a_ev * (1. + b_ev * cr_pow(pr0, (1. / 6.))) * (L.q_Rain - cc) * cr_pow(pr0, (4. / 9.)) : 0.;
+            const double S_s_dep = (t_u < t_0) ? c_s_dep * (1. + b_s_dep * cr_pow(ps0, (5. / 26.))) * (cc - L.q_Ice) * cr_pow(ps0, (8. / 13.)) : 0.;
             const double S_i_melt = ((t_u > t_0) && (ic > 0.)) ? ic / dt_snow_dim : 0.;
             double S_s_melt = 0.;
             if (t_u > t_0) {
                 const double p_SL = .01 * (a.r_air * a.R_Air * t_surface * t_0);
                 const double hight = (double)i * (a.L_atm / (double)(im - 1));
-                const double p_t_in = pow(((t_0 - a.gam * hight * 1.e-2) / t_0), exp_pressure) * p_SL;
+                const double p_t_in = cr_pow(((t_0 - a.gam * hight * 1.e-2) / t_0), exp_pressure) * p_SL;
                 double t0v = t_0;
                 const double E_Rain_t_in = a.hp * exp_func(t0v, 17.2694, 35.86);
                 const double q_Rain_t_in = a.ep * E_Rain_t_in / (p_t_in - E_Rain_t_in);
-                S_s_melt = c_s_melt * (1. + b_s_melt * pow(ps0, (5. / 26.))) * ((t_u - t_0) + a_s_melt * (cc - q_Rain_t_in))
-                           * pow(ps0, (8. / 13.));
+                S_s_melt = c_s_melt * (1. + b_s_melt * cr_pow(ps0, (5. / 26.))) * ((t_u - t_0) + a_s_melt * (cc - q_Rain_t_in))
+                           * cr_pow(ps0, (8. / 13.));
             }
-            const double S_r_frz = (t_r_frz - t_u > 0.) ? c_r_frz * pow((t_r_frz - t_u), (3. / 2.)) * pow(pr0, (3. / 2.)) : 0.;
+            const double S_r_frz = (t_r_frz - t_u > 0.) ? c_r_frz * cr_pow((t_r_frz - t_u), (3. / 2.)) * cr_pow(pr0, (3. / 2.)) : 0.;
             const double scc = AT(s_c_c, i);
             double sv = -scc + S_ev - S_i_dep - S_s_dep - S_nuc;
             double sc = scc - S_c_au - S_ac - S_c_frz + S_i_melt - S_rim - S_shed;
@@ -382,18 +383,18 @@ __global__ __launch_bounds__(1024) void k_ice_points_passes(IceArgs a) {
         S_c_frz = ((t_u < t_hn) && (cl > 0.)) ? cl / dt_rain_dim : 0.;
         S_c_au = ((t_u >= t_0) && (cl > 0.)) ? c_c_au * cl : 0.;
         S_i_au = ((t_u <= t_0) && (ic > 0.)) ? c_i_au * ic : 0.;
-        S_d_au = (t_u <= t_0) ? S_i_dep / (1.5 * (pow((m_s_0 / L.m_i), (2. / 3.)) - 1.)) : 0.;
+        S_d_au = (t_u <= t_0) ? S_i_dep / (1.5 * (cr_pow((m_s_0 / L.m_i), (2. / 3.)) - 1.)) : 0.;
         S_i_melt = ((t_u > t_0) && (ic > 0.)) ? ic / dt_snow_dim : 0.;
         if (t_u > t_0) {  // the bracket of S_s_melt, :3087-3096
             const double exp_pressure = a.g / (1.e-2 * a.gam * a.R_Air);
             const double p_SL = .01 * (a.r_air * a.R_Air * a.t[g.q] * t_0);
             const double hight = (double)i * (a.L_atm / (double)(im - 1));
-            const double p_t_in = pow(((t_0 - a.gam * hight * 1.e-2) / t_0), exp_pressure) * p_SL;
+            const double p_t_in = cr_pow(((t_0 - a.gam * hight * 1.e-2) / t_0), exp_pressure) * p_SL;
             const double E_Rain_t_in = a.hp * exp_func(t_0, 17.2694, 35.86);
             const double q_Rain_t_in = a.ep * E_Rain_t_in / (p_t_in - E_Rain_t_in);
             melt = ((t_u - t_0) + a_s_melt * (cc - q_Rain_t_in));
         }
-        if (t_r_frz - t_u > 0.) frz = pow((t_r_frz - t_u), (3. / 2.));
+        if (t_r_frz - t_u > 0.) frz = cr_pow((t_r_frz - t_u), (3. / 2.));
         // preparatory pass, :2875-2954
         sr = ((t_u >= t_0) && (c_c_au * cl > 0.)) ? c_c_au * cl : 0.;
         ss = ((t_u < t_0) && (c_i_au * ic > 0.)) ? c_i_au * ic : 0.;
@@ -404,19 +405,19 @@ __global__ __launch_bounds__(1024) void k_ice_points_passes(IceArgs a) {
         if (pass > 0 && g.physics) {
             const double pr0 = s_pr[(i) * COLS + tx], ps0 = s_ps[(i) * COLS + tx];
             const double S_nuc = pass == 1 ? S_nuc_first : S_nuc_later;
-            const double S_ac = (t_u > t_0) ? c_ac * cl * pow(pr0, (7. / 9.)) : 0.;
+            const double S_ac = (t_u > t_0) ? c_ac * cl * cr_pow(pr0, (7. / 9.)) : 0.;
             const double S_rim = (t_u < t_0) ? c_rim * cl * ps0 : 0.;
             const double S_shed = (t_u >= t_0) ? c_rim * cl * ps0 : 0.;
             double S_agg = 0., S_i_cri = 0., S_r_cri = 0.;
             if (t_u <= t_0) {
                 S_agg = c_agg * ic * ps0;
-                S_i_cri = c_i_cri * ic * pow(pr0, (7. / 9.));
-                S_r_cri = c_r_cri * ic / L.m_i * pow(pr0, (13. / 9.));
+                S_i_cri = c_i_cri * ic * cr_pow(pr0, (7. / 9.));
+                S_r_cri = c_r_cri * ic / L.m_i * cr_pow(pr0, (13. / 9.));
             }
-            const double S_ev = (t_u >= t_0) ? a_ev * (1. + b_ev * pow(pr0, (1. / 6.))) * (L.q_Rain - cc) * pow(pr0, (4. / 9.)) : 0.;
-            const double S_s_dep = (t_u < t_0) ? c_s_dep * (1. + b_s_dep * pow(ps0, (5. / 26.))) * (cc - L.q_Ice) * pow(ps0, (8. / 13.)) : 0.;
-            const double S_s_melt = (t_u > t_0) ? c_s_melt * (1. + b_s_melt * pow(ps0, (5. / 26.))) * melt * pow(ps0, (8. / 13.)) : 0.;
-            const double S_r_frz = (t_r_frz - t_u > 0.) ? c_r_frz * frz * pow(pr0, (3. / 2.)) : 0.;
+            const double S_ev = (t_u >= t_0) ? a_ev * (1. + b_ev * cr_pow(pr0, (1. / 6.))) * (L.q_Rain - cc) * cr_pow(pr0, (4. / 9.)) : 0.;
+            const double S_s_dep = (t_u < t_0) ? c_s_dep * (1. + b_s_dep * cr_pow(ps0, (5. / 26.))) * (cc - L.q_Ice) * cr_pow(ps0, (8. / 13.)) : 0.;
+            const double S_s_melt = (t_u > t_0) ? c_s_melt * (1. + b_s_melt * cr_pow(ps0, (5. / 26.))) * melt * cr_pow(ps0, (8. / 13.)) : 0.;
+            const double S_r_frz = (t_r_frz - t_u > 0.) ? c_r_frz * frz * cr_pow(pr0, (3. / 2.)) : 0.;
             sv = -scc + S_ev - S_i_dep - S_s_dep - S_nuc;
             sc = scc - S_c_au - S_ac - S_c_frz + S_i_melt - S_rim - S_shed;
             si = S_nuc + S_c_frz + S_i_dep - S_i_melt - S_i_au - S_d_au - S_agg - S_i_cri;
@@ -521,7 +522,7 @@ __device__ AdjOut adj_point(const AdjArgs& a, int i, double t_in, double t_groun
     const double p_SL = .01 * (a.r_air * a.R_Air * t_ground * t_0);
     const double hight = (double)i * (a.L_atm / (double)(a.im - 1));
     double p_h;
-    if (i != 0) p_h = pow(((t_in * t_0 - a.gam * hight * 1.e-2) / (t_in * t_0)), exp_pressure) * p_SL;
+    if (i != 0) p_h = cr_pow(((t_in * t_0 - a.gam * hight * 1.e-2) / (t_in * t_0)), exp_pressure) * p_SL;
     else p_h = p_SL;
     if (t_Celsius >= 0.) {  // warm cloud phase, :2566-2629
         double q_T = cc + cl;
@@ -573,7 +574,7 @@ __device__ AdjOut adj_point(const AdjArgs& a, int i, double t_in, double t_groun
             if (q_c_b < 0.) q_c_b = 0.;
             if (q_i_b < 0.) q_i_b = 0.;
             if (i != 0) {
-                if (T > a.gam * hight * 1.e-2) p_h = pow(((T - a.gam * hight * 1.e-2) / (T)), exp_pressure) * p_SL;
+                if (T > a.gam * hight * 1.e-2) p_h = cr_pow(((T - a.gam * hight * 1.e-2) / (T)), exp_pressure) * p_SL;
                 else p_h = p_SL;  // the reference logs a warning here
             } else p_h = p_SL;
             E_Rain = a.hp * exp_func(T, 17.2694, 35.86);

@@ -162,6 +162,7 @@ def load_library():
     lib.atomdev_default_atm_slice.restype = None
     lib.atomdev_atm_run_time_slice.argtypes = [vp, C.POINTER(AtmSlice), C.POINTER(AtmLoopState)]
     lib.atomdev_fill2d.argtypes = [vp, C.c_int, C.c_double]
+    lib.atomdev_selftest_math.argtypes = [vp, C.c_int, C.c_size_t, dp, dp, dp]
     lib.atomdev_atm_bc_pressure.argtypes = [vp]
     lib.atomdev_hyd_read_surface_salinity.argtypes = [vp, C.c_char_p]
     lib.atomdev_hyd_ic_ekman_spiral.argtypes = [vp, C.c_int]
@@ -384,6 +385,19 @@ class DeviceModel:
 
     def bc_co2(self, start):
         self._check(self.lib.atomdev_atm_bc_co2(self._h, C.byref(start)))
+
+    def selftest_math(self, kind, x, y=None):
+        """atomdev_selftest_math: kind 0 exp, 1 pow, 2 x^4, 3 fourth root, 4 division by a known reciprocal, 5 division."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        out = np.empty_like(x)
+        dp = C.POINTER(C.c_double)
+        yp = None
+        if y is not None:
+            y = np.ascontiguousarray(y, dtype=np.float64)
+            assert y.shape == x.shape
+            yp = y.ctypes.data_as(dp)
+        self._check(self.lib.atomdev_selftest_math(self._h, kind, x.size, x.ctypes.data_as(dp), yp, out.ctypes.data_as(dp)))
+        return out
 
     def restrain_temperature(self, mean_temperature):
         """cAtmosphereModel::restrain_temperature; mean_temperature: the curve's value for the time slice in C."""

@@ -366,6 +366,17 @@ typedef struct atomdev_atm_slice {
 void atomdev_default_atm_slice(atomdev_atm_slice* s);
 int atomdev_atm_run_time_slice(atomdev_t* h, const atomdev_atm_slice* s, atomdev_atm_loop_state* state);
 
+/* The library's arithmetic helpers evaluated on the device for n caller-supplied operands (host pointers): the
+ * double-double exp / pow / x^4 / fourth root the column physics uses in place of the device library's functions, and the
+ * sweeps' division by a known reciprocal beside the hardware's IEEE division.  For property tests; no counterpart in the
+ * reference. */
+enum atomdev_selftest {
+    ATOMDEV_SELFTEST_EXP = 0, ATOMDEV_SELFTEST_POW, ATOMDEV_SELFTEST_POW4, ATOMDEV_SELFTEST_ROOT4,
+    ATOMDEV_SELFTEST_DIV_BY,   /* x / y as the sweeps divide: x * (1/y) and two fused corrections */
+    ATOMDEV_SELFTEST_DIVIDE    /* x / y */
+};
+int atomdev_selftest_math(atomdev_t* h, int kind, size_t n, const double* x, const double* y, double* out);
+
 /* ---- hydrosphere ---- */
 /* BC_Hydrosphere::RB_radius / RB_theta / RB_phi (hydrosphere/BC_Hyd.cpp:38-158) */
 int atomdev_hyd_bc_radius(atomdev_t* h);
