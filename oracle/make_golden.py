@@ -169,16 +169,17 @@ def thermo_case():
 
 def atm_slice_inputs():
     """The reference's own input files of the atmosphere as compact arrays (tests/harness.py writes them back digit for
-    digit): the two 1-degree surface files in hundredths, the Golonka topography of the golden time slices (the doubles
+    digit): the three 1-degree surface files (temperature, precipitation, salinity) in hundredths, the Golonka topography of the golden time slices (the doubles
     their text stands for), and the mean temperatures the model's curve gives for the time slices involved."""
     import ctypes as C
     data = "/root/reference/data"
     out = {}
-    for key, name in (("temperature_c100", "SurfaceTemperature_NASA.xyz"), ("precipitation_c100", "SurfacePrecipitation_NASA.xyz")):
+    for key, name in (("temperature_c100", "SurfaceTemperature_NASA.xyz"), ("precipitation_c100", "SurfacePrecipitation_NASA.xyz"),
+                      ("salinity_c100", "SurfaceSalinity_NASA.xyz")):
         v = np.loadtxt(os.path.join(data, name))[:, 2]
         c = np.round(v * 100.).astype(np.int64)
-        assert np.abs(c).max() < 32768 and np.array_equal(c / 100., v)
-        out[key] = c.astype(np.int16)
+        assert np.abs(c).max() < 2 ** 31 and np.array_equal(c / 100., v)
+        out[key] = c.astype(np.int32)
     for Ma in sorted({m for case in H.ATM_SLICE_CASES for m in case[:1]}):
         v = np.loadtxt(os.path.join(data, "Paleotopography_bathymetry/Golonka_rev210/%dMa_Golonka.xyz" % Ma))[:, 2]
         out["topography_%d" % Ma] = v
@@ -193,7 +194,7 @@ def atm_slice_inputs():
     import tempfile
     with tempfile.TemporaryDirectory() as tmp:
         H.write_atm_slice_inputs(tmp)
-        for name, ref in [("SurfaceTemperature_NASA.xyz", "SurfaceTemperature_NASA.xyz"), ("SurfacePrecipitation_NASA.xyz", "SurfacePrecipitation_NASA.xyz")] + \
+        for name, ref in [(n, n) for n in ("SurfaceTemperature_NASA.xyz", "SurfacePrecipitation_NASA.xyz", "SurfaceSalinity_NASA.xyz")] + \
                          [("%dMa_Golonka.xyz" % m, "Paleotopography_bathymetry/Golonka_rev210/%dMa_Golonka.xyz" % m) for m, _ in H.ATM_SLICE_CASES]:
             a, b = open(os.path.join(tmp, name), "rb").read(), open(os.path.join(data, ref), "rb").read()
             print("  %s: %s" % (name, "same bytes" if a == b else "same values" if np.array_equal(np.loadtxt(os.path.join(tmp, name))[:, 2], np.loadtxt(os.path.join(data, ref))[:, 2]) else "DIFFERENT"))

@@ -1019,12 +1019,13 @@ ATM_SLICE_CASES = [(0, None), (40, 30), (140, 130)]     # (Ma, the slice before 
 
 
 def write_atm_slice_inputs(directory):
-    """Writes the reference's input files of the atmosphere (the 1-degree surface temperature and precipitation, the
-    Golonka topography of the golden cases' time slices) from tests/golden/atm_slice_inputs.npz, in the reference's text
+    """Writes the reference's input files (the 1-degree surface temperature, precipitation and salinity, the Golonka
+    topography of the golden cases' time slices) from tests/golden/atm_slice_inputs.npz, in the reference's text
     formats (the surface files digit for digit, the topography as numbers that read back to the same doubles).  Returns (temperature file, precipitation file, {Ma: mean temperature of the curve})."""
     z = np.load(ATM_SLICE_INPUTS)
     jm, km = 181, 361
-    for name, key in (("SurfaceTemperature_NASA.xyz", "temperature_c100"), ("SurfacePrecipitation_NASA.xyz", "precipitation_c100")):
+    for name, key in (("SurfaceTemperature_NASA.xyz", "temperature_c100"), ("SurfacePrecipitation_NASA.xyz", "precipitation_c100"),
+                      ("SurfaceSalinity_NASA.xyz", "salinity_c100")):
         v = z[key].astype(np.int64)
         with open(os.path.join(directory, name), "w") as fh:
             n = 0
@@ -1089,3 +1090,14 @@ def atm_slice_record(m, output_path, tag):
     for fn in sorted(os.listdir(output_path)):
         out["%s/file/%s" % (tag, fn)] = np.array(hashlib.sha256(open(os.path.join(output_path, fn), "rb").read()).hexdigest())
     return out
+
+
+def hyd_reset_arrays(dims, p):
+    """cHydrosphereModel::reset_arrays (hydrosphere/cHydrosphereModel.cpp:636-694): t and c at ta and ca, the rest 0."""
+    f = {k: np.zeros(dims) for k in HYD_FIELDS}
+    for k, v in (("T", p.ta), ("C", p.ca)):
+        f[k][...] = v; f[k + "N"][...] = v
+    for k in ("P_DYN", "P_DYNN", "P_STAT"):
+        f[k][...] = p.pa
+    g = {k: np.zeros(dims[1:]) for k in FIELDS2D + RUN_DATA_FIELDS2D}
+    return f, g

@@ -5,7 +5,8 @@ reference's own input files (tests/golden/atm_slice_inputs.npz writes them back)
   field bit for bit, every output file byte for byte (CPU, where the reference is);
 * the oracle against the golden record of three time slices (0, 40 and 140 Ma) at the reference's iteration counts
   (tests/golden/atm_time_slice.npz, made by oracle/make_golden.py from the compiled reference);
-* the device's atomdev_atm_run_time_slice against the oracle and against that record.
+* the device's atomdev_atm_run_time_slice against the oracle and against that record, and the hydrosphere's time slice
+  of the same Ma behind it (atmosphere -> transfer file -> hydrosphere), device against oracle.
 
 Bars.  The slice runs pow/exp in the sweep and in the column physics, and the saturation adjustment iterates to a 1e-5
 exit test: last-place differences of libm grow with every call (tests/test_loops.py measures it).  The device is held to
@@ -23,7 +24,7 @@ import harness as H
 
 DIMS = (41, 181, 361)
 DEFAULT_COUNTS = (2, 10, 2, 2)      # param.py:33-36
-DEVICE_TOL = 2e-10      # measured: 1.06e-10 (c at 140 Ma), 4.4e-11 (S_c at 140 Ma), 3.7e-11 (S_c at 0 Ma)
+DEVICE_TOL = 1e-10      # measured: 1.7e-11 (S_c at 0 Ma), 8.7e-12 (S_c at 140 Ma), 1.7e-12 (c at 40 Ma)
 
 
 def _oracle_slice(tmp_path, Ma, prev, counts, curve):
@@ -88,6 +89,41 @@ def test_atm_time_slice_oracle_golden(tmp_path):
     _check_against_record(o, out, "Ma0", np.load(H.ATM_SLICE_GOLDEN))
 
 
+def _coupled_hydrosphere(tmp_path, Ma, o_atm, transfer_file):
+    """The hydrosphere's time slice of the same Ma behind the atmosphere's (cHydrosphereModel.cpp:234-610, the reference's
+    iteration counts): the device reads the transfer file the device atmosphere wrote, the oracle takes the oracle
+    atmosphere's surface through the same text round trip; the same Golonka file as sea ground, the surface salinity
+    file at 0 Ma."""
+    dims = DIMS
+    p = H.default_params(H.HYD)
+    f, g = H.hyd_reset_arrays(dims, p)
+    oh = H.CpuModel("oracle", H.HYD, *dims, p, f, g)
+    dh = atom_amd.DeviceModel(H.HYD, *dims, atom_amd.Params.from_buffer_copy(bytes(p)))
+    dh.upload_all(f, g)
+    bath = str(tmp_path / ("%dMa_Golonka.xyz" % Ma))
+    salt = str(tmp_path / "SurfaceSalinity_NASA.xyz")
+    oh.lib.oracle_transfer_atm_to_hyd(o_atm.ctx, oh.ctx)
+    st = H.hyd_start(dims[0], 0, Ma)
+    H.hyd_start_of_slice(oh, st, bath, salt)
+    H.hyd_2d_loop(oh, 10, 2)
+    H.hyd_3d_loop(oh, 2, 2, run_data=True)
+    dh.run_time_slice(bath, salt if Ma == 0 else None, transfer_file, Ma=Ma)
+    errs = {}
+    for k in list(f) + list(g):
+        if k == "RESIDUUM":
+            continue
+        ref = oh.f[k] if k in f else oh.g[k]
+        assert np.isfinite(ref).all(), k
+        errs[k] = H.max_rel_err(dh.download(k), ref)
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:4]
+    print("  coupled hydrosphere slice, device against oracle, the four largest: " + ", ".join("%s %.2e" % kv for kv in worst))
+    for k, e in errs.items():
+        assert e <= DEVICE_TOL, (k, e)
+    for k in ("T", "U", "V", "W", "C", "P_DYN", "UPWELLING"):
+        assert not np.array_equal(oh.f[k] if k in f else oh.g[k], f[k] if k in f else g[k]), k
+    dh.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("Ma,prev", H.ATM_SLICE_CASES)
 def test_atm_time_slice_device(Ma, prev, tmp_path):
@@ -134,4 +170,5 @@ def test_atm_time_slice_device(Ma, prev, tmp_path):
         assert digest == str(z["%s/file/%s" % (tag, fn)]), fn
     print("  the six output files carry the reference's bytes; carried members: q_v_hyp %.6e S_nuc %.6e S_i_dep %.6e"
           % (state.q_v_hyp, state.S_nuc, state.S_i_dep))
+    _coupled_hydrosphere(tmp_path, Ma, o, os.path.join(out_d, "[%s]_Transfer_Atm.vw" % name))
     d.close()
