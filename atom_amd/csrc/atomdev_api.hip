@@ -147,9 +147,11 @@ extern "C" int atomdev_create(int model, int im, int jm, int km, const atomdev_p
     h->n3 = (size_t)im * jm * km; h->n2 = (size_t)jm * km;
     h->p = *p;
     h->flags = nullptr; h->flags_dirty = true; h->h0i_valid = false;
-    h->profile_rk = false; h->prof_used = 0;
+    h->profile_rk = 0; h->prof_used = 0;
     h->scr[0] = h->scr[1] = nullptr; h->tab_rm2sin = h->tab_irm2sin = h->tab_coefv = nullptr;
-    h->rk_variant = 0;
+    // the atmosphere's sweep calls pow() per point and is held to a tolerance on every path: its default is the tolerance
+    // form of the sweep; the hydrosphere's default is the exact form, whose results carry the reference's bits
+    h->rk_variant = model == ATOMDEV_ATM ? 2 : 0;
     h->ws_params = nullptr; h->ws_err = nullptr; h->surf = nullptr; h->xfer = nullptr; h->batch = nullptr; h->batch_bytes = 0;
     if (const char* e = getenv("ATOMDEV_RK_VARIANT")) h->rk_variant = atoi(e);
     h->rad = h->sinthe = h->costhe = h->plane = nullptr; h->red = nullptr;
@@ -352,7 +354,7 @@ extern "C" int atomdev_profile_rk(atomdev_t* h, int enable) {
     ATOMDEV_REQUIRE(h != nullptr, "atomdev_profile_rk: null handle");
     ATOMDEV_TRY(hipSetDevice(h->device));
     ATOMDEV_TRY(hipStreamSynchronize(h->stream));
-    h->profile_rk = enable != 0;
+    h->profile_rk = enable;
     h->prof_used = 0;
     return 0;
 }
@@ -372,6 +374,8 @@ extern "C" int atomdev_profile_read(atomdev_t* h, float* total_ms, int* sweeps) 
     h->prof_used = 0;
     return 0;
 }
+
+extern "C" int atomdev_get_rk_variant(const atomdev_t* h) { return h ? h->rk_variant : -1; }
 
 extern "C" int atomdev_set_rk_variant(atomdev_t* h, int variant) {
     ATOMDEV_REQUIRE(h != nullptr, "atomdev_set_rk_variant: null handle");

@@ -68,7 +68,7 @@ struct atomdev {
     size_t static_scratch_bytes;
     void* pinned;                   // 256 bytes of page-locked host memory for results read back without staging
     int rk_variant;                 // 0: wave-specialised sweep (default), 1: one thread per theta line, 2: 0 in its tolerance form
-    bool profile_rk;                // bracket RK sweep kernels with events
+    int profile_rk;                 // bracket the RK sweeps with events: 1 the sweep kernel alone, 2 with the kernels that prepare it
     std::vector<hipEvent_t> prof_ev;  // pairs (start, stop), prof_used of them recorded
     size_t prof_used;
 };

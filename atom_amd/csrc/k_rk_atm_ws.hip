@@ -536,6 +536,8 @@ int ATM_WS_ENTRY(atomdev* h) {
         ATOMDEV_TRY(hipMemcpy(h->ws_params, &P, sizeof(P), hipMemcpyHostToDevice));
     }
     dim3 pg((h->km + 127) / 128, h->jm, h->im - 2);
+    if (h->profile_rk == 2)
+        if (int rc = atomdev_prof_begin(h)) return rc;  // the bracket of the whole operator
     if (h->h0i_valid)
         hipLaunchKernelGGL(k_atm_prep<false>, pg, dim3(128), 0, h->stream, h->f[ATOMDEV_T], h->g[ATOMDEV_TOPOGRAPHY], h->flags,
                            h->scr[0], h->scr[1], h->k);
@@ -544,7 +546,8 @@ int ATM_WS_ENTRY(atomdev* h) {
                            h->scr[0], h->scr[1], h->k);
     ATOMDEV_TRY(hipGetLastError());
     h->h0i_valid = true;
-    if (int rc = atomdev_prof_begin(h)) return rc;  // the event bracket times the sweep kernel alone
+    if (h->profile_rk == 1)
+        if (int rc = atomdev_prof_begin(h)) return rc;  // the bracket of the sweep kernel alone
     const unsigned gx = (h->km - 2 + 63) / 64, rounds = (h->im - 2 + 7) / 8;
     dim3 grid(8 * rounds * gx);
     ATOMDEV_REQUIRE(h->n3 * sizeof(double) < ((size_t)1 << 32), "atm_rk3d: field larger than 4 GiB");

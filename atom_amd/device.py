@@ -190,6 +190,7 @@ def load_library():
     lib.atomdev_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
     lib.atomdev_profile_rk.argtypes = [vp, C.c_int]
     lib.atomdev_set_rk_variant.argtypes = [vp, C.c_int]
+    lib.atomdev_get_rk_variant.argtypes = [vp]
     lib.atomdev_profile_read.argtypes = [vp, C.POINTER(C.c_float), ip]
     _lib = lib
     return lib
@@ -557,11 +558,16 @@ class DeviceModel:
         return ms.value
 
     def set_rk_variant(self, variant):
-        """0: wave-specialised RK sweep (default); 1: one thread per theta line."""
+        """0: wave-specialised RK sweep, exact form; 1: one thread per theta line; 2: the tolerance form of 0."""
         self._check(self.lib.atomdev_set_rk_variant(self._h, variant))
 
+    def rk_variant(self):
+        """atomdev_get_rk_variant: the form of the 3-D sweeps in use."""
+        return self.lib.atomdev_get_rk_variant(self._h)
+
     def profile_rk(self, enable=True):
-        self._check(self.lib.atomdev_profile_rk(self._h, 1 if enable else 0))
+        """True / 1: bracket the sweep kernels; 2: the sweep with the kernel that prepares it; False: off."""
+        self._check(self.lib.atomdev_profile_rk(self._h, int(enable)))
 
     def profile_read(self):
         """(summed RK sweep kernel milliseconds, number of sweeps) since the last read."""

@@ -41,12 +41,12 @@ HYD_STEP = ["hyd_bc_radius", "hyd_bc_theta", "hyd_bc_phi", "hyd_pressure_density
 
 
 def make_model(H, atom_amd, model, device, seed):
-    p = H.default_params(model)
+    p = atom_amd.default_params(model)   # the product's own defaults (param.py), no checker involved
     f, g = H.make_inputs(model, IM, JM, KM, seed, "allfluid", p)
     names = H.ATM_FIELDS if model == H.ATM else H.HYD_FIELDS
     f = {k: f[k] for k in names}
     f["H"], g["TOPOGRAPHY"] = H.load_mask_0Ma(model)
-    d = atom_amd.DeviceModel(model, IM, JM, KM, atom_amd.Params.from_buffer_copy(bytes(p)), device=device)
+    d = atom_amd.DeviceModel(model, IM, JM, KM, p, device=device)
     d.upload_all(f, g)
     d.sync()
     return d, p, f, g
@@ -67,7 +67,7 @@ def cpu_baseline(H, p, f, g, budget_s=12.0):
     (oracle/atom_oracle.c, bit-identical to the compiled reference).  Where the
     compiled reference itself travelled with the tree (oracle/_ref), its own
     solveRungeKutta_3D_Atmosphere is timed once as well."""
-    m = H.CpuModel("oracle", H.ATM, IM, JM, KM, p, f, g)
+    m = H.CpuModel("oracle", H.ATM, IM, JM, KM, H.Params.from_buffer_copy(bytes(p)), f, g)
     n, t0 = 0, time.perf_counter()
     rk_s = 0.0
     while True:
@@ -81,11 +81,17 @@ def cpu_baseline(H, p, f, g, budget_s=12.0):
             break
     dt = time.perf_counter() - t0
     m.close()
+    try:
+        host_cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        host_cores = os.cpu_count()
     out = {"value": UPDATES * n / dt, "unit": "grid-point RK updates/s", "cores": 1, "kind": "port",
-           "sample": "%d step(s) of the same workload (41x181x361, 0 Ma mask), %.1f s; RK sweep alone %.2f s/sweep"
-                     % (n, dt, rk_s / n)}
+           "host_cores": host_cores, "host_cores_machine": os.cpu_count(),
+           "sample": "%d step(s) of the same workload (41x181x361, 0 Ma mask), %.1f s on 1 of %d cores this process may use "
+                     "(the sweep is one lexicographic Gauss-Seidel chain: the reference runs it on one core); RK sweep alone "
+                     "%.2f s/sweep" % (n, dt, host_cores, rk_s / n)}
     if H.have_ref():
-        r = H.CpuModel("ref", H.ATM, IM, JM, KM, p, f, g)
+        r = H.CpuModel("ref", H.ATM, IM, JM, KM, H.Params.from_buffer_copy(bytes(p)), f, g)
         t1 = time.perf_counter()
         r.op("atm_rk3d")
         out["reference_rk_sweep_s"] = time.perf_counter() - t1  # includes flat<->jagged Array copies of the shim
@@ -96,8 +102,8 @@ def cpu_baseline(H, p, f, g, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo to rehearse "
                                                       "several ranks on one GPU)")
@@ -150,6 +156,23 @@ def main():
     elapsed = time.perf_counter() - t0
     rk_ms, rk_n = atm.profile_read()
     atm.profile_rk(False)
+    variant = atm.rk_variant()
+
+    # outside the timed region: the sweep with the kernel that prepares its inputs in one bracket, and the exact form
+    def sweep_ms(profile_mode, rk_variant, steps=40):
+        atm.set_rk_variant(rk_variant)
+        for s in range(4):
+            dev_step(atm, ATM_STEP, s, "atm_pressure3d")
+        atm.profile_rk(profile_mode)
+        for s in range(steps):
+            dev_step(atm, ATM_STEP, s, "atm_pressure3d")
+        ms, n = atm.profile_read()
+        atm.profile_rk(False)
+        atm.set_rk_variant(variant)
+        return ms / n
+
+    operator_ms = sweep_ms(2, variant) if rank == 0 else None
+    exact_ms = sweep_ms(1, 0) if rank == 0 else None
 
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
@@ -165,7 +188,7 @@ def main():
         hyd.profile_rk(True)
         hyd.sync()
         th = time.perf_counter()
-        nh = 10
+        nh = 100
         for s in range(nh):
             dev_step(hyd, HYD_STEP, s, "hyd_pressure3d")
         hyd.sync()
@@ -178,17 +201,28 @@ def main():
         except Exception:
             pass
         hyd_info = {"updates_per_s": UPDATES * nh / th, "ms_per_step": 1e3 * th / nh, "rk_traffic": hyd_traffic,
+                    "rk_traffic_source": "profiles/pmc_hyd_rk3d.json (offline PMC pass, not measured in this run)",
                     "rk_sweep_ms": hms / hn,
                     "rk_hbm_frac": UPDATES * HYD_BYTES_PER_UPDATE / (hms / hn * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
     if rank == 0:
         rk_avg_s = rk_ms / rk_n * 1e-3
         achieved = UPDATES * ATM_BYTES_PER_UPDATE / rk_avg_s / 1e9
-        traffic = None
+        traffic, issue = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_atm_rk3d.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                rec = json.load(open(pmc))
+                traffic = rec.get("hbm_bytes_per_launch")
+                # the second bound of this kernel: fp64 vector instructions issue at one per 4.2 cycles per SIMD (measured),
+                # 234 workgroups x 4 SIMDs are in use
+                valu = rec.get("sq_insts_valu_per_launch")
+                if valu:
+                    simds, clock_hz, cycles = 936, 2.07e9, 4.2
+                    floor_s = valu * cycles / simds / clock_hz
+                    issue = {"bound": "fp64 issue", "valu_wave_insts": valu, "cycles_per_inst": cycles, "simds_used": simds,
+                             "clock_ghz": clock_hz / 1e9, "floor_ms": floor_s * 1e3, "frac": floor_s / rk_avg_s,
+                             "source": "profiles/pmc_atm_rk3d.json (offline PMC pass)"}
             except Exception:
                 traffic = None
         out = {
@@ -204,7 +238,13 @@ def main():
                        "grid": [IM, JM, KM], "updates_per_step_per_gpu": UPDATES, "parallelism": "independent slices"},
             "roofline": {"bound": "hbm", "kernel": "k_atm_rk3d_ws", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "bytes_per_update": ATM_BYTES_PER_UPDATE, "kernel_ms": rk_avg_s * 1e3, "launches": rk_n},
+                         "traffic_source": "profiles/pmc_atm_rk3d.json (offline PMC pass, not measured in this run)",
+                         "bytes_per_update": ATM_BYTES_PER_UPDATE, "kernel_ms": rk_avg_s * 1e3, "launches": rk_n,
+                         "rk_variant": variant,
+                         "operator_ms": operator_ms,    # the sweep and the kernel that prepares its pressure-height term
+                         "frac_operator": UPDATES * ATM_BYTES_PER_UPDATE / (operator_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "exact_form_kernel_ms": exact_ms,
+                         "fp64_issue": issue},
             "hydrosphere": hyd_info,
         }
         if not args.no_cpu:

@@ -504,20 +504,25 @@ int atomdev_timer_start(atomdev_t* h);
 int atomdev_timer_stop(atomdev_t* h, float* milliseconds);
 
 /* Tuning knob without a reference counterpart: which kernel form the 3-D RK sweeps
- * use.  0 (default): wave-specialised, one prognostic variable per wave, 64 lines
- * per workgroup.  1: one thread per theta line.  Both give the same bits.  2: the
- * kernel of 0 in its tolerance form - a division by a loop-invariant divisor is one
- * multiplication by its reciprocal and products feeding sums are fused - which costs up
+ * use.  0: wave-specialised, one prognostic variable per wave, 64 lines per workgroup, every
+ * operation rounded as the reference's.  1: one thread per theta line.  Both give the same
+ * bits.  2: the kernel of 0 in its tolerance form - a division by a loop-invariant divisor is
+ * one multiplication by its reciprocal and products feeding sums are fused - which costs up
  * to one unit in the last place per operation (measured on the 1-degree grid: every field
- * of a sweep within 3e-14 of variant 0) and about a fifth less time.  The
- * environment variable ATOMDEV_RK_VARIANT sets the initial value. */
+ * of a sweep within 3e-14 of variant 0, a whole time slice with the column physics as far from
+ * the reference as with variant 0) and about a fifth less time.  Initial value: 2 for an
+ * atmosphere handle (its sweep calls pow() per point and is held to a tolerance in any form),
+ * 0 for a hydrosphere handle (bit-exact against the reference); the environment variable
+ * ATOMDEV_RK_VARIANT overrides both.  atomdev_get_rk_variant returns the current value. */
 int atomdev_set_rk_variant(atomdev_t* h, int variant);
+int atomdev_get_rk_variant(const atomdev_t* h);
 
 /* Per-launch timing of the 3-D RK sweep kernels, without host synchronisation in
  * between: while enabled, every atomdev_atm_rk3d / atomdev_hyd_rk3d call brackets
- * its sweep kernel(s) with HIP events on the handle's stream.  atomdev_profile_read
- * waits for the stream, returns the summed kernel time and the number of sweeps
- * since the last read, and resets both. */
+ * its sweep kernel(s) with HIP events on the handle's stream (enable = 1), or the sweep
+ * together with the kernel that prepares its per-point inputs (enable = 2; the atmosphere's
+ * pressure-height term).  atomdev_profile_read waits for the stream, returns the summed
+ * time and the number of sweeps since the last read, and resets both. */
 int atomdev_profile_rk(atomdev_t* h, int enable);
 int atomdev_profile_read(atomdev_t* h, float* total_ms, int* sweeps);
 
