@@ -152,7 +152,7 @@ extern "C" int atomdev_create(int model, int im, int jm, int km, const atomdev_p
     // the atmosphere's sweep calls pow() per point and is held to a tolerance on every path: its default is the tolerance
     // form of the sweep; the hydrosphere's default is the exact form, whose results carry the reference's bits
     h->rk_variant = model == ATOMDEV_ATM ? 2 : 0;
-    h->ws_params = nullptr; h->ws_err = nullptr; h->surf = nullptr; h->xfer = nullptr; h->batch = nullptr; h->batch_bytes = 0;
+    h->ws_params = nullptr; h->surf = nullptr; h->xfer = nullptr; h->batch = nullptr; h->batch_bytes = 0;
     if (const char* e = getenv("ATOMDEV_RK_VARIANT")) h->rk_variant = atoi(e);
     h->rad = h->sinthe = h->costhe = h->plane = nullptr; h->red = nullptr;
     h->static_scratch = nullptr; h->static_scratch_bytes = 0; h->pinned = nullptr;
@@ -183,6 +183,7 @@ extern "C" int atomdev_create(int model, int im, int jm, int km, const atomdev_p
     if ((rc = atomdev_check(hipMalloc(&h->red, h->red_bytes), "hipMalloc(red)"))) return fail(rc);
 
     if ((rc = atomdev_check(hipHostMalloc(&h->pinned, 256, hipHostMallocDefault), "hipHostMalloc(pinned)"))) return fail(rc);
+    memset(h->pinned, 0, 256);
     if ((rc = atomdev_static_scratch_init(h))) return fail(rc);
     if ((rc = upload_tables(h))) return fail(rc);
     for (int n = 0; n < 2; n++)
@@ -196,11 +197,11 @@ extern "C" int atomdev_set_params(atomdev_t* h, const atomdev_params* p) {
     ATOMDEV_REQUIRE(h != nullptr && p != nullptr, "atomdev_set_params: null argument");
     ATOMDEV_REQUIRE(p->dt > 0 && p->dr > 0 && p->dthe > 0 && p->dphi > 0, "atomdev_set_params: step sizes must be positive");
     ATOMDEV_TRY(hipSetDevice(h->device));
-    ATOMDEV_TRY(hipStreamSynchronize(h->stream));
+    if (int rc__ = atomdev_sync_stream(h)) return rc__;
     h->p = *p;
     fill_constants(h);
     if (int rc = upload_tables(h)) return rc;
-    if (h->ws_params) { ATOMDEV_TRY(hipFree(h->ws_params)); h->ws_params = nullptr; h->ws_err = nullptr; }  // holds a copy of the constants
+    if (h->ws_params) { ATOMDEV_TRY(hipFree(h->ws_params)); h->ws_params = nullptr; }  // holds a copy of the constants
     h->h0i_valid = false;
     return 0;
 }
@@ -255,7 +256,7 @@ extern "C" int atomdev_upload(atomdev_t* h, int field, const double* host) {
     if (int rc = check3d(h, field, host, "atomdev_upload")) return rc;
     ATOMDEV_TRY(hipSetDevice(h->device));
     ATOMDEV_TRY(hipMemcpyAsync(h->f[field], host, h->n3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    ATOMDEV_TRY(hipStreamSynchronize(h->stream));  // the host buffer may be reused at once
+    if (int rc__ = atomdev_sync_stream(h)) return rc__;  // the host buffer may be reused at once
     if (field == ATOMDEV_H) h->flags_dirty = true;
     return 0;
 }
@@ -264,7 +265,7 @@ extern "C" int atomdev_download(atomdev_t* h, int field, double* host) {
     if (int rc = check3d(h, field, host, "atomdev_download")) return rc;
     ATOMDEV_TRY(hipSetDevice(h->device));
     ATOMDEV_TRY(hipMemcpyAsync(host, h->f[field], h->n3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    ATOMDEV_TRY(hipStreamSynchronize(h->stream));
+    if (int rc__ = atomdev_sync_stream(h)) return rc__;
     return 0;
 }
 
@@ -272,7 +273,7 @@ extern "C" int atomdev_upload2d(atomdev_t* h, int field, const double* host) {
     ATOMDEV_REQUIRE(h && host && field >= 0 && field < ATOMDEV_N2D, "atomdev_upload2d: bad argument");
     ATOMDEV_TRY(hipSetDevice(h->device));
     ATOMDEV_TRY(hipMemcpyAsync(h->g[field], host, h->n2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    ATOMDEV_TRY(hipStreamSynchronize(h->stream));
+    if (int rc__ = atomdev_sync_stream(h)) return rc__;
     if (field == ATOMDEV_TOPOGRAPHY) h->h0i_valid = false;
     return 0;
 }
@@ -281,7 +282,7 @@ extern "C" int atomdev_download2d(atomdev_t* h, int field, double* host) {
     ATOMDEV_REQUIRE(h && host && field >= 0 && field < ATOMDEV_N2D, "atomdev_download2d: bad argument");
     ATOMDEV_TRY(hipSetDevice(h->device));
     ATOMDEV_TRY(hipMemcpyAsync(host, h->g[field], h->n2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    ATOMDEV_TRY(hipStreamSynchronize(h->stream));
+    if (int rc__ = atomdev_sync_stream(h)) return rc__;
     return 0;
 }
 
@@ -294,7 +295,7 @@ static int copy_columns(atomdev_t* h, int field, int k0, int nk, void* buf, bool
     double* f = h->f[field] + k0;
     if (to_buf) ATOMDEV_TRY(hipMemcpy2DAsync(buf, w, f, pitch, w, rows, hipMemcpyDefault, h->stream));
     else ATOMDEV_TRY(hipMemcpy2DAsync(f, pitch, buf, w, w, rows, hipMemcpyDefault, h->stream));
-    ATOMDEV_TRY(hipStreamSynchronize(h->stream));
+    if (int rc__ = atomdev_sync_stream(h)) return rc__;
     if (!to_buf && field == ATOMDEV_H) h->flags_dirty = true;
     return 0;
 }
@@ -307,17 +308,25 @@ extern "C" int atomdev_set_columns(atomdev_t* h, int field3d, int k0, int nk, co
     return copy_columns(h, field3d, k0, nk, const_cast<void*>(src), false, "atomdev_set_columns");
 }
 
+// Waits for the handle's stream and then looks at the word in page-locked host memory that a kernel sets when it
+// could not finish its work properly (the hydrosphere sweep's wait between workgroups).  Every entry point that hands
+// data to the host or reports completion waits through this function, so such a failure surfaces with the first
+// result that could contain it, once.
+int atomdev_sync_stream(atomdev* h) {
+    ATOMDEV_TRY(hipStreamSynchronize(h->stream));
+    volatile int* err = atomdev_kernel_error_word(h);
+    if (*err) {
+        *err = 0;
+        atomdev_set_error("hyd_rk3d: level im-2 gave up waiting for the salinity rows of level im-3; the fields of the last sweep are not valid");
+        return 1;
+    }
+    return 0;
+}
+
 extern "C" int atomdev_sync(atomdev_t* h) {
     ATOMDEV_REQUIRE(h != nullptr, "atomdev_sync: null handle");
     ATOMDEV_TRY(hipSetDevice(h->device));
-    ATOMDEV_TRY(hipStreamSynchronize(h->stream));
-    if (h->ws_err) {  // a wave of the hydrosphere sweep that waited for another workgroup and gave up
-        int err = 0;
-        ATOMDEV_TRY(hipMemcpy(&err, h->ws_err, sizeof(int), hipMemcpyDeviceToHost));
-        if (err) ATOMDEV_TRY(hipMemset(h->ws_err, 0, sizeof(int)));  // reported once
-        ATOMDEV_REQUIRE(err == 0, "hyd_rk3d: level im-2 gave up waiting for the salinity rows of level im-3; the fields of the last sweep are not valid");
-    }
-    return 0;
+    return atomdev_sync_stream(h);
 }
 
 extern "C" int atomdev_timer_start(atomdev_t* h) {
@@ -353,7 +362,7 @@ int atomdev_prof_end(atomdev* h) { return h->profile_rk ? prof_record(h) : 0; }
 extern "C" int atomdev_profile_rk(atomdev_t* h, int enable) {
     ATOMDEV_REQUIRE(h != nullptr, "atomdev_profile_rk: null handle");
     ATOMDEV_TRY(hipSetDevice(h->device));
-    ATOMDEV_TRY(hipStreamSynchronize(h->stream));
+    if (int rc__ = atomdev_sync_stream(h)) return rc__;
     h->profile_rk = enable;
     h->prof_used = 0;
     return 0;
@@ -362,7 +371,7 @@ extern "C" int atomdev_profile_rk(atomdev_t* h, int enable) {
 extern "C" int atomdev_profile_read(atomdev_t* h, float* total_ms, int* sweeps) {
     ATOMDEV_REQUIRE(h && total_ms && sweeps, "atomdev_profile_read: null argument");
     ATOMDEV_TRY(hipSetDevice(h->device));
-    ATOMDEV_TRY(hipStreamSynchronize(h->stream));
+    if (int rc__ = atomdev_sync_stream(h)) return rc__;
     float sum = 0.f;
     for (size_t i = 0; i + 1 < h->prof_used; i += 2) {
         float ms = 0.f;

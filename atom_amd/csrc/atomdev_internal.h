@@ -63,10 +63,10 @@ struct atomdev {
     void* surf;                     // skewed copy of the surface fields for the 2-D sweep (lazy)
     void* ws_params;                // device copy of the wave-specialised sweep's argument block(s) (lazy)
     const double* ws_cur0;          // hyd: f[T] at the time the blocks were built (tells the buffer orientation)
-    int* ws_err;                    // hyd: device word the sweep sets when a wait between workgroups gave up (lazy)
     void* static_scratch;           // this GPU's copy of the library's static scratch array (k_accuracy.hip)
     size_t static_scratch_bytes;
-    void* pinned;                   // 256 bytes of page-locked host memory for results read back without staging
+    void* pinned;                   // 256 bytes of page-locked host memory: results read back without staging (first half),
+                                    // the word kernels set on a failure they detect themselves (byte 128)
     int rk_variant;                 // 0: wave-specialised sweep (default), 1: one thread per theta line, 2: 0 in its tolerance form
     int profile_rk;                 // bracket the RK sweeps with events: 1 the sweep kernel alone, 2 with the kernels that prepare it
     std::vector<hipEvent_t> prof_ev;  // pairs (start, stop), prof_used of them recorded
@@ -84,6 +84,8 @@ int atomdev_upload_mask_bytes(atomdev* h, const uint8_t* solid);  // k_pointwise
 int atomdev_fill_theta_neumann(atomdev* h, int field);            // k_bc_pressure.hip
 int atomdev_fill_phi_seam(atomdev* h, int field, int j0, int j1);  // k_bc_pressure.hip
 int atomdev_static_scratch_init(atomdev* h);  // k_accuracy.hip
+int atomdev_sync_stream(atomdev* h);          // atomdev_api.hip: hipStreamSynchronize + the kernels' own failure word
+inline volatile int* atomdev_kernel_error_word(atomdev* h) { return (volatile int*)((char*)h->pinned + 128); }
 int atomdev_atm_rk3d_ws(atomdev* h);    // k_rk_atm_ws.hip
 int atomdev_atm_rk3d_ws_fast(atomdev* h);  // k_rk_atm_ws.hip compiled with -DATOMDEV_RK_FAST
 int atomdev_hyd_rk3d_ws(atomdev* h);    // k_rk_hyd_ws.hip

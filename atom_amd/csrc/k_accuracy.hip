@@ -237,7 +237,7 @@ int residuum(atomdev* h, bool three_d, bool ge, double* min, int loc[3], const R
         }
     } else {
         if (need > h->red_bytes) {
-            ATOMDEV_TRY(hipStreamSynchronize(h->stream));
+            if (int rc__ = atomdev_sync_stream(h)) return rc__;
             ATOMDEV_TRY(hipFree(h->red));
             h->red = nullptr; h->red_bytes = 0;
             ATOMDEV_TRY(hipMalloc(&h->red, need));
@@ -267,7 +267,7 @@ int residuum(atomdev* h, bool three_d, bool ge, double* min, int loc[3], const R
     double stack_res[2];
     double* res = fixed ? fixed->host_result : stack_res;   // pinned memory of the handle / pageable
     ATOMDEV_TRY(hipMemcpyAsync(res, out, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    ATOMDEV_TRY(hipStreamSynchronize(h->stream));
+    if (int rc__ = atomdev_sync_stream(h)) return rc__;
     *min = res[0];
     long pos = (long)res[1];
     if (pos >= 0) {
@@ -296,7 +296,7 @@ int steady(atomdev* h, const int* ids, int nf, size_t off, size_t n, bool last, 
     ATOMDEV_TRY(hipGetLastError());
     Best res[9];
     ATOMDEV_TRY(hipMemcpyAsync(res, fin, nf * sizeof(Best), hipMemcpyDeviceToHost, h->stream));
-    ATOMDEV_TRY(hipStreamSynchronize(h->stream));
+    if (int rc__ = atomdev_sync_stream(h)) return rc__;
     const long long n2 = (long long)h->n2;
     for (int f = 0; f < nf; f++) {
         double v = res[f].v;
@@ -376,7 +376,7 @@ int minmax(atomdev* h, const double* x, bool two_d, double out[2], int loc[6]) {
     ATOMDEV_TRY(hipGetLastError());
     struct { Ext e; double first; } r;
     ATOMDEV_TRY(hipMemcpyAsync(&r, fin, sizeof(r), hipMemcpyDeviceToHost, h->stream));
-    ATOMDEV_TRY(hipStreamSynchronize(h->stream));
+    if (int rc__ = atomdev_sync_stream(h)) return rc__;
     const long long none = 1LL << 62;
     // seeds: MinMax_Atm starts both scans from the first element (which the 2-D scan, interior only, never visits);
     // MinMax_Hyd starts the maximum from 0 and the minimum from the maximum it found

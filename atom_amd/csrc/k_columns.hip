@@ -508,7 +508,7 @@ extern "C" int atomdev_atm_radiation_multi_layer(atomdev_t* h, const atomdev_rad
     const size_t need = (size_t)h->jm * sizeof(int);
     ATOMDEV_REQUIRE(need <= h->red_bytes, "atomdev_atm_radiation_multi_layer: scratch too small");
     ATOMDEV_TRY(hipMemcpyAsync(h->red, i_trop, need, hipMemcpyHostToDevice, h->stream));
-    ATOMDEV_TRY(hipStreamSynchronize(h->stream));  // the caller's array may change after the call
+    if (int rc__ = atomdev_sync_stream(h)) return rc__;  // the caller's array may change after the call
     RadArgs a;
     a.t = h->f[ATOMDEV_T]; a.c = h->f[ATOMDEV_C]; a.cloud = h->f[ATOMDEV_CLOUD]; a.ice = h->f[ATOMDEV_ICE];
     a.epsilon_3d = h->f[ATOMDEV_EPSILON_3D]; a.radiation_3d = h->f[ATOMDEV_RADIATION_3D];

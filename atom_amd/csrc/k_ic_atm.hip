@@ -479,7 +479,7 @@ int upload_tropopause(atomdev* h, const int* im_tropopause, int add, const char*
         ATOMDEV_REQUIRE(im_tropopause[j] + add >= 1 && im_tropopause[j] + add <= h->im - 1,
                         std::string(who) + ": a tropopause level (with the paleo shift) outside 1 .. im-1");
     ATOMDEV_TRY(hipMemcpyAsync(h->red, im_tropopause, (size_t)h->jm * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    ATOMDEV_TRY(hipStreamSynchronize(h->stream));  // the caller's array may go out of scope
+    if (int rc__ = atomdev_sync_stream(h)) return rc__;  // the caller's array may go out of scope
     *dev = (int*)h->red;
     return 0;
 }
@@ -533,7 +533,7 @@ extern "C" int atomdev_atm_ic_cell_structure(atomdev_t* h, const int* im_tropopa
     ATOMDEV_TRY(hipMemcpyAsync(h->red, &table, sizeof(table), hipMemcpyHostToDevice, h->stream));
     trop = (int*)((char*)h->red + sizeof(CellOps));
     ATOMDEV_TRY(hipMemcpyAsync(trop, im_tropopause, (size_t)h->jm * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    ATOMDEV_TRY(hipStreamSynchronize(h->stream));  // both sources leave scope
+    if (int rc__ = atomdev_sync_stream(h)) return rc__;  // both sources leave scope
     FieldsUVW F{ { h->f[ATOMDEV_U], h->f[ATOMDEV_V], h->f[ATOMDEV_W] } };
     hipLaunchKernelGGL(k_atm_cell_structure, dim3((h->km + 63) / 64, h->im), dim3(64), 0, h->stream, F, h->flags, trop, (const CellOps*)h->red,
                        h->im, h->jm, h->km, h->p.u_0);
@@ -554,7 +554,7 @@ extern "C" int atomdev_atm_read_surface_temperature(atomdev_t* h, const char* pa
         plane[(size_t)j * km + k_half] = (plane[(size_t)j * km + k_half + 1] + plane[(size_t)j * km + k_half - 1]) / 2.;
     ATOMDEV_TRY(hipMemcpyAsync(h->f[ATOMDEV_T], plane.data(), h->n2 * 8, hipMemcpyHostToDevice, h->stream));
     ATOMDEV_TRY(hipMemcpyAsync(h->g[ATOMDEV_TEMPERATURE_NASA], plane.data(), h->n2 * 8, hipMemcpyHostToDevice, h->stream));
-    ATOMDEV_TRY(hipStreamSynchronize(h->stream));
+    if (int rc__ = atomdev_sync_stream(h)) return rc__;
     return 0;
 }
 
@@ -567,7 +567,7 @@ extern "C" int atomdev_atm_read_surface_precipitation(atomdev_t* h, const char* 
     for (int k = 0; k < km; k++)
         for (int j = 0; j < jm; j++) plane[(size_t)j * km + k] = values[(size_t)k * jm + j];
     ATOMDEV_TRY(hipMemcpyAsync(h->g[ATOMDEV_PRECIPITATION_NASA], plane.data(), h->n2 * 8, hipMemcpyHostToDevice, h->stream));
-    ATOMDEV_TRY(hipStreamSynchronize(h->stream));
+    if (int rc__ = atomdev_sync_stream(h)) return rc__;
     return 0;
 }
 
@@ -640,7 +640,7 @@ extern "C" int atomdev_atm_restrain_temperature(atomdev_t* h, double mean_temper
     const int jm = h->jm, km = h->km;
     std::vector<double> sea(h->n2);
     ATOMDEV_TRY(hipMemcpyAsync(sea.data(), h->f[ATOMDEV_T], h->n2 * 8, hipMemcpyDeviceToHost, h->stream));
-    ATOMDEV_TRY(hipStreamSynchronize(h->stream));
+    if (int rc__ = atomdev_sync_stream(h)) return rc__;
     // calculate_mean_temperature with the weights of calculate_node_weights (:952-988): one running sum in the reference's
     // order, the result a float
     double ret = 0., weight = 0.;

@@ -150,7 +150,7 @@ extern "C" int atomdev_hyd_ic_ekman_spiral(atomdev_t* h, int i_beg) {
         tab[2 * im + i] = std::cos(gam_z);
     }
     ATOMDEV_TRY(hipMemcpyAsync(h->plane, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, h->stream));
-    ATOMDEV_TRY(hipStreamSynchronize(h->stream));  // tab leaves scope
+    if (int rc__ = atomdev_sync_stream(h)) return rc__;  // tab leaves scope
     const double pi180 = 180. / M_PI;
     const double Ekman_angle = 45.0 / pi180;  // :77-81
     const unsigned nb = (unsigned)((h->n2 + 255) / 256);
@@ -203,7 +203,7 @@ extern "C" int atomdev_hyd_read_surface_salinity(atomdev_t* h, const char* path)
     ATOMDEV_TRY(hipMemcpyAsync(top.data(), level, h->n2 * 8, hipMemcpyDeviceToHost, h->stream));
     bool opened = false;
     const bool fast = text_third_of_triples(path, h->n2, values, &opened);  // overlaps the download
-    ATOMDEV_TRY(hipStreamSynchronize(h->stream));
+    if (int rc__ = atomdev_sync_stream(h)) return rc__;
     ATOMDEV_REQUIRE(opened, std::string("could not open SurfaceSalinity_File file at ") + path);
     if (fast) {
         for (int k = 0; k < km; k++)
@@ -223,7 +223,7 @@ extern "C" int atomdev_hyd_read_surface_salinity(atomdev_t* h, const char* path)
             }
     }
     ATOMDEV_TRY(hipMemcpyAsync(level, top.data(), h->n2 * 8, hipMemcpyHostToDevice, h->stream));
-    ATOMDEV_TRY(hipStreamSynchronize(h->stream));
+    if (int rc__ = atomdev_sync_stream(h)) return rc__;
     return 0;
 }
 

@@ -880,7 +880,7 @@ extern "C" int atomdev_atm_two_category_ice_scheme(atomdev_t* h, double state[2]
     ATOMDEV_TRY(hipGetLastError());
     double last[4];
     ATOMDEV_TRY(hipMemcpyAsync(last, a.last, sizeof(last), hipMemcpyDeviceToHost, h->stream));
-    ATOMDEV_TRY(hipStreamSynchronize(h->stream));
+    if (int rc__ = atomdev_sync_stream(h)) return rc__;
     if (last[0] != 0.) state[0] = last[1];
     if (last[2] != 0.) state[1] = last[3];
     return 0;
@@ -926,7 +926,7 @@ extern "C" int atomdev_atm_ice_water_saturation_adjustment(atomdev_t* h, double*
             if (pass > 0) {
                 ATOMDEV_TRY(hipGetLastError());
                 ATOMDEV_TRY(hipMemcpyAsync(last, a.last, sizeof(last), hipMemcpyDeviceToHost, h->stream));
-                ATOMDEV_TRY(hipStreamSynchronize(h->stream));
+                if (int rc__ = atomdev_sync_stream(h)) return rc__;
                 const size_t left = (size_t)last[1];
                 if (left == 0) break;
                 // the first unfinished column in visiting order always has what it needs
@@ -946,12 +946,12 @@ extern "C" int atomdev_atm_ice_water_saturation_adjustment(atomdev_t* h, double*
         hipLaunchKernelGGL(k_adj_finish, dim3(1), dim3(64), 0, h->stream, a);
         ATOMDEV_TRY(hipGetLastError());
         ATOMDEV_TRY(hipMemcpyAsync(last, a.last, sizeof(last), hipMemcpyDeviceToHost, h->stream));
-        ATOMDEV_TRY(hipStreamSynchronize(h->stream));
+        if (int rc__ = atomdev_sync_stream(h)) return rc__;
         if (last[1] != 0.) {
             hipLaunchKernelGGL(k_adj_inherit, dim3(1), dim3(1024), 0, h->stream, a);
             ATOMDEV_TRY(hipGetLastError());
             ATOMDEV_TRY(hipMemcpyAsync(last, a.last, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-            ATOMDEV_TRY(hipStreamSynchronize(h->stream));
+            if (int rc__ = atomdev_sync_stream(h)) return rc__;
         }
     }
     *q_v_hyp = last[0];

@@ -132,7 +132,7 @@ int atomdev_upload_mask_bytes(atomdev* h, const uint8_t* solid) {
     ATOMDEV_TRY(hipMemcpyAsync(h->flags, solid, h->n3, hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(k_expand_mask, dim3(blocks_for(h->n3)), dim3(TPB), 0, h->stream, h->flags, h->f[ATOMDEV_H], h->n3);
     ATOMDEV_TRY(hipGetLastError());
-    ATOMDEV_TRY(hipStreamSynchronize(h->stream));  // the host buffer may be reused at once
+    if (int rc__ = atomdev_sync_stream(h)) return rc__;  // the host buffer may be reused at once
     h->flags_dirty = true;
     return 0;
 }

@@ -122,7 +122,7 @@ int write_plot_data(atomdev* h, const char* path, bool atm) {
     const int n2d = atm ? 2 : 3;
     for (int n = 0; n < n2d; n++)
         ATOMDEV_TRY(hipMemcpyAsync(&s[(5 + n) * n2], h->g[atm ? f2a[n] : f2h[n]], n2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    ATOMDEV_TRY(hipStreamSynchronize(h->stream));
+    if (int rc__ = atomdev_sync_stream(h)) return rc__;
     FILE* f = std::fopen(path, "w");
     ATOMDEV_REQUIRE(f, std::string("could not open PlotData file ") + path);
     std::string out = atm ? "lons(deg), lats(deg), topography, v-velocity(m/s), w-velocity(m/s), velocity-mag(m/s), "
@@ -177,7 +177,7 @@ extern "C" int atomdev_hyd_run_data(atomdev_t* h) {
     hipLaunchKernelGGL(k_hyd_run_columns, dim3(nb2), dim3(TPB), 0, h->stream, a);
     double rad_top = 0.;
     ATOMDEV_TRY(hipMemcpyAsync(&rad_top, h->rad + (im - 1), sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    ATOMDEV_TRY(hipStreamSynchronize(h->stream));
+    if (int rc__ = atomdev_sync_stream(h)) return rc__;
     double *up = h->g[ATOMDEV_UPWELLING], *down = h->g[ATOMDEV_DOWNWELLING];
     hipLaunchKernelGGL(k_hyd_bottom_water, dim3(nb2), dim3(TPB), 0, h->stream, a.aux_v, a.aux_w, h->sinthe, rad_top, P.dthe, P.dphi,
                        P.u_0, jm, km, h->g[ATOMDEV_BOTTOM_WATER], up, down);

@@ -107,17 +107,29 @@ __device__ __forceinline__ double ldg_agent(const double* base, unsigned off) {
 __device__ __forceinline__ int ld_progress(const int* progress) {
     return __hip_atomic_load((const __attribute__((address_space(1))) int*)progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// Waits until the producer's progress word has reached `need` and returns what it read; gives up after about a second.
+// The hand-off between two workgroups of one launch.  Producer: write-through (sc1) stores of the rows, a wait until the
+// memory system has acknowledged them (vmcnt(0), issued by the caller), then the progress word.  Consumer: the progress
+// word, then sc1 loads of the rows.  The hardware issues a wave's memory instructions in program order; the two
+// compiler barriers keep the compiler from moving an access across the word, which relaxed atomics alone would allow.
+__device__ __forceinline__ void announce_rows(int* progress, int rows, int lane) {
+    asm volatile("" ::: "memory");
+    if (lane == 0) __hip_atomic_store(progress, rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" ::: "memory");
+}
+// Waits until the producer's progress word has reached `need` and returns what it read; gives up after about a second
+// and says so in *err (page-locked host memory the next synchronising call of the library looks at).
 __device__ __forceinline__ int wait_rows(const int* progress, int need, int* err) {
     int seen = ld_progress(progress);
     for (int n = 0; seen < need; n++) {
         __builtin_amdgcn_s_sleep(4);
         if (n > (1 << 21)) {
-            __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return need;
+            __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            seen = need;
+            break;
         }
         seen = ld_progress(progress);
     }
+    asm volatile("" ::: "memory");
     return seen;
 }
 
@@ -292,7 +304,7 @@ __device__ __forceinline__ void sweep_role(const HydWsArgs& a, const DevConst& K
             // Only the stores of the step before (row j-2, issued three stages ago) can still be in flight here:
             // once they have completed, the row may be announced.
             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-            if (lane == 0) __hip_atomic_store(progress, j - 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            announce_rows(progress, j - 2, lane);
         }
         STAMP(0);
         // ---- take over the prefetched inputs of this step, start loading the next step's ----
@@ -470,7 +482,7 @@ __device__ __forceinline__ void sweep_role(const HydWsArgs& a, const DevConst& K
     if (feeds_top) {
         stg_agent(XO, o0 - rowB, xm1);
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-        if (lane == 0) __hip_atomic_store(progress, jm - 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        announce_rows(progress, jm - 2, lane);
     } else {
         stg(XO, o0 - rowB, xm1);
     }
@@ -555,7 +567,7 @@ int HYD_WS_ENTRY(atomdev* h) {
     ATOMDEV_REQUIRE(h->n3 * sizeof(double) < ((size_t)1 << 32), "hyd_rk3d: field larger than 4 GiB");
     // Two argument blocks, one per orientation of the (current, alternate) buffer pair; the sweep
     // swaps the pair, so consecutive sweeps alternate between them.
-    struct Blocks { HydWsParams p[2]; const double* src[2][5]; double* dst[2][5]; int progress[128]; int err; };
+    struct Blocks { HydWsParams p[2]; const double* src[2][5]; double* dst[2][5]; int progress[128]; };
     if (!h->ws_params) {
         Blocks* B = new Blocks();
         for (int o = 0; o < 2; o++) {
@@ -581,7 +593,6 @@ int HYD_WS_ENTRY(atomdev* h) {
         h->ws_cur0 = h->f[ATOMDEV_T];
         delete B;
         ATOMDEV_TRY(e);
-        h->ws_err = &((Blocks*)h->ws_params)->err;
     }
     const int o = (h->f[ATOMDEV_T] == h->ws_cur0) ? 0 : 1;
     Blocks* D = (Blocks*)h->ws_params;
@@ -595,7 +606,7 @@ int HYD_WS_ENTRY(atomdev* h) {
     ATOMDEV_TRY(hipGetLastError());
     const size_t lds = (size_t)h->jm * 4 * sizeof(double);
     // levels 1 .. im-2, one workgroup per 64 lines
-    hipLaunchKernelGGL(k_hyd_rk3d_ws, dim3(8 * ((h->im - 2 + 7) / 8) * gx), dim3(320), lds, h->stream, P, h->im - 2, D->progress, &D->err);
+    hipLaunchKernelGGL(k_hyd_rk3d_ws, dim3(8 * ((h->im - 2 + 7) / 8) * gx), dim3(320), lds, h->stream, P, h->im - 2, D->progress, (int*)atomdev_kernel_error_word(h));
     ATOMDEV_TRY(hipGetLastError());
     if (int rc = atomdev_prof_end(h)) return rc;
     for (int n = 0; n < 5; n++) { double* t = h->f[X[n]]; h->f[X[n]] = h->alt[X[n]]; h->alt[X[n]] = t; }

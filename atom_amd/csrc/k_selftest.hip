@@ -22,7 +22,17 @@ __global__ void k_selftest(int kind, size_t n, const double* __restrict__ x, con
     out[q] = r;
 }
 
+__global__ void k_raise_error(int* err) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
 }  // namespace
+
+extern "C" int atomdev_selftest_raise_kernel_error(atomdev_t* h) {
+    ATOMDEV_REQUIRE(h, "atomdev_selftest_raise_kernel_error: null handle");
+    ATOMDEV_TRY(hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_raise_error, dim3(1), dim3(1), 0, h->stream, (int*)atomdev_kernel_error_word(h));
+    ATOMDEV_TRY(hipGetLastError());
+    return 0;
+}
 
 extern "C" int atomdev_selftest_math(atomdev_t* h, int kind, size_t n, const double* x, const double* y, double* out) {
     ATOMDEV_REQUIRE(h && x && out && n > 0, "atomdev_selftest_math: bad argument");

@@ -54,7 +54,7 @@ int planes(atomdev* atm, int rounded) {
                        atm->g[ATOMDEV_EVAPORATION_DALTON], atm->g[ATOMDEV_PRECIPITATION], atm->p.u_0, atm->n2, rounded,
                        atm->xfer);
     ATOMDEV_TRY(hipGetLastError());
-    ATOMDEV_TRY(hipStreamSynchronize(atm->stream));
+    if (int rc__ = atomdev_sync_stream(atm)) return rc__;
     return 0;
 }
 
@@ -67,7 +67,7 @@ int load_planes(atomdev* hyd, const double* src) {
     for (int n = 0; n < 6; n++)
         if (dst[n]) ATOMDEV_TRY(hipMemcpyAsync(dst[n], src + (size_t)n * n2, bytes, hipMemcpyDefault, hyd->stream));
     ATOMDEV_TRY(hipMemsetAsync(hyd->f[ATOMDEV_P_DYN] + top, 0, bytes, hyd->stream));  // PostProcess_Hyd.cpp:666
-    ATOMDEV_TRY(hipStreamSynchronize(hyd->stream));
+    if (int rc__ = atomdev_sync_stream(hyd)) return rc__;
     return 0;
 }
 

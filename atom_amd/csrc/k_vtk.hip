@@ -72,7 +72,7 @@ int write_vtk(atomdev* h, int kind, int index, int Ma, const char* path) {
         v.resize(n2);
         return atomdev_check(hipMemcpyAsync(v.data(), h->g[field], n2 * 8, hipMemcpyDeviceToHost, h->stream), "hipMemcpyAsync(2-D field)");
     };
-    auto sync = [&]() { return atomdev_check(hipStreamSynchronize(h->stream), "hipStreamSynchronize"); };
+    auto sync = [&]() { return atomdev_sync_stream(h); };
 
     Text out;
     // header and the point coordinates, built by repeated addition as in the reference
@@ -291,7 +291,7 @@ struct VtsFile {
     ~VtsFile() { if (f) std::fclose(f); }
     int fetch(int id) {
         ATOMDEV_TRY(hipMemcpyAsync(field.data(), h->f[id], h->n3 * 8, hipMemcpyDeviceToHost, h->stream));
-        ATOMDEV_TRY(hipStreamSynchronize(h->stream));
+        if (int rc__ = atomdev_sync_stream(h)) return rc__;
         return 0;
     }
     // values of the fetched field in (k, j, i) order, `blank` after every row of levels and after every meridian

@@ -163,6 +163,7 @@ def load_library():
     lib.atomdev_atm_run_time_slice.argtypes = [vp, C.POINTER(AtmSlice), C.POINTER(AtmLoopState)]
     lib.atomdev_fill2d.argtypes = [vp, C.c_int, C.c_double]
     lib.atomdev_selftest_math.argtypes = [vp, C.c_int, C.c_size_t, dp, dp, dp]
+    lib.atomdev_selftest_raise_kernel_error.argtypes = [vp]
     lib.atomdev_atm_bc_pressure.argtypes = [vp]
     lib.atomdev_hyd_read_surface_salinity.argtypes = [vp, C.c_char_p]
     lib.atomdev_hyd_ic_ekman_spiral.argtypes = [vp, C.c_int]

@@ -376,6 +376,10 @@ enum atomdev_selftest {
     ATOMDEV_SELFTEST_DIVIDE    /* x / y */
 };
 int atomdev_selftest_math(atomdev_t* h, int kind, size_t n, const double* x, const double* y, double* out);
+/* Enqueues a kernel that sets the word by which a kernel reports a failure it detects itself (the hydrosphere sweep's
+ * bounded wait between workgroups): the next call that waits for the handle's stream - downloads, queries, file
+ * writers, atomdev_sync - must fail once, and the call after it succeed.  For tests of that path. */
+int atomdev_selftest_raise_kernel_error(atomdev_t* h);
 
 /* ---- hydrosphere ---- */
 /* BC_Hydrosphere::RB_radius / RB_theta / RB_phi (hydrosphere/BC_Hyd.cpp:38-158) */

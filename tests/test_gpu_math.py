@@ -84,3 +84,23 @@ def test_div_by_is_the_ieee_quotient():
     bad = np.nonzero(got != ref)[0]
     assert bad.size == 0, (bad.size, a[bad[:5]], b[bad[:5]])
     d.close()
+
+
+def test_a_failure_a_kernel_reports_surfaces_with_the_next_result():
+    """The hydrosphere sweep's bounded wait between workgroups reports a give-up through a word in page-locked host memory:
+    whichever call hands the next result to the host fails, once."""
+    for take in ("download", "residuum", "get_columns", "sync"):
+        d = atom_amd.DeviceModel(H.HYD, 9, 21, 31)
+        d.op("hyd_bc_theta")
+        d._check(d.lib.atomdev_selftest_raise_kernel_error(d._h))
+        with pytest.raises(atom_amd.AtomDevError, match="gave up waiting"):
+            if take == "download":
+                d.download("T")
+            elif take == "residuum":
+                d.residuum("hyd_residuum3d")
+            elif take == "get_columns":
+                d.get_columns("T", 0, 4)
+            else:
+                d.sync()
+        d.download("T"); d.sync()      # reported once
+        d.close()
