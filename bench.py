@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 IM, JM, KM = 41, 181, 361
+GRIDS = {"1": (41, 181, 361), "0.25": (41, 721, 1441)}   # degrees -> grid; the refined one takes the 0 Ma mask upsampled by 4
 UPDATES = (IM - 2) * (JM - 2) * (KM - 2)
 ATM_BYTES_PER_UPDATE = 280   # reads 9 state + 8 xn + h + 5 sources, writes 8 state + 3 aux + buoyancy
 HYD_BYTES_PER_UPDATE = 208
@@ -41,11 +42,19 @@ HYD_STEP = ["hyd_bc_radius", "hyd_bc_theta", "hyd_bc_phi", "hyd_pressure_density
 
 
 def make_model(H, atom_amd, model, device, seed):
-    p = atom_amd.default_params(model)   # the product's own defaults (param.py), no checker involved
+    p = atom_amd.default_params(model, IM, JM, KM)   # the product's own defaults (param.py), no checker involved
     f, g = H.make_inputs(model, IM, JM, KM, seed, "allfluid", p)
     names = H.ATM_FIELDS if model == H.ATM else H.HYD_FIELDS
     f = {k: f[k] for k in names}
     f["H"], g["TOPOGRAPHY"] = H.load_mask_0Ma(model)
+    if (IM, JM, KM) != GRIDS["1"]:
+        jj = np.rint(np.arange(JM) * 180. / (JM - 1)).astype(int)
+        kk = np.rint(np.arange(KM) * 360. / (KM - 1)).astype(int)
+        f["H"], g["TOPOGRAPHY"] = np.ascontiguousarray(f["H"][:, jj][:, :, kk]), np.ascontiguousarray(g["TOPOGRAPHY"][jj][:, kk])
+        for k in names:   # the 1-degree noise at 1/256 of its amplitude: second differences as on the 1-degree grid next to the poles
+            if k not in ("H", "RESIDUUM", "R_WATER", "R_SALT_WATER", "P_STAT"):
+                m = f[k].mean()
+                f[k] = m + (f[k] - m) / 256.
     d = atom_amd.DeviceModel(model, IM, JM, KM, p, device=device)
     d.upload_all(f, g)
     d.sync()
@@ -87,7 +96,7 @@ def cpu_baseline(H, p, f, g, budget_s=12.0):
         host_cores = os.cpu_count()
     out = {"value": UPDATES * n / dt, "unit": "grid-point RK updates/s", "cores": 1, "kind": "port",
            "host_cores": host_cores, "host_cores_machine": os.cpu_count(),
-           "sample": "%d step(s) of the same workload (41x181x361, 0 Ma mask), %.1f s on 1 of %d cores this process may use "
+           "sample": "%d step(s) of the same workload (0 Ma mask), %.1f s on 1 of %d cores this process may use "
                      "(the sweep is one lexicographic Gauss-Seidel chain: the reference runs it on one core); RK sweep alone "
                      "%.2f s/sweep" % (n, dt, host_cores, rk_s / n)}
     if H.have_ref():
@@ -107,7 +116,11 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo to rehearse "
                                                       "several ranks on one GPU)")
+    ap.add_argument("--grid", default="1", choices=sorted(GRIDS), help="horizontal resolution in degrees (default 1: the metric's grid)")
     args = ap.parse_args()
+    global IM, JM, KM, UPDATES
+    IM, JM, KM = GRIDS[args.grid]
+    UPDATES = (IM - 2) * (JM - 2) * (KM - 2)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -197,7 +210,7 @@ def main():
         hyd.close()
         hyd_traffic = None
         try:
-            hyd_traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_hyd_rk3d.json"))).get("hbm_bytes_per_launch")
+            hyd_traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_hyd_rk3d.json"))).get("hbm_bytes_per_launch") if args.grid == "1" else None
         except Exception:
             pass
         hyd_info = {"updates_per_s": UPDATES * nh / th, "ms_per_step": 1e3 * th / nh, "rk_traffic": hyd_traffic,
@@ -210,7 +223,7 @@ def main():
         achieved = UPDATES * ATM_BYTES_PER_UPDATE / rk_avg_s / 1e9
         traffic, issue = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_atm_rk3d.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and args.grid == "1":
             try:
                 rec = json.load(open(pmc))
                 traffic = rec.get("hbm_bytes_per_launch")
@@ -226,7 +239,7 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "grid-point RK updates/s (41x181x361 fp64)",
+            "metric": "grid-point RK updates/s (%dx%dx%d fp64)" % (IM, JM, KM),
             "value": UPDATES * args.steps * world / elapsed,
             "unit": "grid-point RK updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -234,7 +247,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic fields (numpy PCG64 seed 1234+rank), real 0 Ma land mask",
             "config": {"workload": "atmosphere 3-D hot-path iteration (BC fills, limiter, solid ground, fused RK4+RHS sweep, "
-                                   "limiter, old->new copy; pressure Jacobi every 2nd step), 41x181x361, one slice per GPU",
+                                   "limiter, old->new copy; pressure Jacobi every 2nd step), %dx%dx%d, one slice per GPU" % (IM, JM, KM),
                        "grid": [IM, JM, KM], "updates_per_step_per_gpu": UPDATES, "parallelism": "independent slices"},
             "roofline": {"bound": "hbm", "kernel": "k_atm_rk3d_ws", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -22,4 +22,10 @@ for passname, counter, key in (("fetch", "FETCH_SIZE", "read"), ("write", "WRITE
     out[key] = {"counter": counter, "kernel_avg": k, "kernel_launches": nk, "copy_avg": c, "copy_launches": nc,
                 "copy_known_bytes": copy_bytes, "bytes_per_unit": scale, "bytes_per_launch": k * scale}
 out["hbm_bytes_per_launch"] = out["read"]["bytes_per_launch"] + out["write"]["bytes_per_launch"]
+try:  # wave-level vector instructions per launch, for the fp64-issue bound (pass sq1)
+    out["sq_insts_valu_per_launch"], _ = avg("sq1", "SQ_INSTS_VALU", sub)
+    out["sq_wave_cycles_per_launch"], _ = avg("sq1", "SQ_WAVE_CYCLES", sub)
+    out["sq_wait_any_per_launch"], _ = avg("sq2", "SQ_WAIT_ANY", sub)
+except ZeroDivisionError:
+    pass
 print(json.dumps(out, indent=1))
