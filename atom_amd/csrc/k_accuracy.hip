@@ -59,7 +59,7 @@ __global__ void k_residuum3d(const double* __restrict__ u, const double* __restr
     double dwdphi = (w[p + 1] - w[p - 1]) / (2. * K.dphi);
     double res = dudr + 2. * u[p] / rad[i] + dvdthe / rad[i] + costhe / rmsinthe * v[p] + dwdphi / rmsinthe;
     field[p] = res;
-    seq[((size_t)(i - 1) * (jm - 2) + (j - 1)) * (km - 2) + (k - 1)] = res;
+    if (seq) seq[((size_t)(i - 1) * (jm - 2) + (j - 1)) * (km - 2) + (k - 1)] = res;
 }
 
 // surface form, level 0 (Accuracy_Atm.cpp:58-78)
@@ -442,6 +442,149 @@ extern "C" int atomdev_hyd_residuum3d(atomdev_t* h, double* min, int loc[3]) {
     ATOMDEV_TRY(hipSetDevice(h->device));
     return residuum(h, true, true, min, loc);
 }
+// ---- the queries of a model that holds a slab of longitudes of a wider grid ----
+// The residuum scan runs over the lexicographic sequence of the WHOLE grid, in which the slabs' points interleave row by
+// row; what a slab can contribute to one jump of the scan (see the top of the file) is a summary of its own points of the
+// suffix: the maximum magnitude with its first position, the first non-negative point, the last point that is no NaN, each
+// with the value there.  The caller combines the slabs' summaries and repeats for the next jump.
+
+namespace {
+
+struct Suffix {
+    double amax, pmax, xmax;   // largest |res|, its first position in the global sequence, res there (amax -1: none)
+    double pnn, xnn;           // first position with res >= 0 (-1: none), res there
+    double plast, xlast;       // last position whose res is no NaN (-1: none), res there
+};
+__device__ __forceinline__ void merge(Suffix& a, const Suffix& b) {
+    if (b.amax > a.amax || (b.amax == a.amax && b.pmax >= 0. && (a.pmax < 0. || b.pmax < a.pmax))) { a.amax = b.amax; a.pmax = b.pmax; a.xmax = b.xmax; }
+    if (b.pnn >= 0. && (a.pnn < 0. || b.pnn < a.pnn)) { a.pnn = b.pnn; a.xnn = b.xnn; }
+    if (b.plast > a.plast) { a.plast = b.plast; a.xlast = b.xlast; }
+}
+
+__global__ __launch_bounds__(TPB) void k_suffix_partial(const double* __restrict__ field, int im, int jm, int km, int k0, int nk, int kg0,
+                                                        int kmg, double from, Suffix* __restrict__ part) {
+    __shared__ Suffix sh[TPB];
+    Suffix b = { -1., -1., 0., -1., 0., -1., 0. };
+    const size_t n = (size_t)(im - 2) * (jm - 2) * nk;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (size_t)gridDim.x * blockDim.x) {
+        const int kk = (int)(q % nk);
+        const size_t row = q / nk;  // (i-1)(jm-2) + (j-1)
+        const int kg = kg0 + kk;
+        if (kg < 1 || kg > kmg - 2) continue;
+        const double t = (double)row * (double)(kmg - 2) + (double)(kg - 1);
+        if (t < from) continue;
+        const int i = (int)(row / (jm - 2)) + 1, j = (int)(row % (jm - 2)) + 1;
+        const double x = field[idx3(jm, km, i, j, k0 + kk)];
+        Suffix c = { -1., -1., 0., -1., 0., -1., 0. };
+        if (fabs(x) >= 0.) { c.amax = fabs(x); c.pmax = t; c.xmax = x; c.plast = t; c.xlast = x; }
+        if (x >= 0.) { c.pnn = t; c.xnn = x; }
+        merge(b, c);
+    }
+    sh[threadIdx.x] = b;
+    __syncthreads();
+    for (int st = TPB / 2; st > 0; st >>= 1) {
+        if (threadIdx.x < st) merge(sh[threadIdx.x], sh[threadIdx.x + st]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
+}
+__global__ __launch_bounds__(TPB) void k_suffix_final(const Suffix* __restrict__ part, int nblocks, Suffix* __restrict__ out) {
+    __shared__ Suffix sh[TPB];
+    Suffix b = { -1., -1., 0., -1., 0., -1., 0. };
+    for (int n = threadIdx.x; n < nblocks; n += blockDim.x) merge(b, part[n]);
+    sh[threadIdx.x] = b;
+    __syncthreads();
+    for (int st = TPB / 2; st > 0; st >>= 1) {
+        if (threadIdx.x < st) merge(sh[threadIdx.x], sh[threadIdx.x + st]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = sh[0];
+}
+
+struct PartArgs { const double* x[9]; const double* xn[9]; };
+template <bool LAST>
+__global__ __launch_bounds__(TPB) void k_steady_part(PartArgs s, int im, int jm, int km, int k0, int nk, int kg0, int kmg, Best* __restrict__ part) {
+    __shared__ Best sh[TPB];
+    const int f = blockIdx.y;
+    Best b; b.v = -1.; b.idx = LAST ? -1 : (1LL << 62);
+    const size_t n = (size_t)im * jm * nk;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (size_t)gridDim.x * blockDim.x) {
+        const int kk = (int)(q % nk);
+        const size_t row = q / nk;  // i jm + j
+        const size_t p = row * km + k0 + kk;
+        take<LAST>(b, fabs(s.x[f][p] - s.xn[f][p]), (long long)(row * kmg + kg0 + kk));
+    }
+    sh[threadIdx.x] = b;
+    __syncthreads();
+    for (int st = TPB / 2; st > 0; st >>= 1) {
+        if (threadIdx.x < st) take<LAST>(sh[threadIdx.x], sh[threadIdx.x + st].v, sh[threadIdx.x + st].idx);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[(size_t)f * gridDim.x + blockIdx.x] = sh[0];
+}
+
+bool slab_ok(const atomdev* h, int k0, int nk, int kg0, int kmg) {
+    return k0 >= 0 && nk >= 1 && k0 + nk <= h->km && kg0 >= 0 && kg0 + nk <= kmg;
+}
+
+}  // namespace
+
+extern "C" int atomdev_residuum3d_field(atomdev_t* h) {
+    ATOMDEV_REQUIRE(h, "atomdev_residuum3d_field: null handle");
+    ATOMDEV_TRY(hipSetDevice(h->device));
+    dim3 grid((h->km - 2 + 127) / 128, h->jm - 2, h->im - 2);
+    hipLaunchKernelGGL(k_residuum3d, grid, dim3(128), 0, h->stream, h->f[ATOMDEV_U], h->f[ATOMDEV_V], h->f[ATOMDEV_W],
+                       h->f[ATOMDEV_RESIDUUM], (double*)nullptr, h->rad, h->sinthe, h->costhe, h->k);
+    ATOMDEV_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int atomdev_residuum3d_suffix(atomdev_t* h, int k0, int nk, int kg0, int km_global, double from, double out[7]) {
+    ATOMDEV_REQUIRE(h && out && slab_ok(h, k0, nk, kg0, km_global), "atomdev_residuum3d_suffix: bad argument");
+    ATOMDEV_TRY(hipSetDevice(h->device));
+    const int nblocks = 1024;
+    ATOMDEV_REQUIRE((nblocks + 1) * sizeof(Suffix) <= h->red_bytes, "atomdev_residuum3d_suffix: scratch too small");
+    Suffix* part = (Suffix*)h->red;
+    hipLaunchKernelGGL(k_suffix_partial, dim3(nblocks), dim3(TPB), 0, h->stream, h->f[ATOMDEV_RESIDUUM], h->im, h->jm, h->km, k0, nk, kg0,
+                       km_global, from, part);
+    hipLaunchKernelGGL(k_suffix_final, dim3(1), dim3(TPB), 0, h->stream, part, nblocks, part + nblocks);
+    ATOMDEV_TRY(hipGetLastError());
+    Suffix r;
+    ATOMDEV_TRY(hipMemcpyAsync(&r, part + nblocks, sizeof r, hipMemcpyDeviceToHost, h->stream));
+    if (int rc__ = atomdev_sync_stream(h)) return rc__;
+    out[0] = r.amax; out[1] = r.pmax; out[2] = r.xmax; out[3] = r.pnn; out[4] = r.xnn; out[5] = r.plast; out[6] = r.xlast;
+    return 0;
+}
+
+extern "C" int atomdev_steady3d_part(atomdev_t* h, int k0, int nk, int kg0, int km_global, double* values, double* positions) {
+    ATOMDEV_REQUIRE(h && values && positions && slab_ok(h, k0, nk, kg0, km_global), "atomdev_steady3d_part: bad argument");
+    ATOMDEV_TRY(hipSetDevice(h->device));
+    static const int FA[9] = { ATOMDEV_U, ATOMDEV_V, ATOMDEV_W, ATOMDEV_T, ATOMDEV_C, ATOMDEV_CLOUD, ATOMDEV_ICE, ATOMDEV_CO2, ATOMDEV_P_DYN };
+    static const int FH[6] = { ATOMDEV_U, ATOMDEV_V, ATOMDEV_W, ATOMDEV_T, ATOMDEV_C, ATOMDEV_P_DYN };
+    const bool atm = h->model == ATOMDEV_ATM;
+    const int nf = atm ? 9 : 6;
+    const int* F = atm ? FA : FH;
+    const int nblocks = 256;
+    Best* part = (Best*)h->red;
+    ATOMDEV_REQUIRE(((size_t)nf * nblocks + 16) * sizeof(Best) <= h->red_bytes, "atomdev_steady3d_part: scratch too small");
+    Best* fin = part + (size_t)nf * nblocks;
+    PartArgs s;
+    for (int f = 0; f < nf; f++) { s.x[f] = h->f[F[f]]; s.xn[f] = h->f[F[f] + 9]; }
+    if (atm) {
+        hipLaunchKernelGGL(k_steady_part<false>, dim3(nblocks, nf), dim3(TPB), 0, h->stream, s, h->im, h->jm, h->km, k0, nk, kg0, km_global, part);
+        hipLaunchKernelGGL(k_steady_final<false>, dim3(nf), dim3(TPB), 0, h->stream, part, nblocks, nf, fin);
+    } else {
+        hipLaunchKernelGGL(k_steady_part<true>, dim3(nblocks, nf), dim3(TPB), 0, h->stream, s, h->im, h->jm, h->km, k0, nk, kg0, km_global, part);
+        hipLaunchKernelGGL(k_steady_final<true>, dim3(nf), dim3(TPB), 0, h->stream, part, nblocks, nf, fin);
+    }
+    ATOMDEV_TRY(hipGetLastError());
+    Best res[9];
+    ATOMDEV_TRY(hipMemcpyAsync(res, fin, nf * sizeof(Best), hipMemcpyDeviceToHost, h->stream));
+    if (int rc__ = atomdev_sync_stream(h)) return rc__;
+    for (int f = 0; f < nf; f++) { values[f] = res[f].v; positions[f] = (double)res[f].idx; }
+    return 0;
+}
+
 extern "C" int atomdev_atm_steady3d(atomdev_t* h, double out[9], int loc[27]) {
     ATOMDEV_REQUIRE(h && h->model == ATOMDEV_ATM && out && loc, "atomdev_atm_steady3d: bad argument");
     ATOMDEV_TRY(hipSetDevice(h->device));

@@ -164,6 +164,9 @@ def load_library():
     lib.atomdev_fill2d.argtypes = [vp, C.c_int, C.c_double]
     lib.atomdev_selftest_math.argtypes = [vp, C.c_int, C.c_size_t, dp, dp, dp]
     lib.atomdev_selftest_raise_kernel_error.argtypes = [vp]
+    lib.atomdev_residuum3d_field.argtypes = [vp]
+    lib.atomdev_residuum3d_suffix.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, dp]
+    lib.atomdev_steady3d_part.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, dp, dp]
     lib.atomdev_atm_bc_pressure.argtypes = [vp]
     lib.atomdev_hyd_read_surface_salinity.argtypes = [vp, C.c_char_p]
     lib.atomdev_hyd_ic_ekman_spiral.argtypes = [vp, C.c_int]
@@ -387,6 +390,21 @@ class DeviceModel:
 
     def bc_co2(self, start):
         self._check(self.lib.atomdev_atm_bc_co2(self._h, C.byref(start)))
+
+    # ---- the queries of a slab of a wider grid (atom_amd/slabs.py) ----
+    def residuum_field(self):
+        self._check(self.lib.atomdev_residuum3d_field(self._h))
+
+    def residuum_suffix(self, k0, nk, kg0, km_global, start):
+        out = (C.c_double * 7)()
+        self._check(self.lib.atomdev_residuum3d_suffix(self._h, k0, nk, kg0, km_global, float(start), out))
+        return list(out)
+
+    def steady_part(self, k0, nk, kg0, km_global):
+        nf = 9 if self.model == ATM else 6
+        v, p = (C.c_double * nf)(), (C.c_double * nf)()
+        self._check(self.lib.atomdev_steady3d_part(self._h, k0, nk, kg0, km_global, v, p))
+        return list(v), list(p)
 
     def selftest_math(self, kind, x, y=None):
         """atomdev_selftest_math: kind 0 exp, 1 pow, 2 x^4, 3 fourth root, 4 division by a known reciprocal, 5 division."""

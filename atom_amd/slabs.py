@@ -1,33 +1,41 @@
 """Phi-slab decomposition of one model over several GPUs (one process per GPU).
 
-The 3-D Runge-Kutta sweeps have no phi coupling (the phi derivatives of RHS_Atm.cpp:146-149 and
-RHS_Hyd.cpp:136-139 are multiplied by h_d_k = 0), so a slab of longitudes can be swept without any
-exchange.  What does couple neighbouring longitudes is
-  * the land-mask tests of the right-hand sides (k+-1, k+-2; static),
-  * the pressure Jacobi sweep (p_dynn at k+-1, aux_w at k+-1 and k+-2: Pressure_Atm.cpp:140-155),
-  * the phi-seam fills, which set columns 0 and km-1 to the mean of the Neumann extrapolations
-    from columns 1, 2 and km-2, km-3 (BC_Atm.cpp:115-150, Pressure_Atm.cpp:57-66, 170-176).
+What couples neighbouring longitudes in the 3-D iteration (cAtmosphereModel.cpp:756-874, cHydrosphereModel.cpp:420-610):
+  * the land-mask tests of the right-hand sides and of the pressure step (k+-1, k+-2): static, part of every slab's mask;
+  * the pressure Jacobi sweep: p_dynn at k+-1, aux_w at k+-1 and k+-2 (Pressure_Atm.cpp:140-155, Pressure_Hyd.cpp);
+  * the phi-seam fills, which set columns 0 and km-1 to the mean of the Neumann extrapolations from columns 1, 2 and
+    km-2, km-3 (BC_Atm.cpp:115-150, Pressure_Atm.cpp:57-66, 170-176);
+  * the continuity residuum (w at k+-1, Accuracy_Atm.cpp:82-116), an order-dependent scan over the whole grid.
+The 3-D Runge-Kutta sweeps do not: their phi derivatives are multiplied by h_d_k = 0 (RHS_Atm.cpp:146-149,
+RHS_Hyd.cpp:136-139), so a column's new values depend on that column and on the mask around it only.
 
 Layout.  Every rank holds an ordinary, smaller model (its own handle, its own km) made of
-    [copies of global columns 0..S-1]   only on the last rank
-    [G ghost columns]                   left neighbour's last owned columns (not on rank 0)
+    [copies of global columns 0..S-1]       only on the last rank
+    [G ghost columns]                       left neighbour's last owned columns (not on rank 0)
     [owned columns]
-    [G ghost columns]                   right neighbour's first owned columns (not on the last rank)
+    [G ghost columns]                       right neighbour's first owned columns (not on the last rank)
     [copies of global columns km-S..km-1]   only on rank 0
-and runs the unmodified single-domain operators on it.  With G = 3 every k-stencil of an owned
-column (reach 2) and every k-window test (k >= 2, k <= km-3) evaluates exactly as in the single
-domain; the seam copies make the LOCAL seam fill of the two edge ranks equal to the global one, and
-S = 5 keeps the copies of columns 1, 2 / km-2, km-3 exact through one stencil application inside an
-operator (the pressure step fills the seam of p_dyn right after its Jacobi sweep).  Columns next to
-the junction between two segments compute garbage; they are never owned and are overwritten by the
-next refresh.  Results at owned columns are bit-identical to the single-domain run.
+and runs the unmodified single-domain operators on it.  With G = 3 every k-stencil of an owned column (reach 2) and
+every k-window test (k >= 2, k <= km-3) evaluates exactly as in the single domain.  The seam copies make the LOCAL seam
+fill of the two edge ranks equal to the global one: the copies of columns km-3 .. km-1 (0 .. 2 on the last rank) stay
+valid through every column-local operator because their mask neighbourhood lies inside the S = 5 copies.  The other
+non-owned columns hold whatever the operators make of them; they never feed an owned column except through the
+fields named below, which their owners send first.
 
-Refresh.  Ghost and seam columns are re-sent by their owner after the operators whose results
-at those columns are not reproducible locally: the RK sweeps (mask tests two columns beyond the
-slab edge) and the pressure step.  Pointwise operators and the r / theta fills keep valid ghosts valid.
+Exchange.  Before a pressure step: p_dynn, aux_u, aux_v, aux_w at the ghost and seam columns (the aux fields are
+final after the last RK sweep, p_dynn after the old -> new copy, so the messages are posted right there and travel
+while the limiter, the queries and the copy run; the pressure step waits for them).  Before a residuum query: w.
+Nothing after an RK sweep, nothing for the pointwise operators and the r / theta / phi fills.
 
-Not sharded: the 2-D surface loop (phi-coupled Gauss-Seidel, 65 k points) and the order-dependent
-residuum / steady queries; they stay on one GPU.
+Queries.  Every rank evaluates its owned columns (atomdev_residuum3d_suffix, atomdev_steady3d_part); the reference's
+scan over the whole grid's lexicographic sequence is run as its jumps, each jump one all-gather of a seven-number
+summary per rank; the steady maxima combine with the position in the whole grid as tie-break.  Results and locations
+are those of the single domain.
+
+Start of a slice.  The file readers, the initial conditions and the 2-D surface loop (a phi-coupled Gauss-Seidel
+sweep over 65 k points) run on one full-width model on rank 0; `distribute` hands every rank its columns of every
+field, `collect` brings the owned columns back.  The column physics of the atmosphere (class members carried from
+column to column in the whole grid's visiting order) is not sharded.
 """
 import numpy as np
 
@@ -37,13 +45,11 @@ S = 5  # seam copies held by the two edge ranks
 ATM_STATE = ["T", "U", "V", "W", "P_DYN", "C", "CLOUD", "ICE", "CO2"]
 HYD_STATE = ["T", "U", "V", "W", "P_DYN", "C"]
 
-# fields whose ghost copies an operator invalidates (everything else keeps valid ghosts valid)
-NONLOCAL_WRITES = {
-    "atm_rk3d": ["T", "U", "V", "W", "C", "CLOUD", "ICE", "CO2", "AUX_U", "AUX_V", "AUX_W", "BUOYANCY"],
-    "hyd_rk3d": ["T", "U", "V", "W", "C", "AUX_U", "AUX_V", "AUX_W", "BUOYANCY", "SALT_BALANCE", "SALT_FINGER",
-                 "SALT_DIFFUSION", "R_WATER", "R_SALT_WATER"],
-    "atm_pressure3d": ["P_DYN", "AUX_U", "AUX_V", "AUX_W"],
-    "hyd_pressure3d": ["P_DYN", "AUX_U", "AUX_V", "AUX_W"],
+# fields whose ghost / seam copies must be the owners' before an operator runs
+NEEDS = {
+    "atm_pressure3d": ["P_DYNN", "AUX_U", "AUX_V", "AUX_W"],
+    "hyd_pressure3d": ["P_DYNN", "AUX_U", "AUX_V", "AUX_W"],
+    "residuum": ["W"],
 }
 NOT_SHARDED = {"atm_rk2d", "hyd_rk2d", "atm_pressure2d", "hyd_pressure2d"}
 
@@ -112,14 +118,16 @@ class SlabPlan:
 class SlabModel:
     """One rank's slab: `engine` is that rank's model (atom_amd.DeviceModel on its GPU) built with
     km = plan.local_km(rank); `dist` is torch.distributed (initialised) or None for a single rank.
-    Exchange buffers live on `xdev` ("cuda:N" for RCCL, "cpu" for gloo)."""
+    Exchange buffers live on `xdev` ("cuda:N" for RCCL, "cpu" for gloo) and are allocated once per message."""
 
-    def __init__(self, engine, plan, rank, dist=None, xdev="cpu"):
-        self.e, self.plan, self.rank, self.dist, self.xdev = engine, plan, rank, dist, xdev
+    def __init__(self, engine, plan, rank, dist=None, xdev="cpu", model=0):
+        self.e, self.plan, self.rank, self.dist, self.xdev, self.model = engine, plan, rank, dist, xdev, model
         if plan.world > 1 and dist is None:
             raise ValueError("a plan over several ranks needs torch.distributed")
         self.cols = plan.columns(rank)
-        self._transfers = plan.transfers()
+        self._transfers = [t for t in plan.transfers() if rank in t[:2]]
+        self._buffers = {}   # (transfer index, number of fields) -> persistent tensor
+        self._pending = []   # posted exchanges: (work handles, receives to unpack)
 
     # ---- data in and out ----------------------------------------------------
     def scatter(self, fields3d, fields2d):
@@ -133,38 +141,217 @@ class SlabModel:
         off, n = self.plan.owned_local(self.rank)
         return self.plan.owned[self.rank][0], self.e.get_columns(name, off, n)
 
-    # ---- operators ----------------------------------------------------------
-    def op(self, name):
-        if name in NOT_SHARDED and self.plan.world > 1:
-            raise ValueError("%s is not sharded: run the surface loop on one GPU" % name)
-        self.e.op(name)
-        self.refresh(NONLOCAL_WRITES.get(name, ()))
-
-    def move_data_to_new_arrays(self, level=-1):
-        self.e.move_data_to_new_arrays(level)
-
-    def refresh(self, names):
-        """Owners re-send the ghost / seam copies of the named 3-D fields."""
-        names = list(names)
-        if self.plan.world == 1 or not names:
-            return
-        import torch
-        for owner, holder, k_src, k_dst, n in self._transfers:
-            if self.rank != owner and self.rank != holder:
-                continue
-            buf = torch.empty((len(names), self.e.im, self.e.jm, n), dtype=torch.float64, device=self.xdev)
-            if self.rank == owner:
-                for m, name in enumerate(names):
-                    self.e.get_columns(name, k_src, n, out=self._view(buf[m]))
-                self.dist.send(buf, dst=holder)
+    def distribute(self, full, names3d, names2d=()):
+        """Rank 0 holds `full`, a model of the whole grid (anything with download(name)); every rank receives its local
+        columns - ghosts and seam copies included - of the named fields and uploads them.  `full` is None elsewhere."""
+        for name in list(names3d) + list(names2d):
+            if self.plan.world == 1:
+                a = full.download(name)
             else:
-                self.dist.recv(buf, src=owner)
-                for m, name in enumerate(names):
-                    self.e.set_columns(name, k_dst, self._view(buf[m]))
+                parts = None
+                if self.rank == 0:
+                    a = full.download(name)
+                    parts = [np.ascontiguousarray(a[..., self.plan.columns(r)]) for r in range(self.plan.world)]
+                box = [None]
+                self.dist.scatter_object_list(box, parts, src=0)
+                a = box[0]
+            self.e.upload(name, a)
+
+    def collect(self, names3d):
+        """The owned columns of the named 3-D fields assembled on rank 0: {name: (im, jm, km) array} there, None elsewhere."""
+        mine = {k: self.owned_block(k) for k in names3d}
+        if self.plan.world == 1:
+            return {k: np.ascontiguousarray(b) for k, (_, b) in mine.items()}
+        mine = {k: (g0, np.ascontiguousarray(b)) for k, (g0, b) in mine.items()}
+        gathered = [None] * self.plan.world if self.rank == 0 else None
+        self.dist.gather_object(mine, gathered, dst=0)
+        if self.rank != 0:
+            return None
+        out = {}
+        for k in names3d:
+            a = np.empty((self.e.im, self.e.jm, self.plan.km))
+            for part in gathered:
+                g0, blk = part[k]
+                a[:, :, g0:g0 + blk.shape[-1]] = blk
+            out[k] = a
+        return out
+
+    # ---- exchange -------------------------------------------------------------
+    def _buffer(self, index, nfields, n):
+        import torch
+        key = (index, nfields)
+        if key not in self._buffers:
+            self._buffers[key] = torch.empty((nfields, self.e.im, self.e.jm, n), dtype=torch.float64, device=self.xdev)
+        return self._buffers[key]
 
     def _view(self, t):
         # engines take numpy arrays for host buffers and tensors (data_ptr) for device buffers
         return t.numpy() if t.device.type == "cpu" else t
+
+    def begin_exchange(self, names):
+        """Owners post the ghost / seam copies of the named 3-D fields, holders post the receives; returns at once."""
+        names = list(names)
+        if self.plan.world == 1 or not names:
+            return
+        on_device = self.xdev != "cpu"
+        works, unpack = [], []
+        packed = False
+        for index, (owner, holder, k_src, k_dst, n) in enumerate(self._transfers):
+            buf = self._buffer((index, tuple(names)), len(names), n)
+            if self.rank == owner:
+                for m, name in enumerate(names):
+                    self.e.get_columns(name, k_src, n, out=self._view(buf[m]))
+                packed = True
+        if packed and on_device:
+            self.e.sync()   # the packing copies ran on the handle's stream; the collective library reads on its own
+        ops = []
+        for index, (owner, holder, k_src, k_dst, n) in enumerate(self._transfers):
+            buf = self._buffer((index, tuple(names)), len(names), n)
+            if self.rank == owner:
+                ops.append(self.dist.P2POp(self.dist.isend, buf, holder))
+            else:
+                ops.append(self.dist.P2POp(self.dist.irecv, buf, owner))
+                unpack.append((buf, names, k_dst))
+        works = self.dist.batch_isend_irecv(ops)   # one group: no ordering between the messages of different neighbours
+        self._pending.append((works, unpack, on_device))
+
+    def finish_exchange(self, only_last=False):
+        """Waits for every posted exchange (or the one posted last) and stores what arrived into the ghost / seam columns."""
+        todo = [self._pending.pop()] if only_last and self._pending else self._pending
+        if not only_last:
+            self._pending = []
+        for works, unpack, on_device in todo:
+            for w in works:
+                w.wait()
+            if on_device:
+                import torch
+                torch.cuda.current_stream().synchronize()   # wait() orders the collective against torch's stream only
+            for buf, names, k_dst in unpack:
+                for m, name in enumerate(names):
+                    self.e.set_columns(name, k_dst, self._view(buf[m]))
+
+    def refresh(self, names):
+        """begin_exchange and the wait for it; exchanges posted earlier stay in flight."""
+        if self.plan.world == 1 or not list(names):
+            return
+        self.begin_exchange(names)
+        self.finish_exchange(only_last=True)
+
+    # ---- operators ----------------------------------------------------------
+    def op(self, name):
+        if name in NOT_SHARDED and self.plan.world > 1:
+            raise ValueError("%s is not sharded: the surface loop runs on the full-width model of rank 0" % name)
+        if name in NEEDS:
+            self.finish_exchange()
+            self.refresh(NEEDS[name])
+        self.e.op(name)
+
+    def move_data_to_new_arrays(self, level=-1):
+        self.e.move_data_to_new_arrays(level)
+
+    # ---- queries --------------------------------------------------------------
+    def _all(self, values):
+        """Every rank's list of numbers, in rank order."""
+        if self.plan.world == 1:
+            return [list(values)]
+        box = [None] * self.plan.world
+        self.dist.all_gather_object(box, list(values))
+        return box
+
+    def residuum(self, min0=0.0, loc0=(0, 0, 0)):
+        """residuumQuery_3D of the whole grid (Accuracy_Atm.cpp:82-116, Accuracy_Hyd.cpp:88-116): (value, location)."""
+        self.refresh(NEEDS["residuum"])
+        self.e.residuum_field()
+        off, n = self.plan.owned_local(self.rank)
+        kg0, kmg = self.plan.owned[self.rank][0], self.plan.km
+        ge = self.model == 1               # the hydrosphere compares with >= and starts from 0
+        m = 0.0 if ge else float(min0)
+        pos = -1
+        s = 0.0
+        total = float((self.e.im - 2) * (self.e.jm - 2) * (kmg - 2))
+
+        def first(cands):                  # smallest position among (position, value) pairs with position >= 0
+            cands = [c for c in cands if c[0] >= 0]
+            return min(cands) if cands else (-1.0, 0.0)
+
+        while s < total:
+            parts = self._all(self.e.residuum_suffix(off, n, kg0, kmg, s))
+            if m < 0.0:                    # every point replaces a negative state up to the first non-negative one
+                q, xq = first([(p[3], p[4]) for p in parts])
+                if q >= 0:
+                    m, pos, s = xq, q, q + 1
+                    continue
+                last = max([(p[5], p[6]) for p in parts])
+                if last[0] >= 0:
+                    m, pos = last[1], last[0]
+                break
+            amax = max(p[0] for p in parts)
+            if amax < 0 or not (amax >= m if ge else amax > m):
+                break
+            P, xP = first([(p[1], p[2]) for p in parts if p[0] == amax])
+            m, pos, s = xP, P, P + 1
+        if pos < 0:
+            return m, tuple(loc0)
+        pos = int(pos)
+        nk, nj = kmg - 2, self.e.jm - 2
+        return m, (pos // (nj * nk) + 1, (pos // nk) % nj + 1, pos % nk + 1)
+
+    def steady(self):
+        """steadyQuery_3D of the whole grid: (values, locations), fields in the order of atomdev_*_steady3d."""
+        off, n = self.plan.owned_local(self.rank)
+        kg0, kmg = self.plan.owned[self.rank][0], self.plan.km
+        v, p = self.e.steady_part(off, n, kg0, kmg)
+        parts = self._all(list(v) + list(p))
+        nf = len(v)
+        last = self.model == 1
+        values, locs = [], []
+        n2 = self.e.jm * kmg
+        for f in range(nf):
+            best_v, best_p = -1.0, None
+            for part in parts:
+                pv, pp = part[f], part[nf + f]
+                if pv > best_v or (pv == best_v and best_p is not None and (pp > best_p if last else pp < best_p)):
+                    best_v, best_p = pv, pp
+            if best_v < 0.0 or (not last and best_v == 0.0):
+                best_v, best_p = 0.0, 0
+            q = int(best_p)
+            values.append(best_v)
+            locs.append((q // n2, (q % n2) // kmg, q % kmg))
+        return values, locs
+
+    # ---- the 3-D loop of the flow solver --------------------------------------
+    def run_3d_loop(self, pressure_iters=2, velocity_iters=2, queries=True):
+        """The pressure / velocity iterations of run_3D_loop without the column physics, exchanges posted as early as their
+        data is final.  Returns the queries' results in call order: (residuum, location) before and after every sweep and
+        (values, locations) of the steady query."""
+        atm = self.model == 0
+        pre = "atm_" if atm else "hyd_"
+        log = []
+        if atm:
+            self.move_data_to_new_arrays(-1)    # cAtmosphereModel.cpp:753; the hydrosphere's loop has no such copy
+        for _ in range(pressure_iters):
+            for v in range(1, velocity_iters + 1):
+                if queries:
+                    first = self.residuum()
+                    log.append(first)
+                if atm:
+                    ops = ["bc_radius", "bc_theta", "bc_phi", "value_limitation", "solid_ground", "rk3d", "value_limitation"]
+                else:
+                    ops = ["bc_radius", "bc_theta", "bc_phi", "pressure_density", "value_limitation", "rk3d", "solid_ground"]
+                for op in ops:
+                    self.e.op(pre + op)
+                    if op == "rk3d" and v == velocity_iters:
+                        self.begin_exchange(["AUX_U", "AUX_V", "AUX_W"])   # final until the next sweep
+                if queries:
+                    log.append(self.residuum(*first) if atm else self.residuum())
+                    log.append(self.steady())
+                if atm:
+                    self.e.msl_data(1)      # Results_MSL_Atm::run_MSL_data, column by column (:854-859)
+                self.move_data_to_new_arrays(-1)
+            self.begin_exchange(["P_DYNN"])
+            self.finish_exchange()
+            self.e.op(pre + "pressure3d")
+        return log
 
 
 def create_device_slab(model, im, jm, km_global, params, rank, world, dist=None, device=-1, xdev=None):
@@ -173,5 +360,9 @@ def create_device_slab(model, im, jm, km_global, params, rank, world, dist=None,
     plan = SlabPlan(km_global, world)
     engine = DeviceModel(model, im, jm, plan.local_km(rank), params, device=device)
     if xdev is None:
-        xdev = "cpu" if dist is None or dist.get_backend() != "nccl" else "cuda:%d" % max(device, 0)
-    return SlabModel(engine, plan, rank, dist, xdev)
+        if dist is None or dist.get_backend() != "nccl":
+            xdev = "cpu"
+        else:
+            import torch
+            xdev = "cuda:%d" % (torch.cuda.current_device() if device < 0 else device)
+    return SlabModel(engine, plan, rank, dist, xdev, model)

@@ -366,6 +366,22 @@ typedef struct atomdev_atm_slice {
 void atomdev_default_atm_slice(atomdev_atm_slice* s);
 int atomdev_atm_run_time_slice(atomdev_t* h, const atomdev_atm_slice* s, atomdev_atm_loop_state* state);
 
+/* The accuracy queries of a model that holds a slab of longitudes - the columns [kg0, kg0 + nk) of a grid with km_global
+ * columns, stored at its local columns [k0, k0 + nk) - for runs that split one model over several GPUs.  No counterpart in the
+ * reference, which has one domain.
+ * atomdev_residuum3d_field: the continuity residuum at every interior local point into ATOMDEV_RESIDUUM (w one column
+ *   beyond each end of the slab must be valid).
+ * atomdev_residuum3d_suffix: what the slab contributes to one step of the reference's order-dependent scan over the whole
+ *   grid's lexicographic sequence (Accuracy_Atm.cpp:82-116): over its points at global sequence position >= from,
+ *   out = { largest |res| (-1: none), its first position, res there, first position with res >= 0 (-1: none), res there,
+ *   last position whose res is no NaN (-1: none), res there }.
+ * atomdev_steady3d_part: max |x - xn| of every field of the steady query (9 for the atmosphere, 6 for the hydrosphere, in the
+ *   order of atomdev_*_steady3d) over the slab's columns, and its position (i jm + j) km_global + k - the first one for the
+ *   atmosphere, the last one for the hydrosphere, as the two reference classes compare.  A value of -1: no point. */
+int atomdev_residuum3d_field(atomdev_t* h);
+int atomdev_residuum3d_suffix(atomdev_t* h, int k0, int nk, int kg0, int km_global, double from, double out[7]);
+int atomdev_steady3d_part(atomdev_t* h, int k0, int nk, int kg0, int km_global, double* values, double* positions);
+
 /* The library's arithmetic helpers evaluated on the device for n caller-supplied operands (host pointers): the
  * double-double exp / pow / x^4 / fourth root the column physics uses in place of the device library's functions, and the
  * sweeps' division by a known reciprocal beside the hardware's IEEE division.  For property tests; no counterpart in the
