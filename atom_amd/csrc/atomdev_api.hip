@@ -156,6 +156,7 @@ extern "C" int atomdev_create(int model, int im, int jm, int km, const atomdev_p
     if (const char* e = getenv("ATOMDEV_RK_VARIANT")) h->rk_variant = atoi(e);
     h->rad = h->sinthe = h->costhe = h->plane = nullptr; h->red = nullptr;
     h->static_scratch = nullptr; h->static_scratch_bytes = 0; h->pinned = nullptr;
+    h->stage = nullptr; h->stage_bytes = 0;
     fill_constants(h);
 
     int rc = 0;
@@ -216,6 +217,7 @@ extern "C" int atomdev_destroy(atomdev_t* h) {
     if (h->plane) (void)hipFree(h->plane);
     if (h->red) (void)hipFree(h->red);
     if (h->pinned) (void)hipHostFree(h->pinned);
+    if (h->stage) (void)hipFree(h->stage);
     if (h->rad) (void)hipFree(h->rad);
     if (h->sinthe) (void)hipFree(h->sinthe);
     if (h->costhe) (void)hipFree(h->costhe);
@@ -298,6 +300,64 @@ static int copy_columns(atomdev_t* h, int field, int k0, int nk, void* buf, bool
     if (int rc__ = atomdev_sync_stream(h)) return rc__;
     if (!to_buf && field == ATOMDEV_H) h->flags_dirty = true;
     return 0;
+}
+
+// ---- several fields' columns in one message buffer ----
+struct PackArgs { double* f[16]; };
+template <bool PACK>
+__global__ void k_pack_columns(PackArgs a, double* __restrict__ buf, size_t rows, int km, int k0, int nk) {
+    const size_t per_field = rows * nk;
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= per_field) return;
+    const size_t row = q / nk;
+    const int kk = (int)(q % nk);
+    double* x = a.f[blockIdx.y] + row * km + k0 + kk;
+    double* b = buf + (size_t)blockIdx.y * per_field + q;
+    if (PACK) *b = *x; else *x = *b;
+}
+
+static int pack_columns(atomdev_t* h, const int* fields, int nf, int k0, int nk, void* buf, bool pack, const char* who) {
+    ATOMDEV_REQUIRE(h && fields && buf && nf >= 1 && nf <= 16, std::string(who) + ": bad argument");
+    ATOMDEV_REQUIRE(k0 >= 0 && nk >= 1 && k0 + nk <= h->km, std::string(who) + ": column range outside the grid");
+    ATOMDEV_TRY(hipSetDevice(h->device));
+    PackArgs a;
+    for (int n = 0; n < nf; n++) {
+        ATOMDEV_REQUIRE(fields[n] >= 0 && fields[n] < ATOMDEV_N3D && h->f[fields[n]], std::string(who) + ": a field this model does not have");
+        a.f[n] = h->f[fields[n]];
+        if (!pack && fields[n] == ATOMDEV_H) h->flags_dirty = true;
+    }
+    const size_t rows = (size_t)h->im * h->jm, bytes = (size_t)nf * rows * nk * sizeof(double);
+    hipPointerAttribute_t attr;
+    const bool on_device = hipPointerGetAttributes(&attr, buf) == hipSuccess && attr.type == hipMemoryTypeDevice;
+    if (!on_device) (void)hipGetLastError();  // plain host memory is "not found": clear the sticky error
+    double* dev = (double*)buf;
+    if (!on_device) {  // host buffer: one contiguous copy through a staging buffer of the handle
+        if (bytes > h->stage_bytes) {
+            if (int rc__ = atomdev_sync_stream(h)) return rc__;
+            if (h->stage) ATOMDEV_TRY(hipFree(h->stage));
+            h->stage = nullptr; h->stage_bytes = 0;
+            ATOMDEV_TRY(hipMalloc(&h->stage, bytes));
+            h->stage_bytes = bytes;
+        }
+        dev = (double*)h->stage;
+        if (!pack) ATOMDEV_TRY(hipMemcpyAsync(dev, buf, bytes, hipMemcpyHostToDevice, h->stream));
+    }
+    const dim3 grid((unsigned)((rows * nk + 255) / 256), nf);
+    if (pack) hipLaunchKernelGGL(k_pack_columns<true>, grid, dim3(256), 0, h->stream, a, dev, rows, h->km, k0, nk);
+    else hipLaunchKernelGGL(k_pack_columns<false>, grid, dim3(256), 0, h->stream, a, dev, rows, h->km, k0, nk);
+    ATOMDEV_TRY(hipGetLastError());
+    if (!on_device) {
+        if (pack) ATOMDEV_TRY(hipMemcpyAsync(buf, dev, bytes, hipMemcpyDeviceToHost, h->stream));
+        return atomdev_sync_stream(h);  // the host buffer is complete / may be reused
+    }
+    return 0;  // device buffer: ordered on the handle's stream, the caller waits once (atomdev_sync) before it hands the buffer on
+}
+
+extern "C" int atomdev_pack_columns(atomdev_t* h, const int* fields3d, int nf, int k0, int nk, void* dst) {
+    return pack_columns(h, fields3d, nf, k0, nk, dst, true, "atomdev_pack_columns");
+}
+extern "C" int atomdev_unpack_columns(atomdev_t* h, const int* fields3d, int nf, int k0, int nk, const void* src) {
+    return pack_columns(h, fields3d, nf, k0, nk, const_cast<void*>(src), false, "atomdev_unpack_columns");
 }
 
 extern "C" int atomdev_get_columns(atomdev_t* h, int field3d, int k0, int nk, void* dst) {

@@ -67,6 +67,8 @@ struct atomdev {
     size_t static_scratch_bytes;
     void* pinned;                   // 256 bytes of page-locked host memory: results read back without staging (first half),
                                     // the word kernels set on a failure they detect themselves (byte 128)
+    void* stage;                    // device staging buffer of atomdev_pack_columns / _unpack_columns for host buffers (lazy)
+    size_t stage_bytes;
     int rk_variant;                 // 0: wave-specialised sweep (default), 1: one thread per theta line, 2: 0 in its tolerance form
     int profile_rk;                 // bracket the RK sweeps with events: 1 the sweep kernel alone, 2 with the kernels that prepare it
     std::vector<hipEvent_t> prof_ev;  // pairs (start, stop), prof_used of them recorded

@@ -164,6 +164,8 @@ def load_library():
     lib.atomdev_fill2d.argtypes = [vp, C.c_int, C.c_double]
     lib.atomdev_selftest_math.argtypes = [vp, C.c_int, C.c_size_t, dp, dp, dp]
     lib.atomdev_selftest_raise_kernel_error.argtypes = [vp]
+    for name in ("atomdev_pack_columns", "atomdev_unpack_columns"):
+        getattr(lib, name).argtypes = [vp, ip, C.c_int, C.c_int, C.c_int, vp]
     lib.atomdev_residuum3d_field.argtypes = [vp]
     lib.atomdev_residuum3d_suffix.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, dp]
     lib.atomdev_steady3d_part.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, dp, dp]
@@ -390,6 +392,19 @@ class DeviceModel:
 
     def bc_co2(self, start):
         self._check(self.lib.atomdev_atm_bc_co2(self._h, C.byref(start)))
+
+    def pack_columns(self, names, k0, nk, buf):
+        """atomdev_pack_columns: columns k0 .. k0+nk-1 of the named 3-D fields into buf, a dense (len(names), im, jm, nk)
+        float64 buffer on the host (numpy) or on the device (anything with data_ptr())."""
+        ids = (C.c_int * len(names))(*[F3[n] for n in names])
+        nbytes = len(names) * self.im * self.jm * nk * 8
+        self._check(self.lib.atomdev_pack_columns(self._h, ids, len(names), k0, nk, self._buffer_pointer(buf, nbytes)))
+
+    def unpack_columns(self, names, k0, buf):
+        ids = (C.c_int * len(names))(*[F3[n] for n in names])
+        nk = buf.shape[-1]
+        nbytes = len(names) * self.im * self.jm * nk * 8
+        self._check(self.lib.atomdev_unpack_columns(self._h, ids, len(names), k0, nk, self._buffer_pointer(buf, nbytes)))
 
     # ---- the queries of a slab of a wider grid (atom_amd/slabs.py) ----
     def residuum_field(self):

@@ -199,8 +199,11 @@ class SlabModel:
         for index, (owner, holder, k_src, k_dst, n) in enumerate(self._transfers):
             buf = self._buffer((index, tuple(names)), len(names), n)
             if self.rank == owner:
-                for m, name in enumerate(names):
-                    self.e.get_columns(name, k_src, n, out=self._view(buf[m]))
+                if hasattr(self.e, "pack_columns"):
+                    self.e.pack_columns(names, k_src, n, self._view(buf))      # one kernel, one message
+                else:
+                    for m, name in enumerate(names):
+                        self.e.get_columns(name, k_src, n, out=self._view(buf[m]))
                 packed = True
         if packed and on_device:
             self.e.sync()   # the packing copies ran on the handle's stream; the collective library reads on its own
@@ -227,8 +230,11 @@ class SlabModel:
                 import torch
                 torch.cuda.current_stream().synchronize()   # wait() orders the collective against torch's stream only
             for buf, names, k_dst in unpack:
-                for m, name in enumerate(names):
-                    self.e.set_columns(name, k_dst, self._view(buf[m]))
+                if hasattr(self.e, "unpack_columns"):
+                    self.e.unpack_columns(names, k_dst, self._view(buf))
+                else:
+                    for m, name in enumerate(names):
+                        self.e.set_columns(name, k_dst, self._view(buf[m]))
 
     def refresh(self, names):
         """begin_exchange and the wait for it; exchanges posted earlier stay in flight."""

@@ -41,6 +41,41 @@ HYD_STEP = ["hyd_bc_radius", "hyd_bc_theta", "hyd_bc_phi", "hyd_pressure_density
             "hyd_solid_ground", "move3d"]
 
 
+def make_slab(H, atom_amd, dist, rank, world, device, seed, backend):
+    """This rank's phi-slab of the atmosphere on the global grid (atom_amd/slabs.py): the mask columns it holds, seeded fields."""
+    from atom_amd import slabs
+    p = atom_amd.default_params(H.ATM, IM, JM, KM)
+    sm = slabs.create_device_slab(H.ATM, IM, JM, KM, p, rank, world, dist, device=device, xdev=None if backend == "nccl" else "cpu")
+    kml = sm.e.km
+    f, g = H.make_inputs(H.ATM, IM, JM, kml, seed, "allfluid", p)
+    f = {k: f[k] for k in H.ATM_FIELDS}
+    h, topo = H.load_mask_0Ma(H.ATM)
+    jj = np.rint(np.arange(JM) * 180. / (JM - 1)).astype(int)
+    kk = np.rint(sm.cols * 360. / (KM - 1)).astype(int)
+    f["H"], g["TOPOGRAPHY"] = np.ascontiguousarray(h[:, jj][:, :, kk]), np.ascontiguousarray(topo[jj][:, kk])
+    if (IM, JM, KM) != GRIDS["1"]:
+        H.shrink_noise(f, 256.)
+    sm.e.upload_all(f, g)
+    sm.e.sync()
+    return sm
+
+
+def slab_step(sm, s):
+    """One velocity iteration of the slab; the exchange for the pressure step is posted as soon as its data is final."""
+    pressure = (s + 1) % 2 == 0
+    for op in ATM_STEP:
+        if op == "move3d":
+            sm.e.move_data_to_new_arrays(-1)
+        else:
+            sm.e.op(op)
+            if op == "atm_rk3d" and pressure:
+                sm.begin_exchange(["AUX_U", "AUX_V", "AUX_W"])
+    if pressure:
+        sm.begin_exchange(["P_DYNN"])
+        sm.finish_exchange()
+        sm.e.op("atm_pressure3d")
+
+
 def make_model(H, atom_amd, model, device, seed):
     p = atom_amd.default_params(model, IM, JM, KM)   # the product's own defaults (param.py), no checker involved
     f, g = H.make_inputs(model, IM, JM, KM, seed, "allfluid", p)
@@ -108,6 +143,53 @@ def cpu_baseline(H, p, f, g, budget_s=12.0):
     return out
 
 
+def run_slabs(args, H, atom_amd, torch, dist, rank, world, local_rank, barrier):
+    """Strong scaling: one atmosphere on the chosen grid, its longitudes split over the ranks."""
+    sm = make_slab(H, atom_amd, dist, rank, world, local_rank, 1234 + rank, args.backend)
+    for s in range(args.warmup + args.warmup % 2):
+        slab_step(sm, s)
+    sm.e.sync()
+    sm.e.profile_rk(True)
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        slab_step(sm, s)
+    sm.e.sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    rk_ms, rk_n = sm.e.profile_read()
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        own = sm.plan.owned[0][1] - sm.plan.owned[0][0]
+        slab_updates = (IM - 2) * (JM - 2) * own
+        rk_s = rk_ms / rk_n * 1e-3
+        achieved = slab_updates * ATM_BYTES_PER_UPDATE / rk_s / 1e9
+        exchanged = sum(n for o, hd, a, b2, n in sm._transfers if o == 0) * IM * JM * 8 * 4   # four fields per pressure step
+        print(json.dumps({
+            "metric": "grid-point RK updates/s (%dx%dx%d fp64)" % (IM, JM, KM),
+            "value": UPDATES * args.steps / elapsed, "unit": "grid-point RK updates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic fields (numpy PCG64 seed 1234+rank per slab), real 0 Ma land mask" + ("" if args.grid == "1" else " upsampled"),
+            "config": {"workload": "ONE atmosphere, 3-D hot-path iteration, %dx%dx%d split into %d phi-slabs (3 ghost columns per edge, "
+                                   "5 seam copies on the edge ranks); per pressure step every rank sends p_dynn, aux_u, aux_v, aux_w at its "
+                                   "neighbours' ghost columns" % (IM, JM, KM, world),
+                       "grid": [IM, JM, KM], "updates_per_step": UPDATES, "parallelism": "phi-slabs x%d" % world,
+                       "backend": args.backend, "exchange_bytes_per_pressure_step_rank0": exchanged},
+            "roofline": {"bound": "hbm", "kernel": "k_atm_rk3d_ws (rank 0's slab of %d owned columns)" % own, "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "bytes_per_update": ATM_BYTES_PER_UPDATE, "kernel_ms": rk_s * 1e3, "launches": rk_n,
+                         "rk_variant": sm.e.rk_variant()},
+            "cpu_baseline": None}))
+    sm.e.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -117,6 +199,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo to rehearse "
                                                       "several ranks on one GPU)")
     ap.add_argument("--grid", default="1", choices=sorted(GRIDS), help="horizontal resolution in degrees (default 1: the metric's grid)")
+    ap.add_argument("--mode", default="slices", choices=["slices", "slabs"],
+                    help="slices (default): every GPU its own time slice, weak scaling; slabs: ONE model split into phi-slabs over "
+                         "the GPUs with halo exchange around the pressure step, strong scaling (meant for --grid 0.25)")
     args = ap.parse_args()
     global IM, JM, KM, UPDATES
     IM, JM, KM = GRIDS[args.grid]
@@ -153,6 +238,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.mode == "slabs":
+        run_slabs(args, H, atom_amd, torch, dist, rank, world, local_rank, barrier)
+        return
     atm, p, f, g = make_model(H, atom_amd, H.ATM, local_rank, 1234 + rank)
 
     for s in range(args.warmup):

@@ -366,6 +366,13 @@ typedef struct atomdev_atm_slice {
 void atomdev_default_atm_slice(atomdev_atm_slice* s);
 int atomdev_atm_run_time_slice(atomdev_t* h, const atomdev_atm_slice* s, atomdev_atm_loop_state* state);
 
+/* nk columns from k0 of several 3-D fields as one dense message [nf][im][jm][nk] (halo exchange between slabs).  dst / src
+ * may be host memory (copied through a staging buffer of the handle; the call returns when the buffer is complete) or
+ * device memory (packed by a kernel on the handle's stream; the call returns at once and atomdev_sync orders it).  No
+ * counterpart in the reference. */
+int atomdev_pack_columns(atomdev_t* h, const int* fields3d, int nf, int k0, int nk, void* dst);
+int atomdev_unpack_columns(atomdev_t* h, const int* fields3d, int nf, int k0, int nk, const void* src);
+
 /* The accuracy queries of a model that holds a slab of longitudes - the columns [kg0, kg0 + nk) of a grid with km_global
  * columns, stored at its local columns [k0, k0 + nk) - for runs that split one model over several GPUs.  No counterpart in the
  * reference, which has one domain.
