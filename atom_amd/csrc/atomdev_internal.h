@@ -107,11 +107,14 @@ int atomdev_hyd_rk3d_ws_fast(atomdev* h);  // k_rk_hyd_ws.hip compiled with -DAT
     } while (0)
 
 #ifdef __HIPCC__
-// a / b for a divisor whose correctly rounded reciprocal rb is known: one
-// product and two fused corrections give the correctly rounded quotient (the
-// residual a - q*b is exact), at a quarter of the cost of the generic IEEE
-// division sequence.  Valid for finite, normal, non-overflowing operands, which
-// is what the model's bounded fields and grid constants are.
+// a / b for a divisor whose correctly rounded reciprocal rb is known: one product and two fused corrections (the
+// residual a - q*b is exact), at a quarter of the cost of the generic IEEE division sequence.  This is not a theorem
+// for every operand pair: there are divisors for which some dividend makes the corrected quotient differ from the
+// correctly rounded one.  The divisors here are grid constants and table entries; that the result has the bits of
+// a / b is checked on the device over 10^7 operand pairs (dividends over the fields' range, divisors over the
+// constants' range, divisors with every significand bit set among them: tests/test_gpu_math.py) and, end to end, by
+// the bit-exact parity tests of every kernel that uses it.  Finite, normal, non-overflowing operands only.
+// Building with -DATOMDEV_TRUE_DIV replaces it by the hardware's division sequence.
 __device__ __forceinline__ double div_by(double a, double b, double rb) {
 #ifdef ATOMDEV_TRUE_DIV
     (void)rb;

@@ -11,7 +11,7 @@ step() {  # step <seconds> <log> <command...>
   local rc=$?
   if [ $rc -ne 0 ]; then echo "FAILED rc=$rc: $*"; tail -30 $log; exit $rc; fi
 }
-step 900 gpurun_out/final/pytest.log python -u -m pytest tests -m gpu -x -q --timeout 150 --timeout-method thread
+step 1150 gpurun_out/final/pytest.log python -u -m pytest tests -m gpu -x -q --timeout 900 --timeout-method thread
 tail -3 gpurun_out/final/pytest.log
 step 200 gpurun_out/final/smoke.log python -u -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')"
 tail -1 gpurun_out/final/smoke.log
