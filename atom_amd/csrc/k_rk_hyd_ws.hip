@@ -509,6 +509,10 @@ __global__ __launch_bounds__(320) void k_hyd_rk3d_ws(const HydWsParams* __restri
     const int wave = threadIdx.x >> 6;
     const int i = 1 + lev;
     const int jm = K.jm;
+#ifdef ATOMDEV_EXP_WGTIME  // timing experiment only: duration of every workgroup goes to level 0 of aux_u
+    const long long wg_t0 = __builtin_readcyclecounter();
+    const long long wg_w0 = wall_clock64();
+#endif
     {
         const double rm = a.rad[i], rm2 = rm * rm;
         for (int j = threadIdx.x; j < jm; j += 320) {
@@ -533,6 +537,12 @@ __global__ __launch_bounds__(320) void k_hyd_rk3d_ws(const HydWsParams* __restri
         case R_C: sweep_role<R_C>(a, K, sh, tab, bx, i, pw, err, a.c, a.co, a.cn); break;
         default: sweep_role<R_W>(a, K, sh, tab, bx, i, pw, err, a.w, a.wo, a.wn); break;
     }
+#ifdef ATOMDEV_EXP_WGTIME
+    if ((threadIdx.x & 63) == 0) {
+        a.aux_u[(lev * gx + bx) * 8 + wave] = (double)(__builtin_readcyclecounter() - wg_t0);
+        if (threadIdx.x == 0) { a.aux_u[16384 + lev * gx + bx] = (double)wg_w0; a.aux_u[32768 + lev * gx + bx] = (double)wall_clock64(); }
+    }
+#endif
 }
 
 // Copies the boundary shell (i, j or k on a face) of src to dst: the sweep writes interior points only.

@@ -361,8 +361,14 @@ class SlabModel:
 
 
 def create_device_slab(model, im, jm, km_global, params, rank, world, dist=None, device=-1, xdev=None):
-    """The product constructor: this rank's slab on its GPU."""
+    """The product constructor: this rank's slab on its GPU.  A process that exchanges through device buffers (RCCL) must
+    have imported torch before the first DeviceModel was created: torch brings a HIP runtime of its own, which the library
+    shares when it is loaded first and which finds no device when it is loaded second."""
     from .device import DeviceModel
+    if dist is not None and dist.get_backend() == "nccl":
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("torch sees no GPU: import torch before the first atom_amd.DeviceModel of the process is created")
     plan = SlabPlan(km_global, world)
     engine = DeviceModel(model, im, jm, plan.local_km(rank), params, device=device)
     if xdev is None:
