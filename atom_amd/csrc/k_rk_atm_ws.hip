@@ -42,14 +42,28 @@
 // is one multiplication by its reciprocal and products feeding sums fuse, which costs up to one unit in the
 // last place per operation (the sweep then agrees with the reference to about 1e-13 instead of bit for bit
 // plus pow) and removes a third of the instructions of every RK stage.
+//
+// The tolerance form goes one step further.  With the neighbour rows fixed during the four stages of a row, every
+// right-hand side is affine in the variable's own stage value x except for the advection product with v:
+//     rhs = -v (A x + B) + P x + Q   (+ R u for v, - K (humid/dry - 1) for u, + the evaporation source of c at level 1)
+// so A, B, P, Q are worked out once per row from the same derivative forms, geometry factors and source terms, and a
+// stage is three or four fused multiply-adds.  The buoyancy term k (r_humid - r_dry) / r_dry with
+// r_humid = r_dry (1 + c) / (1 + k c) is evaluated as k ((1 + c) / (1 + k c) - 1): the dry density drops out, and the
+// t wave publishes it only on level 1, where the evaporation source of c needs it.
 #ifdef ATOMDEV_RK_FAST
 #define ATM_WS_ENTRY atomdev_atm_rk3d_ws_fast
 #define k_atm_rk3d_ws k_atm_rk3d_wsf
 #define k_atm_prep k_atm_prepf
 #define DIVC(a, b, rb) ((a) * (rb))
+#ifndef ATOMDEV_RK_NOAFFINE
+#define ATM_WS_AFFINE 1
+#endif
 #else
 #define ATM_WS_ENTRY atomdev_atm_rk3d_ws
 #define DIVC(a, b, rb) div_by(a, b, rb)
+#endif
+#ifndef ATM_WS_AFFINE
+#define ATM_WS_AFFINE 0
 #endif
 
 namespace {
@@ -290,19 +304,29 @@ __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K
     if constexpr (isT) { ph_cur = ldg(E1, o0); ph_nxt = ldg(E1, o1); }
 
     // what the other waves need of a new t or c value (RHS_Atm.cpp:385, 390-404)
+    constexpr bool AFFINE = ATM_WS_AFFINE;
+    const bool t_feeds_c = (i == 1);  // affine form: the dry density has one reader, the c wave of level 1
     auto publish_t = [&](int buf, double tval, double ph) {
-        const double r_dry = fdiv_normal(ph, k1 * (tval * k2));
-        sh.rdry[buf][lane] = r_dry;
-        sh.yr[buf][lane] = rcp_refined(r_dry);
+        if constexpr (AFFINE) {
+            if (t_feeds_c) sh.rdry[buf][lane] = fdiv_normal(ph, k1 * (tval * k2));
+        } else {
+            const double r_dry = fdiv_normal(ph, k1 * (tval * k2));
+            sh.rdry[buf][lane] = r_dry;
+            sh.yr[buf][lane] = rcp_refined(r_dry);
+        }
     };
     double c_opc = 0., c_cb = 0., c_cy = 0.;   // c wave: what it published for the value it is working with
     auto publish_c = [&](int buf, double cval) {
         c_cb = 1. + k1 * cval;
         c_opc = 1. + cval;
         c_cy = rcp_refined(c_cb);
-        sh.opc[buf][lane] = c_opc;
-        sh.cb[buf][lane] = c_cb;
-        sh.cy[buf][lane] = c_cy;
+        if constexpr (AFFINE) {
+            sh.opc[buf][lane] = __builtin_fma(c_opc, c_cy, -1.);  // humid over dry density, minus one
+        } else {
+            sh.opc[buf][lane] = c_opc;
+            sh.cb[buf][lane] = c_cb;
+            sh.cy[buf][lane] = c_cy;
+        }
     };
 
     // stage-1 values of row 1
@@ -374,6 +398,42 @@ __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K
         if constexpr (hasH0I) h_0 = e_a;  // h_0_i
 
         double st = x0, acc = 0., rhs = 0., RS = 0.;
+        // ---- affine form: coefficients of the row ----
+        double cA = 0., cB = 0., cP = 0., cQ = 0., cR = 0., cKK = 0., cFac = 0., cMc = 0.;
+        if constexpr (AFFINE) {
+            double A1, B1, Pb, Qb, B1u = 0.;
+            const double g = costhe * i_rm2sin;
+            if (all_bw) {
+                A1 = h_d_j * TK.i_dthe;
+                B1 = -xm1 * A1;
+                Pb = A1 * g; Qb = B1 * g;
+                if constexpr (isV) B1u = -um1 * A1;
+            } else {
+                const double hD = h_d_j * TF.iD1, hE = h_d_j * TK.i_dthe2;
+                A1 = TF.a * hD; B1 = (xB + xC) * hD;
+                const double A2 = TF.e * hE, B2 = (xF + xG) * hE;
+                Pb = __builtin_fma(A2, i_rm2, A1 * g); Qb = __builtin_fma(B2, i_rm2, B1 * g);
+                if constexpr (isV) B1u = (uB + uC) * hD;
+            }
+            cA = A1 * i_rm; cB = B1 * i_rm;
+            cP = Pb * i_dv; cQ = Qb * i_dv;
+            if constexpr (isT) cQ += e_b + e_c;
+            if constexpr (isU || isW || ROLE == R_CO2 || ROLE == R_ICE || ROLE == R_CLOUD) cP = __builtin_fma(-h_0, i_dm, cP);
+            if constexpr (ROLE == R_ICE || ROLE == R_CLOUD || isC) cQ += e_b;
+            if constexpr (isU) cKK = k2 * k3;
+            if constexpr (isV) {
+                const double two = 2. * i_rm2 * i_dv;
+                cP = cP - coef_v * h_d_j * i_dv - h_0 * i_dm;
+                cR = two * A1;
+                cQ = __builtin_fma(two, B1u, cQ) - pg_v;
+            }
+            if constexpr (isC) {
+                if (lvl1) {  // RHS_Atm.cpp:412-430
+                    cFac = land ? 0. : k3 * i_k4 * om2c0 * e_a;
+                    cMc = m3c0 - c_lvl3;
+                }
+            }
+        }
 #pragma unroll
         for (int s = 0; s < 4; s++) {
             const int rb = s & 1, wb = rb ^ 1;
@@ -385,6 +445,19 @@ __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K
             if (s == 3) load_table(j + 1);
             double v;
             if constexpr (isV) v = st; else v = sh.v[rb][lane];
+          if constexpr (AFFINE) {
+            const double t1 = __builtin_fma(cA, st, cB);
+            double lin = __builtin_fma(cP, st, cQ);
+            if constexpr (isU) { RS = cKK * sh.opc[rb][lane]; lin -= RS; }
+            if constexpr (isV) lin = __builtin_fma(cR, sh.u[rb][lane], lin);
+            if constexpr (isC) {
+                if (lvl1) {
+                    const double r_humid = sh.rdry[rb][lane] * (c_opc * c_cy);
+                    lin = __builtin_fma(r_humid * __builtin_fma(4., st, cMc), cFac, lin);
+                }
+            }
+            rhs = __builtin_fma(-v, t1, lin);
+          } else {
             double d1, d2 = 0., brk;
             if (all_bw) {
                 d1 = DIVC(h_d_j * (st - xm1), TK.dthe, TK.i_dthe);
@@ -427,6 +500,7 @@ __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K
                     rhs = rhs + vapour_evaporation;
                 }
             }
+          }
             // RungeKutta_Atm.cpp:58-152.  rhs * .5 * dt == rhs * (.5 * dt) and acc + 2. * rhs == fma(2, rhs, acc)
             // bit for bit (scaling by a power of two is exact), one instruction less each.
             if (s == 0) { acc = rhs; st = xn + rhs * hdt; }

@@ -33,14 +33,24 @@
 // Compiled twice, like k_rk_atm_ws.hip: as it stands every quotient carries the bits of the reference's division;
 // with -DATOMDEV_RK_FAST -ffp-contract=fast divisions by loop-invariant divisors become multiplications by the
 // reciprocal and products feeding sums fuse (tolerance form, about 1e-13 from the exact form).
+// The tolerance form also uses that, with the neighbour rows and the level above fixed during the four stages of a
+// row, every right-hand side is affine in the variable's own stage value x apart from the two advection products:
+//     rhs = -u (Ar x + Br) - v (A x + B) + P x + Q   (+ R u for v, the density terms of u and v, the surface source of c)
+// Ar, Br, A, B, P, Q are worked out once per row; a stage is five or six fused multiply-adds.
 #ifdef ATOMDEV_RK_FAST
 #define HYD_WS_ENTRY atomdev_hyd_rk3d_ws_fast
 #define k_hyd_rk3d_ws k_hyd_rk3d_wsf
 #define k_copy_shell k_copy_shellf
 #define DIVC(a, b, rb) ((a) * (rb))
+#ifndef ATOMDEV_RK_NOAFFINE
+#define HYD_WS_AFFINE 1
+#endif
 #else
 #define HYD_WS_ENTRY atomdev_hyd_rk3d_ws
 #define DIVC(a, b, rb) div_by(a, b, rb)
+#endif
+#ifndef HYD_WS_AFFINE
+#define HYD_WS_AFFINE 0
 #endif
 
 namespace {
@@ -365,6 +375,42 @@ __device__ __forceinline__ void sweep_role(const HydWsArgs& a, const DevConst& K
         double rw = rw_cur;   // c wave: r_water, likewise
 
         double st = x0, acc = 0., rhs = 0., RS = 0., pg_v = 0., sb = 0.;
+        // ---- affine form: coefficients of the row ----
+        constexpr bool AFFINE = HYD_WS_AFFINE;
+        double cAr = 0., cBr = 0., cA = 0., cB = 0., cP = 0., cQ = 0., cR = 0., cFac = 0., cM = 0.;
+        if constexpr (AFFINE) {
+            double A1, B1, A2 = 0., B2 = 0., B1u = 0.;
+            if (all_bw) {
+                A1 = h_d_j * TK.i_dthe;
+                B1 = -xm1 * A1;
+                if constexpr (isV) B1u = -um1 * A1;
+            } else {
+                const double hD = h_d_j * TF.iD1, hE = h_d_j * TK.i_dthe2;
+                A1 = TF.a * hD; B1 = (xB + xC) * hD;
+                A2 = TF.e * hE; B2 = (xF + xG) * hE;
+                if constexpr (isV) B1u = (uB + uC) * hD;
+            }
+            cAr = rlive ? -i_dr : 0.; cBr = rlive ? xa * i_dr : 0.;   // dr1 = cAr x + cBr
+            const double g = costhe * i_rm2sin;
+            // the diffusion bracket: (2 or 4) dr1 / rm + d2 / rm2 + d1 cos / (rm2 sin)
+            const double kr = (isU ? 4. : 2.) * i_rm;
+            double Pb = __builtin_fma(A1, g, kr * cAr), Qb = __builtin_fma(B1, g, kr * cBr);
+            if (!all_bw) { Pb = __builtin_fma(A2, i_rm2, Pb); Qb = __builtin_fma(B2, i_rm2, Qb); }
+            cA = A1 * i_rm; cB = B1 * i_rm;
+            cP = __builtin_fma(-h_0, i_dm, Pb * i_dv); cQ = Qb * i_dv;
+            if constexpr (isV) {
+                const double two = 2. * i_rm2 * i_dv;
+                cP = __builtin_fma(-coef_v * h_d_j, i_dv, cP);
+                cR = two * A1;
+                cQ = __builtin_fma(two, B1u, cQ);
+            }
+            if constexpr (isC) {
+                if (top) {  // RHS_Hyd.cpp:355-372
+                    cFac = land ? 0. : k2 * k4 * (1. - 2. * c_top) * ep;
+                    cM = -3. * c_top - c_below;
+                }
+            }
+        }
 #pragma unroll
         for (int s = 0; s < 4; s++) {
             const int rb = s & 1, wb = rb ^ 1;
@@ -381,6 +427,32 @@ __device__ __forceinline__ void sweep_role(const HydWsArgs& a, const DevConst& K
             if constexpr (isU) u = st; else u = sh.u[rb][lane];
             if constexpr (isV) v = st; else v = sh.v[rb][lane];
 
+          if constexpr (AFFINE) {
+            const double tr = __builtin_fma(cAr, st, cBr);
+            const double tv = __builtin_fma(cA, st, cB);
+            double lin = __builtin_fma(cP, st, cQ);
+            if constexpr (isU) {
+                const double swr = sh.swr[rb][lane];
+                RS = k1 * __builtin_fma(rsw, sh.yswr[rb][lane], -1.);  // RHS_Hyd.cpp:374: g (r_salt_water - ref) / ref
+                sb = swr - rsw;
+                if (land) rsw = 1032.;
+                lin += RS;
+            }
+            if constexpr (isV) {
+                pg_v = pg_num * sh.yswr[rb][lane];
+                lin = __builtin_fma(cR, u, lin) - pg_v;
+            }
+            if constexpr (isC) {
+                if (top) {
+                    const double swr = rw + .7 * st * k1;
+                    double sal = swr * __builtin_fma(4., st, cM) * cFac;
+                    sal = fmin(fmax(sal, -20.), 20.);
+                    lin += sal;
+                }
+                if (land) rw = 1007.;  // seen by the following stages (RHS_Hyd.cpp:395-402)
+            }
+            rhs = __builtin_fma(-u, tr, __builtin_fma(-v, tv, lin));
+          } else {
             double d1, d2 = 0.;
             if (all_bw) {
                 d1 = DIVC(h_d_j * (st - xm1), TK.dthe, TK.i_dthe);
@@ -435,6 +507,7 @@ __device__ __forceinline__ void sweep_role(const HydWsArgs& a, const DevConst& K
                 else brk = DIVC(dr1 * 2., rm, i_rm) + DIVC(d2, rm2, i_rm2) + DIVC(d1, rm2sin, i_rm2sin) * costhe;
                 rhs = -adv + DIVC(brk, dv, i_dv) - DIVC(h_0 * st, dm, i_dm);
             }
+          }
 
             // RungeKutta_Hyd.cpp:56-120 (stage 3 advances w from its stage-2 value, :101)
             // rhs * .5 * dt == rhs * (.5 * dt) and acc + 2. * rhs == fma(2, rhs, acc) bit for bit (scaling by a
