@@ -7,9 +7,18 @@
 // updated values at (j-1, k), (j-2, k), (j, k-1), (j, k-2) and the old values at
 // (j+1, k), (j+2, k), (j, k+1), (j, k+2).  All points of an anti-diagonal
 // j + k = d are mutually independent and see exactly those values if diagonals are
-// processed in increasing d.  One workgroup walks the diagonals with a barrier
-// between them (65 k points on the 1-degree grid: latency-bound, not worth more
-// than one CU).
+// processed in increasing d: the sweep is a chain of jm + km - 4 dependent point
+// evaluations, and what it costs is the time of ONE point evaluation times that length.
+// So the work is split to make a point short, not to make the machine full:
+//   * everything of a point that does not depend on results of the sweep (which of the
+//     reference's difference forms survives, its coefficients, the old neighbour values,
+//     the pressure gradient) is computed for all points at once by k_rk2d_prepare;
+//   * the chain itself runs as waves of 32 rows with TWO lanes per row, one for v and one
+//     for w (the two right-hand sides have the same shape), which swap their stage values
+//     with a lane permutation; a wave is a workgroup of its own, on its own compute unit,
+//     and hands its last row to the wave of the next 32 rows through memory.  That
+//     dependency points one way only, so the waves run as a pipeline and the latency of
+//     the hand-over is paid once per wave, not once per diagonal.
 #include <vector>
 
 #include "atomdev_internal.h"
@@ -61,35 +70,54 @@ struct PointIn {
 enum : unsigned { M_L = 1, M_FLUID_C = 2, M_TP = 4, M_TM = 8, M_PP = 16, M_PM = 32, M_PP2 = 64, M_PM2 = 128 };
 struct PointOut { double v, w, aux_v, aux_w; };
 
-// All four RK stages at one surface point (RungeKutta_Atm.cpp:176-214 around RHS_Atm.cpp:498-678).
-__device__ __forceinline__ PointOut rk_point(const PointIn& in, const RowGeo& G, bool win_j, bool win_k,
-                                             const Rk2dArgs& a, const DevConst& K) {
-    const double dt = K.dt;
-    const double rm = a.rm, rm2 = rm * rm;
-    const bool L = in.m & M_L, fluid_c = in.m & M_FLUID_C;
-    const bool l_tp = in.m & M_TP, l_tm = in.m & M_TM, l_pp = in.m & M_PP, l_pm = in.m & M_PM, l_pp2 = in.m & M_PP2, l_pm2 = in.m & M_PM2;
+// What the mask, the old values and the geometry decide about a point before any stage runs.
+struct PointCoef {
+    Diff T1, P1, T2;                      // theta first, phi first, "theta second" difference
     double h_0_j, h_d_j, h_0_k, h_d_k;
-    if (fluid_c && (l_tp || l_tm)) { h_0_j = 1.; h_d_j = 0.; } else { h_0_j = 0.; h_d_j = 1.; }
-    if (fluid_c && (l_pp || l_pm)) { h_0_k = 1.; h_d_k = 0.; } else { h_0_k = 0.; h_d_k = 1.; }
+    bool o_fwd, o_bwd;                    // T2 is the phi one-sided form on the + / - side
+    double pg_v, pg_w;                    // pressure gradient terms (p does not change during the sweep)
+};
 
-    // ---- the surviving variant of every difference ----
+__device__ __forceinline__ PointCoef point_coef(unsigned m, double p_c, double p_tp, double p_tm, double p_pp, double p_pm,
+                                                const RowGeo& G, bool win_j, bool win_k, const Rk2dArgs& a, const DevConst& K) {
+    PointCoef C;
+    const bool L = m & M_L, fluid_c = m & M_FLUID_C;
+    const bool l_tp = m & M_TP, l_tm = m & M_TM, l_pp = m & M_PP, l_pm = m & M_PM, l_pp2 = m & M_PP2, l_pm2 = m & M_PM2;
+    if (fluid_c && (l_tp || l_tm)) { C.h_0_j = 1.; C.h_d_j = 0.; } else { C.h_0_j = 0.; C.h_d_j = 1.; }
+    if (fluid_c && (l_pp || l_pm)) { C.h_0_k = 1.; C.h_d_k = 0.; } else { C.h_0_k = 0.; C.h_d_k = 1.; }
     // central {0, 1, -1} / 2 d; forward two-point {-1, 1, 0} / d; backward two-point {1, 0, -1} / d (wins)
     const bool t_fwd = win_j && L && !l_tp, t_bwd = win_j && L && !l_tm;
     const bool p_fwd = L && !l_pp, p_bwd = win_k ? (L && !l_pm) : (fluid_c && l_pm);
     const int t_sel = t_bwd ? 2 : (t_fwd ? 1 : 0), p_sel = p_bwd ? 2 : (p_fwd ? 1 : 0);
-    Diff T1, P1, T2;
+    Diff &T1 = C.T1, &P1 = C.P1, &T2 = C.T2;
     T1.cc = t_sel == 2 ? 1. : (t_sel == 1 ? -1. : 0.); T1.c1 = t_sel == 2 ? 0. : 1.; T1.c2 = t_sel == 1 ? 0. : -1.;
-    T1.h = h_d_j; T1.div = t_sel ? K.dthe : K.two_dthe; T1.idiv = t_sel ? K.i_dthe : K.i_two_dthe;
+    T1.h = C.h_d_j; T1.div = t_sel ? K.dthe : K.two_dthe; T1.idiv = t_sel ? K.i_dthe : K.i_two_dthe;
     P1.cc = p_sel == 2 ? 1. : (p_sel == 1 ? -1. : 0.); P1.c1 = p_sel == 2 ? 0. : 1.; P1.c2 = p_sel == 1 ? 0. : -1.;
-    P1.h = h_d_k; P1.div = p_sel ? K.dphi : K.two_dphi; P1.idiv = p_sel ? a.i_dphi : a.i_two_dphi;
+    P1.h = C.h_d_k; P1.div = p_sel ? K.dphi : K.two_dphi; P1.idiv = p_sel ? a.i_dphi : a.i_two_dphi;
     // theta second derivative and its two neighbour operands: zero {0, 0, 0} inside window_j, central {-2, 1, 1}
     // outside it, zero again outside window_k; inside window_k the PHI one-sided form {2, -2, 1} on (k, k+-1, k+-2)
     // where the centre is land and both cells on that side are fluid (the s = -1 side wins)
-    const bool o_fwd = win_k && L && !l_pp && !l_pp2, o_bwd = win_k && L && !l_pm && !l_pm2;
-    const bool one_sided = o_fwd || o_bwd, central2 = !win_j && win_k && !one_sided;
+    C.o_fwd = win_k && L && !l_pp && !l_pp2; C.o_bwd = win_k && L && !l_pm && !l_pm2;
+    const bool one_sided = C.o_fwd || C.o_bwd, central2 = !win_j && win_k && !one_sided;
     T2.cc = one_sided ? 2. : (central2 ? -2. : 0.); T2.c1 = one_sided ? -2. : (central2 ? 1. : 0.);
     T2.c2 = (one_sided || central2) ? 1. : 0.;
-    T2.h = one_sided ? h_d_k : h_d_j; T2.div = one_sided ? K.dphi2 : K.dthe2; T2.idiv = one_sided ? K.i_dphi2 : K.i_dthe2;
+    T2.h = one_sided ? C.h_d_k : C.h_d_j; T2.div = one_sided ? K.dphi2 : K.dthe2; T2.idiv = one_sided ? K.i_dphi2 : K.i_dthe2;
+    const double dpdthe = diff(T1, p_c, p_tp, p_tm), dpdphi = diff(P1, p_c, p_pp, p_pm);
+    C.pg_v = div_by(div_by(C.h_d_j * dpdthe, a.rm, a.i_rm), a.rho, a.i_rho);         // h_d_j * dpdthe / rm / rho
+    C.pg_w = div_by(div_by(C.h_d_k * dpdphi, G.rmsin, G.i_rmsin), a.rho, a.i_rho);
+    return C;
+}
+
+// All four RK stages at one surface point (RungeKutta_Atm.cpp:176-214 around RHS_Atm.cpp:498-678), v and w in
+// one thread: the form the row-major kernel k_rk2d uses.
+__device__ __forceinline__ PointOut rk_point(const PointIn& in, const RowGeo& G, bool win_j, bool win_k,
+                                             const Rk2dArgs& a, const DevConst& K) {
+    const double dt = K.dt;
+    const double rm = a.rm, rm2 = rm * rm;
+    const PointCoef C = point_coef(in.m, in.p_c, in.p_tp, in.p_tm, in.p_pp, in.p_pm, G, win_j, win_k, a, K);
+    const Diff &T1 = C.T1, &P1 = C.P1, &T2 = C.T2;
+    const double h_0_j = C.h_0_j, h_d_j = C.h_d_j, h_0_k = C.h_0_k, h_d_k = C.h_d_k;
+    const bool o_fwd = C.o_fwd, o_bwd = C.o_bwd;
     // (operands copied out of the struct as opaque values: a select between two struct members otherwise becomes a
     // load through a selected address and pins the whole struct in scratch memory)
     double s_tp[2] = { in.v_tp, in.w_tp }, s_tm[2] = { in.v_tm, in.w_tm }, s_pp[2] = { in.v_pp, in.w_pp };
@@ -100,10 +128,7 @@ __device__ __forceinline__ PointOut rk_point(const PointIn& in, const RowGeo& G,
     }
     const double v2A = o_bwd ? s_pm[0] : (o_fwd ? s_pp[0] : s_tp[0]), v2B = o_bwd ? s_pm2[0] : (o_fwd ? s_pp2[0] : s_tm[0]);
     const double w2A = o_bwd ? s_pm[1] : (o_fwd ? s_pp[1] : s_tp[1]), w2B = o_bwd ? s_pm2[1] : (o_fwd ? s_pp2[1] : s_tm[1]);
-    // pressure gradient terms do not change during the stages
-    const double dpdthe = diff(T1, in.p_c, in.p_tp, in.p_tm), dpdphi = diff(P1, in.p_c, in.p_pp, in.p_pm);
-    const double pg_v = div_by(div_by(h_d_j * dpdthe, rm, a.i_rm), a.rho, a.i_rho);         // h_d_j * dpdthe / rm / rho
-    const double pg_w = div_by(div_by(h_d_k * dpdphi, G.rmsin, G.i_rmsin), a.rho, a.i_rho);
+    const double pg_v = C.pg_v, pg_w = C.pg_w;
 
     double vc = in.vc, wc = in.wc;
     const double vn = in.vn, wn = in.wn;
@@ -155,9 +180,10 @@ __device__ __forceinline__ RowGeo row_geometry(const Rk2dArgs& a, int j) {
     return g;
 }
 
-// Fallback for grids with more interior rows than one workgroup has threads: the fields stay in their
-// row-major layout, a thread takes whatever rows of the diagonal fall to it, and every neighbour goes
-// through global memory (the barrier orders the writes of diagonal d before the reads of d + 1).
+// The plain form (atomdev_set_rk_variant(1), kept for A/B runs: same bits): one workgroup walks the diagonals
+// with a barrier between them, the fields stay in their row-major layout, a thread takes whatever rows of the
+// diagonal fall to it, and every neighbour goes through global memory (the barrier orders the writes of
+// diagonal d before the reads of d + 1).
 __global__ __launch_bounds__(256) void k_rk2d(Rk2dArgs a, DevConst K) {
     extern __shared__ RowGeo geo[];  // [jm]
     const int jm = K.jm, km = K.km;
@@ -191,118 +217,212 @@ __global__ __launch_bounds__(256) void k_rk2d(Rk2dArgs a, DevConst K) {
     }
 }
 
-// ---- the same sweep with one thread per row ----
-// Surface fields in a skewed copy: point (j, k) lives at [j + k][j] (pitch P), so the points of one anti-
-// diagonal, and each of their neighbour sets, are contiguous across the rows = across the lanes of a wave.
-struct Skewed {
-    double *v, *w, *p, *vn, *wn, *aux_v, *aux_w;
-    uint8_t* fl;
-    int P;
+// ---- the sweep as a pipeline of narrow waves ----
+constexpr int CH_ROWS = 32;   // rows of a chain wave (two lanes per row: v and w)
+constexpr int PK = 13;        // 16-byte entries of a lane's packet for one point
+
+// Packet of lane x (0: v, 1: w) for point (j, k), as doubles:
+//   0 xc   1 xn                                  old centre value, "new"-array value
+//   2 t1.cc  3 t1.c1 * x(j+1,k)  4 t1.c2  5 t1.h  6 t1.div  7 t1.idiv
+//   8 p1.cc  9 p1.c1 * x(j,k+1) 10 p1.c2 11 p1.h 12 p1.div 13 p1.idiv
+//  14 t2.cc 15 t2.c1 16 t2.c2 17 t2.h 18 t2.div 19 t2.idiv
+//  20 sA  21 sB      T2's operands where they are old values: x(j,k+1), x(j,k+2) (o_fwd) or x(j+1,k) (central)
+//  22 pg_x  23 coef * h_d_x  24 h_0_x
+//  25 (as two 32-bit integers) low word 1: T2's operands are this sweep's x(j,k-1), x(j,k-2); high word 1: operand
+//     B is x(j-1,k)
+// Group g holds rows 1 + 32 g ... and stores the packets of its step n (row r of the group is at k = n + 1 - r)
+// together: pk[((g * ndd + n) * PK + e) * 64 + lane], 1 KB per entry and wave.
+struct Chain {
+    double2* pk;
+    double* bnd;   // [group][x][k]: the row above the group's first row (row 0 itself for group 0)
+    int ndd;       // steps stored per group
 };
+constexpr unsigned long long BND_EMPTY = 0xFFF4A70DA70DA70Dull;  // "not written yet" (a NaN no arithmetic produces)
 
-// One surface of a batched launch (several independent models in one grid: blockIdx.y of the copy kernels,
-// blockIdx.x of the sweep selects the model).  A launch for a single model passes its arguments by value.
-struct BatchItem { Rk2dArgs a; Skewed s; DevConst K; };
+struct BatchItem { Rk2dArgs a; Chain c; DevConst K; };
 
-__global__ void k_skew(Rk2dArgs a, Skewed s, int jm, int km, const BatchItem* __restrict__ items) {
-    if (items) { a = items[blockIdx.y].a; s = items[blockIdx.y].s; }
+__global__ __launch_bounds__(256) void k_rk2d_prepare(Rk2dArgs a, Chain c, DevConst K, int groups,
+                                                      const BatchItem* __restrict__ items) {
+    if (items) { a = items[blockIdx.y].a; c = items[blockIdx.y].c; K = items[blockIdx.y].K; }
+    const int jm = K.jm, km = K.km;
     const int id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= jm * km) return;
     const int j = id / km, k = id - j * km;
-    const size_t o = (size_t)(j + k) * s.P + j;
-    s.v[o] = a.v[id]; s.w[o] = a.w[id]; s.p[o] = a.p[id]; s.vn[o] = a.vn[id]; s.wn[o] = a.wn[id]; s.fl[o] = a.fl[id];
-}
-
-__global__ void k_unskew(Rk2dArgs a, Skewed s, int jm, int km, const BatchItem* __restrict__ items) {
-    if (items) { a = items[blockIdx.y].a; s = items[blockIdx.y].s; }
-    const int id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= jm * km) return;
-    const int j = id / km, k = id - j * km;
-    if (j < 1 || j > jm - 2 || k < 1 || k > km - 2) return;  // the sweep writes interior points only
-    const size_t o = (size_t)(j + k) * s.P + j;
-    a.v[id] = s.v[o]; a.w[id] = s.w[o]; a.aux_v[id] = s.aux_v[o]; a.aux_w[id] = s.aux_w[o];
-}
-
-// What a thread reads from memory for its point on a diagonal; fetched one diagonal ahead.
-struct Fetched {
-    PointIn in;          // without v_tm, w_tm, v_pm, w_pm, v_pm2, w_pm2 (results of this sweep)
-    double v_b, w_b;     // (j, 0): the phi-boundary values, wanted when k == 1
-    double v_t0, w_t0;   // (0, k): the theta-boundary row, wanted by row 1
-    bool active;
-};
-
-// Thread t owns row j = t + 1 and walks it with the diagonals (k = d - j).  Of the values the sweep itself
-// produces, (j, k-1) and (j, k-2) are the thread's own last two results (registers) and (j-1, k) is the
-// neighbour thread's result of the previous diagonal (LDS, double-buffered); everything else is old or
-// static data, fetched from the skewed copy one diagonal ahead.  So no global memory access sits on the
-// chain of 538 dependent diagonals (1-degree grid), only an LDS exchange and one barrier per diagonal.
-template <int MAX_THREADS>
-__global__ __launch_bounds__(MAX_THREADS) void k_rk2d_rows(Rk2dArgs a, Skewed s, DevConst K,
-                                                           const BatchItem* __restrict__ items) {
-    if (items) { a = items[blockIdx.x].a; s = items[blockIdx.x].s; K = items[blockIdx.x].K; }
-    extern __shared__ double ex[];  // [2][P][2]: new (v, w) of row j on the last two diagonals
-    const int jm = K.jm, km = K.km, P = s.P;
-    const int j = (int)threadIdx.x + 1;
-    const bool row = j <= jm - 2;
-    const bool win_j = (j >= 2) && (j < jm - 3);
-    RowGeo G = row_geometry(a, row ? j : 1);
-    const int dmax = (jm - 2) + (km - 2);
-
-    auto fetch = [&](int d) {
-        Fetched f;
-        const int k = d - j;
-        f.active = row && k >= 1 && k <= km - 2;
-        f.v_b = f.w_b = f.v_t0 = f.w_t0 = 0.;
-        PointIn& in = f.in;
-        in.vc = in.wc = in.vn = in.wn = in.v_tp = in.v_tm = in.v_pp = in.v_pm = in.w_tp = in.w_tm = in.w_pp = in.w_pm = 0.;
-        in.v_pp2 = in.v_pm2 = in.w_pp2 = in.w_pm2 = in.p_c = in.p_tp = in.p_tm = in.p_pp = in.p_pm = 0.;
-        in.m = 0;
-        if (f.active) {
-            const size_t o = (size_t)d * P + j;           // (j, k)
-            const size_t o_tp = o + P + 1, o_tm = o - P - 1, o_pp = o + P, o_pm = o - P;
-            in.vc = s.v[o]; in.wc = s.w[o]; in.vn = s.vn[o]; in.wn = s.wn[o];
-            in.v_tp = s.v[o_tp]; in.w_tp = s.w[o_tp]; in.v_pp = s.v[o_pp]; in.w_pp = s.w[o_pp];
-            in.p_c = s.p[o]; in.p_tp = s.p[o_tp]; in.p_tm = s.p[o_tm]; in.p_pp = s.p[o_pp]; in.p_pm = s.p[o_pm];
-            in.m = land_mask(s.fl[o], a.hyd, s.fl[o_tp], s.fl[o_tm], s.fl[o_pp], s.fl[o_pm]);
-            if ((k >= 2) && (k < km - 3)) {
-                if (!(s.fl[o_pp + P] & FL_LAND)) in.m &= ~M_PP2;
-                if (!(s.fl[o_pm - P] & FL_LAND)) in.m &= ~M_PM2;
-                in.v_pp2 = s.v[o_pp + P]; in.w_pp2 = s.w[o_pp + P];
-            }
-            if (k == 1) { f.v_b = s.v[o_pm]; f.w_b = s.w[o_pm]; }
-            if (j == 1) { f.v_t0 = s.v[o_tm]; f.w_t0 = s.w[o_tm]; }
+    // the row above every group: static for group 0, "not written yet" for the others
+    if (j < groups) {
+        c.bnd[((size_t)j * 2 + 0) * km + k] = j == 0 ? a.v[k] : __longlong_as_double((long long)BND_EMPTY);
+        c.bnd[((size_t)j * 2 + 1) * km + k] = j == 0 ? a.w[k] : __longlong_as_double((long long)BND_EMPTY);
+    }
+    if (j < 1 || j > jm - 2 || k < 1 || k > km - 2) return;
+    const size_t q = id;
+    const long R = km;
+    const bool win_j = (j >= 2) && (j < jm - 3), win_k = (k >= 2) && (k < km - 3);
+    unsigned m = land_mask(a.fl[q], a.hyd, a.fl[q + R], a.fl[q - R], a.fl[q + 1], a.fl[q - 1]);
+    double x_pp2[2] = { 0., 0. };
+    if (win_k) {
+        if (!(a.fl[q + 2] & FL_LAND)) m &= ~M_PP2;
+        if (!(a.fl[q - 2] & FL_LAND)) m &= ~M_PM2;
+        x_pp2[0] = a.v[q + 2]; x_pp2[1] = a.w[q + 2];
+    }
+    const RowGeo G = row_geometry(a, j);
+    const PointCoef C = point_coef(m, a.p[q], a.p[q + R], a.p[q - R], a.p[q + 1], a.p[q - 1], G, win_j, win_k, a, K);
+    const int g = (j - 1) / CH_ROWS, r = (j - 1) - g * CH_ROWS, n = k - 1 + r;
+    double* out = (double*)(c.pk + ((size_t)g * c.ndd + n) * PK * 64);
+    const bool one_sided = C.o_fwd || C.o_bwd;
+    const long long sel = (C.o_bwd ? 1ll : 0ll) | (!one_sided ? (1ll << 32) : 0ll);
+#pragma unroll
+    for (int x = 0; x < 2; x++) {
+        const double* f = x ? a.w : a.v;
+        const double* fn = x ? a.wn : a.vn;
+        const double x_tp = f[q + R], x_pp = f[q + 1];
+        double e[2 * PK];
+        e[0] = f[q]; e[1] = fn[q];
+        e[2] = C.T1.cc; e[3] = C.T1.c1 * x_tp; e[4] = C.T1.c2; e[5] = C.T1.h; e[6] = C.T1.div; e[7] = C.T1.idiv;
+        e[8] = C.P1.cc; e[9] = C.P1.c1 * x_pp; e[10] = C.P1.c2; e[11] = C.P1.h; e[12] = C.P1.div; e[13] = C.P1.idiv;
+        e[14] = C.T2.cc; e[15] = C.T2.c1; e[16] = C.T2.c2; e[17] = C.T2.h; e[18] = C.T2.div; e[19] = C.T2.idiv;
+        e[20] = C.o_fwd ? x_pp : x_tp; e[21] = x_pp2[x];
+        e[22] = x ? C.pg_w : C.pg_v;
+        e[23] = G.coef * (x ? C.h_d_k : C.h_d_j);
+        e[24] = x ? C.h_0_k : C.h_0_j;
+        e[25] = __longlong_as_double(sel);
+        const int lane = 2 * r + x;
+#pragma unroll
+        for (int n2 = 0; n2 < PK; n2++) {
+            out[((size_t)n2 * 64 + lane) * 2] = e[2 * n2];
+            out[((size_t)n2 * 64 + lane) * 2 + 1] = e[2 * n2 + 1];
         }
-        return f;
-    };
-
-    double v_m1 = 0., w_m1 = 0., v_m2 = 0., w_m2 = 0.;  // own results at k-1, k-2
-    Fetched nx = fetch(2);
-    for (int d = 2; d <= dmax; d++) {
-        const Fetched cur = nx;
-        nx = fetch(d + 1);
-        if (cur.active) {
-            const int k = d - j;
-            if (k == 1) { v_m1 = cur.v_b; w_m1 = cur.w_b; }
-            PointIn in = cur.in;
-            if (j == 1) { in.v_tm = cur.v_t0; in.w_tm = cur.w_t0; }
-            else {
-                const double* e = ex + ((size_t)((d - 1) & 1) * P + (j - 1)) * 2;
-                in.v_tm = e[0]; in.w_tm = e[1];
-            }
-            in.v_pm = v_m1; in.w_pm = w_m1; in.v_pm2 = v_m2; in.w_pm2 = w_m2;
-            const bool win_k = (k >= 2) && (k < km - 3);
-            const PointOut o = rk_point(in, G, win_j, win_k, a, K);
-            const size_t q = (size_t)d * P + j;
-            s.v[q] = o.v; s.w[q] = o.w; s.aux_v[q] = o.aux_v; s.aux_w[q] = o.aux_w;
-            double* e = ex + ((size_t)(d & 1) * P + j) * 2;
-            e[0] = o.v; e[1] = o.w;
-            v_m2 = v_m1; w_m2 = w_m1; v_m1 = o.v; w_m1 = o.w;
-        }
-        lds_barrier();
     }
 }
 
-// arguments of one model's surface sweep; allocates the skewed copy on first use
+// the value of the other lane of the pair (lanes 2 r and 2 r + 1 swap)
+__device__ __forceinline__ double pair_swap(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true);  // quad_perm [1, 0, 3, 2]
+    hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double flip_sign(double x, int mask) {  // mask: 0 or the sign bit
+    return __hiloint2double(__double2hiint(x) ^ mask, __double2loint(x));
+}
+// pointers known to be global memory (the items of a batch are read from memory, which hides that from the compiler)
+typedef __attribute__((address_space(1))) double* gdouble_t;
+typedef const __attribute__((address_space(1))) double* gcdouble_t;
+typedef double pair_t __attribute__((ext_vector_type(2)));   // one 16-byte entry of a packet
+typedef const __attribute__((address_space(1))) pair_t* gcpair_t;
+__device__ __forceinline__ double ld_agent(gcdouble_t p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(gdouble_t p, double x) {
+    __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+struct Packet { pair_t e[PK]; };
+
+// One wave = rows j0 .. j0 + 31, lane 2 r + x.  Step n: row r is at k = n + 1 - r.  Of the values this sweep
+// produces, x(j, k-1) and x(j, k-2) are the lane's own last two results, x(j-1, k) is the result the lane two
+// below produced in the step before (the first row takes it from the wave of the rows above, through `bnd`, device
+// scope); the partner lane's centre value and phi derivative of every stage come by lane permutation.  Everything
+// else is in the packet, loaded one step ahead.  Both right-hand sides (RHS_Atm.cpp:664-677) in one form:
+//   k_x = -(v dx/dthe / rm + w dx/dphi / (rm sin)) - pg_x + s ( (d2x / rm2 + dx/dthe / (rm2 sin) cos - coef h x)
+//          + s (d other/dphi 2 cos / (rm2 sin2)) ) / re - h0 x / d2,       s = -1 for v, +1 for w
+// where adding a negated value is the subtraction the reference writes, bit for bit.
+__global__ __launch_bounds__(64) void k_rk2d_chain(Rk2dArgs a, Chain c, DevConst K, const BatchItem* __restrict__ items,
+                                                   int* __restrict__ err) {
+    if (items) { a = items[blockIdx.y].a; c = items[blockIdx.y].c; K = items[blockIdx.y].K; }
+    const int jm = K.jm, km = K.km;
+    const int g = blockIdx.x, lane = threadIdx.x, r = lane >> 1, x = lane & 1;
+    const int j0 = 1 + g * CH_ROWS, j = j0 + r;
+    const bool row = j <= jm - 2;
+    const int rlast = min(CH_ROWS, jm - 1 - j0) - 1;
+    const bool feeds = r == rlast && g + 1 < (int)gridDim.x, polls = r == 0;
+    const RowGeo G = row_geometry(a, row ? j : 1);
+    const double rm = a.rm, rm2 = rm * rm, dt = K.dt;
+    const double d2 = x ? K.dphi2 : K.dthe2, i_d2 = x ? K.i_dphi2 : K.i_dthe2;
+    const int smask = x ? 0 : (int)0x80000000;
+    const gcpair_t pk = (gcpair_t)(c.pk + (size_t)g * c.ndd * PK * 64 + lane);
+    const gcdouble_t bin = (gcdouble_t)(c.bnd + ((size_t)g * 2 + x) * km);
+    const gdouble_t bout = (gdouble_t)(c.bnd + ((size_t)(g + 1) * 2 + x) * km);
+    const gdouble_t out = (gdouble_t)((x ? a.w : a.v) + (size_t)(row ? j : 1) * km);
+    const gdouble_t out_aux = (gdouble_t)((x ? a.aux_w : a.aux_v) + (size_t)(row ? j : 1) * km);
+    const double xb = out[0], aux_b = out_aux[0];   // (j, 0): what the row starts from (and keeps)
+    const gdouble_t idle = (gdouble_t)(c.bnd + (size_t)gridDim.x * 2 * km + blockIdx.x * 64 + lane);
+    double x_m1 = 0., x_m2 = 0.;         // own results at k-1, k-2
+
+    auto load = [&](int n) {
+        Packet P;
+        const gcpair_t p = pk + (size_t)n * PK * 64;
+#pragma unroll
+        for (int e = 0; e < PK; e++) P.e[e] = p[e * 64];
+        return P;
+    };
+    const int nlast = km - 3 + rlast;
+    double b_nx = polls ? ld_agent(bin + 1) : 0.;
+    auto step = [&](const Packet& cur, int n) {
+        const int k = n + 1 - r;
+        const bool active = row && k >= 1 && k <= km - 2;
+        double x_tm = __shfl_up(x_m1, 2);
+        if (polls) {
+            double b = b_nx;
+            if (active) {
+                for (int tries = 0; __double_as_longlong(b) == (long long)BND_EMPTY; tries++) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (tries > (1 << 22)) {  // the wave of the rows above never delivered: give up and say so
+                        __hip_atomic_store(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        break;
+                    }
+                    b = ld_agent(bin + k);
+                }
+            }
+            x_tm = b;
+        }
+        b_nx = ld_agent(bin + min(max(k + 1, 0), km - 1));  // every lane, so that nothing has to wait for it here
+        if (k == 1) x_m1 = xb;
+        const double xn = cur.e[0].y;
+        const double t1_cc = cur.e[1].x, t1_a = cur.e[1].y, t1_c2 = cur.e[2].x, t1_h = cur.e[2].y, t1_div = cur.e[3].x, t1_idiv = cur.e[3].y;
+        const double p1_cc = cur.e[4].x, p1_a = cur.e[4].y, p1_c2 = cur.e[5].x, p1_h = cur.e[5].y, p1_div = cur.e[6].x, p1_idiv = cur.e[6].y;
+        const double t2_cc = cur.e[7].x, t2_c1 = cur.e[7].y, t2_c2 = cur.e[8].x, t2_h = cur.e[8].y, t2_div = cur.e[9].x, t2_idiv = cur.e[9].y;
+        const double sA = cur.e[10].x, sB = cur.e[10].y, pg = cur.e[11].x, coefh = cur.e[11].y, h0 = cur.e[12].x;
+        const bool own = __double2loint(cur.e[12].y) != 0, above = __double2hiint(cur.e[12].y) != 0;
+        const double x2A = own ? x_m1 : sA;
+        const double x2B = own ? x_m2 : (above ? x_tm : sB);
+        const double t1_b = t1_c2 * x_tm, p1_b = p1_c2 * x_m1, t2_a = t2_c1 * x2A, t2_b = t2_c2 * x2B;
+        double xc = cur.e[0].x;
+        double kx[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const double dxdthe = div_by(t1_h * ((t1_cc * xc + t1_a) + t1_b), t1_div, t1_idiv);
+            const double dxdphi = div_by(p1_h * ((p1_cc * xc + p1_a) + p1_b), p1_div, p1_idiv);
+            const double d2x = div_by(t2_h * ((t2_cc * xc + t2_a) + t2_b), t2_div, t2_idiv);
+            const double oc = pair_swap(xc), odphi = pair_swap(dxdphi);
+            const double vc = x ? oc : xc, wc = x ? xc : oc;
+            const double adv = div_by(vc * dxdthe, rm, a.i_rm) + div_by(wc * dxdphi, G.rmsin, G.i_rmsin);
+            const double inner = div_by(d2x, rm2, a.i_rm2) + div_by(dxdthe, G.rm2sin, G.i_rm2sin) * G.costhe - coefh * xc;
+            const double cross = flip_sign(div_by(odphi * 2. * G.costhe, G.rm2sin2, G.i_rm2sin2), smask);
+            const double visc = flip_sign(div_by(inner + cross, K.re, K.i_re), smask);
+            kx[s] = -adv + -pg + visc - div_by(h0 * xc, d2, i_d2);
+            if (s < 2) xc = xn + kx[s] * .5 * dt;
+            else if (s == 2) xc = xn + kx[s] * dt;
+        }
+        const double x_new = xn + div_by(dt * (kx[0] + 2. * kx[1] + 2. * kx[2] + kx[3]), 6., K.i_six);
+        // every lane stores in every step (an idle lane into a slot of its own that nobody reads): with a fixed
+        // number of stores per step the waits for the loads can be counted so that they never wait for a store
+        out[active ? k : 0] = active ? x_new : xb;
+        out_aux[active ? k : 0] = active ? kx[3] + pg : aux_b;
+        st_agent(active && feeds ? bout + k : idle, x_new);
+        if (active) { x_m2 = x_m1; x_m1 = x_new; }
+    };
+    // two steps per trip, each with packet registers of its own: the loads of a step are issued a whole step
+    // before their first use and nothing waits for the stores (a step beyond the last one has no active lane)
+    Packet A = load(0);
+    for (int n = 0; n <= nlast; n += 2) {
+        const Packet B = load(n + 1);
+        step(A, n);
+        A = load(n + 2);
+        step(B, n + 1);
+    }
+}
+
+// arguments of one model's surface sweep; allocates the packets on first use
 int rk2d_item(atomdev* h, BatchItem& it) {
     if (int rc = atomdev_refresh_flags(h)) return rc;
     const bool hyd = h->model == ATOMDEV_HYD;
@@ -322,65 +442,52 @@ int rk2d_item(atomdev* h, BatchItem& it) {
     a.i_rm = 1. / a.rm; a.i_rm2 = 1. / (a.rm * a.rm); a.i_rho = 1. / a.rho;
     a.i_two_dphi = 1. / h->k.two_dphi; a.i_dphi = 1. / h->k.dphi;
     it.K = h->k;
-    // skewed copy of the surface: 7 fp64 arrays and the flags, jm + km + 2 diagonals of pitch P
-    const int P = (h->jm + 15) & ~15;
-    const size_t ndiag = (size_t)h->jm + h->km + 2, cells = ndiag * P;
+    const int groups = (h->jm - 2 + CH_ROWS - 1) / CH_ROWS;
+    const int ndd = h->km + CH_ROWS + 4;   // steps 0 .. km - 3 + 31, and up to three more that are loaded ahead
+    const size_t pk_bytes = (size_t)groups * ndd * PK * 64 * sizeof(double2);
+    const size_t bnd_bytes = ((size_t)groups * 2 * h->km + (size_t)groups * 64) * sizeof(double);  // and a slot per lane
     if (!h->surf) {
-        ATOMDEV_TRY(hipMalloc(&h->surf, cells * (7 * sizeof(double) + 1)));
-        ATOMDEV_TRY(hipMemsetAsync(h->surf, 0, cells * (7 * sizeof(double) + 1), h->stream));
+        ATOMDEV_TRY(hipMalloc(&h->surf, pk_bytes + bnd_bytes));
+        ATOMDEV_TRY(hipMemsetAsync(h->surf, 0, pk_bytes + bnd_bytes, h->stream));
     }
-    Skewed& s = it.s;
-    double* base = (double*)h->surf;
-    s.v = base; s.w = base + cells; s.p = base + 2 * cells; s.vn = base + 3 * cells; s.wn = base + 4 * cells;
-    s.aux_v = base + 5 * cells; s.aux_w = base + 6 * cells; s.fl = (uint8_t*)(base + 7 * cells);
-    s.P = P;
+    it.c.pk = (double2*)h->surf;
+    it.c.bnd = (double*)((char*)h->surf + pk_bytes);
+    it.c.ndd = ndd;
     return 0;
 }
 
-// skew, sweep, unskew for n models (items == nullptr: one model, arguments of `one` by value) on `stream`
-int rk2d_launch(const BatchItem& one, const BatchItem* items, int n, int jm, int km, hipStream_t stream) {
-    const int rows = jm - 2, threads = (rows + 63) / 64 * 64;
-    const int P = one.s.P;
+// prepare + chain for n models (items == nullptr: one model, arguments of `one` by value) on `stream`
+int rk2d_launch(const BatchItem& one, const BatchItem* items, int n, int jm, int km, hipStream_t stream, int* err) {
+    const int groups = (jm - 2 + CH_ROWS - 1) / CH_ROWS;
     const unsigned nb = (unsigned)(((size_t)jm * km + 255) / 256);
-    hipLaunchKernelGGL(k_skew, dim3(nb, n), dim3(256), 0, stream, one.a, one.s, jm, km, items);
+    hipLaunchKernelGGL(k_rk2d_prepare, dim3(nb, n), dim3(256), 0, stream, one.a, one.c, one.K, groups, items);
     ATOMDEV_TRY(hipGetLastError());
-    const size_t lds = (size_t)2 * P * 2 * sizeof(double);
-    if (threads <= 256)
-        hipLaunchKernelGGL(k_rk2d_rows<256>, dim3(n), dim3(threads), lds, stream, one.a, one.s, one.K, items);
-    else if (threads <= 768)  // three waves per SIMD: the register allocation still fits without spills
-        hipLaunchKernelGGL(k_rk2d_rows<768>, dim3(n), dim3(threads), lds, stream, one.a, one.s, one.K, items);
-    else
-        hipLaunchKernelGGL(k_rk2d_rows<1024>, dim3(n), dim3(threads), lds, stream, one.a, one.s, one.K, items);
-    ATOMDEV_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_unskew, dim3(nb, n), dim3(256), 0, stream, one.a, one.s, jm, km, items);
-    return atomdev_check(hipGetLastError(), "k_unskew");
+    hipLaunchKernelGGL(k_rk2d_chain, dim3(groups, n), dim3(64), 0, stream, one.a, one.c, one.K, items, err);
+    return atomdev_check(hipGetLastError(), "k_rk2d_chain");
 }
 
 int rk2d(atomdev* h, bool hyd) {
     (void)hyd;
     BatchItem it;
-    const int rows = h->jm - 2, threads = (rows + 63) / 64 * 64;
-    if (threads > 1024 || h->rk_variant == 1) {
-        if (int rc = rk2d_item(h, it)) return rc;
+    if (int rc = rk2d_item(h, it)) return rc;
+    if (h->rk_variant == 1 || h->jm < 3 || h->km < 4) {
         hipLaunchKernelGGL(k_rk2d, dim3(1), dim3(256), (size_t)h->jm * sizeof(RowGeo), h->stream, it.a, h->k);
         return atomdev_check(hipGetLastError(), "k_rk2d");
     }
-    if (int rc = rk2d_item(h, it)) return rc;
-    return rk2d_launch(it, nullptr, 1, h->jm, h->km, h->stream);
+    return rk2d_launch(it, nullptr, 1, h->jm, h->km, h->stream, (int*)atomdev_kernel_error_word(h));
 }
 
 }  // namespace
 
-// The surface sweep is a chain of dependent anti-diagonals that occupies one workgroup, so one model leaves 255
-// of 256 compute units idle: the sweeps of independent models (the time slices of a paleo series, each with its
-// own handle) go into one launch, one workgroup each.  Work already enqueued on the handles' streams is waited
+// The surface sweep is a chain of dependent anti-diagonals that occupies a handful of waves, so one model leaves most
+// of the 256 compute units idle: the sweeps of independent models (the time slices of a paleo series, each with its
+// own handle) go into one launch.  Work already enqueued on the handles' streams is waited
 // for through events, and each stream in turn waits for the batch, so the ordering rules of single calls hold.
 extern "C" int atomdev_rk2d_batch(atomdev_t* const* handles, int n) {
     ATOMDEV_REQUIRE(handles && n >= 1, "atomdev_rk2d_batch: bad argument");
     atomdev* h0 = handles[0];
     ATOMDEV_REQUIRE(h0 != nullptr, "atomdev_rk2d_batch: null handle");
-    const int rows = h0->jm - 2, threads = (rows + 63) / 64 * 64;
-    ATOMDEV_REQUIRE(threads <= 1024, "atomdev_rk2d_batch: more than 1024 interior rows");
+    ATOMDEV_REQUIRE(h0->jm >= 3 && h0->km >= 4, "atomdev_rk2d_batch: surface too small");
     for (int m = 0; m < n; m++) {
         atomdev* h = handles[m];
         ATOMDEV_REQUIRE(h != nullptr, "atomdev_rk2d_batch: null handle");
@@ -409,7 +516,8 @@ extern "C" int atomdev_rk2d_batch(atomdev_t* const* handles, int n) {
     }
     ATOMDEV_TRY(hipMemcpyAsync(h0->batch, items.data(), bytes, hipMemcpyHostToDevice, h0->stream));
     ATOMDEV_TRY(hipStreamSynchronize(h0->stream));  // `items` is host memory that goes out of scope
-    if (int rc = rk2d_launch(items[0], (const BatchItem*)h0->batch, n, h0->jm, h0->km, h0->stream)) return rc;
+    if (int rc = rk2d_launch(items[0], (const BatchItem*)h0->batch, n, h0->jm, h0->km, h0->stream,
+                             (int*)atomdev_kernel_error_word(h0))) return rc;
     ATOMDEV_TRY(hipEventRecord(h0->ev1, h0->stream));
     for (int m = 1; m < n; m++) ATOMDEV_TRY(hipStreamWaitEvent(handles[m]->stream, h0->ev1, 0));
     return 0;
