@@ -4,6 +4,7 @@
 #include <string>
 
 #include "atomdev_internal.h"
+#include "fixed4.h"
 
 namespace {
 
@@ -104,9 +105,9 @@ __global__ void k_fill_r_neumann(Four f, int im, size_t n2) {
 }
 
 std::string four_decimals(double x) {
-    char buf[400];
-    std::snprintf(buf, sizeof(buf), "%.4f", x);  // what an ofstream with precision(4) and ios::fixed prints
-    return buf;
+    std::string s;
+    append_fixed4(s, x);  // what an ofstream with precision(4) and ios::fixed prints
+    return s;
 }
 
 int write_plot_data(atomdev* h, const char* path, bool atm) {

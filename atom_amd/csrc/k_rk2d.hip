@@ -345,8 +345,9 @@ __global__ __launch_bounds__(64) void k_rk2d_chain(Rk2dArgs a, Chain c, DevConst
     const gdouble_t out = (gdouble_t)((x ? a.w : a.v) + (size_t)(row ? j : 1) * km);
     const gdouble_t out_aux = (gdouble_t)((x ? a.aux_w : a.aux_v) + (size_t)(row ? j : 1) * km);
     const double xb = out[0], aux_b = out_aux[0];   // (j, 0): what the row starts from (and keeps)
+    double x_m1 = xb, x_m2 = 0.;         // own results at k-1, k-2 (the first step of a row finds (j, 0) there)
+    bool dead = false;
     const gdouble_t idle = (gdouble_t)(c.bnd + (size_t)gridDim.x * 2 * km + blockIdx.x * 64 + lane);
-    double x_m1 = 0., x_m2 = 0.;         // own results at k-1, k-2
 
     auto load = [&](int n) {
         Packet P;
@@ -361,22 +362,26 @@ __global__ __launch_bounds__(64) void k_rk2d_chain(Rk2dArgs a, Chain c, DevConst
         const int k = n + 1 - r;
         const bool active = row && k >= 1 && k <= km - 2;
         double x_tm = __shfl_up(x_m1, 2);
-        if (polls) {
+        {
             double b = b_nx;
-            if (active) {
-                for (int tries = 0; __double_as_longlong(b) == (long long)BND_EMPTY; tries++) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (tries > (1 << 22)) {  // the wave of the rows above never delivered: give up and say so
-                        __hip_atomic_store(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        break;
+            // the row above belongs to another wave: its value was asked for a step ago and is nearly always there
+            const bool missing = polls && active && !dead && __double_as_longlong(b) == (long long)BND_EMPTY;
+            if (__builtin_expect(__any(missing), 0)) {
+                if (missing) {
+                    for (int tries = 0; __double_as_longlong(b) == (long long)BND_EMPTY; tries++) {
+                        if (tries > (1 << 20)) {  // never delivered: say so, and stop waiting for the rest of the sweep
+                            __hip_atomic_store(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            dead = true;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                        b = ld_agent(bin + k);
                     }
-                    b = ld_agent(bin + k);
                 }
             }
-            x_tm = b;
+            if (polls) x_tm = b;
         }
         b_nx = ld_agent(bin + min(max(k + 1, 0), km - 1));  // every lane, so that nothing has to wait for it here
-        if (k == 1) x_m1 = xb;
         const double xn = cur.e[0].y;
         const double t1_cc = cur.e[1].x, t1_a = cur.e[1].y, t1_c2 = cur.e[2].x, t1_h = cur.e[2].y, t1_div = cur.e[3].x, t1_idiv = cur.e[3].y;
         const double p1_cc = cur.e[4].x, p1_a = cur.e[4].y, p1_c2 = cur.e[5].x, p1_h = cur.e[5].y, p1_div = cur.e[6].x, p1_idiv = cur.e[6].y;

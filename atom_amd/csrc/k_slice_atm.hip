@@ -17,15 +17,41 @@ extern "C" void atomdev_default_atm_loop(atomdev_atm_loop* L) {
     L->nm = 200;  // cAtmosphereModel.h:123
 }
 
-#define STEP(call) do { if (int rc__ = (call)) return rc__; } while (0)
+// With ATOMDEV_STEP_TIMES set in the environment every step of the loops and of the slice is bracketed by a stream
+// synchronisation and its wall time goes to stderr ("step <ms> <call>"): where a slice spends its time, host work
+// (readers, writers) included.  Off by default: the steps are then enqueued back to back.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+namespace {
+struct StepTimes {
+    bool on;
+    StepTimes() : on(std::getenv("ATOMDEV_STEP_TIMES") != nullptr) {}
+};
+const StepTimes g_step_times;
+struct StepClock {
+    atomdev_t* h; const char* what; std::chrono::steady_clock::time_point t0;
+    StepClock(atomdev_t* h_, const char* w) : h(h_), what(w) {
+        if (g_step_times.on) { atomdev_sync(h); t0 = std::chrono::steady_clock::now(); }
+    }
+    ~StepClock() {
+        if (!g_step_times.on) return;
+        atomdev_sync(h);
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        std::fprintf(stderr, "step %.3f %s\n", ms, what);
+    }
+};
+}  // namespace
+#define STEP(call) do { StepClock clock__(h, #call); if (int rc__ = (call)) return rc__; } while (0)
 
 // The surface loops of n independent time slices in lockstep: each operator enqueued for all slices on their own
-// streams, the surface sweeps - one workgroup's worth of dependent diagonals each - in one launch.
+// streams, the surface sweeps - a few waves' worth of dependent diagonals each - in one launch.
 extern "C" int atomdev_atm_run_2d_loops(atomdev_t* const* handles, int n, const atomdev_atm_loop* L) {
     ATOMDEV_REQUIRE(handles && n >= 1 && L, "atomdev_atm_run_2d_loops: bad argument");
     for (int m = 0; m < n; m++)
         ATOMDEV_REQUIRE(handles[m] && handles[m]->model == ATOMDEV_ATM, "atomdev_atm_run_2d_loops: needs atmosphere handles");
-#define EACH(call) do { for (int m = 0; m < n; m++) { atomdev_t* h = handles[m]; if (int rc__ = (call)) return rc__; } } while (0)
+    atomdev_t* const h = handles[0];  // the handle whose stream the step times are taken on
+#define EACH(call) do { StepClock clock__(h, #call); for (int m = 0; m < n; m++) { atomdev_t* h = handles[m]; if (int rc__ = (call)) return rc__; } } while (0)
     std::vector<double> res(n, 0.);
     std::vector<int> loc(3 * (size_t)n, 0);
     double st[3]; int st_loc[9];

@@ -9,6 +9,8 @@
 #include <string>
 
 #include "atomdev_internal.h"
+#include "fixed4.h"
+#include "text_numbers.h"
 
 namespace {
 
@@ -87,27 +89,38 @@ extern "C" int atomdev_atm_write_transfer_file(atomdev_t* atm, const char* path)
     const size_t n2 = atm->n2;
     std::vector<double> x(6 * n2);
     ATOMDEV_TRY(hipMemcpy(x.data(), atm->xfer, 6 * n2 * sizeof(double), hipMemcpyDeviceToHost));
-    std::ofstream f;
-    f.precision(4);
-    f.setf(std::ios::fixed);
-    f.open(path);
-    ATOMDEV_REQUIRE(f.is_open(), std::string("atomdev_atm_write_transfer_file: could not open ") + path);
+    // the text an ofstream with ios::fixed and precision(4) writes: six numbers a line, one space between them
+    FILE* f = std::fopen(path, "w");
+    ATOMDEV_REQUIRE(f, std::string("atomdev_atm_write_transfer_file: could not open ") + path);
+    std::string out;
+    out.reserve(n2 * 60);
     for (size_t q = 0; q < n2; q++)
-        f << x[q] << " " << x[n2 + q] << " " << x[2 * n2 + q] << " " << x[3 * n2 + q] << " " << x[4 * n2 + q] << " "
-          << x[5 * n2 + q] << std::endl;
-    f.close();
-    ATOMDEV_REQUIRE(f.good(), std::string("atomdev_atm_write_transfer_file: write failed: ") + path);
+        for (int n = 0; n < 6; n++) {
+            append_fixed4(out, x[(size_t)n * n2 + q]);
+            out += n < 5 ? ' ' : '\n';
+        }
+    const bool ok = std::fwrite(out.data(), 1, out.size(), f) == out.size();
+    ATOMDEV_REQUIRE(std::fclose(f) == 0 && ok, std::string("atomdev_atm_write_transfer_file: write failed: ") + path);
     return 0;
 }
 
 extern "C" int atomdev_hyd_read_transfer_file(atomdev_t* hyd, const char* path) {
     ATOMDEV_REQUIRE(hyd && hyd->model == ATOMDEV_HYD && path, "atomdev_hyd_read_transfer_file: bad argument");
-    std::ifstream f(path);
-    ATOMDEV_REQUIRE(f.is_open(), std::string("atomdev_hyd_read_transfer_file: could not open ") + path);
     const size_t n2 = hyd->n2;
     std::vector<double> x(6 * n2);
-    for (size_t q = 0; q < n2; q++)
-        for (int n = 0; n < 6; n++) f >> x[(size_t)n * n2 + q];
-    ATOMDEV_REQUIRE(!f.fail(), std::string("atomdev_hyd_read_transfer_file: fewer than jm * km rows of six numbers in ") + path);
+    TextNumbers tn;
+    ATOMDEV_REQUIRE(tn.open(path), std::string("atomdev_hyd_read_transfer_file: could not open ") + path);
+    if (tn.plain()) {  // plain decimal tokens: converted directly, the values the stream extraction returns
+        bool enough = true;
+        for (size_t q = 0; q < n2 && enough; q++)
+            for (int n = 0; n < 6 && enough; n++) enough = tn.next(x[(size_t)n * n2 + q]);
+        ATOMDEV_REQUIRE(enough, std::string("atomdev_hyd_read_transfer_file: fewer than jm * km rows of six numbers in ") + path);
+    }
+    if (!tn.plain() || tn.out_of_range()) {
+        std::ifstream f(path);
+        for (size_t q = 0; q < n2; q++)
+            for (int n = 0; n < 6; n++) f >> x[(size_t)n * n2 + q];
+        ATOMDEV_REQUIRE(!f.fail(), std::string("atomdev_hyd_read_transfer_file: fewer than jm * km rows of six numbers in ") + path);
+    }
     return load_planes(hyd, x.data());
 }

@@ -9,8 +9,16 @@
 #include <vector>
 
 #include "atomdev_internal.h"
+#include "fixed4.h"
 
 namespace {
+
+// element r of a contiguous buffer <-> element r * pitch of a field (scatter != 0: buffer to field)
+__global__ void k_section_column(double* __restrict__ buf, double* __restrict__ field, size_t pitch, size_t rows, int scatter) {
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    if (scatter) field[r * pitch] = buf[r]; else buf[r] = field[r * pitch];
+}
 
 // one section of a 3-D field in the order the writers walk it: radial [j][k], longal [i][k], zonal [i][j]
 struct Section {
@@ -28,16 +36,47 @@ struct Section {
         else if (kind == ATOMDEV_LONGAL) { offset = (size_t)index * km; width = km * 8; pitch = jm * km * 8; rows = h->im; }
         else { offset = (size_t)index; width = 8; pitch = km * 8; rows = (size_t)h->im * jm; }
     }
+    // A zonal section is one double out of every row of the field: as a strided copy that is a transfer per
+    // element, so it is gathered into (scattered from) a contiguous device buffer by a kernel instead.
+    int staging(double*& dev) const {
+        const size_t bytes = size() * sizeof(double);
+        if (bytes > h->stage_bytes) {
+            ATOMDEV_TRY(hipStreamSynchronize(h->stream));
+            if (h->stage) ATOMDEV_TRY(hipFree(h->stage));
+            h->stage = nullptr; h->stage_bytes = 0;
+            ATOMDEV_TRY(hipMalloc(&h->stage, bytes));
+            h->stage_bytes = bytes;
+        }
+        dev = (double*)h->stage;
+        return 0;
+    }
     int get(int field, std::vector<double>& out) const {
         out.resize(size());
         size_t off, width, pitch, rows;
         geometry(off, width, pitch, rows);
+        if (kind == ATOMDEV_ZONAL) {
+            double* dev;
+            if (int rc = staging(dev)) return rc;
+            hipLaunchKernelGGL(k_section_column, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, h->stream, dev, h->f[field] + off,
+                               (size_t)h->km, rows, 0);
+            ATOMDEV_TRY(hipGetLastError());
+            ATOMDEV_TRY(hipMemcpyAsync(out.data(), dev, rows * 8, hipMemcpyDeviceToHost, h->stream));
+            return 0;
+        }
         ATOMDEV_TRY(hipMemcpy2DAsync(out.data(), width, h->f[field] + off, pitch, width, rows, hipMemcpyDeviceToHost, h->stream));
         return 0;
     }
     int put(int field, const std::vector<double>& in) const {
         size_t off, width, pitch, rows;
         geometry(off, width, pitch, rows);
+        if (kind == ATOMDEV_ZONAL) {
+            double* dev;
+            if (int rc = staging(dev)) return rc;
+            ATOMDEV_TRY(hipMemcpyAsync(dev, in.data(), rows * 8, hipMemcpyHostToDevice, h->stream));
+            hipLaunchKernelGGL(k_section_column, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, h->stream, dev, h->f[field] + off,
+                               (size_t)h->km, rows, 1);
+            return atomdev_check(hipGetLastError(), "k_section_column");
+        }
         ATOMDEV_TRY(hipMemcpy2DAsync(h->f[field] + off, pitch, in.data(), width, width, rows, hipMemcpyHostToDevice, h->stream));
         return 0;
     }
@@ -45,7 +84,7 @@ struct Section {
 
 struct Text {
     std::string s;
-    void num(double x) { char b[400]; std::snprintf(b, sizeof(b), "%.4f", x); s += b; }  // precision(4), ios::fixed
+    void num(double x) { append_fixed4(s, x); }  // precision(4), ios::fixed
     void line(double x) { num(x); s += '\n'; }
     void triple(double x, double y, double z) { num(x); s += ' '; num(y); s += ' '; num(z); s += '\n'; }
     void scalars(const char* name) { s += "SCALARS "; s += name; s += " float 1\nLOOKUP_TABLE default\n"; }
@@ -194,7 +233,14 @@ int write_vtk(atomdev* h, int kind, int index, int Ma, const char* path) {
             temperature_celsius();
             // :452-482: total water and the two saturation ratios, kept in aux_w, aux_u, aux_v
             std::vector<double> total(n), sat_water(n), sat_ice(n), t0(jm);
-            ATOMDEV_TRY(hipMemcpy2DAsync(t0.data(), 8, h->f[ATOMDEV_T] + index, (size_t)km * 8, 8, jm, hipMemcpyDeviceToHost, h->stream));
+            {   // the ground temperatures of the section: one double a row
+                double* dev;
+                if (int rc = sec.staging(dev)) return rc;
+                hipLaunchKernelGGL(k_section_column, dim3((unsigned)((jm + 255) / 256)), dim3(256), 0, h->stream, dev,
+                                   h->f[ATOMDEV_T] + index, (size_t)km, (size_t)jm, 0);
+                ATOMDEV_TRY(hipGetLastError());
+                ATOMDEV_TRY(hipMemcpyAsync(t0.data(), dev, (size_t)jm * 8, hipMemcpyDeviceToHost, h->stream));
+            }
             if (int rc = sync()) return rc;
             for (int i = 0; i < im; i++)
                 for (int j = 0; j < jm; j++) {
@@ -300,7 +346,13 @@ struct VtsFile {
         const int im = h->im, jm = h->jm, km = h->km;
         for (int k = 0; k < km; k++) {
             for (int j = 0; j < jm; j++) {
-                for (int i = 0; i < im; i++) std::fprintf(f, "%.4f\n", value(field[idx3(jm, km, i, j, k)]));
+                char line[4096], *p = line;  // a row of levels at a time
+                for (int i = 0; i < im; i++) {
+                    if (p - line > (long)sizeof(line) - 420) { std::fwrite(line, 1, (size_t)(p - line), f); p = line; }
+                    p = put_fixed4(p, value(field[idx3(jm, km, i, j, k)]));
+                    *p++ = '\n';
+                }
+                std::fwrite(line, 1, (size_t)(p - line), f);
                 std::fputs(blank, f);
             }
             std::fputs(blank, f);
@@ -344,7 +396,8 @@ int write_panorama(atomdev* h, const char* path) {
             for (int j = 0; j < jm; j++) {
                 for (int i = 0; i < im; i++) {
                     const size_t q = idx3(jm, km, i, j, k);
-                    std::fprintf(f, "%.4f %.4f %.4f\n", out.field[q], v[q], w[q]);
+                    { char b[1300], *e = put_fixed4(b, out.field[q]); *e++ = ' '; e = put_fixed4(e, v[q]); *e++ = ' ';
+                      e = put_fixed4(e, w[q]); *e++ = '\n'; std::fwrite(b, 1, (size_t)(e - b), f); }
                 }
                 std::fputs("\n\n", f);
             }
@@ -388,7 +441,8 @@ int write_panorama(atomdev* h, const char* path) {
             for (int j = 0; j < jm; j++) {
                 for (int i = 0; i < im; i++) {
                     if (k == 0 || j == 0) x = 0.; else x = x + dx;
-                    std::fprintf(f, "%.4f %.4f %.4f\n", x, y, z);
+                    { char b[1300], *e = put_fixed4(b, x); *e++ = ' '; e = put_fixed4(e, y); *e++ = ' ';
+                      e = put_fixed4(e, z); *e++ = '\n'; std::fwrite(b, 1, (size_t)(e - b), f); }
                 }
                 x = 0;
                 y = y + dy;

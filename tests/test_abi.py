@@ -78,6 +78,18 @@ def test_text_numbers_match_stream_extraction(tmp_path):
     assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout + r.stderr
 
 
+def test_fixed4_is_printf(tmp_path):
+    """The writers' four-decimal formatter (atom_amd/csrc/fixed4.h) gives the bytes of printf("%.4f") on 5 000 000 values:
+    random ones over sixty binades, dyadic values (the only ones that can sit on a half of the last place) and their
+    neighbours, (k + 1/2) / 10^4 and its neighbours, zeros of both signs, huge values, infinities and NaNs."""
+    import subprocess
+    exe = str(tmp_path / "fixed4_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(H.ROOT, "atom_amd", "csrc"),
+                           os.path.join(H.ROOT, "tests", "fixed4_check.cpp"), "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout + r.stderr
+
+
 def test_cr_math_is_correctly_rounded(tmp_path):
     """The double-double exp, pow, x^4 and fourth root of atom_amd/csrc/cr_math.h on 4 000 000 arguments each in the ranges
     the column physics uses: never on the wrong side of a case the x87 long-double functions decide; glibc's own double
