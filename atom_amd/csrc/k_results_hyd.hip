@@ -5,6 +5,7 @@
 
 #include "atomdev_internal.h"
 #include "fixed4.h"
+#include "host_parallel.h"
 
 namespace {
 
@@ -104,12 +105,6 @@ __global__ void k_fill_r_neumann(Four f, int im, size_t n2) {
     x[top] = c43 * x[top - n2] - c13 * x[top - 2 * n2];
 }
 
-std::string four_decimals(double x) {
-    std::string s;
-    append_fixed4(s, x);  // what an ofstream with precision(4) and ios::fixed prints
-    return s;
-}
-
 int write_plot_data(atomdev* h, const char* path, bool atm) {
     ATOMDEV_TRY(hipSetDevice(h->device));
     const int jm = h->jm, km = h->km, L = atm ? 0 : h->im - 1;
@@ -131,22 +126,31 @@ int write_plot_data(atomdev* h, const char* path, bool atm) {
                           : "lons(deg), lats(deg), topography, v-velocity(m/s), w-velocity(m/s), velocity-mag(m/s), "
                             "temperature(Celsius), salinity(psu), bottom_water(m/s), upwelling(m/s), downwelling(m/s)\n";
     const double u_0 = h->p.u_0, t_0 = h->p.t_0;
-    for (int k = 0; k < km; k++)
+    std::fwrite(out.data(), 1, out.size(), f);
+    // the rows of a longitude are a piece of text of their own; a few host threads make the pieces side by side
+    std::vector<std::string> piece(km);
+    host_parallel_run((size_t)km, [&](size_t kk) {
+        const int k = (int)kk;
+        std::string& o = piece[kk];
+        o.reserve((size_t)jm * 96);
+        char b[400 * 9 + 64];
         for (int j = 0; j < jm; j++) {
             const size_t q = (size_t)j * km + k;
             const double v = s[n2 + q] * u_0, w = s[2 * n2 + q] * u_0;
             const double vel_mag = std::sqrt(v * v + w * w);  // pow(x, 2) is x * x, correctly rounded either way
-            out += std::to_string(k) + " " + std::to_string(90 - j) + " " + four_decimals(s[q]) + " " + four_decimals(v) + " " +
-                   four_decimals(w) + " " + four_decimals(vel_mag) + " ";
-            if (atm)
-                out += four_decimals(s[3 * n2 + q] * t_0 - t_0) + " " + four_decimals(s[4 * n2 + q] * 1000.) + " " +
-                       four_decimals(s[5 * n2 + q]) + " " + four_decimals(s[6 * n2 + q]) + " \n";
-            else
-                out += four_decimals(s[3 * n2 + q] * 273.15 - 273.15) + " " + four_decimals(s[4 * n2 + q] * 35.) + " " +
-                       four_decimals(s[5 * n2 + q]) + " " + four_decimals(s[6 * n2 + q]) + "   " + four_decimals(s[7 * n2 + q]) + " \n";
-            if (out.size() > (1u << 20)) { std::fwrite(out.data(), 1, out.size(), f); out.clear(); }
+            char* e = b + std::snprintf(b, 64, "%d %d ", k, 90 - j);
+            auto num = [&e](double x, const char* after) { e = put_fixed4(e, x); while (*after) *e++ = *after++; };
+            num(s[q], " "); num(v, " "); num(w, " "); num(vel_mag, " ");
+            if (atm) {
+                num(s[3 * n2 + q] * t_0 - t_0, " "); num(s[4 * n2 + q] * 1000., " "); num(s[5 * n2 + q], " "); num(s[6 * n2 + q], " \n");
+            } else {
+                num(s[3 * n2 + q] * 273.15 - 273.15, " "); num(s[4 * n2 + q] * 35., " "); num(s[5 * n2 + q], " ");
+                num(s[6 * n2 + q], "   "); num(s[7 * n2 + q], " \n");
+            }
+            o.append(b, (size_t)(e - b));
         }
-    std::fwrite(out.data(), 1, out.size(), f);
+    });
+    for (const std::string& o : piece) std::fwrite(o.data(), 1, o.size(), f);
     const bool bad = std::ferror(f) != 0;
     ATOMDEV_REQUIRE(std::fclose(f) == 0 && !bad, std::string("write failed: ") + path);
     return 0;

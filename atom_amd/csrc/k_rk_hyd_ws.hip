@@ -28,6 +28,8 @@
 //
 // The sweep is out of place (see k_rk_hyd.hip): it reads the current buffers and writes the
 // alternate set, whose boundary shell is refreshed beforehand by k_copy_shell.
+#include <cstdlib>
+
 #include "atomdev_internal.h"
 
 // Compiled twice, like k_rk_atm_ws.hip: as it stands every quotient carries the bits of the reference's division;
@@ -566,20 +568,44 @@ __device__ __forceinline__ void sweep_role(const HydWsArgs& a, const DevConst& K
     if constexpr (isV || isW || isC) stg(O1, o0 - rowB, so1);
 }
 
-// Levels 1 .. im-2, one workgroup of five waves (one variable each) per 64 lines.
-__global__ __launch_bounds__(320) void k_hyd_rk3d_ws(const HydWsParams* __restrict__ P, int nlev, int* __restrict__ progress,
+// Levels 1 .. im-2, one workgroup of five waves (one variable each) per 64 lines (NB = 1) - or TEN waves for two
+// neighbouring blocks of 64 lines of one level (NB = 2).  A compute unit has four SIMDs and a SIMD issues one
+// instruction every ~4 cycles whichever of its waves it comes from: with five waves the SIMD that carries two of them
+// (t + w, ~950 instructions a row against 550 - 780 on the other three) sets the pace of every stage.  Waves go to
+// SIMDs round robin (wave n on SIMD n % 4); with ten waves the order below puts {c, v} of a block on a SIMD of their
+// own and {t, u, w} of a block together on another: ~1 500 instructions a row for two blocks - a fifth less per
+// block, but half as long again per row.  So two blocks per workgroup pay where the grid has more blocks than the
+// chip can hold side by side (0.25 degree: -12 %, tolerance form -23 %), and cost where every block has a compute
+// unit of its own anyway (1 degree: +24 %); the launch picks.  The two blocks are independent recurrences that only
+// share the stage barrier.
+struct WaveJob { int block, role; };
+template <int NB>
+__device__ __forceinline__ WaveJob wave_job(int wave) {
+    if (NB == 1) return { 0, wave };  // t, v, u, c, w
+    // wave:  0    1    2    3    4    5    6    7    8    9
+    // SIMD:  0    1    2    3    0    1    2    3    0    1
+    //       A.t  B.t  A.c  B.c  A.u  B.u  A.v  B.v  A.w  B.w
+    const int role[5] = { R_T, R_C, R_U, R_V, R_W };
+    return { wave & 1, role[wave >> 1] };
+}
+
+template <int NB>
+__global__ __launch_bounds__(320 * NB) void k_hyd_rk3d_ws(const HydWsParams* __restrict__ P, int nlev, int* __restrict__ progress,
                                                       int* __restrict__ err) {
     const HydWsArgs& a = P->a;
     const DevConst& K = P->K;
-    __shared__ Shared sh;
+    __shared__ Shared sh2[NB];
     extern __shared__ double tab[];  // [jm][4]: cos(the), rm^2 sin(the), its reciprocal, viscous v coefficient
     // all longitude blocks of a level on one XCD (they share cache lines; see k_rk_atm_ws.hip); level im-3 comes
-    // one block index before level im-2 of the same longitude block
-    const int gx = (K.km - 2 + 63) / 64;
+    // one workgroup index before level im-2 of the same longitude blocks
+    const int gx = (K.km - 2 + 63) / 64, gp = (gx + NB - 1) / NB;
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const int lev = xcd + 8 * (idx / gx), bx = idx % gx;
+    const int lev = xcd + 8 * (idx / gp), pair = idx % gp;
     if (lev >= nlev) return;
-    const int wave = threadIdx.x >> 6;
+    const WaveJob job = wave_job<NB>(threadIdx.x >> 6);
+    const int bx = NB * pair + job.block;
+    const int wave = job.role;
+    Shared& sh = sh2[job.block];
     const int i = 1 + lev;
     const int jm = K.jm;
 #ifdef ATOMDEV_EXP_WGTIME  // timing experiment only: duration of every workgroup goes to level 0 of aux_u
@@ -588,7 +614,7 @@ __global__ __launch_bounds__(320) void k_hyd_rk3d_ws(const HydWsParams* __restri
 #endif
     {
         const double rm = a.rad[i], rm2 = rm * rm;
-        for (int j = threadIdx.x; j < jm; j += 320) {
+        for (int j = threadIdx.x; j < jm; j += (int)blockDim.x) {
             const double sinthe = a.sinthe[j], costhe = a.costhe[j];
             const double rm2sinthe = rm2 * sinthe;
             tab[4 * j + 0] = costhe;
@@ -597,6 +623,10 @@ __global__ __launch_bounds__(320) void k_hyd_rk3d_ws(const HydWsParams* __restri
             tab[4 * j + 3] = 1. + costhe * costhe / (sinthe * sinthe);  // RHS_Hyd.cpp:422 (no rm here)
         }
         __syncthreads();
+    }
+    if (bx >= gx) {  // the level has an odd number of blocks: these waves only keep the barrier rhythm of the workgroup
+        for (int n = 0; n < 1 + 4 * (jm - 2); n++) lds_barrier();
+        return;
     }
 #ifdef ATOMDEV_EXP_NOPAIR  // timing experiment only: level im-2 takes a stale salinity row
     int* pw = nullptr;
@@ -688,8 +718,16 @@ int HYD_WS_ENTRY(atomdev* h) {
                        D->progress, (int)gx);
     ATOMDEV_TRY(hipGetLastError());
     const size_t lds = (size_t)h->jm * 4 * sizeof(double);
-    // levels 1 .. im-2, one workgroup per 64 lines
-    hipLaunchKernelGGL(k_hyd_rk3d_ws, dim3(8 * ((h->im - 2 + 7) / 8) * gx), dim3(320), lds, h->stream, P, h->im - 2, D->progress, (int*)atomdev_kernel_error_word(h));
+    // levels 1 .. im-2; two blocks of 64 lines per workgroup where one block each would be more workgroups than two per
+    // compute unit (see the kernel)
+    int cus = 0;
+    ATOMDEV_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
+    const char* force = std::getenv("ATOMDEV_HYD_BLOCKS_PER_GROUP");  // 1 or 2: A/B timing
+    const bool two = force ? force[0] == '2' : (size_t)(h->im - 2) * gx > (size_t)2 * cus;
+    if (two)
+        hipLaunchKernelGGL(k_hyd_rk3d_ws<2>, dim3(8 * ((h->im - 2 + 7) / 8) * ((gx + 1) / 2)), dim3(640), lds, h->stream, P, h->im - 2, D->progress, (int*)atomdev_kernel_error_word(h));
+    else
+        hipLaunchKernelGGL(k_hyd_rk3d_ws<1>, dim3(8 * ((h->im - 2 + 7) / 8) * gx), dim3(320), lds, h->stream, P, h->im - 2, D->progress, (int*)atomdev_kernel_error_word(h));
     ATOMDEV_TRY(hipGetLastError());
     if (int rc = atomdev_prof_end(h)) return rc;
     for (int n = 0; n < 5; n++) { double* t = h->f[X[n]]; h->f[X[n]] = h->alt[X[n]]; h->alt[X[n]] = t; }

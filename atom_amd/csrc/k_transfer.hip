@@ -10,6 +10,7 @@
 
 #include "atomdev_internal.h"
 #include "fixed4.h"
+#include "host_parallel.h"
 #include "text_numbers.h"
 
 namespace {
@@ -92,14 +93,19 @@ extern "C" int atomdev_atm_write_transfer_file(atomdev_t* atm, const char* path)
     // the text an ofstream with ios::fixed and precision(4) writes: six numbers a line, one space between them
     FILE* f = std::fopen(path, "w");
     ATOMDEV_REQUIRE(f, std::string("atomdev_atm_write_transfer_file: could not open ") + path);
-    std::string out;
-    out.reserve(n2 * 60);
-    for (size_t q = 0; q < n2; q++)
-        for (int n = 0; n < 6; n++) {
-            append_fixed4(out, x[(size_t)n * n2 + q]);
-            out += n < 5 ? ' ' : '\n';
-        }
-    const bool ok = std::fwrite(out.data(), 1, out.size(), f) == out.size();
+    const size_t rows = 4096, pieces = (n2 + rows - 1) / rows;   // a few host threads make the text side by side
+    std::vector<std::string> piece(pieces);
+    host_parallel_run(pieces, [&](size_t c) {
+        std::string& out = piece[c];
+        out.reserve(rows * 60);
+        for (size_t q = c * rows; q < n2 && q < (c + 1) * rows; q++)
+            for (int n = 0; n < 6; n++) {
+                append_fixed4(out, x[(size_t)n * n2 + q]);
+                out += n < 5 ? ' ' : '\n';
+            }
+    });
+    bool ok = true;
+    for (const std::string& out : piece) ok = ok && std::fwrite(out.data(), 1, out.size(), f) == out.size();
     ATOMDEV_REQUIRE(std::fclose(f) == 0 && ok, std::string("atomdev_atm_write_transfer_file: write failed: ") + path);
     return 0;
 }

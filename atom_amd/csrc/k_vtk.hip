@@ -4,12 +4,14 @@
 // columns per file, the derived columns computed as the reference computes them (with the host's libm, as there),
 // and what the reference leaves behind in aux_u / aux_v / aux_w written back to the device fields.
 #include <cmath>
+#include <algorithm>
 #include <cstdio>
 #include <string>
 #include <vector>
 
 #include "atomdev_internal.h"
 #include "fixed4.h"
+#include "host_parallel.h"
 
 namespace {
 
@@ -82,15 +84,55 @@ struct Section {
     }
 };
 
+// The file as a list of pieces - literal text, a column of numbers (one a line) or a table of triples - whose text
+// is made by a few host threads side by side and written in order.
 struct Text {
-    std::string s;
-    void num(double x) { append_fixed4(s, x); }  // precision(4), ios::fixed
-    void line(double x) { num(x); s += '\n'; }
-    void triple(double x, double y, double z) { num(x); s += ' '; num(y); s += ' '; num(z); s += '\n'; }
-    void scalars(const char* name) { s += "SCALARS "; s += name; s += " float 1\nLOOKUP_TABLE default\n"; }
+    struct Piece {
+        std::string text;                 // literal, or the rendered numbers
+        std::vector<double> a, b, c;      // column: a; triples: a, b, c (an empty one stands for zeros)
+        double multiplier = 1.;
+        int kind = 0;                     // 0 literal, 1 column, 2 triples
+    };
+    std::vector<Piece> pieces;
+    std::string& s_ref() {
+        if (pieces.empty() || pieces.back().kind != 0) pieces.emplace_back();
+        return pieces.back().text;
+    }
+    void lit(const std::string& t) { s_ref() += t; }
+    void scalars(const char* name) { lit(std::string("SCALARS ") + name + " float 1\nLOOKUP_TABLE default\n"); }
     void column(const char* name, const std::vector<double>& a, double multiplier) {
         scalars(name);
-        for (double x : a) line(x * multiplier);
+        pieces.emplace_back();
+        pieces.back().kind = 1; pieces.back().a = a; pieces.back().multiplier = multiplier;
+    }
+    void triples(const std::vector<double>& a, const std::vector<double>& b, const std::vector<double>& c) {
+        pieces.emplace_back();
+        pieces.back().kind = 2; pieces.back().a = a; pieces.back().b = b; pieces.back().c = c;
+    }
+    static void render(Piece& p) {
+        if (p.kind == 0) return;
+        const size_t n = p.kind == 1 ? p.a.size() : std::max(p.a.size(), std::max(p.b.size(), p.c.size()));
+        p.text.clear();
+        p.text.reserve(n * (p.kind == 1 ? 12 : 36));
+        char b[1300];
+        for (size_t q = 0; q < n; q++) {
+            char* e = b;
+            if (p.kind == 1) e = put_fixed4(e, p.a[q] * p.multiplier);  // precision(4), ios::fixed
+            else {
+                e = put_fixed4(e, p.a.empty() ? 0. : p.a[q]); *e++ = ' ';
+                e = put_fixed4(e, p.b.empty() ? 0. : p.b[q]); *e++ = ' ';
+                e = put_fixed4(e, p.c.empty() ? 0. : p.c[q]);
+            }
+            *e++ = '\n';
+            p.text.append(b, (size_t)(e - b));
+        }
+        p.a = std::vector<double>(); p.b = std::vector<double>(); p.c = std::vector<double>();
+    }
+    bool write(FILE* f) {
+        host_parallel_run(pieces.size(), [this](size_t n) { render(pieces[n]); });
+        bool ok = true;
+        for (const Piece& p : pieces) ok = ok && std::fwrite(p.text.data(), 1, p.text.size(), f) == p.text.size();
+        return ok;
     }
 };
 
@@ -118,22 +160,25 @@ int write_vtk(atomdev* h, int kind, int index, int Ma, const char* path) {
     static const char* title[2][3] = {
         { "Radial_Data_Atmosphere_Circulation", "Longitudinal_Data_Atmosphere_Circulation", "Zonal_Data_Atmosphere_Circulation" },
         { "Radial_Data_Hydrosphere_Circulation", "Longitudinal_Data_Hydrosphere_Circulation", "Zonal_Data_Hydrosphere_Circulation" } };
-    out.s += "# vtk DataFile Version 3.0\n";
-    out.s += title[atm ? 0 : 1][kind]; out.s += "\nASCII\nDATASET STRUCTURED_GRID\n";
-    out.s += "DIMENSIONS " + std::to_string(sec.n_inner) + " " + std::to_string(sec.n_outer) + " 1\n";
-    out.s += "POINTS " + std::to_string(sec.n_outer * sec.n_inner) + " float\n";
+    out.lit("# vtk DataFile Version 3.0\n");
+    out.lit(std::string(title[atm ? 0 : 1][kind]) + "\nASCII\nDATASET STRUCTURED_GRID\n");
+    out.lit("DIMENSIONS " + std::to_string(sec.n_inner) + " " + std::to_string(sec.n_outer) + " 1\n");
+    out.lit("POINTS " + std::to_string(sec.n_outer * sec.n_inner) + " float\n");
     {
         double x = 0., y = 0., z = 0.;
         const double dx = .1, step = kind == ATOMDEV_RADIAL ? .1 : (kind == ATOMDEV_LONGAL ? .025 : .05);
+        std::vector<double> px, py, pz;
+        px.reserve(n); py.reserve(n); pz.reserve(n);
         for (int a = 0; a < sec.n_outer; a++) {
             for (int b = 0; b < sec.n_inner; b++) {
                 double& moving = kind == ATOMDEV_LONGAL ? z : y;
                 if (b == 0) moving = 0.; else moving = moving + step;
-                out.triple(x, y, z);
+                px.push_back(x); py.push_back(y); pz.push_back(z);
             }
             (kind == ATOMDEV_LONGAL ? z : y) = 0.;
             x = x + dx;
         }
+        out.triples(px, py, pz);
     }
     const std::string point_data = "POINT_DATA " + std::to_string(sec.n_outer * sec.n_inner) + "\n";
 
@@ -151,8 +196,9 @@ int write_vtk(atomdev* h, int kind, int index, int Ma, const char* path) {
         return 0;
     };
     auto temperature_celsius = [&]() {
-        out.scalars("Temperature");
-        for (double x : t) out.line(x * P.t_0 - P.t_0);
+        std::vector<double> celsius(t.size());
+        for (size_t q = 0; q < t.size(); q++) celsius[q] = t[q] * P.t_0 - P.t_0;
+        out.column("Temperature", celsius, 1.);
     };
     if (int rc = sync()) return rc;
 
@@ -190,7 +236,7 @@ int write_vtk(atomdev* h, int kind, int index, int Ma, const char* path) {
                 if (int rc = sec.put(ATOMDEV_AUX_W, aux_w)) return rc;
                 if (int rc = sync()) return rc;
             }
-            out.s += point_data;
+            out.lit(point_data);
             out.column("u-Component", u, 1.); out.column("v-Component", v, 1.); out.column("w-Component", w, 1.);
             temperature_celsius();
             if (int rc = columns({ { "Temp_NASA", ATOMDEV_TEMP_NASA_CELSIUS, 1., true }, { "Temp_NASA_diff", ATOMDEV_AUX_V, 1., false },
@@ -208,10 +254,10 @@ int write_vtk(atomdev* h, int kind, int index, int Ma, const char* path) {
                                    { "Evaporation_Penman", ATOMDEV_EVAPORATION_PENMAN, 1., true }, { "Evaporation_Dalton", ATOMDEV_EVAPORATION_DALTON, 1., true },
                                    { "Heat_Evaporation", ATOMDEV_Q_EVAPORATION, 1., true }, { "Evap-Precip", ATOMDEV_AUX_W, 1., false },
                                    { "Vegetation", ATOMDEV_VEGETATION, 1., true }, { "CO2-Concentration", ATOMDEV_CO2, P.co2_0, false } })) return rc;
-            out.s += "VECTORS v-w-Cell float \n";
-            for (size_t q = 0; q < n; q++) out.triple(v[q], w[q], 0.);
+            out.lit("VECTORS v-w-Cell float \n");
+            out.triples(v, w, {});
         } else if (kind == ATOMDEV_LONGAL) {
-            out.s += point_data;
+            out.lit(point_data);
             out.column("u-Component", u, 1.); out.column("v-Component", v, 1.); out.column("w-Component", w, 1.);
             temperature_celsius();
             std::vector<double> total(n);
@@ -225,10 +271,10 @@ int write_vtk(atomdev* h, int kind, int index, int Ma, const char* path) {
                                    { "BuoyancyForce", ATOMDEV_BUOYANCY, 1., false }, { "Q_Latent", ATOMDEV_Q_LATENT, 1., false },
                                    { "Q_Sensible", ATOMDEV_Q_SENSIBLE, 1., false }, { "Epsilon_3D", ATOMDEV_EPSILON_3D, 1., false },
                                    { "CO2-Concentration", ATOMDEV_CO2, P.co2_0, false } })) return rc;
-            out.s += "VECTORS u-w-Cell float\n";
-            for (size_t q = 0; q < n; q++) out.triple(u[q], 0., w[q]);
+            out.lit("VECTORS u-w-Cell float\n");
+            out.triples(u, {}, w);
         } else {
-            out.s += point_data;
+            out.lit(point_data);
             out.column("u-Component", u, 1.); out.column("v-Component", v, 1.); out.column("w-Component", w, 1.);
             temperature_celsius();
             // :452-482: total water and the two saturation ratios, kept in aux_w, aux_u, aux_v
@@ -270,12 +316,12 @@ int write_vtk(atomdev* h, int kind, int index, int Ma, const char* path) {
                                    { "Epsilon_3D", ATOMDEV_EPSILON_3D, 1., false }, { "Q_Latent", ATOMDEV_Q_LATENT, 1., false },
                                    { "Q_Sensible", ATOMDEV_Q_SENSIBLE, 1., false }, { "PressureDynamic", ATOMDEV_P_DYN, p_scale, false },
                                    { "PressureStatic", ATOMDEV_P_STAT, 1., false }, { "CO2-Concentration", ATOMDEV_CO2, P.co2_0, false } })) return rc;
-            out.s += "VECTORS u-v-Cell float\n";
-            for (size_t q = 0; q < n; q++) out.triple(u[q], v[q], 0.);
+            out.lit("VECTORS u-v-Cell float\n");
+            out.triples(u, v, {});
         }
     } else {
         const double p_scale = P.u_0 * P.u_0 * P.r_0_water * 1e-3;
-        out.s += point_data;
+        out.lit(point_data);
         if (kind == ATOMDEV_RADIAL) {
             temperature_celsius();
             // :514-520: evaporation - precipitation over water, kept in aux_v
@@ -303,20 +349,20 @@ int write_vtk(atomdev* h, int kind, int index, int Ma, const char* path) {
             if (int rc = columns({ { "Upwelling", ATOMDEV_UPWELLING, 1., true }, { "Downwelling", ATOMDEV_DOWNWELLING, 1., true },
                                    { "BottomWater", ATOMDEV_BOTTOM_WATER, 1., true }, { "Evaporation_Dalton", ATOMDEV_EVAPORATION_DALTON, 1., true },
                                    { "Precipitation", ATOMDEV_PRECIPITATION, 1., true }, { "Evap-Precip", ATOMDEV_AUX_V, 1., false } })) return rc;
-            out.s += "VECTORS v-w-Cell float\n";
-            for (size_t q = 0; q < n; q++) out.triple(v[q], w[q], 0.);
+            out.lit("VECTORS v-w-Cell float\n");
+            out.triples(v, w, {});
         } else if (kind == ATOMDEV_LONGAL) {
-            out.s += "VECTORS u-w-Cell float\n";
-            for (size_t q = 0; q < n; q++) out.triple(u[q], 0., w[q]);
+            out.lit("VECTORS u-w-Cell float\n");
+            out.triples(u, {}, w);
         } else {
-            out.s += "VECTORS u-v-Cell float\n";
-            for (size_t q = 0; q < n; q++) out.triple(u[q], v[q], 0.);
+            out.lit("VECTORS u-v-Cell float\n");
+            out.triples(u, v, {});
         }
     }
     if (int rc = sync()) return rc;
     FILE* f = std::fopen(path, "w");
     ATOMDEV_REQUIRE(f, std::string("could not open VTK file ") + path);
-    const bool ok = std::fwrite(out.s.data(), 1, out.s.size(), f) == out.s.size();
+    const bool ok = out.write(f);
     ATOMDEV_REQUIRE(std::fclose(f) == 0 && ok, std::string("write failed: ") + path);
     return 0;
 }

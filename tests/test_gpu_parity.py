@@ -85,6 +85,14 @@ def test_hyd_sequence_bitexact(dims, seed, mask):
     _run_sequence(H.HYD, dims, seed, mask, H.HYD_SEQ)
 
 
+@pytest.mark.parametrize("dims,seed,mask", [((9, 21, 70), 23, "blobs"), ((6, 9, 131), 24, "allfluid"), ((7, 13, 200), 25, "blobs")])
+def test_hyd_sequence_two_blocks_per_group_bitexact(dims, seed, mask, monkeypatch):
+    """The sweep's form for grids with more blocks of lines than the chip holds side by side (two blocks per workgroup,
+    ten waves), forced on small grids: two, three (one workgroup half empty) and four blocks per level."""
+    monkeypatch.setenv("ATOMDEV_HYD_BLOCKS_PER_GROUP", "2")
+    _run_sequence(H.HYD, dims, seed, mask, H.HYD_SEQ)
+
+
 def test_hyd_surface_sequence_bitexact():
     _run_sequence(H.HYD, (41, 43, 19), 13, "blobs", H.HYD_SURFACE_SEQ + ["hyd_pressure2d"])
 
