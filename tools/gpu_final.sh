@@ -24,4 +24,15 @@ step 400 gpurun_out/final/op_table.md python -u tools/op_table.py 20
 tail -36 gpurun_out/final/op_table.md
 step 300 gpurun_out/final/loop_time.txt python -u tools/loop_time.py 4
 cat gpurun_out/final/loop_time.txt
+step 120 gpurun_out/final/rk2d_time.txt python -u tools/rk2d_time.py 20
+cat gpurun_out/final/rk2d_time.txt
+step 200 gpurun_out/final/atm_slice_time.txt python -u tools/atm_slice_time.py 0 3
+cat gpurun_out/final/atm_slice_time.txt
+step 200 gpurun_out/final/hyd_slice_time.txt python -u tools/hyd_slice_time.py
+cat gpurun_out/final/hyd_slice_time.txt
+step 300 gpurun_out/final/hyd_series.txt python -u tools/hyd_series_time.py
+cat gpurun_out/final/hyd_series.txt
+# the N > 1 path of bench.py, rehearsed with two ranks sharing the card (gloo: RCCL refuses two ranks on one GPU)
+step 300 gpurun_out/final/bench_2ranks_gloo.json python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29581 bench.py --gpus 2 --backend gloo --steps 100 --warmup 10 --no-cpu
+tail -1 gpurun_out/final/bench_2ranks_gloo.json
 echo "ALL STEPS PASSED"

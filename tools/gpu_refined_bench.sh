@@ -12,5 +12,5 @@ cat gpurun_out/refined/bench_quarter_slab2_one_card.json
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/refined/prof -o quarter -- python3 $R/bench.py --grid 0.25 --steps 10 --warmup 2 --no-cpu > $R/gpurun_out/refined/rocprof.log 2>&1 || { echo "rocprof failed"; tail -5 $R/gpurun_out/refined/rocprof.log; exit 1; }
 cd $R
-f=$(ls gpurun_out/refined/prof/*/*kernel_stats.csv | head -1)
+f=$(ls gpurun_out/refined/prof/*kernel_stats.csv gpurun_out/refined/prof/*/*kernel_stats.csv 2>/dev/null | head -1)
 head -12 $f | cut -d, -f1-8
