@@ -104,10 +104,17 @@ def test_atm_everything_but_rk3d_bitexact():
     _run_sequence(H.ATM, (9, 23, 67), 31, "blobs", seq)
 
 
+@pytest.mark.parametrize("dims", [(5, 7, 7), (5, 8, 7), (5, 34, 7), (5, 35, 40), (5, 66, 9), (5, 7, 130)])
+def test_atm_surface_sweep_small_and_ragged_bitexact(dims):
+    """The surface sweep on surfaces around its block sizes: fewer rows than a wave holds (32), one row more than a
+    wave holds, one more than two waves hold, the smallest grids the library takes, a long thin one."""
+    _run_sequence(H.ATM, dims, 60 + dims[1], "blobs", ["atm_rk2d", "move2d", "atm_rk2d"])
+
+
 @pytest.mark.parametrize("jm", [301, 801, 1101])
 def test_atm_surface_sweep_many_rows_bitexact(jm):
-    """The surface sweep runs one thread per row: 256-, 768- and 1024-thread forms, and beyond 1024 rows the
-    form that loops over the rows of a diagonal; the 1-degree grid only reaches the first."""
+    """The surface sweep runs as a pipeline of waves of 32 rows each: 10, 25 and 35 waves here (the 1-degree grid has
+    six); variant 1 is the plain form, one workgroup walking the diagonals."""
     seq = ["atm_rk2d", "move2d", "atm_rk2d"]
     _run_sequence(H.ATM, (5, jm, 11), 40 + jm, "blobs", seq)
     o, d, names = _pair(H.ATM, (5, 45, 37), 47, "blobs")
