@@ -17,31 +17,7 @@ extern "C" void atomdev_default_atm_loop(atomdev_atm_loop* L) {
     L->nm = 200;  // cAtmosphereModel.h:123
 }
 
-// With ATOMDEV_STEP_TIMES set in the environment every step of the loops and of the slice is bracketed by a stream
-// synchronisation and its wall time goes to stderr ("step <ms> <call>"): where a slice spends its time, host work
-// (readers, writers) included.  Off by default: the steps are then enqueued back to back.
-#include <chrono>
-#include <cstdio>
-#include <cstdlib>
-namespace {
-struct StepTimes {
-    bool on;
-    StepTimes() : on(std::getenv("ATOMDEV_STEP_TIMES") != nullptr) {}
-};
-const StepTimes g_step_times;
-struct StepClock {
-    atomdev_t* h; const char* what; std::chrono::steady_clock::time_point t0;
-    StepClock(atomdev_t* h_, const char* w) : h(h_), what(w) {
-        if (g_step_times.on) { atomdev_sync(h); t0 = std::chrono::steady_clock::now(); }
-    }
-    ~StepClock() {
-        if (!g_step_times.on) return;
-        atomdev_sync(h);
-        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        std::fprintf(stderr, "step %.3f %s\n", ms, what);
-    }
-};
-}  // namespace
+#include "step_clock.h"
 #define STEP(call) do { StepClock clock__(h, #call); if (int rc__ = (call)) return rc__; } while (0)
 
 // The surface loops of n independent time slices in lockstep: each operator enqueued for all slices on their own

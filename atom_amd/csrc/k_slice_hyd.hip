@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "atomdev_internal.h"
+#include "step_clock.h"
 
 extern "C" void atomdev_default_hyd_slice(int im, atomdev_hyd_slice* s) {
     atomdev_default_hyd_start(im, &s->start);
@@ -30,16 +31,16 @@ extern "C" int atomdev_hyd_run_time_slices(atomdev_t* const* handles, const atom
                         && slices[m].velocity_iter_max == s0.velocity_iter_max && slices[m].pressure_iter_max == s0.pressure_iter_max,
                         "atomdev_hyd_run_time_slices: the slices of one call share their iteration counts");
     }
-#define EACH(call) do { for (int m = 0; m < n; m++) { atomdev_t* h = handles[m]; const atomdev_hyd_slice& s = slices[m]; (void)s; \
+#define EACH(call) do { StepClock clock__(handles[0], #call); for (int m = 0; m < n; m++) { atomdev_t* h = handles[m]; const atomdev_hyd_slice& s = slices[m]; (void)s; \
                         if (int rc__ = (call)) return rc__; } } while (0)
     // :234-297: the atmosphere's surface, the sea ground, the initial conditions, the first old -> new copies
     // the readers are host work (text files, the needle smoothing): one host thread per slice, at most 16 at a time
     auto read_files = [&](int m) -> int {
         atomdev_t* h = handles[m];
         const atomdev_hyd_slice& s = slices[m];
-        if (s.transfer_file) if (int rc = atomdev_hyd_read_transfer_file(h, s.transfer_file)) return rc;
-        if (int rc = atomdev_hyd_read_sea_ground(h, s.bathymetry_file)) return rc;
-        if (s.start.Ma == 0 && s.salinity_file) if (int rc = atomdev_hyd_read_surface_salinity(h, s.salinity_file)) return rc;
+        if (s.transfer_file) { StepClock c__(h, "atomdev_hyd_read_transfer_file"); if (int rc = atomdev_hyd_read_transfer_file(h, s.transfer_file)) return rc; }
+        { StepClock c__(h, "atomdev_hyd_read_sea_ground"); if (int rc = atomdev_hyd_read_sea_ground(h, s.bathymetry_file)) return rc; }
+        if (s.start.Ma == 0 && s.salinity_file) { StepClock c__(h, "atomdev_hyd_read_surface_salinity"); if (int rc = atomdev_hyd_read_surface_salinity(h, s.salinity_file)) return rc; }
         return 0;
     };
     if (n == 1) {
@@ -71,8 +72,11 @@ extern "C" int atomdev_hyd_run_time_slices(atomdev_t* const* handles, const atom
             EACH(atomdev_hyd_bc_theta(h));
             EACH(atomdev_hyd_bc_phi(h));
             EACH(atomdev_hyd_value_limitation(h));
-            if (n == 1) { if (int rc = atomdev_hyd_rk2d(handles[0])) return rc; }
-            else if (int rc = atomdev_rk2d_batch(handles, n)) return rc;
+            {
+                StepClock clock__(handles[0], "atomdev_hyd_rk2d");
+                if (n == 1) { if (int rc = atomdev_hyd_rk2d(handles[0])) return rc; }
+                else if (int rc = atomdev_rk2d_batch(handles, n)) return rc;
+            }
             EACH(atomdev_move_data_to_new_arrays(h, h->im - 1));
         }
         EACH(atomdev_hyd_pressure2d(h));

@@ -117,10 +117,10 @@ extern "C" int atomdev_hyd_read_transfer_file(atomdev_t* hyd, const char* path) 
     TextNumbers tn;
     ATOMDEV_REQUIRE(tn.open(path), std::string("atomdev_hyd_read_transfer_file: could not open ") + path);
     if (tn.plain()) {  // plain decimal tokens: converted directly, the values the stream extraction returns
-        bool enough = true;
-        for (size_t q = 0; q < n2 && enough; q++)
-            for (int n = 0; n < 6 && enough; n++) enough = tn.next(x[(size_t)n * n2 + q]);
-        ATOMDEV_REQUIRE(enough, std::string("atomdev_hyd_read_transfer_file: fewer than jm * km rows of six numbers in ") + path);
+        std::vector<double> every;
+        tn.all(every);
+        ATOMDEV_REQUIRE(every.size() >= 6 * n2, std::string("atomdev_hyd_read_transfer_file: fewer than jm * km rows of six numbers in ") + path);
+        host_parallel_run(6, [&](size_t n) { for (size_t q = 0; q < n2; q++) x[n * n2 + q] = every[6 * q + n]; });
     }
     if (!tn.plain() || tn.out_of_range()) {
         std::ifstream f(path);

@@ -72,7 +72,7 @@ def test_text_numbers_match_stream_extraction(tmp_path):
     300 000 tokens in ten formats plus the edge cases, and refuses every token a stream would treat differently."""
     import subprocess
     exe = str(tmp_path / "text_numbers_check")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(H.ROOT, "atom_amd", "csrc"),
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-I", os.path.join(H.ROOT, "atom_amd", "csrc"),
                            os.path.join(H.ROOT, "tests", "text_numbers_check.cpp"), "-o", exe])
     r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout + r.stderr

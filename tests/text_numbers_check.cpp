@@ -27,6 +27,16 @@ int main(int argc, char** argv) {
         in >> b; if (in.fail()) { in.clear(); }
         if (memcmp(&a, &b, 8) != 0 && bad++ < 10) printf("MISMATCH %s: %a vs %a\n", tok[n].c_str(), a, b);
     }
+    {   // the same file taken whole (several threads, each on a piece of the text): the same values in the same order
+        TextNumbers whole; whole.open((dir + "/tok.txt").c_str());
+        std::vector<double> v; whole.all(v);
+        std::istringstream again(text);
+        if (v.size() != tok.size()) { printf("all(): %zu values for %zu tokens\n", v.size(), tok.size()); bad++; }
+        for (size_t e = 0; e < v.size() && e < tok.size(); e++) {
+            double b = 0; again >> b; if (again.fail()) again.clear();
+            if (memcmp(&v[e], &b, 8) != 0 && bad++ < 10) printf("MISMATCH in all() at %zu (%s)\n", e, tok[e].c_str());
+        }
+    }
     double a; printf("%zu tokens, %zu mismatches, end %d\n", n, bad, (int)tn.next(a));
     { FILE* g = fopen((dir + "/bad.txt").c_str(), "w"); fputs("1 2 1e400", g); fclose(g); std::vector<double> v; bool op;
       if (text_third_of_triples((dir + "/bad.txt").c_str(), 1, v, &op)) { printf("out-of-range token taken\n"); bad++; } }
