@@ -375,11 +375,35 @@ extern "C" int atomdev_set_columns(atomdev_t* h, int field3d, int k0, int nk, co
 int atomdev_sync_stream(atomdev* h) {
     ATOMDEV_TRY(hipStreamSynchronize(h->stream));
     volatile int* err = atomdev_kernel_error_word(h);
-    if (*err) {
+    if (const int code = *err) {
         *err = 0;
-        atomdev_set_error("hyd_rk3d: level im-2 gave up waiting for the salinity rows of level im-3; the fields of the last sweep are not valid");
+        atomdev_set_error(code == 2 ? "rk2d: a wave of the surface sweep gave up waiting for the row above it; the surface fields of the last sweep are not valid"
+                                    : "hyd_rk3d: level im-2 gave up waiting for the salinity rows of level im-3; the fields of the last sweep are not valid");
         return 1;
     }
+    return 0;
+}
+
+// Text files whose numbers are on the host already: inside a one-call slice (defer_files) the text is made and written
+// by a thread of its own while the slice goes on, and atomdev_join_files waits for all of them; otherwise at once.
+int atomdev_defer_file(atomdev* h, std::function<std::string()> job) {
+    if (h->defer_files) {
+        h->pending_files.push_back(std::async(std::launch::async, std::move(job)));
+        return 0;
+    }
+    const std::string e = job();
+    if (!e.empty()) { atomdev_set_error(e); return 1; }
+    return 0;
+}
+
+int atomdev_join_files(atomdev* h) {
+    std::string first;
+    for (std::future<std::string>& f : h->pending_files) {
+        const std::string e = f.get();
+        if (first.empty()) first = e;
+    }
+    h->pending_files.clear();
+    if (!first.empty()) { atomdev_set_error(first); return 1; }
     return 0;
 }
 

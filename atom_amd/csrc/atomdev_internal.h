@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <functional>
+#include <future>
 #include <string>
 #include <vector>
 
@@ -71,6 +73,8 @@ struct atomdev {
     size_t stage_bytes;
     int rk_variant;                 // 0: wave-specialised sweep (default), 1: one thread per theta line, 2: 0 in its tolerance form
     int profile_rk;                 // bracket the RK sweeps with events: 1 the sweep kernel alone, 2 with the kernels that prepare it
+    bool defer_files = false;         // inside a one-call slice: text files are finished by threads of their own
+    std::vector<std::future<std::string>> pending_files;  // their error texts (empty: written)
     std::vector<hipEvent_t> prof_ev;  // pairs (start, stop), prof_used of them recorded
     size_t prof_used;
 };
@@ -87,6 +91,8 @@ int atomdev_fill_theta_neumann(atomdev* h, int field);            // k_bc_pressu
 int atomdev_fill_phi_seam(atomdev* h, int field, int j0, int j1);  // k_bc_pressure.hip
 int atomdev_static_scratch_init(atomdev* h);  // k_accuracy.hip
 int atomdev_sync_stream(atomdev* h);          // atomdev_api.hip: hipStreamSynchronize + the kernels' own failure word
+int atomdev_defer_file(atomdev* h, std::function<std::string()> job);  // atomdev_api.hip
+int atomdev_join_files(atomdev* h);                                   // atomdev_api.hip
 inline volatile int* atomdev_kernel_error_word(atomdev* h) { return (volatile int*)((char*)h->pinned + 128); }
 int atomdev_atm_rk3d_ws(atomdev* h);    // k_rk_atm_ws.hip
 int atomdev_atm_rk3d_ws_fast(atomdev* h);  // k_rk_atm_ws.hip compiled with -DATOMDEV_RK_FAST

@@ -148,6 +148,13 @@ extern "C" int atomdev_atm_run_time_slice(atomdev_t* h, const atomdev_atm_slice*
     ATOMDEV_REQUIRE(s->bathymetry_file && s->temperature_file && s->precipitation_file, "atomdev_atm_run_time_slice: needs the three input files");
     ATOMDEV_REQUIRE(!s->output_path || s->bathymetry_name, "atomdev_atm_run_time_slice: output files need bathymetry_name");
     const atomdev_params& P = h->p;
+    // the text of the output files is made by threads of their own while the slice goes on; all are waited for before
+    // the call returns, whichever way it returns
+    struct Files {
+        atomdev_t* h;
+        explicit Files(atomdev_t* h_) : h(h_) { h->defer_files = true; }
+        ~Files() { h->defer_files = false; (void)atomdev_join_files(h); }
+    } files(h);
     // reset_arrays (:384-472)
     for (int g = 0; g < ATOMDEV_N2D; g++) STEP(atomdev_fill2d(h, g, 0.));
     for (int f = 0; f < ATOMDEV_N3D; f++)
@@ -189,5 +196,7 @@ extern "C" int atomdev_atm_run_time_slice(atomdev_t* h, const atomdev_atm_slice*
     STEP(run_3d_loop(h, &L, S, s, &iterations));
     STEP(atomdev_atm_restrain_temperature(h, s->mean_temperature));
     STEP(write_files(h, s, iterations, true));
+    h->defer_files = false;
+    STEP(atomdev_join_files(h));
     return atomdev_sync(h);
 }

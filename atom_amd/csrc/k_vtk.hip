@@ -6,6 +6,7 @@
 #include <cmath>
 #include <algorithm>
 #include <cstdio>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -360,11 +361,16 @@ int write_vtk(atomdev* h, int kind, int index, int Ma, const char* path) {
         }
     }
     if (int rc = sync()) return rc;
-    FILE* f = std::fopen(path, "w");
-    ATOMDEV_REQUIRE(f, std::string("could not open VTK file ") + path);
-    const bool ok = out.write(f);
-    ATOMDEV_REQUIRE(std::fclose(f) == 0 && ok, std::string("write failed: ") + path);
-    return 0;
+    // everything the file holds is on the host now: its text can be made while the caller goes on
+    auto text = std::make_shared<Text>(std::move(out));
+    const std::string file(path);
+    return atomdev_defer_file(h, [text, file]() -> std::string {
+        FILE* f = std::fopen(file.c_str(), "w");
+        if (!f) return "could not open VTK file " + file;
+        const bool ok = text->write(f);
+        if (std::fclose(f) != 0 || !ok) return "write failed: " + file;
+        return std::string();
+    });
 }
 
 }  // namespace
