@@ -28,6 +28,7 @@
 //
 // The sweep is out of place (see k_rk_hyd.hip): it reads the current buffers and writes the
 // alternate set, whose boundary shell is refreshed beforehand by k_copy_shell.
+#include <algorithm>
 #include <cstdlib>
 
 #include "atomdev_internal.h"
@@ -714,7 +715,9 @@ int HYD_WS_ENTRY(atomdev* h) {
     ATOMDEV_REQUIRE(gx <= 128, "hyd_rk3d: more than 128 longitude blocks");
     ATOMDEV_REQUIRE(h->im >= 5, "hyd_rk3d: the grid needs at least 5 levels");
     if (int rc = atomdev_prof_begin(h)) return rc;
-    hipLaunchKernelGGL(k_copy_shell, dim3(8, h->im, 5), dim3(256), 0, h->stream, &D->src[o][0], &D->dst[o][0], h->im, h->jm, h->km,
+    // (the two whole levels are most of the shell: enough workgroups for them; on the others the extra ones find nothing)
+    const unsigned shell_blocks = (unsigned)std::min<size_t>(64, (h->n2 + 1023) / 1024);
+    hipLaunchKernelGGL(k_copy_shell, dim3(shell_blocks, h->im, 5), dim3(256), 0, h->stream, &D->src[o][0], &D->dst[o][0], h->im, h->jm, h->km,
                        D->progress, (int)gx);
     ATOMDEV_TRY(hipGetLastError());
     const size_t lds = (size_t)h->jm * 4 * sizeof(double);
