@@ -114,7 +114,11 @@ __global__ void k_atm_prep(const double* __restrict__ t, const double* __restric
     const double t0jk = t[q];
     const double t0K = t0jk * K.t_0;
     const double p_SL = .01 * (K.p_SL_factor * t0jk * K.t_0);
+#if ATM_WS_AFFINE  // tolerance form: x^y as exp(y log x), a few units in the last place off and half the instructions
+    const double p_h = exp(K.exp_pressure * log((t0K - K.gam * hight * 1.e-2) / t0K)) * p_SL;
+#else
     const double p_h = pow((t0K - K.gam * hight * 1.e-2) / t0K, K.exp_pressure) * p_SL;
+#endif
     ph100[p] = 100. * p_h;
     if constexpr (WITH_H0I) {  // static: depends on the mask and the topography only
         double h_0_i = 1.;

@@ -291,8 +291,10 @@ __device__ __forceinline__ void sweep_role(const HydWsArgs& a, const DevConst& K
     if constexpr (isC) { rw_cur = ldg(E1, o0); rw_nxt = ldg(E1, o1); }
 
     // what the u and v waves need of a new c value (RHS_Hyd.cpp:345)
+    double c_swr = 0.;  // c wave: the salt water density it published for the value it is working with
     auto publish_c = [&](int buf, double cval, double rw) {
         const double swr = rw + .7 * cval * k1;
+        c_swr = swr;
         sh.swr[buf][lane] = swr;
         sh.yswr[buf][lane] = rcp_refined(swr);
     };
@@ -327,6 +329,7 @@ __device__ __forceinline__ void sweep_role(const HydWsArgs& a, const DevConst& K
         const double bathy = n_bathy, rsw_in = n_r1;
         const double c_below = n_cb;
         const double c_top = xa_raw, ep = n_ev - n_pr;
+        const double m3ct = -3. * c_top, om2ct = 1. - 2. * c_top;
         if (polls) {  // row j+1 of the level below must be in memory before it is fetched (row jm-1 is a boundary row)
             const int need = j + 1 < jm - 2 ? j + 1 : jm - 2;
             known = n_prog > known ? n_prog : known;
@@ -447,8 +450,7 @@ __device__ __forceinline__ void sweep_role(const HydWsArgs& a, const DevConst& K
             }
             if constexpr (isC) {
                 if (top) {
-                    const double swr = rw + .7 * st * k1;
-                    double sal = swr * __builtin_fma(4., st, cM) * cFac;
+                    double sal = c_swr * __builtin_fma(4., st, cM) * cFac;
                     sal = fmin(fmax(sal, -20.), 20.);
                     lin += sal;
                 }
@@ -463,20 +465,27 @@ __device__ __forceinline__ void sweep_role(const HydWsArgs& a, const DevConst& K
                 d1 = DIVC(h_d_j * ((TF.a * st + xB) + xC), TF.D1, TF.iD1);
                 d2 = DIVC(h_d_j * ((TF.e * st + xF) + xG), TK.dthe2, TK.i_dthe2);
             }
-            const double dr1 = rlive ? DIVC(xa - st, dr, i_dr) : 0.;  // RHS_Hyd.cpp:206-211
+            // RHS_Hyd.cpp:206-211.  On level im-2 no radial difference is live: dr1 is +0 there and so is its quotient
+            // by rm, which the whole workgroup skips (the sums below still see the two zeros).
+            double dr1 = 0., dr1_rm = 0.;  // dr1 and (2 or 4) dr1 / rm
+            if (!top) {
+                dr1 = rlive ? DIVC(xa - st, dr, i_dr) : 0.;
+                dr1_rm = DIVC(dr1 * (isU ? 4. : 2.), rm, i_rm);
+            }
             const double adv = u * dr1 + DIVC(v * d1, rm, i_rm);
 
             // RHS_Hyd.cpp:406-437 with the exact-zero terms removed
             if constexpr (isT || isC) {
                 double brk;
-                if (all_bw) brk = DIVC(dr1 * 2., rm, i_rm) + DIVC(d1 * costhe, rm2sin, i_rm2sin);
-                else brk = DIVC(dr1 * 2., rm, i_rm) + DIVC(d2, rm2, i_rm2) + DIVC(d1 * costhe, rm2sin, i_rm2sin);
+                if (all_bw) brk = dr1_rm + DIVC(d1 * costhe, rm2sin, i_rm2sin);
+                else brk = dr1_rm + DIVC(d2, rm2, i_rm2) + DIVC(d1 * costhe, rm2sin, i_rm2sin);
                 rhs = -adv + DIVC(brk, dv, i_dv);
                 if constexpr (isC) {
                     if (top) {  // RHS_Hyd.cpp:355-372
-                        const double swr = rw + .7 * st * k1;
-                        double salinity_surface = DIVC(swr * (-3. * c_top + 4. * st - c_below), k3, k4)
-                                                  * (1. - 2. * c_top) * ep;
+                        // the density is the one published with this stage value (same operands, same operations);
+                        // 4 st is exact, so the fused form of -3 c_top + 4 st rounds once, like the sum it replaces
+                        double salinity_surface = DIVC(c_swr * (__builtin_fma(4., st, m3ct) - c_below), k3, k4)
+                                                  * om2ct * ep;
                         double salinity_evaporation = k2 * salinity_surface;
                         if (land) salinity_evaporation = 0.;
                         if (salinity_evaporation >= 20.) salinity_evaporation = 20.;
@@ -488,8 +497,8 @@ __device__ __forceinline__ void sweep_role(const HydWsArgs& a, const DevConst& K
                 rhs = rhs - DIVC(h_0 * st, dm, i_dm);
             } else if constexpr (isU) {
                 double brk;
-                if (all_bw) brk = DIVC(4. * dr1, rm, i_rm) + DIVC(d1 * costhe, rm2sin, i_rm2sin);
-                else brk = DIVC(d2, rm2, i_rm2) + DIVC(4. * dr1, rm, i_rm) + DIVC(d1 * costhe, rm2sin, i_rm2sin);
+                if (all_bw) brk = dr1_rm + DIVC(d1 * costhe, rm2sin, i_rm2sin);
+                else brk = DIVC(d2, rm2, i_rm2) + dr1_rm + DIVC(d1 * costhe, rm2sin, i_rm2sin);
                 const double swr = sh.swr[rb][lane];
                 RS = DIVC(k1 * (rsw - swr), swr, sh.yswr[rb][lane]);  // RHS_Hyd.cpp:374
                 sb = swr - rsw;
@@ -499,15 +508,15 @@ __device__ __forceinline__ void sweep_role(const HydWsArgs& a, const DevConst& K
                 const double d1u = DIVC(h_d_j * ((TF.a * u + uB) + uC), TF.D1, TF.iD1);
                 pg_v = DIVC(pg_num, sh.swr[rb][lane], sh.yswr[rb][lane]);
                 double brk;
-                if (all_bw) brk = DIVC(dr1 * 2., rm, i_rm) + DIVC(d1, rm2sin, i_rm2sin) * costhe;
-                else brk = DIVC(dr1 * 2., rm, i_rm) + DIVC(d2, rm2, i_rm2) + DIVC(d1, rm2sin, i_rm2sin) * costhe;
+                if (all_bw) brk = dr1_rm + DIVC(d1, rm2sin, i_rm2sin) * costhe;
+                else brk = dr1_rm + DIVC(d2, rm2, i_rm2) + DIVC(d1, rm2sin, i_rm2sin) * costhe;
                 rhs = -adv - pg_v
                       + DIVC(brk - coef_v * h_d_j * v + DIVC(2. * d1u, rm2, i_rm2), dv, i_dv)
                       - DIVC(h_0 * v, dm, i_dm);
             } else {  // R_W
                 double brk;
-                if (all_bw) brk = DIVC(dr1 * 2., rm, i_rm) + DIVC(d1, rm2sin, i_rm2sin) * costhe;
-                else brk = DIVC(dr1 * 2., rm, i_rm) + DIVC(d2, rm2, i_rm2) + DIVC(d1, rm2sin, i_rm2sin) * costhe;
+                if (all_bw) brk = dr1_rm + DIVC(d1, rm2sin, i_rm2sin) * costhe;
+                else brk = dr1_rm + DIVC(d2, rm2, i_rm2) + DIVC(d1, rm2sin, i_rm2sin) * costhe;
                 rhs = -adv + DIVC(brk, dv, i_dv) - DIVC(h_0 * st, dm, i_dm);
             }
           }
