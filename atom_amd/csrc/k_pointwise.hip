@@ -63,10 +63,21 @@ __device__ __forceinline__ void store_if_changed(double* p, double was, double x
 }
 
 // BC_Thermo::Value_Limitation_Atm (atmosphere/BC_Thermo.cpp:3235-3275)
+// REST: only what a sweep that stores limited values has left to do - the points the sweep does not store (the six
+// faces of the grid) and p_dyn on land.
+template <bool REST>
 __global__ void k_atm_value_limitation(double* u, double* v, double* w, double* t, double* c, double* cloud, double* ice,
-                                       double* co2, double* p_dyn, const uint8_t* __restrict__ flags, size_t n) {
+                                       double* co2, double* p_dyn, const uint8_t* __restrict__ flags, size_t n,
+                                       int im, int jm, int km) {
     size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= n) return;
+    if constexpr (REST) {
+        const int k = (int)(id % (size_t)km), j = (int)((id / (size_t)km) % (size_t)jm), i = (int)(id / ((size_t)km * jm));
+        if (i > 0 && i < im - 1 && j > 0 && j < jm - 1 && k > 0 && k < km - 1) {
+            if (flags[id] & FL_LAND) p_dyn[id] = 0.;
+            return;
+        }
+    }
     const double u0 = u[id], v0 = v[id], w0 = w[id], t0 = t[id], c0 = c[id], cl0 = cloud[id], ic0 = ice[id], co0 = co2[id];
     double x;
     x = u0; if (x >= .106) x = .106; if (x <= -.106) x = -.106; double uu = x;
@@ -190,9 +201,17 @@ extern "C" int atomdev_atm_value_limitation(atomdev_t* h) {
     ATOMDEV_REQUIRE(h && h->model == ATOMDEV_ATM, "atomdev_atm_value_limitation: not an atmosphere handle");
     ATOMDEV_TRY(hipSetDevice(h->device));
     if (int rc = atomdev_refresh_flags(h)) return rc;
-    hipLaunchKernelGGL(k_atm_value_limitation, dim3(blocks_for(h->n3)), dim3(TPB), 0, h->stream, h->f[ATOMDEV_U],
+    hipLaunchKernelGGL(k_atm_value_limitation<false>, dim3(blocks_for(h->n3)), dim3(TPB), 0, h->stream, h->f[ATOMDEV_U],
                        h->f[ATOMDEV_V], h->f[ATOMDEV_W], h->f[ATOMDEV_T], h->f[ATOMDEV_C], h->f[ATOMDEV_CLOUD],
-                       h->f[ATOMDEV_ICE], h->f[ATOMDEV_CO2], h->f[ATOMDEV_P_DYN], h->flags, h->n3);
+                       h->f[ATOMDEV_ICE], h->f[ATOMDEV_CO2], h->f[ATOMDEV_P_DYN], h->flags, h->n3, h->im, h->jm, h->km);
+    ATOMDEV_TRY(hipGetLastError());
+    return 0;
+}
+
+int atomdev_atm_limit_rest(atomdev* h) {
+    hipLaunchKernelGGL(k_atm_value_limitation<true>, dim3(blocks_for(h->n3)), dim3(TPB), 0, h->stream, h->f[ATOMDEV_U],
+                       h->f[ATOMDEV_V], h->f[ATOMDEV_W], h->f[ATOMDEV_T], h->f[ATOMDEV_C], h->f[ATOMDEV_CLOUD],
+                       h->f[ATOMDEV_ICE], h->f[ATOMDEV_CO2], h->f[ATOMDEV_P_DYN], h->flags, h->n3, h->im, h->jm, h->km);
     ATOMDEV_TRY(hipGetLastError());
     return 0;
 }

@@ -217,14 +217,16 @@ __global__ __launch_bounds__(64) void k_atm_rk3d(AtmRkArgs a, DevConst K) {
 
 }  // namespace
 
-extern "C" int atomdev_atm_rk3d(atomdev_t* h) {
-    ATOMDEV_REQUIRE(h && h->model == ATOMDEV_ATM, "atomdev_atm_rk3d: not an atmosphere handle");
+namespace {
+int rk3d(atomdev* h, bool limit) {
     ATOMDEV_TRY(hipSetDevice(h->device));
     if (int rc = atomdev_refresh_flags(h)) return rc;
+    if (h->rk_variant == 2 || h->rk_variant == 0) {
+        if (int rc = h->rk_variant == 2 ? atomdev_atm_rk3d_ws_fast(h, limit) : atomdev_atm_rk3d_ws(h, limit)) return rc;
+        return limit ? atomdev_atm_limit_rest(h) : 0;
+    }
     // c at level 3 as the level-1 points must see it: before the sweep touches it
     ATOMDEV_TRY(hipMemcpyAsync(h->plane, h->f[ATOMDEV_C] + 3 * h->n2, h->n2 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    if (h->rk_variant == 2) return atomdev_atm_rk3d_ws_fast(h);
-    if (h->rk_variant == 0) return atomdev_atm_rk3d_ws(h);
     AtmRkArgs a;
     a.t = h->f[ATOMDEV_T]; a.u = h->f[ATOMDEV_U]; a.v = h->f[ATOMDEV_V]; a.w = h->f[ATOMDEV_W];
     a.c = h->f[ATOMDEV_C]; a.cloud = h->f[ATOMDEV_CLOUD]; a.ice = h->f[ATOMDEV_ICE]; a.co2 = h->f[ATOMDEV_CO2];
@@ -242,5 +244,16 @@ extern "C" int atomdev_atm_rk3d(atomdev_t* h) {
     hipLaunchKernelGGL(k_atm_rk3d, grid, dim3(64), 0, h->stream, a, h->k);
     ATOMDEV_TRY(hipGetLastError());
     if (int rc = atomdev_prof_end(h)) return rc;
-    return 0;
+    return limit ? atomdev_atm_value_limitation(h) : 0;
+}
+}  // namespace
+
+extern "C" int atomdev_atm_rk3d(atomdev_t* h) {
+    ATOMDEV_REQUIRE(h && h->model == ATOMDEV_ATM, "atomdev_atm_rk3d: not an atmosphere handle");
+    return rk3d(h, false);
+}
+
+extern "C" int atomdev_atm_rk3d_limited(atomdev_t* h) {
+    ATOMDEV_REQUIRE(h && h->model == ATOMDEV_ATM, "atomdev_atm_rk3d_limited: not an atmosphere handle");
+    return rk3d(h, true);
 }

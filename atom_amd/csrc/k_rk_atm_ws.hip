@@ -101,15 +101,19 @@ struct Shared {
 
 // ---- prep: everything per point that does not change during the sweep -------------------------
 // ph100 = 100 * p_h, p_h from RHS_Atm.cpp:384-389; h0i = h_0_i from RHS_Atm.cpp:110-124.
+// c3 (when given): c at level 3 as the sweep found it, which the level-1 points read (RHS_Atm.cpp:412-430) while
+// level 3 itself is being updated.
 template <bool WITH_H0I>
 __global__ void k_atm_prep(const double* __restrict__ t, const double* __restrict__ topo, const uint8_t* __restrict__ flags,
-                           double* __restrict__ ph100, double* __restrict__ h0i, DevConst K) {
+                           double* __restrict__ ph100, double* __restrict__ h0i, const double* __restrict__ c,
+                           double* __restrict__ c3, DevConst K) {
     const int jm = K.jm, km = K.km;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = blockIdx.y, i = 1 + blockIdx.z;
     if (k >= km) return;
     const size_t q = (size_t)j * km + k;
     const size_t p = (size_t)i * jm * km + q;
+    if (c3 && i == 3) c3[q] = c[p];
     const double hight = (double)i * K.topo_step;
     const double t0jk = t[q];
     const double t0K = t0jk * K.t_0;
@@ -206,6 +210,21 @@ __device__ __forceinline__ void theta_terms(int mode, double xm2, double xm1, do
     G = mode == 0 ? xm1 : (mode == 1 ? 0. : xm2);
 }
 
+// BC_Thermo::Value_Limitation_Atm (BC_Thermo.cpp:3235-3275) for the variable of one role: the same comparisons
+// in the same order as the pointwise kernel (a value that is not a number passes, unless the cell is land).
+template <int ROLE>
+__device__ __forceinline__ double limited(double x, bool land) {
+    if constexpr (ROLE == R_U) { if (x >= .106) x = .106; if (x <= -.106) x = -.106; if (land) x = 0.; }
+    if constexpr (ROLE == R_V) { if (x >= .125) x = .125; if (x <= -.125) x = -.125; if (land) x = 0.; }
+    if constexpr (ROLE == R_W) { if (x >= 3.5) x = 3.5; if (x <= -.469) x = -.469; if (land) x = 0.; }
+    if constexpr (ROLE == R_T) { if (x >= 1.165) x = 1.165; if (x <= -.78) x = -.78; }
+    if constexpr (ROLE == R_C) { if (x >= .03) x = .03; if (x < 0.) x = 0.; }
+    if constexpr (ROLE == R_CLOUD) { if (x >= .01) x = .01; if (x < 0.) x = 0.; if (land) x = 0.; }
+    if constexpr (ROLE == R_ICE) { if (x >= .005) x = .005; if (x < 0.) x = 0.; if (land) x = 0.; }
+    if constexpr (ROLE == R_CO2) { if (x >= 5.36) x = 5.36; if (x <= 1.) x = 1.; if (land) x = 1.; }
+    return x;
+}
+
 // The whole sweep of one wave.  ROLE is a template parameter so that every wave runs
 // straight-line code for its own variable; all roles execute the same number of barriers
 // (one before the first step, four per step), whatever their lanes do.
@@ -215,7 +234,10 @@ __device__ __forceinline__ void theta_terms(int mode, double xm2, double xm1, do
 // of row j+1 is read from LDS in stage 4.  Nothing loaded in a step is used before the next step.
 template <int ROLE>
 __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K, Shared& sh, const double* tab,
-                                           int bx, int i, double* __restrict__ X, const double* __restrict__ XN) {
+                                           int bx, int i, double* __restrict__ X, const double* __restrict__ XN,
+                                           const bool limit) {
+    // limit: what goes to memory is the value as the limiter that follows the sweep in the model's loop would leave it;
+    // the sweep itself goes on with the value it computed, as it does when the limiter runs afterwards.
     constexpr bool isV = ROLE == R_V, isU = ROLE == R_U, isT = ROLE == R_T, isC = ROLE == R_C, isW = ROLE == R_W;
     constexpr bool hasH0I = ROLE == R_U || ROLE == R_CO2 || ROLE == R_ICE || ROLE == R_CLOUD;
     const int jm = K.jm, km = K.km;
@@ -344,6 +366,7 @@ __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K
     // wait inside the loop is the one at the end of a step.
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     double so1 = 0., so2 = 0.;  // side outputs of the previous row, stored with it during the next step
+    bool land_prev = false;     // ... and whether that row's cell is land
 
     for (int j = 1; j < jm - 1; j++) {
         // (Idle lanes shadow the last line: they load what its owner loads and store the same bits.)
@@ -438,14 +461,15 @@ __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K
                 }
             }
         }
+        auto store_prev = [&]() {  // results of the previous row
+            stg(X, o0 - rowB, limit ? limited<ROLE>(xm1, land_prev) : xm1);
+            if constexpr (isU) { stg(O1, o0 - rowB, so1); stg(O2, o0 - rowB, so2); }
+            if constexpr (isV || isW) stg(O1, o0 - rowB, so1);
+        };
 #pragma unroll
         for (int s = 0; s < 4; s++) {
             const int rb = s & 1, wb = rb ^ 1;
-            if (exp_st && s == 1 && j > 1) {  // results of the previous row
-                stg(X, o0 - rowB, xm1);
-                if constexpr (isU) { stg(O1, o0 - rowB, so1); stg(O2, o0 - rowB, so2); }
-                if constexpr (isV || isW) stg(O1, o0 - rowB, so1);
-            }
+            if (exp_st && s == 1 && j > 1) store_prev();
             if (s == 3) load_table(j + 1);
             double v;
             if constexpr (isV) v = st; else v = sh.v[rb][lane];
@@ -535,16 +559,17 @@ __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K
         else __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0): the first step stores nothing
         STAMP(10);
         xm2 = xm1; xm1 = st; x0 = xp1; xp1 = xp2;
+        land_prev = land;
         if constexpr (isV) { ym2 = ym1; ym1 = y0; y0 = yp1; yp1 = yp2; um2 = um1; up1 = up2; }
         if constexpr (isT) { ph_cur = ph_nxt; ph_nxt = n_ph2; }
         o0 += rowB; o1 += rowB; o2 += rowB; q1 += rowB;
     }
-    stg(X, o0 - rowB, xm1);  // row jm-2
+    stg(X, o0 - rowB, limit ? limited<ROLE>(xm1, land_prev) : xm1);  // row jm-2
     if constexpr (isU) { stg(O1, o0 - rowB, so1); stg(O2, o0 - rowB, so2); }
     if constexpr (isV || isW) stg(O1, o0 - rowB, so1);
 }
 
-__global__ __launch_bounds__(512) void k_atm_rk3d_ws(const AtmWsParams* __restrict__ P) {
+__global__ __launch_bounds__(512) void k_atm_rk3d_ws(const AtmWsParams* __restrict__ P, int limit) {
     const AtmWsArgs& a = P->a;
     const DevConst& K = P->K;
     __shared__ Shared sh;
@@ -572,14 +597,14 @@ __global__ __launch_bounds__(512) void k_atm_rk3d_ws(const AtmWsParams* __restri
         __syncthreads();
     }
     switch (threadIdx.x >> 6) {
-        case R_U: sweep_role<R_U>(a, K, sh, tab, bx, i, a.u, a.un); break;
-        case R_V: sweep_role<R_V>(a, K, sh, tab, bx, i, a.v, a.vn); break;
-        case R_T: sweep_role<R_T>(a, K, sh, tab, bx, i, a.t, a.tn); break;
-        case R_W: sweep_role<R_W>(a, K, sh, tab, bx, i, a.w, a.wn); break;
-        case R_CO2: sweep_role<R_CO2>(a, K, sh, tab, bx, i, a.co2, a.co2n); break;
-        case R_ICE: sweep_role<R_ICE>(a, K, sh, tab, bx, i, a.ice, a.icen); break;
-        case R_CLOUD: sweep_role<R_CLOUD>(a, K, sh, tab, bx, i, a.cloud, a.cloudn); break;
-        default: sweep_role<R_C>(a, K, sh, tab, bx, i, a.c, a.cn); break;
+        case R_U: sweep_role<R_U>(a, K, sh, tab, bx, i, a.u, a.un, limit != 0); break;
+        case R_V: sweep_role<R_V>(a, K, sh, tab, bx, i, a.v, a.vn, limit != 0); break;
+        case R_T: sweep_role<R_T>(a, K, sh, tab, bx, i, a.t, a.tn, limit != 0); break;
+        case R_W: sweep_role<R_W>(a, K, sh, tab, bx, i, a.w, a.wn, limit != 0); break;
+        case R_CO2: sweep_role<R_CO2>(a, K, sh, tab, bx, i, a.co2, a.co2n, limit != 0); break;
+        case R_ICE: sweep_role<R_ICE>(a, K, sh, tab, bx, i, a.ice, a.icen, limit != 0); break;
+        case R_CLOUD: sweep_role<R_CLOUD>(a, K, sh, tab, bx, i, a.cloud, a.cloudn, limit != 0); break;
+        default: sweep_role<R_C>(a, K, sh, tab, bx, i, a.c, a.cn, limit != 0); break;
     }
 #ifdef ATOMDEV_EXP_WGTIME
     if ((threadIdx.x & 63) == 0) {
@@ -591,7 +616,7 @@ __global__ __launch_bounds__(512) void k_atm_rk3d_ws(const AtmWsParams* __restri
 
 }  // namespace
 
-int ATM_WS_ENTRY(atomdev* h) {
+int ATM_WS_ENTRY(atomdev* h, bool limit) {
     AtmWsParams P;
     AtmWsArgs& a = P.a;
     a.t = h->f[ATOMDEV_T]; a.u = h->f[ATOMDEV_U]; a.v = h->f[ATOMDEV_V]; a.w = h->f[ATOMDEV_W];
@@ -614,14 +639,18 @@ int ATM_WS_ENTRY(atomdev* h) {
         ATOMDEV_TRY(hipMemcpy(h->ws_params, &P, sizeof(P), hipMemcpyHostToDevice));
     }
     dim3 pg((h->km + 127) / 128, h->jm, h->im - 2);
+    // c at level 3 as the level-1 points must see it: the preparing kernel copies it where it passes level 3
+    double* c3 = nullptr;
+    if (h->im >= 5) c3 = h->plane;
+    else ATOMDEV_TRY(hipMemcpyAsync(h->plane, h->f[ATOMDEV_C] + 3 * h->n2, h->n2 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     if (h->profile_rk == 2)
         if (int rc = atomdev_prof_begin(h)) return rc;  // the bracket of the whole operator
     if (h->h0i_valid)
         hipLaunchKernelGGL(k_atm_prep<false>, pg, dim3(128), 0, h->stream, h->f[ATOMDEV_T], h->g[ATOMDEV_TOPOGRAPHY], h->flags,
-                           h->scr[0], h->scr[1], h->k);
+                           h->scr[0], h->scr[1], h->f[ATOMDEV_C], c3, h->k);
     else
         hipLaunchKernelGGL(k_atm_prep<true>, pg, dim3(128), 0, h->stream, h->f[ATOMDEV_T], h->g[ATOMDEV_TOPOGRAPHY], h->flags,
-                           h->scr[0], h->scr[1], h->k);
+                           h->scr[0], h->scr[1], h->f[ATOMDEV_C], c3, h->k);
     ATOMDEV_TRY(hipGetLastError());
     h->h0i_valid = true;
     if (h->profile_rk == 1)
@@ -630,7 +659,7 @@ int ATM_WS_ENTRY(atomdev* h) {
     dim3 grid(8 * rounds * gx);
     ATOMDEV_REQUIRE(h->n3 * sizeof(double) < ((size_t)1 << 32), "atm_rk3d: field larger than 4 GiB");
     const size_t tab_bytes = (size_t)h->jm * 4 * sizeof(double);
-    hipLaunchKernelGGL(k_atm_rk3d_ws, grid, dim3(512), tab_bytes, h->stream, (const AtmWsParams*)h->ws_params);
+    hipLaunchKernelGGL(k_atm_rk3d_ws, grid, dim3(512), tab_bytes, h->stream, (const AtmWsParams*)h->ws_params, limit ? 1 : 0);
     ATOMDEV_TRY(hipGetLastError());
     if (int rc = atomdev_prof_end(h)) return rc;
     return 0;

@@ -139,6 +139,11 @@ int atomdev_atm_solid_ground(atomdev_t* h);
 /* RungeKutta_Atmosphere::solveRungeKutta_3D_Atmosphere + RHS_Atmosphere::
  * RK_RHS_3D_Atmosphere (atmosphere/RungeKutta_Atm.cpp:32-156, RHS_Atm.cpp:68-493) */
 int atomdev_atm_rk3d(atomdev_t* h);
+/* atomdev_atm_rk3d and the atomdev_atm_value_limitation that cAtmosphereModel::run_3D_loop calls right after it
+ * (atmosphere/cAtmosphereModel.cpp:809-825) as one call: every field ends with the bits the two calls leave.  The
+ * sweep stores its results already limited (it goes on computing with the unlimited ones, as it does when the limiter
+ * runs afterwards), and one small kernel limits the points the sweep does not store and clears p_dyn on land. */
+int atomdev_atm_rk3d_limited(atomdev_t* h);
 /* solveRungeKutta_2D_Atmosphere + RK_RHS_2D_Atmosphere
  * (atmosphere/RungeKutta_Atm.cpp:163-217, RHS_Atm.cpp:498-678) */
 int atomdev_atm_rk2d(atomdev_t* h);

@@ -810,6 +810,48 @@ def test_rk_variants_same_bits(model, op, dims, seed):
             assert H.max_rel_err(out[2][k], out[0][k]) <= 1e-12, (op, k, H.max_rel_err(out[2][k], out[0][k]))
 
 
+@pytest.mark.parametrize("dims,seed,real_mask", [((9, 21, 70), 51, False), ((6, 9, 131), 52, False), ((5, 7, 7), 53, False),
+                                                 ((41, 181, 361), 54, True)])
+def test_atm_rk3d_limited_is_sweep_then_limiter(dims, seed, real_mask):
+    """atomdev_atm_rk3d_limited against atomdev_atm_rk3d followed by atomdev_atm_value_limitation, every field bit for bit,
+    in every form of the sweep, over two rounds (the second starts from limited fields).  The inputs are stretched so
+    that every limit is exceeded somewhere, p_dyn is nonzero on land, and values on the six faces need limiting too."""
+    im, jm, km = dims
+    p = H.default_params(H.ATM, im, jm, km)
+    f, g = H.make_inputs(H.ATM, im, jm, km, seed, "blobs", p)
+    f = {k: f[k] for k in H.ATM_FIELDS}
+    if real_mask:
+        f["H"], g["TOPOGRAPHY"] = H.load_mask_0Ma(H.ATM)
+    rng = np.random.default_rng(seed)
+    for k, scale in (("U", 4.), ("V", 4.), ("W", 40.), ("T", 1.3), ("C", 6.), ("CLOUD", 30.), ("ICE", 30.), ("CO2", 6.)):
+        stretch = np.where(rng.random(f[k].shape) < .2, scale, 1.)
+        sign = np.where(rng.random(f[k].shape) < .1, -1., 1.)
+        f[k] = f[k] * stretch * sign
+        f[k + "N"] = f[k].copy()
+    f["P_DYN"] = f["P_DYN"] + 1.
+    hit = {}
+    for variant in (0, 1, 2):
+        out = []
+        for fused in (False, True):
+            d = atom_amd.DeviceModel(H.ATM, im, jm, km, atom_amd.Params.from_buffer_copy(bytes(p)))
+            d.upload_all(f, g)
+            d.set_rk_variant(variant)
+            for _ in range(2):
+                if fused:
+                    d.op("atm_rk3d_limited")
+                else:
+                    d.op("atm_rk3d")
+                    if variant == 0 and not hit:
+                        u = d.download("U"); hit["u"] = int((np.abs(u[1:-1, 1:-1, 1:-1]) > .106).sum())
+                    d.op("atm_value_limitation")
+            out.append({k: d.download(k) for k in H.ATM_FIELDS})
+            d.close()
+        for k in H.ATM_FIELDS:
+            if k != "RESIDUUM":
+                assert H.bits_equal(out[0][k], out[1][k]), (variant, k, H.max_rel_err(out[1][k], out[0][k]))
+    assert hit["u"] > 0   # the limiter had something to do on interior points
+
+
 def test_residuum_scan_adversarial_fields():
     """The residuum scan (signed store, unsigned compare) on fields built to stress its jump logic:
     many sign changes, long runs of negative values, exact ties and zeros, magnitudes that shrink or

@@ -16,7 +16,7 @@ n3, n2 = im * jm * km, jm * km
 upd = (im - 2) * (jm - 2) * (km - 2)
 # algorithmic bytes per call (reads + writes of the reference's own data movement)
 BYTES = {
-    "atm_rk3d": upd * 280, "hyd_rk3d": upd * 208,
+    "atm_rk3d": upd * 280, "hyd_rk3d": upd * 208, "atm_rk3d_limited": upd * 280,
     "atm_pressure3d": upd * 48, "hyd_pressure3d": upd * 48,
     "atm_value_limitation": n3 * 152, "hyd_value_limitation": n3 * 88,
     "move3d(atm)": n3 * 16 * 9, "move3d(hyd)": n3 * 16 * 6,
@@ -45,7 +45,7 @@ for model, pre in (() if only_physics else ((H.ATM, "atm"), (H.HYD, "hyd"))):
     if model == H.HYD:
         ops.append("hyd_pressure_density")
     else:
-        ops.append("atm_msl_data")
+        ops += ["atm_msl_data", "atm_rk3d_limited"]
     for op in ops:
         def call():
             if op.startswith("move3d"):
