@@ -94,9 +94,10 @@ int atomdev_sync_stream(atomdev* h);          // atomdev_api.hip: hipStreamSynch
 int atomdev_defer_file(atomdev* h, std::function<std::string()> job);  // atomdev_api.hip
 int atomdev_join_files(atomdev* h);                                   // atomdev_api.hip
 inline volatile int* atomdev_kernel_error_word(atomdev* h) { return (volatile int*)((char*)h->pinned + 128); }
-// limit: the values stored are what Value_Limitation_Atm would make of them (interior points of the eight variables)
-int atomdev_atm_rk3d_ws(atomdev* h, bool limit);    // k_rk_atm_ws.hip
-int atomdev_atm_rk3d_ws_fast(atomdev* h, bool limit);  // k_rk_atm_ws.hip compiled with -DATOMDEV_RK_FAST
+// limit: the values stored are what Value_Limitation_Atm would make of them (interior points of the eight variables);
+// limit_before: the kernel that prepares the sweep runs Value_Limitation_Atm (and with it BC_SolidGround) on its way
+int atomdev_atm_rk3d_ws(atomdev* h, bool limit, bool limit_before);    // k_rk_atm_ws.hip
+int atomdev_atm_rk3d_ws_fast(atomdev* h, bool limit, bool limit_before);  // k_rk_atm_ws.hip compiled with -DATOMDEV_RK_FAST
 int atomdev_atm_limit_rest(atomdev* h);  // k_pointwise.hip: the limiter where the sweep does not store, and p_dyn on land
 int atomdev_hyd_rk3d_ws(atomdev* h);    // k_rk_hyd_ws.hip
 int atomdev_hyd_rk3d_ws_fast(atomdev* h);  // k_rk_hyd_ws.hip compiled with -DATOMDEV_RK_FAST

@@ -218,12 +218,17 @@ __global__ __launch_bounds__(64) void k_atm_rk3d(AtmRkArgs a, DevConst K) {
 }  // namespace
 
 namespace {
-int rk3d(atomdev* h, bool limit) {
+int rk3d(atomdev* h, bool limit, bool limit_before) {
     ATOMDEV_TRY(hipSetDevice(h->device));
     if (int rc = atomdev_refresh_flags(h)) return rc;
     if (h->rk_variant == 2 || h->rk_variant == 0) {
-        if (int rc = h->rk_variant == 2 ? atomdev_atm_rk3d_ws_fast(h, limit) : atomdev_atm_rk3d_ws(h, limit)) return rc;
+        if (int rc = h->rk_variant == 2 ? atomdev_atm_rk3d_ws_fast(h, limit, limit_before)
+                                        : atomdev_atm_rk3d_ws(h, limit, limit_before)) return rc;
         return limit ? atomdev_atm_limit_rest(h) : 0;
+    }
+    if (limit_before) {
+        if (int rc = atomdev_atm_value_limitation(h)) return rc;
+        if (int rc = atomdev_atm_solid_ground(h)) return rc;
     }
     // c at level 3 as the level-1 points must see it: before the sweep touches it
     ATOMDEV_TRY(hipMemcpyAsync(h->plane, h->f[ATOMDEV_C] + 3 * h->n2, h->n2 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
@@ -250,10 +255,15 @@ int rk3d(atomdev* h, bool limit) {
 
 extern "C" int atomdev_atm_rk3d(atomdev_t* h) {
     ATOMDEV_REQUIRE(h && h->model == ATOMDEV_ATM, "atomdev_atm_rk3d: not an atmosphere handle");
-    return rk3d(h, false);
+    return rk3d(h, false, false);
 }
 
 extern "C" int atomdev_atm_rk3d_limited(atomdev_t* h) {
     ATOMDEV_REQUIRE(h && h->model == ATOMDEV_ATM, "atomdev_atm_rk3d_limited: not an atmosphere handle");
-    return rk3d(h, true);
+    return rk3d(h, true, false);
+}
+
+extern "C" int atomdev_atm_limit_ground_rk3d_limit(atomdev_t* h) {
+    ATOMDEV_REQUIRE(h && h->model == ATOMDEV_ATM, "atomdev_atm_limit_ground_rk3d_limit: not an atmosphere handle");
+    return rk3d(h, true, true);
 }

@@ -54,6 +54,7 @@
 #define ATM_WS_ENTRY atomdev_atm_rk3d_ws_fast
 #define k_atm_rk3d_ws k_atm_rk3d_wsf
 #define k_atm_prep k_atm_prepf
+#define k_atm_limit_prep k_atm_limit_prepf
 #define DIVC(a, b, rb) ((a) * (rb))
 #ifndef ATOMDEV_RK_NOAFFINE
 #define ATM_WS_AFFINE 1
@@ -100,7 +101,26 @@ struct Shared {
 };
 
 // ---- prep: everything per point that does not change during the sweep -------------------------
-// ph100 = 100 * p_h, p_h from RHS_Atm.cpp:384-389; h0i = h_0_i from RHS_Atm.cpp:110-124.
+// ph100 = 100 * p_h, p_h from RHS_Atm.cpp:384-389 (t0jk: t at the ground of the column)
+__device__ __forceinline__ double ph100_of(double t0jk, double hight, const DevConst& K) {
+    const double t0K = t0jk * K.t_0;
+    const double p_SL = .01 * (K.p_SL_factor * t0jk * K.t_0);
+#if ATM_WS_AFFINE  // tolerance form: x^y as exp(y log x), a few units in the last place off and half the instructions
+    const double p_h = exp(K.exp_pressure * log((t0K - K.gam * hight * 1.e-2) / t0K)) * p_SL;
+#else
+    const double p_h = pow((t0K - K.gam * hight * 1.e-2) / t0K, K.exp_pressure) * p_SL;
+#endif
+    return 100. * p_h;
+}
+// h_0_i from RHS_Atm.cpp:110-124: static, depends on the mask and the topography only
+__device__ __forceinline__ double h0i_of(uint8_t fl, double hight, double topo, const DevConst& K) {
+    double h_0_i = 1.;
+    if (fl & FL_LAND) {
+        const double topo_diff = hight - topo;
+        if (!(topo_diff == K.topo_step)) h_0_i = div_by(topo_diff, K.topo_step, K.i_topo_step);
+    }
+    return h_0_i;
+}
 // c3 (when given): c at level 3 as the sweep found it, which the level-1 points read (RHS_Atm.cpp:412-430) while
 // level 3 itself is being updated.
 template <bool WITH_H0I>
@@ -115,23 +135,8 @@ __global__ void k_atm_prep(const double* __restrict__ t, const double* __restric
     const size_t p = (size_t)i * jm * km + q;
     if (c3 && i == 3) c3[q] = c[p];
     const double hight = (double)i * K.topo_step;
-    const double t0jk = t[q];
-    const double t0K = t0jk * K.t_0;
-    const double p_SL = .01 * (K.p_SL_factor * t0jk * K.t_0);
-#if ATM_WS_AFFINE  // tolerance form: x^y as exp(y log x), a few units in the last place off and half the instructions
-    const double p_h = exp(K.exp_pressure * log((t0K - K.gam * hight * 1.e-2) / t0K)) * p_SL;
-#else
-    const double p_h = pow((t0K - K.gam * hight * 1.e-2) / t0K, K.exp_pressure) * p_SL;
-#endif
-    ph100[p] = 100. * p_h;
-    if constexpr (WITH_H0I) {  // static: depends on the mask and the topography only
-        double h_0_i = 1.;
-        if (flags[p] & FL_LAND) {
-            double topo_diff = hight - topo[q];
-            if (!(topo_diff == K.topo_step)) h_0_i = div_by(topo_diff, K.topo_step, K.i_topo_step);
-        }
-        h0i[p] = h_0_i;
-    }
+    ph100[p] = ph100_of(t[q], hight, K);
+    if constexpr (WITH_H0I) h0i[p] = h0i_of(flags[p], hight, topo[q], K);
 }
 
 // Values that every stage of every step needs are pinned into vector registers: the
@@ -223,6 +228,41 @@ __device__ __forceinline__ double limited(double x, bool land) {
     if constexpr (ROLE == R_ICE) { if (x >= .005) x = .005; if (x < 0.) x = 0.; if (land) x = 0.; }
     if constexpr (ROLE == R_CO2) { if (x >= 5.36) x = 5.36; if (x <= 1.) x = 1.; if (land) x = 1.; }
     return x;
+}
+
+// Value_Limitation_Atm on every point and, in the same pass, what k_atm_prep prepares - from the limited values: a
+// point of levels 1 .. im-2 limits the ground temperature of its column itself (limiting what another thread has
+// already limited changes nothing).  BC_SolidGround (BC_Bath_Atm.cpp:94-119) right after this limiter would write
+// what the limiter's land rule has just written, so the pass stands for both.
+struct LimitFields { double *u, *v, *w, *t, *c, *cloud, *ice, *co2, *p_dyn; };
+template <bool WITH_H0I>
+__global__ __launch_bounds__(256) void k_atm_limit_prep(LimitFields f, const double* __restrict__ topo,
+                                                        const uint8_t* __restrict__ flags, double* __restrict__ ph100,
+                                                        double* __restrict__ h0i, double* __restrict__ c3, DevConst K, size_t n) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int jm = K.jm, km = K.km;
+    const size_t n2 = (size_t)jm * km;
+    const int i = (int)(p / n2);
+    const size_t q = p - (size_t)i * n2;
+    const uint8_t fl = flags[p];
+    const bool land = fl & FL_LAND;
+    auto limit_field = [&](double* x, auto role) {
+        const double was = x[p], now = limited<decltype(role)::value>(was, land);
+        if (__double_as_longlong(was) != __double_as_longlong(now)) x[p] = now;
+        return now;
+    };
+    limit_field(f.u, std::integral_constant<int, R_U>()); limit_field(f.v, std::integral_constant<int, R_V>());
+    limit_field(f.w, std::integral_constant<int, R_W>()); limit_field(f.t, std::integral_constant<int, R_T>());
+    const double c_now = limit_field(f.c, std::integral_constant<int, R_C>());
+    limit_field(f.cloud, std::integral_constant<int, R_CLOUD>()); limit_field(f.ice, std::integral_constant<int, R_ICE>());
+    limit_field(f.co2, std::integral_constant<int, R_CO2>());
+    if (land) f.p_dyn[p] = 0.;
+    if (i < 1 || i > K.im - 2) return;
+    if (c3 && i == 3) c3[q] = c_now;
+    const double hight = (double)i * K.topo_step;
+    ph100[p] = ph100_of(limited<R_T>(f.t[q], false), hight, K);
+    if constexpr (WITH_H0I) h0i[p] = h0i_of(fl, hight, topo[q], K);
 }
 
 // The whole sweep of one wave.  ROLE is a template parameter so that every wave runs
@@ -616,7 +656,7 @@ __global__ __launch_bounds__(512) void k_atm_rk3d_ws(const AtmWsParams* __restri
 
 }  // namespace
 
-int ATM_WS_ENTRY(atomdev* h, bool limit) {
+int ATM_WS_ENTRY(atomdev* h, bool limit, bool limit_before) {
     AtmWsParams P;
     AtmWsArgs& a = P.a;
     a.t = h->f[ATOMDEV_T]; a.u = h->f[ATOMDEV_U]; a.v = h->f[ATOMDEV_V]; a.w = h->f[ATOMDEV_W];
@@ -645,7 +685,17 @@ int ATM_WS_ENTRY(atomdev* h, bool limit) {
     else ATOMDEV_TRY(hipMemcpyAsync(h->plane, h->f[ATOMDEV_C] + 3 * h->n2, h->n2 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     if (h->profile_rk == 2)
         if (int rc = atomdev_prof_begin(h)) return rc;  // the bracket of the whole operator
-    if (h->h0i_valid)
+    if (limit_before) {
+        LimitFields lf = { h->f[ATOMDEV_U], h->f[ATOMDEV_V], h->f[ATOMDEV_W], h->f[ATOMDEV_T], h->f[ATOMDEV_C],
+                           h->f[ATOMDEV_CLOUD], h->f[ATOMDEV_ICE], h->f[ATOMDEV_CO2], h->f[ATOMDEV_P_DYN] };
+        const unsigned nb = (unsigned)((h->n3 + 255) / 256);
+        if (h->h0i_valid)
+            hipLaunchKernelGGL(k_atm_limit_prep<false>, dim3(nb), dim3(256), 0, h->stream, lf, h->g[ATOMDEV_TOPOGRAPHY], h->flags,
+                               h->scr[0], h->scr[1], c3, h->k, h->n3);
+        else
+            hipLaunchKernelGGL(k_atm_limit_prep<true>, dim3(nb), dim3(256), 0, h->stream, lf, h->g[ATOMDEV_TOPOGRAPHY], h->flags,
+                               h->scr[0], h->scr[1], c3, h->k, h->n3);
+    } else if (h->h0i_valid)
         hipLaunchKernelGGL(k_atm_prep<false>, pg, dim3(128), 0, h->stream, h->f[ATOMDEV_T], h->g[ATOMDEV_TOPOGRAPHY], h->flags,
                            h->scr[0], h->scr[1], h->f[ATOMDEV_C], c3, h->k);
     else

@@ -97,9 +97,7 @@ int run_3d_loop(atomdev_t* h, const atomdev_atm_loop* L, atomdev_atm_loop_state*
             STEP(atomdev_atm_bc_theta(h));
             STEP(atomdev_atm_bc_phi(h));
             if (L->column_physics && v % 2 == 0) STEP(atomdev_atm_ice_water_saturation_adjustment(h, &S->q_v_hyp));  // :787-789
-            STEP(atomdev_atm_value_limitation(h));
-            STEP(atomdev_atm_solid_ground(h));
-            STEP(atomdev_atm_rk3d_limited(h));  // :809 and the limiter of :825 in one
+            STEP(atomdev_atm_limit_ground_rk3d_limit(h));  // :791, :793, :809 and the limiter of :825 in one
             if (L->column_physics && L->RadiationModel == 1) STEP(atomdev_atm_radiation_multi_layer(h, &L->radiation, L->i_trop));  // :828-831
             if (L->queries) {  // the same Accuracy_Atm object as before the sweep: its state is carried (:776-777, 833)
                 STEP(atomdev_atm_residuum3d(h, &res, loc));

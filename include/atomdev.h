@@ -144,6 +144,13 @@ int atomdev_atm_rk3d(atomdev_t* h);
  * sweep stores its results already limited (it goes on computing with the unlimited ones, as it does when the limiter
  * runs afterwards), and one small kernel limits the points the sweep does not store and clears p_dyn on land. */
 int atomdev_atm_rk3d_limited(atomdev_t* h);
+/* The four calls that cAtmosphereModel::run_3D_loop makes in a row - Value_Limitation_Atm, BC_SolidGround,
+ * solveRungeKutta_3D_Atmosphere, Value_Limitation_Atm (atmosphere/cAtmosphereModel.cpp:791, 793, 809, 825) - as one:
+ * every field ends with the bits atomdev_atm_value_limitation, atomdev_atm_solid_ground, atomdev_atm_rk3d and
+ * atomdev_atm_value_limitation leave.  The first limiter runs in the kernel that prepares the sweep's per-point
+ * inputs (BC_SolidGround after it writes what the limiter's land rule has just written), the last one as in
+ * atomdev_atm_rk3d_limited. */
+int atomdev_atm_limit_ground_rk3d_limit(atomdev_t* h);
 /* solveRungeKutta_2D_Atmosphere + RK_RHS_2D_Atmosphere
  * (atmosphere/RungeKutta_Atm.cpp:163-217, RHS_Atm.cpp:498-678) */
 int atomdev_atm_rk2d(atomdev_t* h);

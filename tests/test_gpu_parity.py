@@ -813,7 +813,8 @@ def test_rk_variants_same_bits(model, op, dims, seed):
 @pytest.mark.parametrize("dims,seed,real_mask", [((9, 21, 70), 51, False), ((6, 9, 131), 52, False), ((5, 7, 7), 53, False),
                                                  ((41, 181, 361), 54, True)])
 def test_atm_rk3d_limited_is_sweep_then_limiter(dims, seed, real_mask):
-    """atomdev_atm_rk3d_limited against atomdev_atm_rk3d followed by atomdev_atm_value_limitation, every field bit for bit,
+    """atomdev_atm_rk3d_limited against atomdev_atm_rk3d followed by atomdev_atm_value_limitation, and
+    atomdev_atm_limit_ground_rk3d_limit against limiter, solid ground, sweep, limiter: every field bit for bit,
     in every form of the sweep, over two rounds (the second starts from limited fields).  The inputs are stretched so
     that every limit is exceeded somewhere, p_dyn is nonzero on land, and values on the six faces need limiting too."""
     im, jm, km = dims
@@ -830,25 +831,26 @@ def test_atm_rk3d_limited_is_sweep_then_limiter(dims, seed, real_mask):
         f[k + "N"] = f[k].copy()
     f["P_DYN"] = f["P_DYN"] + 1.
     hit = {}
+    seqs = {"two": ["atm_rk3d", "atm_value_limitation"], "two in one": ["atm_rk3d_limited"],
+            "four": ["atm_value_limitation", "atm_solid_ground", "atm_rk3d", "atm_value_limitation"],
+            "four in one": ["atm_limit_ground_rk3d_limit"]}
     for variant in (0, 1, 2):
-        out = []
-        for fused in (False, True):
+        out = {}
+        for name, seq in seqs.items():
             d = atom_amd.DeviceModel(H.ATM, im, jm, km, atom_amd.Params.from_buffer_copy(bytes(p)))
             d.upload_all(f, g)
             d.set_rk_variant(variant)
             for _ in range(2):
-                if fused:
-                    d.op("atm_rk3d_limited")
-                else:
-                    d.op("atm_rk3d")
-                    if variant == 0 and not hit:
+                for op in seq:
+                    d.op(op)
+                    if op == "atm_rk3d" and name == "two" and not hit:
                         u = d.download("U"); hit["u"] = int((np.abs(u[1:-1, 1:-1, 1:-1]) > .106).sum())
-                    d.op("atm_value_limitation")
-            out.append({k: d.download(k) for k in H.ATM_FIELDS})
+            out[name] = {k: d.download(k) for k in H.ATM_FIELDS}
             d.close()
         for k in H.ATM_FIELDS:
             if k != "RESIDUUM":
-                assert H.bits_equal(out[0][k], out[1][k]), (variant, k, H.max_rel_err(out[1][k], out[0][k]))
+                for n in ("two", "four"):
+                    assert H.bits_equal(out[n][k], out[n + " in one"][k]), (variant, n, k, H.max_rel_err(out[n + " in one"][k], out[n][k]))
     assert hit["u"] > 0   # the limiter had something to do on interior points
 
 
