@@ -658,22 +658,26 @@ __global__ __launch_bounds__(320 * NB) void k_hyd_rk3d_ws(const HydWsParams* __r
 #endif
 }
 
-// Copies the boundary shell (i, j or k on a face) of src to dst: the sweep writes interior points only.
+// Copies the boundary shell (i, j or k on a face) of src to dst: the sweep writes interior points only.  Workgroups
+// 0 .. 2 A - 1 share the two whole levels, the others take B each of the interior levels' rim (rows j = 0, jm-1 and
+// columns k = 0, km-1); blockIdx.y is the field.
 __global__ void k_copy_shell(const double* const* __restrict__ src, double* const* __restrict__ dst, int im, int jm, int km,
-                             int* __restrict__ progress, int nprogress) {
-    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)  // the sweep that follows starts from "no row finished"
+                             int* __restrict__ progress, int nprogress, int A, int B) {
+    if (blockIdx.x == 0 && blockIdx.y == 0)  // the sweep that follows starts from "no row finished"
         for (int n = threadIdx.x; n < nprogress; n += blockDim.x) progress[n] = 0;
-    const double* __restrict__ s = src[blockIdx.z];
-    double* __restrict__ d = dst[blockIdx.z];
-    const int i = blockIdx.y;
-    const size_t base = (size_t)i * jm * km;
-    if (i == 0 || i == im - 1) {  // whole level
-        for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < jm * km; q += gridDim.x * blockDim.x) d[base + q] = s[base + q];
+    const double* __restrict__ s = src[blockIdx.y];
+    double* __restrict__ d = dst[blockIdx.y];
+    const int b = blockIdx.x;
+    if (b < 2 * A) {  // whole level
+        const size_t base = b < A ? 0 : (size_t)(im - 1) * jm * km;
+        const int part = b < A ? b : b - A;
+        for (int q = part * blockDim.x + threadIdx.x; q < jm * km; q += A * blockDim.x) d[base + q] = s[base + q];
         return;
     }
-    // rows j = 0, jm-1 and columns k = 0, km-1 of an interior level
+    const int i = 1 + (b - 2 * A) / B, part = (b - 2 * A) % B;
+    const size_t base = (size_t)i * jm * km;
     const int n = 2 * km + 2 * jm;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+    for (int e = part * blockDim.x + threadIdx.x; e < n; e += B * blockDim.x) {
         size_t q;
         if (e < km) q = e;
         else if (e < 2 * km) q = (size_t)(jm - 1) * km + (e - km);
@@ -724,10 +728,10 @@ int HYD_WS_ENTRY(atomdev* h) {
     ATOMDEV_REQUIRE(gx <= 128, "hyd_rk3d: more than 128 longitude blocks");
     ATOMDEV_REQUIRE(h->im >= 5, "hyd_rk3d: the grid needs at least 5 levels");
     if (int rc = atomdev_prof_begin(h)) return rc;
-    // (the two whole levels are most of the shell: enough workgroups for them; on the others the extra ones find nothing)
-    const unsigned shell_blocks = (unsigned)std::min<size_t>(64, (h->n2 + 1023) / 1024);
-    hipLaunchKernelGGL(k_copy_shell, dim3(shell_blocks, h->im, 5), dim3(256), 0, h->stream, &D->src[o][0], &D->dst[o][0], h->im, h->jm, h->km,
-                       D->progress, (int)gx);
+    const int shell_a = (int)std::min<size_t>(64, (h->n2 + 1023) / 1024);
+    const int shell_b = (int)std::min<size_t>(8, (2 * (size_t)(h->km + h->jm) + 1023) / 1024);
+    hipLaunchKernelGGL(k_copy_shell, dim3(2 * shell_a + (h->im - 2) * shell_b, 5), dim3(256), 0, h->stream, &D->src[o][0], &D->dst[o][0],
+                       h->im, h->jm, h->km, D->progress, (int)gx, shell_a, shell_b);
     ATOMDEV_TRY(hipGetLastError());
     const size_t lds = (size_t)h->jm * 4 * sizeof(double);
     // levels 1 .. im-2; two blocks of 64 lines per workgroup where one block each would be more workgroups than two per
