@@ -245,24 +245,29 @@ __global__ __launch_bounds__(256) void k_atm_limit_prep(LimitFields f, const dou
     const size_t n2 = (size_t)jm * km;
     const int i = (int)(p / n2);
     const size_t q = p - (size_t)i * n2;
+    // every load first, then the pressure power (which needs the ground temperature only) while they are on their way
     const uint8_t fl = flags[p];
-    const bool land = fl & FL_LAND;
-    auto limit_field = [&](double* x, auto role) {
-        const double was = x[p], now = limited<decltype(role)::value>(was, land);
-        if (__double_as_longlong(was) != __double_as_longlong(now)) x[p] = now;
-        return now;
-    };
-    limit_field(f.u, std::integral_constant<int, R_U>()); limit_field(f.v, std::integral_constant<int, R_V>());
-    limit_field(f.w, std::integral_constant<int, R_W>()); limit_field(f.t, std::integral_constant<int, R_T>());
-    const double c_now = limit_field(f.c, std::integral_constant<int, R_C>());
-    limit_field(f.cloud, std::integral_constant<int, R_CLOUD>()); limit_field(f.ice, std::integral_constant<int, R_ICE>());
-    limit_field(f.co2, std::integral_constant<int, R_CO2>());
-    if (land) f.p_dyn[p] = 0.;
-    if (i < 1 || i > K.im - 2) return;
-    if (c3 && i == 3) c3[q] = c_now;
+    const bool inner = i >= 1 && i <= K.im - 2;
+    const double t_ground = inner ? f.t[q] : 1.;
+    const double topo_q = (WITH_H0I && inner) ? topo[q] : 0.;
+    const double u0 = f.u[p], v0 = f.v[p], w0 = f.w[p], t0 = f.t[p], c0 = f.c[p], cl0 = f.cloud[p], ic0 = f.ice[p], co0 = f.co2[p];
     const double hight = (double)i * K.topo_step;
-    ph100[p] = ph100_of(limited<R_T>(f.t[q], false), hight, K);
-    if constexpr (WITH_H0I) h0i[p] = h0i_of(fl, hight, topo[q], K);
+    if (inner) {
+        ph100[p] = ph100_of(limited<R_T>(t_ground, false), hight, K);
+        if constexpr (WITH_H0I) h0i[p] = h0i_of(fl, hight, topo_q, K);
+    }
+    const bool land = fl & FL_LAND;
+    auto put = [&](double* x, double was, double now) {
+        if (__double_as_longlong(was) != __double_as_longlong(now)) x[p] = now;
+    };
+    put(f.u, u0, limited<R_U>(u0, land)); put(f.v, v0, limited<R_V>(v0, land)); put(f.w, w0, limited<R_W>(w0, land));
+    put(f.t, t0, limited<R_T>(t0, land));
+    const double c_now = limited<R_C>(c0, land);
+    put(f.c, c0, c_now);
+    put(f.cloud, cl0, limited<R_CLOUD>(cl0, land)); put(f.ice, ic0, limited<R_ICE>(ic0, land));
+    put(f.co2, co0, limited<R_CO2>(co0, land));
+    if (land) f.p_dyn[p] = 0.;
+    if (c3 && i == 3) c3[q] = c_now;
 }
 
 // The whole sweep of one wave.  ROLE is a template parameter so that every wave runs
