@@ -298,6 +298,14 @@ def main():
         hyd.sync()
         th = time.perf_counter() - th
         hms, hn = hyd.profile_read()
+        # the same sweep in its tolerance form (ATOMDEV_RK_VARIANT=2; the hydrosphere's default is the exact form)
+        hyd.set_rk_variant(2)
+        for s in range(3):
+            dev_step(hyd, HYD_STEP, s, "hyd_pressure3d")
+        hyd.profile_read()
+        for s in range(40):
+            dev_step(hyd, HYD_STEP, s, "hyd_pressure3d")
+        hms2, hn2 = hyd.profile_read()
         hyd.close()
         hyd_traffic = None
         try:
@@ -307,7 +315,9 @@ def main():
         hyd_info = {"updates_per_s": UPDATES * nh / th, "ms_per_step": 1e3 * th / nh, "rk_traffic": hyd_traffic,
                     "rk_traffic_source": "profiles/pmc_hyd_rk3d.json (offline PMC pass, not measured in this run)",
                     "rk_sweep_ms": hms / hn,
-                    "rk_hbm_frac": UPDATES * HYD_BYTES_PER_UPDATE / (hms / hn * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                    "rk_hbm_frac": UPDATES * HYD_BYTES_PER_UPDATE / (hms / hn * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "rk_sweep_ms_tolerance_form": hms2 / hn2,
+                    "rk_hbm_frac_tolerance_form": UPDATES * HYD_BYTES_PER_UPDATE / (hms2 / hn2 * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
     if rank == 0:
         rk_avg_s = rk_ms / rk_n * 1e-3
