@@ -224,7 +224,9 @@ int rk3d(atomdev* h, bool limit, bool limit_before) {
     if (h->rk_variant == 2 || h->rk_variant == 0) {
         if (int rc = h->rk_variant == 2 ? atomdev_atm_rk3d_ws_fast(h, limit, limit_before)
                                         : atomdev_atm_rk3d_ws(h, limit, limit_before)) return rc;
-        return limit ? atomdev_atm_limit_rest(h) : 0;
+        // (after a limiter that ran just before the sweep nothing is left for the second one outside the sweep's own
+        // points: the faces and p_dyn are as the first one left them, and limiting twice changes nothing)
+        return (limit && !limit_before) ? atomdev_atm_limit_rest(h) : 0;
     }
     if (limit_before) {
         if (int rc = atomdev_atm_value_limitation(h)) return rc;

@@ -148,8 +148,8 @@ int atomdev_atm_rk3d_limited(atomdev_t* h);
  * solveRungeKutta_3D_Atmosphere, Value_Limitation_Atm (atmosphere/cAtmosphereModel.cpp:791, 793, 809, 825) - as one:
  * every field ends with the bits atomdev_atm_value_limitation, atomdev_atm_solid_ground, atomdev_atm_rk3d and
  * atomdev_atm_value_limitation leave.  The first limiter runs in the kernel that prepares the sweep's per-point
- * inputs (BC_SolidGround after it writes what the limiter's land rule has just written), the last one as in
- * atomdev_atm_rk3d_limited. */
+ * inputs (BC_SolidGround after it writes what the limiter's land rule has just written), the last one in the sweep's
+ * stores (outside the sweep's points the first limiter has left it nothing to do). */
 int atomdev_atm_limit_ground_rk3d_limit(atomdev_t* h);
 /* solveRungeKutta_2D_Atmosphere + RK_RHS_2D_Atmosphere
  * (atmosphere/RungeKutta_Atm.cpp:163-217, RHS_Atm.cpp:498-678) */
