@@ -27,7 +27,7 @@
 // of its own, level im-2 costs a whole second sweep time on six workgroups.)
 //
 // The sweep is out of place (see k_rk_hyd.hip): it reads the current buffers and writes the
-// alternate set, whose boundary shell is refreshed beforehand by k_copy_shell.
+// alternate set, whose boundary shell is refreshed by extra workgroups of the same launch (copy_shell).
 #include <algorithm>
 #include <cstdlib>
 
@@ -43,7 +43,6 @@
 #ifdef ATOMDEV_RK_FAST
 #define HYD_WS_ENTRY atomdev_hyd_rk3d_ws_fast
 #define k_hyd_rk3d_ws k_hyd_rk3d_wsf
-#define k_copy_shell k_copy_shellf
 #define DIVC(a, b, rb) ((a) * (rb))
 #ifndef ATOMDEV_RK_NOAFFINE
 #define HYD_WS_AFFINE 1
@@ -563,6 +562,8 @@ __device__ __forceinline__ void sweep_role(const HydWsArgs& a, const DevConst& K
         if constexpr (isC) { rw_cur = rw_nxt; rw_nxt = n_rw2; }
         o0 += rowB; o1 += rowB; o2 += rowB; q1 += rowB;
     }
+    // the next sweep starts from "no row finished": the reader of the word is the last to touch it
+    if (polls && lane == 0) __hip_atomic_store(progress, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // row jm-2
     if (feeds_top) {
         stg_agent(XO, o0 - rowB, xm1);
@@ -599,11 +600,51 @@ __device__ __forceinline__ WaveJob wave_job(int wave) {
     return { wave & 1, role[wave >> 1] };
 }
 
+// Copies the boundary shell (i, j or k on a face) of the five variables from the current buffers to the alternate
+// ones: the sweep writes interior points only.  Work of the `ncopy` extra workgroups at the end of the sweep's grid,
+// which run beside it on whatever the sweep's own workgroups leave free.  Per variable: levels 0 and im-1 whole, then
+// of every other level the rows j = 0, jm-1 and the columns k = 0, km-1.
+__device__ void copy_shell(const double* const* __restrict__ src, double* const* __restrict__ dst, unsigned part, unsigned parts,
+                           int im, int jm, int km) {
+    const unsigned n2 = (unsigned)jm * km, rim = 2u * km + 2u * jm;
+    const unsigned per_field = 2u * n2 + (unsigned)(im - 2) * rim;
+    const size_t total = (size_t)5 * per_field, stride = (size_t)parts * blockDim.x;
+    auto offset = [&](unsigned e) -> size_t {
+        if (e < n2) return e;
+        if (e < 2u * n2) return (size_t)(im - 1) * n2 + (e - n2);
+        const unsigned r = e - 2u * n2, i = 1u + r / rim, x = r % rim;
+        size_t q;
+        if (x < (unsigned)km) q = x;
+        else if (x < 2u * km) q = (size_t)(jm - 1) * km + (x - km);
+        else if (x < 2u * km + jm) q = (size_t)(x - 2u * km) * km;
+        else q = (size_t)(x - 2u * km - jm) * km + (km - 1);
+        return (size_t)i * n2 + q;
+    };
+    for (size_t idx = (size_t)part * blockDim.x + threadIdx.x; idx < total; idx += 4 * stride) {
+        double v[4]; size_t o[4]; unsigned f[4]; bool ok[4];
+#pragma unroll
+        for (int n = 0; n < 4; n++) {
+            const size_t id = idx + n * stride;
+            ok[n] = id < total;
+            f[n] = ok[n] ? (unsigned)(id / per_field) : 0u;
+            o[n] = ok[n] ? offset((unsigned)(id - (size_t)f[n] * per_field)) : 0;
+            v[n] = ok[n] ? src[f[n]][o[n]] : 0.;
+        }
+#pragma unroll
+        for (int n = 0; n < 4; n++) if (ok[n]) dst[f[n]][o[n]] = v[n];
+    }
+}
+
 template <int NB>
 __global__ __launch_bounds__(320 * NB) void k_hyd_rk3d_ws(const HydWsParams* __restrict__ P, int nlev, int* __restrict__ progress,
-                                                      int* __restrict__ err) {
+                                                      int* __restrict__ err, const double* const* __restrict__ shell_src,
+                                                      double* const* __restrict__ shell_dst, int ncopy) {
     const HydWsArgs& a = P->a;
     const DevConst& K = P->K;
+    if (blockIdx.x >= gridDim.x - (unsigned)ncopy) {  // before anything a workgroup does together
+        copy_shell(shell_src, shell_dst, blockIdx.x - (gridDim.x - (unsigned)ncopy), (unsigned)ncopy, K.im, K.jm, K.km);
+        return;
+    }
     __shared__ Shared sh2[NB];
     extern __shared__ double tab[];  // [jm][4]: cos(the), rm^2 sin(the), its reciprocal, viscous v coefficient
     // all longitude blocks of a level on one XCD (they share cache lines; see k_rk_atm_ws.hip); level im-3 comes
@@ -658,35 +699,6 @@ __global__ __launch_bounds__(320 * NB) void k_hyd_rk3d_ws(const HydWsParams* __r
 #endif
 }
 
-// Copies the boundary shell (i, j or k on a face) of src to dst: the sweep writes interior points only.  Workgroups
-// 0 .. 2 A - 1 share the two whole levels, the others take B each of the interior levels' rim (rows j = 0, jm-1 and
-// columns k = 0, km-1); blockIdx.y is the field.
-__global__ void k_copy_shell(const double* const* __restrict__ src, double* const* __restrict__ dst, int im, int jm, int km,
-                             int* __restrict__ progress, int nprogress, int A, int B) {
-    if (blockIdx.x == 0 && blockIdx.y == 0)  // the sweep that follows starts from "no row finished"
-        for (int n = threadIdx.x; n < nprogress; n += blockDim.x) progress[n] = 0;
-    const double* __restrict__ s = src[blockIdx.y];
-    double* __restrict__ d = dst[blockIdx.y];
-    const int b = blockIdx.x;
-    if (b < 2 * A) {  // whole level
-        const size_t base = b < A ? 0 : (size_t)(im - 1) * jm * km;
-        const int part = b < A ? b : b - A;
-        for (int q = part * blockDim.x + threadIdx.x; q < jm * km; q += A * blockDim.x) d[base + q] = s[base + q];
-        return;
-    }
-    const int i = 1 + (b - 2 * A) / B, part = (b - 2 * A) % B;
-    const size_t base = (size_t)i * jm * km;
-    const int n = 2 * km + 2 * jm;
-    for (int e = part * blockDim.x + threadIdx.x; e < n; e += B * blockDim.x) {
-        size_t q;
-        if (e < km) q = e;
-        else if (e < 2 * km) q = (size_t)(jm - 1) * km + (e - km);
-        else if (e < 2 * km + jm) q = (size_t)(e - 2 * km) * km;
-        else q = (size_t)(e - 2 * km - jm) * km + (km - 1);
-        d[base + q] = s[base + q];
-    }
-}
-
 }  // namespace
 
 int HYD_WS_ENTRY(atomdev* h) {
@@ -728,11 +740,6 @@ int HYD_WS_ENTRY(atomdev* h) {
     ATOMDEV_REQUIRE(gx <= 128, "hyd_rk3d: more than 128 longitude blocks");
     ATOMDEV_REQUIRE(h->im >= 5, "hyd_rk3d: the grid needs at least 5 levels");
     if (int rc = atomdev_prof_begin(h)) return rc;
-    const int shell_a = (int)std::min<size_t>(64, (h->n2 + 1023) / 1024);
-    const int shell_b = (int)std::min<size_t>(8, (2 * (size_t)(h->km + h->jm) + 1023) / 1024);
-    hipLaunchKernelGGL(k_copy_shell, dim3(2 * shell_a + (h->im - 2) * shell_b, 5), dim3(256), 0, h->stream, &D->src[o][0], &D->dst[o][0],
-                       h->im, h->jm, h->km, D->progress, (int)gx, shell_a, shell_b);
-    ATOMDEV_TRY(hipGetLastError());
     const size_t lds = (size_t)h->jm * 4 * sizeof(double);
     // levels 1 .. im-2; two blocks of 64 lines per workgroup where one block each would be more workgroups than two per
     // compute unit (see the kernel)
@@ -740,10 +747,17 @@ int HYD_WS_ENTRY(atomdev* h) {
     ATOMDEV_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
     const char* force = std::getenv("ATOMDEV_HYD_BLOCKS_PER_GROUP");  // 1 or 2: A/B timing
     const bool two = force ? force[0] == '2' : (size_t)(h->im - 2) * gx > (size_t)2 * cus;
+    // the shell of the alternate buffers is refreshed by extra workgroups of the same launch: about 32 points a thread
+    const size_t shell = (size_t)5 * (2 * h->n2 + (size_t)(h->im - 2) * 2 * (h->km + h->jm));
+    const unsigned threads = two ? 640 : 320;
+    const unsigned ncopy = (unsigned)std::min<size_t>(256, std::max<size_t>(16, shell / ((size_t)threads * 32)));
+    const unsigned sweep_blocks = 8 * ((h->im - 2 + 7) / 8) * (two ? (gx + 1) / 2 : gx);
     if (two)
-        hipLaunchKernelGGL(k_hyd_rk3d_ws<2>, dim3(8 * ((h->im - 2 + 7) / 8) * ((gx + 1) / 2)), dim3(640), lds, h->stream, P, h->im - 2, D->progress, (int*)atomdev_kernel_error_word(h));
+        hipLaunchKernelGGL(k_hyd_rk3d_ws<2>, dim3(sweep_blocks + ncopy), dim3(640), lds, h->stream, P, h->im - 2, D->progress,
+                           (int*)atomdev_kernel_error_word(h), &D->src[o][0], &D->dst[o][0], (int)ncopy);
     else
-        hipLaunchKernelGGL(k_hyd_rk3d_ws<1>, dim3(8 * ((h->im - 2 + 7) / 8) * gx), dim3(320), lds, h->stream, P, h->im - 2, D->progress, (int*)atomdev_kernel_error_word(h));
+        hipLaunchKernelGGL(k_hyd_rk3d_ws<1>, dim3(sweep_blocks + ncopy), dim3(320), lds, h->stream, P, h->im - 2, D->progress,
+                           (int*)atomdev_kernel_error_word(h), &D->src[o][0], &D->dst[o][0], (int)ncopy);
     ATOMDEV_TRY(hipGetLastError());
     if (int rc = atomdev_prof_end(h)) return rc;
     for (int n = 0; n < 5; n++) { double* t = h->f[X[n]]; h->f[X[n]] = h->alt[X[n]]; h->alt[X[n]] = t; }
