@@ -277,10 +277,9 @@ __global__ __launch_bounds__(256) void k_atm_limit_prep(LimitFields f, const dou
 // Memory schedule of a step (row j): every load (xn, flags and source terms of row j+1, row j+2 of the
 // own variable) is issued at the top, the stores of row j-1's results in stage 2, the geometry table
 // of row j+1 is read from LDS in stage 4.  Nothing loaded in a step is used before the next step.
-template <int ROLE>
+template <int ROLE, bool limit>
 __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K, Shared& sh, const double* tab,
-                                           int bx, int i, double* __restrict__ X, const double* __restrict__ XN,
-                                           const bool limit) {
+                                           int bx, int i, double* __restrict__ X, const double* __restrict__ XN) {
     // limit: what goes to memory is the value as the limiter that follows the sweep in the model's loop would leave it;
     // the sweep itself goes on with the value it computed, as it does when the limiter runs afterwards.
     constexpr bool isV = ROLE == R_V, isU = ROLE == R_U, isT = ROLE == R_T, isC = ROLE == R_C, isW = ROLE == R_W;
@@ -614,7 +613,8 @@ __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K
     if constexpr (isV || isW) stg(O1, o0 - rowB, so1);
 }
 
-__global__ __launch_bounds__(512) void k_atm_rk3d_ws(const AtmWsParams* __restrict__ P, int limit) {
+template <bool LIMIT>
+__global__ __launch_bounds__(512) void k_atm_rk3d_ws(const AtmWsParams* __restrict__ P) {
     const AtmWsArgs& a = P->a;
     const DevConst& K = P->K;
     __shared__ Shared sh;
@@ -642,14 +642,14 @@ __global__ __launch_bounds__(512) void k_atm_rk3d_ws(const AtmWsParams* __restri
         __syncthreads();
     }
     switch (threadIdx.x >> 6) {
-        case R_U: sweep_role<R_U>(a, K, sh, tab, bx, i, a.u, a.un, limit != 0); break;
-        case R_V: sweep_role<R_V>(a, K, sh, tab, bx, i, a.v, a.vn, limit != 0); break;
-        case R_T: sweep_role<R_T>(a, K, sh, tab, bx, i, a.t, a.tn, limit != 0); break;
-        case R_W: sweep_role<R_W>(a, K, sh, tab, bx, i, a.w, a.wn, limit != 0); break;
-        case R_CO2: sweep_role<R_CO2>(a, K, sh, tab, bx, i, a.co2, a.co2n, limit != 0); break;
-        case R_ICE: sweep_role<R_ICE>(a, K, sh, tab, bx, i, a.ice, a.icen, limit != 0); break;
-        case R_CLOUD: sweep_role<R_CLOUD>(a, K, sh, tab, bx, i, a.cloud, a.cloudn, limit != 0); break;
-        default: sweep_role<R_C>(a, K, sh, tab, bx, i, a.c, a.cn, limit != 0); break;
+        case R_U: sweep_role<R_U, LIMIT>(a, K, sh, tab, bx, i, a.u, a.un); break;
+        case R_V: sweep_role<R_V, LIMIT>(a, K, sh, tab, bx, i, a.v, a.vn); break;
+        case R_T: sweep_role<R_T, LIMIT>(a, K, sh, tab, bx, i, a.t, a.tn); break;
+        case R_W: sweep_role<R_W, LIMIT>(a, K, sh, tab, bx, i, a.w, a.wn); break;
+        case R_CO2: sweep_role<R_CO2, LIMIT>(a, K, sh, tab, bx, i, a.co2, a.co2n); break;
+        case R_ICE: sweep_role<R_ICE, LIMIT>(a, K, sh, tab, bx, i, a.ice, a.icen); break;
+        case R_CLOUD: sweep_role<R_CLOUD, LIMIT>(a, K, sh, tab, bx, i, a.cloud, a.cloudn); break;
+        default: sweep_role<R_C, LIMIT>(a, K, sh, tab, bx, i, a.c, a.cn); break;
     }
 #ifdef ATOMDEV_EXP_WGTIME
     if ((threadIdx.x & 63) == 0) {
@@ -714,7 +714,10 @@ int ATM_WS_ENTRY(atomdev* h, bool limit, bool limit_before) {
     dim3 grid(8 * rounds * gx);
     ATOMDEV_REQUIRE(h->n3 * sizeof(double) < ((size_t)1 << 32), "atm_rk3d: field larger than 4 GiB");
     const size_t tab_bytes = (size_t)h->jm * 4 * sizeof(double);
-    hipLaunchKernelGGL(k_atm_rk3d_ws, grid, dim3(512), tab_bytes, h->stream, (const AtmWsParams*)h->ws_params, limit ? 1 : 0);
+    if (limit)
+        hipLaunchKernelGGL(k_atm_rk3d_ws<true>, grid, dim3(512), tab_bytes, h->stream, (const AtmWsParams*)h->ws_params);
+    else
+        hipLaunchKernelGGL(k_atm_rk3d_ws<false>, grid, dim3(512), tab_bytes, h->stream, (const AtmWsParams*)h->ws_params);
     ATOMDEV_TRY(hipGetLastError());
     if (int rc = atomdev_prof_end(h)) return rc;
     return 0;

@@ -606,9 +606,10 @@ __device__ __forceinline__ WaveJob wave_job(int wave) {
 // of every other level the rows j = 0, jm-1 and the columns k = 0, km-1.
 __device__ void copy_shell(const double* const* __restrict__ src, double* const* __restrict__ dst, unsigned part, unsigned parts,
                            int im, int jm, int km) {
+    // (32-bit index arithmetic: the host checks that five shells are fewer than 2^31 points)
     const unsigned n2 = (unsigned)jm * km, rim = 2u * km + 2u * jm;
     const unsigned per_field = 2u * n2 + (unsigned)(im - 2) * rim;
-    const size_t total = (size_t)5 * per_field, stride = (size_t)parts * blockDim.x;
+    const unsigned total = 5u * per_field, stride = parts * blockDim.x;
     auto offset = [&](unsigned e) -> size_t {
         if (e < n2) return e;
         if (e < 2u * n2) return (size_t)(im - 1) * n2 + (e - n2);
@@ -620,14 +621,14 @@ __device__ void copy_shell(const double* const* __restrict__ src, double* const*
         else q = (size_t)(x - 2u * km - jm) * km + (km - 1);
         return (size_t)i * n2 + q;
     };
-    for (size_t idx = (size_t)part * blockDim.x + threadIdx.x; idx < total; idx += 4 * stride) {
+    for (unsigned idx = part * blockDim.x + threadIdx.x; idx < total; idx += 4 * stride) {
         double v[4]; size_t o[4]; unsigned f[4]; bool ok[4];
 #pragma unroll
         for (int n = 0; n < 4; n++) {
-            const size_t id = idx + n * stride;
+            const unsigned id = idx + n * stride;
             ok[n] = id < total;
-            f[n] = ok[n] ? (unsigned)(id / per_field) : 0u;
-            o[n] = ok[n] ? offset((unsigned)(id - (size_t)f[n] * per_field)) : 0;
+            f[n] = ok[n] ? id / per_field : 0u;
+            o[n] = ok[n] ? offset(id - f[n] * per_field) : 0;
             v[n] = ok[n] ? src[f[n]][o[n]] : 0.;
         }
 #pragma unroll
@@ -749,6 +750,7 @@ int HYD_WS_ENTRY(atomdev* h) {
     const bool two = force ? force[0] == '2' : (size_t)(h->im - 2) * gx > (size_t)2 * cus;
     // the shell of the alternate buffers is refreshed by extra workgroups of the same launch: about 32 points a thread
     const size_t shell = (size_t)5 * (2 * h->n2 + (size_t)(h->im - 2) * 2 * (h->km + h->jm));
+    ATOMDEV_REQUIRE(shell + (size_t)4 * 256 * 640 < ((size_t)1 << 31), "hyd_rk3d: boundary shell too large for 32-bit indices");
     const unsigned threads = two ? 640 : 320;
     const unsigned ncopy = (unsigned)std::min<size_t>(256, std::max<size_t>(16, shell / ((size_t)threads * 32)));
     const unsigned sweep_blocks = 8 * ((h->im - 2 + 7) / 8) * (two ? (gx + 1) / 2 : gx);
