@@ -66,6 +66,98 @@ __global__ void k_atm_bc_radius(double* t, double* u, double* v, double* w, Fiel
     }
 }
 
+// BC_radius, BC_theta and BC_phi of the atmosphere (BC_Atm.cpp:39-150) in one launch.  The three fills read what
+// their predecessors wrote only on the faces themselves, so every boundary point works out the values it would have
+// read from the earlier fills from points that no fill writes (same formulas, same operands, same bits):
+//   after_radius: a point of level 0 or im-1 as BC_radius leaves it, from the levels next to it;
+//   after_theta:  a point of row 0 or jm-1 as BC_theta leaves it, from after_radius of rows 1, 2 / jm-2, jm-3;
+//   the seam columns k = 0, km-1 of rows 1 .. jm-2 as BC_phi leaves them, from after_radius of columns 1, 2, km-2, km-3.
+// One hazard is left: BC_theta on the seam columns reads rows 1, 2, jm-2, jm-3 of those columns as they were BEFORE
+// BC_phi rewrites them.  The seam columns of a variable therefore belong to one workgroup, which first takes the
+// row-0 / row-jm-1 values of both columns on every level into LDS and only then writes anything.
+struct BcAll { double* x[9]; double t_tropopause; };   // t u v w p_dyn c cloud ice co2
+enum { B_T = 0, B_U, B_V, B_W, B_P, B_C, B_CLOUD, B_ICE, B_CO2 };
+
+__device__ __forceinline__ double after_radius(const BcAll& b, int f, int i, size_t q, int im, size_t n2) {
+    const double* x = b.x[f];
+    if (i == 0) {
+        if (f == B_U) return 0.;
+        if (f == B_V || f == B_W) return c43 * x[n2 + q] - c13 * x[2 * n2 + q];
+        return x[q];
+    }
+    if (i == im - 1) {
+        if (f == B_T) return b.t_tropopause;
+        if (f == B_U || f == B_V || f == B_W) return 0.;
+        const size_t top = (size_t)(im - 1) * n2 + q;
+        return x[top - 3 * n2] - 3. * x[top - 2 * n2] + 3. * x[top - n2];
+    }
+    return x[(size_t)i * n2 + q];
+}
+__device__ __forceinline__ double after_theta(const BcAll& b, int f, int i, bool north, int k, int im, int jm, int km) {
+    if (f == B_V || f == B_W || f == B_P) return 0.;
+    const size_t n2 = (size_t)jm * km;
+    const int j1 = north ? 1 : jm - 2, j2 = north ? 2 : jm - 3;
+    return c43 * after_radius(b, f, i, (size_t)j1 * km + k, im, n2) - c13 * after_radius(b, f, i, (size_t)j2 * km + k, im, n2);
+}
+
+// the seam columns of row j on level i as BC_phi leaves them
+__device__ __forceinline__ void seam_fill(const BcAll& b, int f, int i, int j, int im, int jm, int km) {
+    const size_t n2 = (size_t)jm * km, q = (size_t)j * km;
+    const double lo = c43 * after_radius(b, f, i, q + 1, im, n2) - c13 * after_radius(b, f, i, q + 2, im, n2);
+    const double hi = c43 * after_radius(b, f, i, q + km - 2, im, n2) - c13 * after_radius(b, f, i, q + km - 3, im, n2);
+    const double m = (lo + hi) / 2.;
+    b.x[f][(size_t)i * n2 + q] = m; b.x[f][(size_t)i * n2 + q + km - 1] = m;
+}
+
+__global__ __launch_bounds__(256) void k_atm_bc_all(BcAll b, int im, int jm, int km, unsigned nb_r, unsigned nb_t, unsigned nb_p) {
+    extern __shared__ double corner[];  // seam workgroups: [4 * im]
+    const size_t n2 = (size_t)jm * km;
+    const int f = (int)blockIdx.y;      // the variable
+    double* x = b.x[f];
+    if (blockIdx.x < nb_r) {  // levels 0 and im-1 inside their rim
+        const unsigned id = blockIdx.x * blockDim.x + threadIdx.x;
+        if (id >= (unsigned)(jm - 2) * (km - 2)) return;
+        const int j = 1 + (int)(id / (unsigned)(km - 2)), k = 1 + (int)(id % (unsigned)(km - 2));
+        const size_t q = (size_t)j * km + k;
+        const bool bottom = f == B_U || f == B_V || f == B_W;  // BC_radius leaves the others alone on level 0
+        const double lo = bottom ? after_radius(b, f, 0, q, im, n2) : 0., up = after_radius(b, f, im - 1, q, im, n2);
+        if (bottom) x[q] = lo;
+        x[(size_t)(im - 1) * n2 + q] = up;
+        return;
+    }
+    if (blockIdx.x < nb_r + nb_t) {  // rows 0 and jm-1 between the seam columns, every level
+        const unsigned id = (blockIdx.x - nb_r) * blockDim.x + threadIdx.x;
+        if (id >= (unsigned)im * (km - 2)) return;
+        const int i = (int)(id / (unsigned)(km - 2)), k = 1 + (int)(id % (unsigned)(km - 2));
+        const double north = after_theta(b, f, i, true, k, im, jm, km), south = after_theta(b, f, i, false, k, im, jm, km);
+        x[idx3(jm, km, i, 0, k)] = north;
+        x[idx3(jm, km, i, jm - 1, k)] = south;
+        return;
+    }
+    if (blockIdx.x < nb_r + nb_t + nb_p) {  // seam columns of rows 3 .. jm-4: nothing in this launch reads them
+        const unsigned id = (blockIdx.x - nb_r - nb_t) * blockDim.x + threadIdx.x;
+        if (id >= (unsigned)im * (unsigned)(jm - 6)) return;
+        const int i = (int)(id / (unsigned)(jm - 6)), j = 3 + (int)(id % (unsigned)(jm - 6));
+        seam_fill(b, f, i, j, im, jm, km);
+        return;
+    }
+    // the seam columns of the variable on the rows that BC_theta reads there (1, 2, jm-3, jm-2), and their ends
+    for (int c = threadIdx.x; c < 4 * im; c += blockDim.x) {
+        const int i = c >> 2, k = (c & 1) ? km - 1 : 0;
+        corner[c] = after_theta(b, f, i, (c & 2) == 0, k, im, jm, km);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 4 * im; c += blockDim.x) {
+        const int i = c >> 2, k = (c & 1) ? km - 1 : 0, j = (c & 2) == 0 ? 0 : jm - 1;
+        x[idx3(jm, km, i, j, k)] = corner[c];
+    }
+    for (int e = threadIdx.x; e < 4 * im; e += blockDim.x) {
+        const int i = e >> 2, r = e & 3, j = r == 0 ? 1 : (r == 1 ? 2 : (r == 2 ? jm - 3 : jm - 2));
+        if (r >= 2 && j <= 2) continue;  // (cannot happen: the library's grids have at least 7 rows)
+        seam_fill(b, f, i, j, im, jm, km);
+    }
+}
+
 // BC_Hydrosphere::RB_radius, hydrosphere/BC_Hyd.cpp:38-83
 __global__ void k_hyd_bc_radius(double* t, double* u, double* v, double* w, double* p_dyn, double* c, double ta, double ca,
                                 int im, int jm, int km) {
@@ -310,6 +402,21 @@ extern "C" int atomdev_atm_bc_radius(atomdev_t* h) {
                        h->f[ATOMDEV_V], h->f[ATOMDEV_W], ex, h->p.t_tropopause, h->im, h->jm, h->km);
     ATOMDEV_TRY(hipGetLastError());
     return 0;
+}
+
+extern "C" int atomdev_atm_bc_radius_theta_phi(atomdev_t* h) {
+    ATOMDEV_REQUIRE(h && h->model == ATOMDEV_ATM, "atomdev_atm_bc_radius_theta_phi: not an atmosphere handle");
+    ATOMDEV_TRY(hipSetDevice(h->device));
+    static const int ids[9] = { ATOMDEV_T, ATOMDEV_U, ATOMDEV_V, ATOMDEV_W, ATOMDEV_P_DYN, ATOMDEV_C, ATOMDEV_CLOUD, ATOMDEV_ICE, ATOMDEV_CO2 };
+    BcAll b;
+    for (int f = 0; f < 9; f++) b.x[f] = h->f[ids[f]];
+    b.t_tropopause = h->p.t_tropopause;
+    const unsigned nb_r = (unsigned)nb((size_t)(h->jm - 2) * (h->km - 2)), nb_t = (unsigned)nb((size_t)h->im * (h->km - 2));
+    ATOMDEV_REQUIRE(h->jm >= 7 && h->km >= 7, "atomdev_atm_bc_radius_theta_phi: needs at least 7 rows and 7 columns");
+    const unsigned nb_p = (unsigned)nb((size_t)h->im * (h->jm - 6));
+    hipLaunchKernelGGL(k_atm_bc_all, dim3(nb_r + nb_t + nb_p + 1, 9), dim3(TPB), (size_t)4 * h->im * sizeof(double), h->stream, b,
+                       h->im, h->jm, h->km, nb_r, nb_t, nb_p);
+    return atomdev_check(hipGetLastError(), "k_atm_bc_all");
 }
 
 extern "C" int atomdev_atm_bc_theta(atomdev_t* h) {

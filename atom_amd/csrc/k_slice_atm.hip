@@ -93,9 +93,7 @@ int run_3d_loop(atomdev_t* h, const atomdev_atm_loop* L, atomdev_atm_loop_state*
     for (int p = 1; p <= L->pressure_iter_max; p++) {
         for (int v = 1; v <= L->velocity_iter_max; v++) {
             if (L->queries) { res = 0.; loc[0] = loc[1] = loc[2] = 0; STEP(atomdev_atm_residuum3d(h, &res, loc)); S->residuum[0] = res; }
-            STEP(atomdev_atm_bc_radius(h));
-            STEP(atomdev_atm_bc_theta(h));
-            STEP(atomdev_atm_bc_phi(h));
+            STEP(atomdev_atm_bc_radius_theta_phi(h));  // :782-784 in one launch
             if (L->column_physics && v % 2 == 0) STEP(atomdev_atm_ice_water_saturation_adjustment(h, &S->q_v_hyp));  // :787-789
             STEP(atomdev_atm_limit_ground_rk3d_limit(h));  // :791, :793, :809 and the limiter of :825 in one
             if (L->column_physics && L->RadiationModel == 1) STEP(atomdev_atm_radiation_multi_layer(h, &L->radiation, L->i_trop));  // :828-831

@@ -37,8 +37,9 @@ HBM_PEAK_GBS = 8000.0
 
 ATM_STEP = ["atm_bc_radius", "atm_bc_theta", "atm_bc_phi", "atm_value_limitation", "atm_solid_ground",
             "atm_rk3d", "atm_value_limitation", "move3d"]
-# on the device limiter, solid ground, sweep and limiter are one call (atomdev_atm_limit_ground_rk3d_limit: same bits)
-ATM_DEV_STEP = ["atm_bc_radius", "atm_bc_theta", "atm_bc_phi", "atm_limit_ground_rk3d_limit", "move3d"]
+# on the device the three boundary fills are one call (atomdev_atm_bc_radius_theta_phi) and so are limiter, solid ground,
+# sweep and limiter (atomdev_atm_limit_ground_rk3d_limit): same bits as the calls one by one
+ATM_DEV_STEP = ["atm_bc_radius_theta_phi", "atm_limit_ground_rk3d_limit", "move3d"]
 HYD_STEP = ["hyd_bc_radius", "hyd_bc_theta", "hyd_bc_phi", "hyd_pressure_density", "hyd_value_limitation", "hyd_rk3d",
             "hyd_solid_ground", "move3d"]
 
@@ -347,7 +348,7 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic fields (numpy PCG64 seed 1234+rank), real 0 Ma land mask",
-            "config": {"workload": "atmosphere 3-D hot-path iteration (BC fills, limiter, solid ground, fused RK4+RHS sweep, "
+            "config": {"workload": "atmosphere 3-D hot-path iteration (BC fills - one call -, limiter, solid ground, fused RK4+RHS sweep, "
                                    "limiter - the four as one call: first limiter in the sweep's preparing kernel, last one in its stores -, "
                                    "old->new copy; pressure Jacobi every 2nd step), %dx%dx%d, one slice per GPU" % (IM, JM, KM),
                        "grid": [IM, JM, KM], "updates_per_step_per_gpu": UPDATES, "parallelism": "independent slices"},

@@ -132,6 +132,9 @@ int atomdev_move_data_to_new_arrays(atomdev_t* h, int level);
 int atomdev_atm_bc_radius(atomdev_t* h);
 int atomdev_atm_bc_theta(atomdev_t* h);
 int atomdev_atm_bc_phi(atomdev_t* h);
+/* The three of them in the order the 3-D loop calls them (atmosphere/cAtmosphereModel.cpp:782-784) as one launch:
+ * every boundary point works out what it would have read from the earlier fills itself.  Same bits as the three calls. */
+int atomdev_atm_bc_radius_theta_phi(atomdev_t* h);
 /* BC_Thermo::Value_Limitation_Atm (atmosphere/BC_Thermo.cpp:3235-3275) */
 int atomdev_atm_value_limitation(atomdev_t* h);
 /* BC_Bathymetry_Atmosphere::BC_SolidGround (atmosphere/BC_Bath_Atm.cpp:94-119) */

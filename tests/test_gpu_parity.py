@@ -854,6 +854,33 @@ def test_atm_rk3d_limited_is_sweep_then_limiter(dims, seed, real_mask):
     assert hit["u"] > 0   # the limiter had something to do on interior points
 
 
+@pytest.mark.parametrize("dims,seed", [((7, 7, 7), 71), ((5, 8, 9), 72), ((9, 21, 70), 73), ((70, 9, 13), 74), ((41, 181, 361), 75)])
+def test_atm_bc_fills_in_one_launch_same_bits(dims, seed):
+    """atomdev_atm_bc_radius_theta_phi against atomdev_atm_bc_radius, _bc_theta, _bc_phi: every field bit for bit, twice in
+    a row (the second call starts from filled faces), from fields whose faces hold values the fills must replace."""
+    im, jm, km = dims
+    p = H.default_params(H.ATM, im, jm, km)
+    f, g = H.make_inputs(H.ATM, im, jm, km, seed, "blobs", p)
+    f = {k: f[k] for k in H.ATM_FIELDS}
+    out = []
+    for fused in (False, True):
+        d = atom_amd.DeviceModel(H.ATM, im, jm, km, atom_amd.Params.from_buffer_copy(bytes(p)))
+        d.upload_all(f, g)
+        for _ in range(2):
+            if fused:
+                d.op("atm_bc_radius_theta_phi")
+            else:
+                d.op("atm_bc_radius"); d.op("atm_bc_theta"); d.op("atm_bc_phi")
+        out.append({k: d.download(k) for k in H.ATM_FIELDS})
+        d.close()
+    changed = 0
+    for k in H.ATM_FIELDS:
+        if k != "RESIDUUM":
+            assert np.array_equal(out[0][k].view(np.int64), out[1][k].view(np.int64)), (k, H.max_rel_err(out[1][k], out[0][k]))
+            changed += int((out[0][k] != f[k]).sum())
+    assert changed > 0
+
+
 def test_residuum_scan_adversarial_fields():
     """The residuum scan (signed store, unsigned compare) on fields built to stress its jump logic:
     many sign changes, long runs of negative values, exact ties and zeros, magnitudes that shrink or
