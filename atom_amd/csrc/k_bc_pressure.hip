@@ -6,6 +6,8 @@
 // one launch never read what another thread of that launch writes; the
 // reference's r -> theta -> phi order is kept as launch order on the handle's
 // stream, so edges and corners receive the same values.
+#include <cstdlib>
+
 #include "atomdev_internal.h"
 
 namespace {
@@ -14,6 +16,7 @@ constexpr int TPB = 256;
 constexpr double c43 = 4. / 3., c13 = 1. / 3.;
 
 struct Fields { double* p[9]; int n; };
+struct PtrList3 { double* p[3]; };
 
 enum { FILL_NEUMANN = 0, FILL_ZERO = 1 };
 struct ThetaFill { double* p[9]; int mode[9]; int n; };
@@ -196,6 +199,75 @@ __global__ void k_p_fill_r(double* p, int im, int jm, int km) {
     p[top] = c43 * p[top - n2] - c13 * p[top - 2 * n2];
 }
 
+// ---- the fills around the pressure step, each group of three in one launch ----
+// Before the sweep: aux_u/v/w radially (k_aux_fill_r), then their theta rows, then the phi seam of EVERY row
+// (Pressure_Atm.cpp:47-101).  After it: p_dyn radially (k_p_fill_r), then the phi seam of every row, then the theta rows
+// of every column (Pressure_Atm.cpp:162-186).  As in k_atm_bc_all a face point works out what it would have read from
+// the earlier fills; here nothing that a later fill reads is rewritten by an earlier one except where the later fill
+// overwrites it anyway, so there is no hazard and every point belongs to one thread.
+enum { AUX_FILLS = 0, P_FILLS = 1 };
+template <int WHICH>
+__device__ __forceinline__ double pr_after_r(const double* __restrict__ x, bool zero_faces, int i, size_t q, int im, size_t n2) {
+    if (i == 0) {
+        if (WHICH == AUX_FILLS) return zero_faces ? 0. : c43 * x[n2 + q] - c13 * x[2 * n2 + q];
+        return x[3 * n2 + q] - 3. * x[2 * n2 + q] + 3. * x[n2 + q];
+    }
+    if (i == im - 1) {
+        const size_t top = (size_t)(im - 1) * n2 + q;
+        if (WHICH == AUX_FILLS && zero_faces) return 0.;
+        return c43 * x[top - n2] - c13 * x[top - 2 * n2];
+    }
+    return x[(size_t)i * n2 + q];
+}
+template <int WHICH>
+__global__ __launch_bounds__(256) void k_pressure_fills(PtrList3 fields, int im, int jm, int km, unsigned nb_r, unsigned nb_t) {
+    double* __restrict__ x = fields.p[blockIdx.y];
+    const bool zf = WHICH == AUX_FILLS && blockIdx.y == 0;  // aux_u is zero on both radial faces
+    const size_t n2 = (size_t)jm * km;
+    auto R = [&](int i, int j, int k) { return pr_after_r<WHICH>(x, zf, i, (size_t)j * km + k, im, n2); };
+    // an interior column k of row j after the radial and (aux only: before the seam) the theta fill
+    auto V = [&](int i, int j, int k) {
+        if (WHICH == AUX_FILLS && (j == 0 || j == jm - 1)) {
+            const int j1 = j == 0 ? 1 : jm - 2, j2 = j == 0 ? 2 : jm - 3;
+            return c43 * R(i, j1, k) - c13 * R(i, j2, k);
+        }
+        return R(i, j, k);
+    };
+    auto seam = [&](int i, int j) {  // what BC_phi's rule makes of row j
+        const double lo = c43 * V(i, j, 1) - c13 * V(i, j, 2), hi = c43 * V(i, j, km - 2) - c13 * V(i, j, km - 3);
+        return (lo + hi) / 2.;
+    };
+    if (blockIdx.x < nb_r) {  // levels 0 and im-1 inside their rim
+        const unsigned id = blockIdx.x * blockDim.x + threadIdx.x;
+        if (id >= (unsigned)(jm - 2) * (km - 2)) return;
+        const int j = 1 + (int)(id / (unsigned)(km - 2)), k = 1 + (int)(id % (unsigned)(km - 2));
+        const double lo = R(0, j, k), up = R(im - 1, j, k);
+        x[idx3(jm, km, 0, j, k)] = lo; x[idx3(jm, km, im - 1, j, k)] = up;
+        return;
+    }
+    if (blockIdx.x < nb_r + nb_t) {  // rows 0 and jm-1: between the seam columns (aux), every column (p_dyn: the theta fill is last)
+        const unsigned kn = WHICH == AUX_FILLS ? (unsigned)(km - 2) : (unsigned)km;
+        const unsigned id = (blockIdx.x - nb_r) * blockDim.x + threadIdx.x;
+        if (id >= (unsigned)im * kn) return;
+        const int i = (int)(id / kn), k = (WHICH == AUX_FILLS ? 1 : 0) + (int)(id % kn);
+        double north, south;
+        if (WHICH == P_FILLS && (k == 0 || k == km - 1)) {
+            north = c43 * seam(i, 1) - c13 * seam(i, 2); south = c43 * seam(i, jm - 2) - c13 * seam(i, jm - 3);
+        } else {
+            north = c43 * R(i, 1, k) - c13 * R(i, 2, k); south = c43 * R(i, jm - 2, k) - c13 * R(i, jm - 3, k);
+        }
+        x[idx3(jm, km, i, 0, k)] = north; x[idx3(jm, km, i, jm - 1, k)] = south;
+        return;
+    }
+    // the seam columns: every row (aux), the rows between the theta rows (p_dyn)
+    const unsigned jn = WHICH == AUX_FILLS ? (unsigned)jm : (unsigned)(jm - 2);
+    const unsigned id = (blockIdx.x - nb_r - nb_t) * blockDim.x + threadIdx.x;
+    if (id >= (unsigned)im * jn) return;
+    const int i = (int)(id / jn), j = (WHICH == AUX_FILLS ? 0 : 1) + (int)(id % jn);
+    const double m = seam(i, j);
+    x[idx3(jm, km, i, j, 0)] = m; x[idx3(jm, km, i, j, km - 1)] = m;
+}
+
 // Interior Jacobi sweep: Pressure_Atm.cpp:104-160 / Pressure_Hyd.cpp:114-173.  Reads
 // p_dynn (old), writes p_dyn.  hyd: aux_v / aux_w are read at level im-1 for every i
 // (Pressure_Hyd.cpp:137-163), the radial land test is h[i+1] == 0., the western
@@ -333,11 +405,20 @@ int pressure3d(atomdev* h, bool hyd) {
     static const int AUX[3] = { ATOMDEV_AUX_U, ATOMDEV_AUX_V, ATOMDEV_AUX_W };
     static const int NE3[3] = { FILL_NEUMANN, FILL_NEUMANN, FILL_NEUMANN };
     const size_t n2 = h->n2;
-    hipLaunchKernelGGL(k_aux_fill_r, dim3(nb(n2)), dim3(TPB), 0, h->stream, h->f[ATOMDEV_AUX_U], h->f[ATOMDEV_AUX_V],
-                       h->f[ATOMDEV_AUX_W], h->im, h->jm, h->km);
-    ATOMDEV_TRY(hipGetLastError());
-    if (int rc = fill_theta(h, AUX, NE3, 3, 0, h->im)) return rc;
-    if (int rc = fill_phi(h, AUX, 3, 0, h->im, 0, h->jm)) return rc;
+    const bool one_launch = h->jm >= 7 && h->km >= 7 && h->im >= 5 && !getenv("ATOMDEV_PRESSURE_FILLS_ONE_BY_ONE");
+    const unsigned nb_r = nb((size_t)(h->jm - 2) * (h->km - 2));
+    if (one_launch) {
+        PtrList3 aux = { { h->f[ATOMDEV_AUX_U], h->f[ATOMDEV_AUX_V], h->f[ATOMDEV_AUX_W] } };
+        const unsigned nb_t = nb((size_t)h->im * (h->km - 2)), nb_s = nb((size_t)h->im * h->jm);
+        hipLaunchKernelGGL(k_pressure_fills<AUX_FILLS>, dim3(nb_r + nb_t + nb_s, 3), dim3(TPB), 0, h->stream, aux, h->im, h->jm, h->km, nb_r, nb_t);
+        ATOMDEV_TRY(hipGetLastError());
+    } else {
+        hipLaunchKernelGGL(k_aux_fill_r, dim3(nb(n2)), dim3(TPB), 0, h->stream, h->f[ATOMDEV_AUX_U], h->f[ATOMDEV_AUX_V],
+                           h->f[ATOMDEV_AUX_W], h->im, h->jm, h->km);
+        ATOMDEV_TRY(hipGetLastError());
+        if (int rc = fill_theta(h, AUX, NE3, 3, 0, h->im)) return rc;
+        if (int rc = fill_phi(h, AUX, 3, 0, h->im, 0, h->jm)) return rc;
+    }
     dim3 grid((h->km - 2 + 127) / 128, h->jm - 2, h->im - 2);
     const double rho = hyd ? h->p.r_0_water : h->p.r_air;
     if (hyd)
@@ -348,6 +429,12 @@ int pressure3d(atomdev* h, bool hyd) {
                            h->f[ATOMDEV_AUX_U], h->f[ATOMDEV_AUX_V], h->f[ATOMDEV_AUX_W], h->flags, h->rad, h->sinthe, rho, h->k);
     ATOMDEV_TRY(hipGetLastError());
     // p_dyn faces: r, then phi (all j), then theta (Pressure_Atm.cpp:162-186)
+    if (one_launch) {
+        PtrList3 pd = { { h->f[ATOMDEV_P_DYN], nullptr, nullptr } };
+        const unsigned nb_t = nb((size_t)h->im * h->km), nb_s = nb((size_t)h->im * (h->jm - 2));
+        hipLaunchKernelGGL(k_pressure_fills<P_FILLS>, dim3(nb_r + nb_t + nb_s, 1), dim3(TPB), 0, h->stream, pd, h->im, h->jm, h->km, nb_r, nb_t);
+        return atomdev_check(hipGetLastError(), "k_pressure_fills");
+    }
     hipLaunchKernelGGL(k_p_fill_r, dim3(nb(n2)), dim3(TPB), 0, h->stream, h->f[ATOMDEV_P_DYN], h->im, h->jm, h->km);
     ATOMDEV_TRY(hipGetLastError());
     static const int PD[1] = { ATOMDEV_P_DYN };

@@ -881,6 +881,32 @@ def test_atm_bc_fills_in_one_launch_same_bits(dims, seed):
     assert changed > 0
 
 
+@pytest.mark.parametrize("model,dims,seed", [(H.ATM, (7, 7, 7), 81), (H.HYD, (5, 8, 9), 82), (H.ATM, (9, 21, 70), 83),
+                                             (H.HYD, (41, 43, 19), 84), (H.ATM, (41, 181, 361), 85), (H.HYD, (41, 181, 361), 86)])
+def test_pressure_fills_in_one_launch_same_bits(model, dims, seed, monkeypatch):
+    """The pressure step with its six boundary fills as two launches (the default) against the same step with the fills
+    one by one (ATOMDEV_PRESSURE_FILLS_ONE_BY_ONE): p_dyn and aux_u/v/w bit for bit, faces included."""
+    im, jm, km = dims
+    p = H.default_params(model, im, jm, km)
+    f, g = H.make_inputs(model, im, jm, km, seed, "blobs", p)
+    names = H.ATM_FIELDS if model == H.ATM else H.HYD_FIELDS
+    f = {k: f[k] for k in names}
+    op = "atm_pressure3d" if model == H.ATM else "hyd_pressure3d"
+    out = []
+    for one_by_one in (True, False):
+        if one_by_one:
+            monkeypatch.setenv("ATOMDEV_PRESSURE_FILLS_ONE_BY_ONE", "1")
+        else:
+            monkeypatch.delenv("ATOMDEV_PRESSURE_FILLS_ONE_BY_ONE", raising=False)
+        d = atom_amd.DeviceModel(model, im, jm, km, atom_amd.Params.from_buffer_copy(bytes(p)))
+        d.upload_all(f, g)
+        d.op(op); d.move_data_to_new_arrays(-1); d.op(op)
+        out.append({k: d.download(k) for k in ("P_DYN", "AUX_U", "AUX_V", "AUX_W")})
+        d.close()
+    for k in out[0]:
+        assert np.array_equal(out[0][k].view(np.int64), out[1][k].view(np.int64)), (k, H.max_rel_err(out[1][k], out[0][k]))
+
+
 def test_residuum_scan_adversarial_fields():
     """The residuum scan (signed store, unsigned compare) on fields built to stress its jump logic:
     many sign changes, long runs of negative values, exact ties and zeros, magnitudes that shrink or
