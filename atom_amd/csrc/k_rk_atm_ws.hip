@@ -183,6 +183,11 @@ __device__ __forceinline__ double rcp_refined(double b) {
 // a / b for operands that need no range scaling (finite, normal, quotient far from overflow and
 // underflow): the compiler's own sequence without its scaling and fix-up instructions.
 __device__ __forceinline__ double fdiv_normal(double a, double b) { return DIVC(a, b, rcp_refined(b)); }
+// 1/b from the hardware estimate (4.6e-8) and one Newton step: 2.2e-15 (tolerance form, where the chain waits for it)
+__device__ __forceinline__ double rcp_one_step(double b) {
+    const double y = __builtin_amdgcn_rcp(b);
+    return __builtin_fma(y, __builtin_fma(-b, y, 1.0), y);
+}
 
 struct ThetaK { double dthe, i_dthe, two_dthe, i_two_dthe, dthe2, i_dthe2; };
 
@@ -376,9 +381,10 @@ __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K
     // what the other waves need of a new t or c value (RHS_Atm.cpp:385, 390-404)
     constexpr bool AFFINE = ATM_WS_AFFINE;
     const bool t_feeds_c = (i == 1);  // affine form: the dry density has one reader, the c wave of level 1
+    double k12 = k1 * k2; PIN(k12);
     auto publish_t = [&](int buf, double tval, double ph) {
         if constexpr (AFFINE) {
-            if (t_feeds_c) sh.rdry[buf][lane] = fdiv_normal(ph, k1 * (tval * k2));
+            if (t_feeds_c) sh.rdry[buf][lane] = ph * rcp_one_step(k12 * tval);  // level 1 is the last to finish: every step of this chain counts
         } else {
             const double r_dry = fdiv_normal(ph, k1 * (tval * k2));
             sh.rdry[buf][lane] = r_dry;
