@@ -161,6 +161,64 @@ __global__ __launch_bounds__(256) void k_atm_bc_all(BcAll b, int im, int jm, int
     }
 }
 
+// RB_radius, RB_theta and RB_phi of the hydrosphere (BC_Hyd.cpp:38-158) in one launch, the same way.  Here the phi fill
+// comes last and takes every row, so nothing a later fill reads is rewritten by an earlier one except where the later
+// one overwrites it anyway: no hazard, every point belongs to one thread.
+struct BcHyd { double* x[6]; double ta, ca; };   // t u v w p_dyn c
+enum { HB_T = 0, HB_U, HB_V, HB_W, HB_P, HB_C };
+__device__ __forceinline__ double hyd_after_radius(const BcHyd& b, int f, int i, size_t q, int im, size_t n2) {
+    const double* x = b.x[f];
+    if (i == 0) {
+        if (f == HB_U) return c43 * x[n2 + q] - c13 * x[2 * n2 + q];
+        if (f == HB_T) return b.ta;
+        if (f == HB_C) return b.ca;
+        return 0.;  // v, w, p_dyn
+    }
+    if (i == im - 1) {
+        const size_t top = (size_t)(im - 1) * n2 + q;
+        if (f == HB_V || f == HB_W) return c43 * x[top - n2] - c13 * x[top - 2 * n2];
+        if (f == HB_U || f == HB_C) return x[top - 3 * n2] - 3. * x[top - 2 * n2] + 3. * x[top - n2];
+        return x[top];  // t, p_dyn: left alone on the surface level
+    }
+    return x[(size_t)i * n2 + q];
+}
+__global__ __launch_bounds__(256) void k_hyd_bc_all(BcHyd b, int im, int jm, int km, unsigned nb_r, unsigned nb_t) {
+    const size_t n2 = (size_t)jm * km;
+    const int f = (int)blockIdx.y;
+    double* x = b.x[f];
+    auto R = [&](int i, int j, int k) { return hyd_after_radius(b, f, i, (size_t)j * km + k, im, n2); };
+    auto theta = [&](int i, bool north, int k) {  // RB_theta: v and w are zero on the two rows, the others extrapolated
+        if (f == HB_V || f == HB_W) return 0.;
+        const int j1 = north ? 1 : jm - 2, j2 = north ? 2 : jm - 3;
+        return c43 * R(i, j1, k) - c13 * R(i, j2, k);
+    };
+    auto V = [&](int i, int j, int k) { return j == 0 ? theta(i, true, k) : (j == jm - 1 ? theta(i, false, k) : R(i, j, k)); };
+    if (blockIdx.x < nb_r) {  // levels 0 and im-1 inside their rim
+        const unsigned id = blockIdx.x * blockDim.x + threadIdx.x;
+        if (id >= (unsigned)(jm - 2) * (km - 2)) return;
+        const int j = 1 + (int)(id / (unsigned)(km - 2)), k = 1 + (int)(id % (unsigned)(km - 2));
+        const double lo = R(0, j, k), up = R(im - 1, j, k);
+        x[idx3(jm, km, 0, j, k)] = lo;
+        if (f != HB_T && f != HB_P) x[idx3(jm, km, im - 1, j, k)] = up;
+        return;
+    }
+    if (blockIdx.x < nb_r + nb_t) {  // rows 0 and jm-1 between the seam columns, every level
+        const unsigned id = (blockIdx.x - nb_r) * blockDim.x + threadIdx.x;
+        if (id >= (unsigned)im * (km - 2)) return;
+        const int i = (int)(id / (unsigned)(km - 2)), k = 1 + (int)(id % (unsigned)(km - 2));
+        const double north = theta(i, true, k), south = theta(i, false, k);
+        x[idx3(jm, km, i, 0, k)] = north; x[idx3(jm, km, i, jm - 1, k)] = south;
+        return;
+    }
+    // the seam columns of every row
+    const unsigned id = (blockIdx.x - nb_r - nb_t) * blockDim.x + threadIdx.x;
+    if (id >= (unsigned)im * (unsigned)jm) return;
+    const int i = (int)(id / (unsigned)jm), j = (int)(id % (unsigned)jm);
+    const double lo = c43 * V(i, j, 1) - c13 * V(i, j, 2), hi = c43 * V(i, j, km - 2) - c13 * V(i, j, km - 3);
+    const double m = (lo + hi) / 2.;
+    x[idx3(jm, km, i, j, 0)] = m; x[idx3(jm, km, i, j, km - 1)] = m;
+}
+
 // BC_Hydrosphere::RB_radius, hydrosphere/BC_Hyd.cpp:38-83
 __global__ void k_hyd_bc_radius(double* t, double* u, double* v, double* w, double* p_dyn, double* c, double ta, double ca,
                                 int im, int jm, int km) {
@@ -530,6 +588,19 @@ extern "C" int atomdev_hyd_bc_radius(atomdev_t* h) {
                        h->f[ATOMDEV_V], h->f[ATOMDEV_W], h->f[ATOMDEV_P_DYN], h->f[ATOMDEV_C], h->p.ta, h->p.ca, h->im, h->jm, h->km);
     ATOMDEV_TRY(hipGetLastError());
     return 0;
+}
+
+extern "C" int atomdev_hyd_bc_radius_theta_phi(atomdev_t* h) {
+    ATOMDEV_REQUIRE(h && h->model == ATOMDEV_HYD, "atomdev_hyd_bc_radius_theta_phi: not a hydrosphere handle");
+    ATOMDEV_REQUIRE(h->jm >= 7 && h->km >= 7 && h->im >= 5, "atomdev_hyd_bc_radius_theta_phi: needs at least 5 levels, 7 rows and 7 columns");
+    ATOMDEV_TRY(hipSetDevice(h->device));
+    static const int ids[6] = { ATOMDEV_T, ATOMDEV_U, ATOMDEV_V, ATOMDEV_W, ATOMDEV_P_DYN, ATOMDEV_C };
+    BcHyd b;
+    for (int f = 0; f < 6; f++) b.x[f] = h->f[ids[f]];
+    b.ta = h->p.ta; b.ca = h->p.ca;
+    const unsigned nb_r = nb((size_t)(h->jm - 2) * (h->km - 2)), nb_t = nb((size_t)h->im * (h->km - 2)), nb_s = nb((size_t)h->im * h->jm);
+    hipLaunchKernelGGL(k_hyd_bc_all, dim3(nb_r + nb_t + nb_s, 6), dim3(TPB), 0, h->stream, b, h->im, h->jm, h->km, nb_r, nb_t);
+    return atomdev_check(hipGetLastError(), "k_hyd_bc_all");
 }
 
 extern "C" int atomdev_hyd_bc_theta(atomdev_t* h) {

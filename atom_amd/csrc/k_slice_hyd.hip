@@ -88,9 +88,7 @@ extern "C" int atomdev_hyd_run_time_slices(atomdev_t* const* handles, const atom
     for (int p = 1; p <= s0.pressure_iter_max; p++) {
         for (int v = 1; v <= s0.velocity_iter_max; v++) {
             EACH(s.queries ? (before[m] = 0., atomdev_hyd_residuum3d(h, &before[m], &loc[3 * m])) : 0);
-            EACH(atomdev_hyd_bc_radius(h));
-            EACH(atomdev_hyd_bc_theta(h));
-            EACH(atomdev_hyd_bc_phi(h));
+            EACH(atomdev_hyd_bc_radius_theta_phi(h));  // RB_radius, RB_theta, RB_phi in one launch
             EACH(atomdev_hyd_pressure_density(h));
             EACH(atomdev_hyd_value_limitation(h));
             EACH(atomdev_hyd_rk3d(h));

@@ -93,7 +93,7 @@ class AtomDevError(RuntimeError):
 
 _OPS = ["atm_bc_radius", "atm_bc_theta", "atm_bc_phi", "atm_bc_radius_theta_phi", "atm_value_limitation", "atm_solid_ground",
         "atm_rk3d", "atm_rk3d_limited", "atm_limit_ground_rk3d_limit", "atm_rk2d", "atm_pressure3d", "atm_pressure2d",
-        "hyd_bc_radius", "hyd_bc_theta", "hyd_bc_phi", "hyd_value_limitation", "hyd_solid_ground",
+        "hyd_bc_radius", "hyd_bc_theta", "hyd_bc_phi", "hyd_bc_radius_theta_phi", "hyd_value_limitation", "hyd_solid_ground",
         "hyd_rk3d", "hyd_rk2d", "hyd_pressure3d", "hyd_pressure2d", "hyd_pressure_density", "atm_latent_heat", "hyd_run_data"]
 
 _lib = None

@@ -40,8 +40,8 @@ ATM_STEP = ["atm_bc_radius", "atm_bc_theta", "atm_bc_phi", "atm_value_limitation
 # on the device the three boundary fills are one call (atomdev_atm_bc_radius_theta_phi) and so are limiter, solid ground,
 # sweep and limiter (atomdev_atm_limit_ground_rk3d_limit): same bits as the calls one by one
 ATM_DEV_STEP = ["atm_bc_radius_theta_phi", "atm_limit_ground_rk3d_limit", "move3d"]
-HYD_STEP = ["hyd_bc_radius", "hyd_bc_theta", "hyd_bc_phi", "hyd_pressure_density", "hyd_value_limitation", "hyd_rk3d",
-            "hyd_solid_ground", "move3d"]
+HYD_STEP = ["hyd_bc_radius_theta_phi", "hyd_pressure_density", "hyd_value_limitation", "hyd_rk3d",
+            "hyd_solid_ground", "move3d"]   # (the three boundary fills as one call: same bits)
 
 
 def make_slab(H, atom_amd, dist, rank, world, device, seed, backend):

@@ -424,6 +424,9 @@ int atomdev_selftest_raise_kernel_error(atomdev_t* h);
 int atomdev_hyd_bc_radius(atomdev_t* h);
 int atomdev_hyd_bc_theta(atomdev_t* h);
 int atomdev_hyd_bc_phi(atomdev_t* h);
+/* The three of them in the order the 3-D loop calls them (hydrosphere/cHydrosphereModel.cpp:443-445) as one launch, like
+ * atomdev_atm_bc_radius_theta_phi.  Same bits as the three calls. */
+int atomdev_hyd_bc_radius_theta_phi(atomdev_t* h);
 /* BC_Thermohalin::Value_Limitation_Hyd (hydrosphere/BC_Thermohalin.cpp:699-722) */
 int atomdev_hyd_value_limitation(atomdev_t* h);
 /* BC_Bathymetry_Hydrosphere::BC_SolidGround (hydrosphere/BC_Bath_Hyd.cpp:120-139) */

@@ -881,6 +881,33 @@ def test_atm_bc_fills_in_one_launch_same_bits(dims, seed):
     assert changed > 0
 
 
+@pytest.mark.parametrize("dims,seed", [((7, 7, 7), 76), ((5, 8, 9), 77), ((9, 21, 70), 78), ((41, 43, 19), 79), ((41, 181, 361), 80)])
+def test_hyd_bc_fills_in_one_launch_same_bits(dims, seed):
+    """atomdev_hyd_bc_radius_theta_phi against atomdev_hyd_bc_radius, _bc_theta, _bc_phi: every field bit for bit, twice in
+    a row, from fields whose faces hold values the fills must replace."""
+    im, jm, km = dims
+    p = H.default_params(H.HYD, im, jm, km)
+    f, g = H.make_inputs(H.HYD, im, jm, km, seed, "blobs", p)
+    f = {k: f[k] for k in H.HYD_FIELDS}
+    out = []
+    for fused in (False, True):
+        d = atom_amd.DeviceModel(H.HYD, im, jm, km, atom_amd.Params.from_buffer_copy(bytes(p)))
+        d.upload_all(f, g)
+        for _ in range(2):
+            if fused:
+                d.op("hyd_bc_radius_theta_phi")
+            else:
+                d.op("hyd_bc_radius"); d.op("hyd_bc_theta"); d.op("hyd_bc_phi")
+        out.append({k: d.download(k) for k in H.HYD_FIELDS})
+        d.close()
+    changed = 0
+    for k in H.HYD_FIELDS:
+        if k != "RESIDUUM":
+            assert np.array_equal(out[0][k].view(np.int64), out[1][k].view(np.int64)), (k, H.max_rel_err(out[1][k], out[0][k]))
+            changed += int((out[0][k] != f[k]).sum())
+    assert changed > 0
+
+
 @pytest.mark.parametrize("model,dims,seed", [(H.ATM, (7, 7, 7), 81), (H.HYD, (5, 8, 9), 82), (H.ATM, (9, 21, 70), 83),
                                              (H.HYD, (41, 43, 19), 84), (H.ATM, (41, 181, 361), 85), (H.HYD, (41, 181, 361), 86)])
 def test_pressure_fills_in_one_launch_same_bits(model, dims, seed, monkeypatch):
