@@ -18,7 +18,7 @@ tail -1 gpurun_out/final/smoke.log
 step 300 gpurun_out/final/bench.json python -u bench.py
 tail -1 gpurun_out/final/bench.json
 cd /tmp && export TMPDIR=/tmp
-step 300 $R/gpurun_out/final/rocprof.log rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/prof -o bench -- python3 $R/bench.py --steps 20 --warmup 5
+step 300 $R/gpurun_out/final/rocprof.log rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/prof -o bench -- python3 $R/bench.py --steps 200 --warmup 20
 cd $R
 step 400 gpurun_out/final/op_table.md python -u tools/op_table.py 20
 tail -36 gpurun_out/final/op_table.md
