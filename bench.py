@@ -352,7 +352,8 @@ def main():
                                    "limiter - the four as one call: first limiter in the sweep's preparing kernel, last one in its stores -, "
                                    "old->new copy; pressure Jacobi every 2nd step), %dx%dx%d, one slice per GPU" % (IM, JM, KM),
                        "grid": [IM, JM, KM], "updates_per_step_per_gpu": UPDATES, "parallelism": "independent slices"},
-            "roofline": {"bound": "hbm", "kernel": "k_atm_rk3d_ws", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": ("k_atm_rk3d_wsf<true>" if variant == 2 else "k_atm_rk3d_ws<true>") if variant != 1 else "k_atm_rk3d",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": "profiles/pmc_atm_rk3d.json (offline PMC pass, not measured in this run)",
                          "bytes_per_update": ATM_BYTES_PER_UPDATE, "kernel_ms": rk_avg_s * 1e3, "launches": rk_n,
