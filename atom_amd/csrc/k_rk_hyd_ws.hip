@@ -382,7 +382,7 @@ __device__ __forceinline__ void sweep_role(const HydWsArgs& a, const DevConst& K
         double st = x0, acc = 0., rhs = 0., RS = 0., pg_v = 0., sb = 0.;
         // ---- affine form: coefficients of the row ----
         constexpr bool AFFINE = HYD_WS_AFFINE;
-        double cAr = 0., cBr = 0., cA = 0., cB = 0., cP = 0., cQ = 0., cR = 0., cFac = 0., cM = 0.;
+        double cAr = 0., cBr = 0., cA = 0., cB = 0., cP = 0., cQ = 0., cR = 0., cFac = 0., cM = 0., cFac4 = 0., cMF = 0.;
         if constexpr (AFFINE) {
             double A1, B1, A2 = 0., B2 = 0., B1u = 0.;
             if (all_bw) {
@@ -413,6 +413,7 @@ __device__ __forceinline__ void sweep_role(const HydWsArgs& a, const DevConst& K
                 if (top) {  // RHS_Hyd.cpp:355-372
                     cFac = land ? 0. : k2 * k4 * (1. - 2. * c_top) * ep;
                     cM = -3. * c_top - c_below;
+                    cFac4 = 4. * cFac; cMF = cM * cFac;
                 }
             }
         }
@@ -449,7 +450,7 @@ __device__ __forceinline__ void sweep_role(const HydWsArgs& a, const DevConst& K
             }
             if constexpr (isC) {
                 if (top) {
-                    double sal = c_swr * __builtin_fma(4., st, cM) * cFac;
+                    double sal = c_swr * __builtin_fma(cFac4, st, cMF);   // = swr (4 st + cM) cFac
                     sal = fmin(fmax(sal, -20.), 20.);
                     lin += sal;
                 }
