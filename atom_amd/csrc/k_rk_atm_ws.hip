@@ -282,7 +282,9 @@ __global__ __launch_bounds__(256) void k_atm_limit_prep(LimitFields f, const dou
 // Memory schedule of a step (row j): every load (xn, flags and source terms of row j+1, row j+2 of the
 // own variable) is issued at the top, the stores of row j-1's results in stage 2, the geometry table
 // of row j+1 is read from LDS in stage 4.  Nothing loaded in a step is used before the next step.
-template <int ROLE, bool limit>
+// L1: the instantiation for level 1 (the t and c waves only: the evaporation source of c and the dry density it needs),
+// so that the other levels carry no test for it inside their stages.
+template <int ROLE, bool limit, bool L1 = false>
 __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K, Shared& sh, const double* tab,
                                            int bx, int i, double* __restrict__ X, const double* __restrict__ XN) {
     // limit: what goes to memory is the value as the limiter that follows the sweep in the model's loop would leave it;
@@ -293,7 +295,7 @@ __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K
     const int lane = threadIdx.x & 63;
     const int kk = 1 + bx * 64 + lane;
     const int k = kk <= km - 2 ? kk : km - 2;  // idle lanes shadow the last line and reproduce its bits
-    const bool lvl1 = isC && (i == 1);
+    const bool lvl1 = isC && (ATM_WS_AFFINE ? L1 : (i == 1));  // (the exact form keeps the test: its roles are large as they are)
     constexpr int NST = isU ? 3 : (isV || isW) ? 2 : 1;  // stores per step
 
     // ---- constants of the dependent chain, in vector registers ----
@@ -380,7 +382,7 @@ __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K
 
     // what the other waves need of a new t or c value (RHS_Atm.cpp:385, 390-404)
     constexpr bool AFFINE = ATM_WS_AFFINE;
-    const bool t_feeds_c = (i == 1);  // affine form: the dry density has one reader, the c wave of level 1
+    constexpr bool t_feeds_c = L1;  // affine form: the dry density has one reader, the c wave of level 1
     double k12 = k1 * k2; PIN(k12);
     auto publish_t = [&](int buf, double tval, double ph) {
         if constexpr (AFFINE) {
@@ -650,12 +652,18 @@ __global__ __launch_bounds__(512) void k_atm_rk3d_ws(const AtmWsParams* __restri
     switch (threadIdx.x >> 6) {
         case R_U: sweep_role<R_U, LIMIT>(a, K, sh, tab, bx, i, a.u, a.un); break;
         case R_V: sweep_role<R_V, LIMIT>(a, K, sh, tab, bx, i, a.v, a.vn); break;
-        case R_T: sweep_role<R_T, LIMIT>(a, K, sh, tab, bx, i, a.t, a.tn); break;
+        case R_T:
+            if (ATM_WS_AFFINE && i == 1) sweep_role<R_T, LIMIT, ATM_WS_AFFINE != 0>(a, K, sh, tab, bx, i, a.t, a.tn);
+            else sweep_role<R_T, LIMIT>(a, K, sh, tab, bx, i, a.t, a.tn);
+            break;
         case R_W: sweep_role<R_W, LIMIT>(a, K, sh, tab, bx, i, a.w, a.wn); break;
         case R_CO2: sweep_role<R_CO2, LIMIT>(a, K, sh, tab, bx, i, a.co2, a.co2n); break;
         case R_ICE: sweep_role<R_ICE, LIMIT>(a, K, sh, tab, bx, i, a.ice, a.icen); break;
         case R_CLOUD: sweep_role<R_CLOUD, LIMIT>(a, K, sh, tab, bx, i, a.cloud, a.cloudn); break;
-        default: sweep_role<R_C, LIMIT>(a, K, sh, tab, bx, i, a.c, a.cn); break;
+        default:
+            if (ATM_WS_AFFINE && i == 1) sweep_role<R_C, LIMIT, ATM_WS_AFFINE != 0>(a, K, sh, tab, bx, i, a.c, a.cn);
+            else sweep_role<R_C, LIMIT>(a, K, sh, tab, bx, i, a.c, a.cn);
+            break;
     }
 #ifdef ATOMDEV_EXP_WGTIME
     if ((threadIdx.x & 63) == 0) {
