@@ -184,8 +184,8 @@ __device__ __forceinline__ void theta_terms(int mode, bool d2zero, double xm2, d
 // flags, the level above and the role's extras, row j+2 of the own variable) is issued at the
 // top, the stores of row j-1's results in stage 2; nothing loaded in a step is used before the
 // next one, and the end-of-step wait leaves only the stores outstanding.
-// TOPC (tolerance form only): the instantiation for level im-2, where the radial terms are dead: no radial advection,
-// no u for the waves that need it for nothing else.
+// TOPC: the instantiation for level im-2 (the others carry no test for it inside their stages).  There the radial terms
+// are dead: the tolerance form drops the radial advection and, for the waves that need it for nothing else, u.
 template <int ROLE, bool TOPC = false>
 __device__ __forceinline__ void sweep_role(const HydWsArgs& a, const DevConst& K, Shared& sh, const double* tab,
                                            int bx, int i, int* progress, int* err,
@@ -202,7 +202,7 @@ __device__ __forceinline__ void sweep_role(const HydWsArgs& a, const DevConst& K
     const int lane = threadIdx.x & 63;
     const int kk = 1 + bx * 64 + lane;
     const int k = kk <= km - 2 ? kk : km - 2;  // idle lanes shadow the last line and reproduce its bits
-    const bool top = TOPC || (i == im - 2);
+    constexpr bool top = TOPC;  // i == im - 2: the kernel picks the instantiation
     const bool feeds_top = ROLE == R_C && progress && !top;   // c wave of level im-3
     const bool polls = ROLE == R_C && progress && top;        // c wave of level im-2
     const bool kwin = (k >= 2) && (k < km - 3);
@@ -433,7 +433,7 @@ __device__ __forceinline__ void sweep_role(const HydWsArgs& a, const DevConst& K
             if (s == 3) load_table(j + 1);
             double u, v;
             if constexpr (isU) u = st;
-            else if constexpr (!TOPC || isV) u = sh.u[rb][lane];
+            else if constexpr (!(TOPC && HYD_WS_AFFINE) || isV) u = sh.u[rb][lane];
             else u = 0.;
             if constexpr (isV) v = st; else v = sh.v[rb][lane];
 
@@ -691,13 +691,13 @@ __global__ __launch_bounds__(320 * NB) void k_hyd_rk3d_ws(const HydWsParams* __r
 #else
     int* pw = (i >= K.im - 3) ? progress + bx : nullptr;
 #endif
-    if (HYD_WS_AFFINE && i == K.im - 2) {  // a uniform choice: the whole workgroup is on one level
+    if (i == K.im - 2) {  // a uniform choice: the whole workgroup is on one level
         switch (wave) {
-            case R_T: sweep_role<R_T, HYD_WS_AFFINE != 0>(a, K, sh, tab, bx, i, pw, err, a.t, a.to, a.tn); break;
-            case R_V: sweep_role<R_V, HYD_WS_AFFINE != 0>(a, K, sh, tab, bx, i, pw, err, a.v, a.vo, a.vn); break;
-            case R_U: sweep_role<R_U, HYD_WS_AFFINE != 0>(a, K, sh, tab, bx, i, pw, err, a.u, a.uo, a.un); break;
-            case R_C: sweep_role<R_C, HYD_WS_AFFINE != 0>(a, K, sh, tab, bx, i, pw, err, a.c, a.co, a.cn); break;
-            default: sweep_role<R_W, HYD_WS_AFFINE != 0>(a, K, sh, tab, bx, i, pw, err, a.w, a.wo, a.wn); break;
+            case R_T: sweep_role<R_T, true>(a, K, sh, tab, bx, i, pw, err, a.t, a.to, a.tn); break;
+            case R_V: sweep_role<R_V, true>(a, K, sh, tab, bx, i, pw, err, a.v, a.vo, a.vn); break;
+            case R_U: sweep_role<R_U, true>(a, K, sh, tab, bx, i, pw, err, a.u, a.uo, a.un); break;
+            case R_C: sweep_role<R_C, true>(a, K, sh, tab, bx, i, pw, err, a.c, a.co, a.cn); break;
+            default: sweep_role<R_W, true>(a, K, sh, tab, bx, i, pw, err, a.w, a.wo, a.wn); break;
         }
     } else {
         switch (wave) {
