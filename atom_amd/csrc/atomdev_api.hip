@@ -153,7 +153,10 @@ extern "C" int atomdev_create(int model, int im, int jm, int km, const atomdev_p
     // form of the sweep; the hydrosphere's default is the exact form, whose results carry the reference's bits
     h->rk_variant = model == ATOMDEV_ATM ? 2 : 0;
     h->ws_params = nullptr; h->surf = nullptr; h->xfer = nullptr; h->batch = nullptr; h->batch_bytes = 0;
-    if (const char* e = getenv("ATOMDEV_RK_VARIANT")) h->rk_variant = atoi(e);
+    if (const char* e = getenv("ATOMDEV_RK_VARIANT")) {
+        const int v = atoi(e);
+        if (v >= 0 && v <= (model == ATOMDEV_ATM ? 3 : 2)) h->rk_variant = v;  // (3 exists for the atmosphere only)
+    }
     h->rad = h->sinthe = h->costhe = h->plane = nullptr; h->red = nullptr;
     h->static_scratch = nullptr; h->static_scratch_bytes = 0; h->pinned = nullptr;
     h->stage = nullptr; h->stage_bytes = 0;
@@ -203,6 +206,7 @@ extern "C" int atomdev_set_params(atomdev_t* h, const atomdev_params* p) {
     fill_constants(h);
     if (int rc = upload_tables(h)) return rc;
     if (h->ws_params) { ATOMDEV_TRY(hipFree(h->ws_params)); h->ws_params = nullptr; }  // holds a copy of the constants
+    if (h->pipe_params) { ATOMDEV_TRY(hipFree(h->pipe_params)); h->pipe_params = nullptr; }
     h->h0i_valid = false;
     return 0;
 }
@@ -225,6 +229,7 @@ extern "C" int atomdev_destroy(atomdev_t* h) {
     if (h->tab_irm2sin) (void)hipFree(h->tab_irm2sin);
     if (h->tab_coefv) (void)hipFree(h->tab_coefv);
     if (h->ws_params) (void)hipFree(h->ws_params);
+    if (h->pipe_params) (void)hipFree(h->pipe_params);
     if (h->surf) (void)hipFree(h->surf);
     if (h->xfer) (void)hipFree(h->xfer);
     if (h->batch) (void)hipFree(h->batch);
@@ -472,7 +477,7 @@ extern "C" int atomdev_get_rk_variant(const atomdev_t* h) { return h ? h->rk_var
 
 extern "C" int atomdev_set_rk_variant(atomdev_t* h, int variant) {
     ATOMDEV_REQUIRE(h != nullptr, "atomdev_set_rk_variant: null handle");
-    ATOMDEV_REQUIRE(variant >= 0 && variant <= 2, "atomdev_set_rk_variant: variant must be 0, 1 or 2");
+    ATOMDEV_REQUIRE(variant >= 0 && variant <= (h->model == ATOMDEV_ATM ? 3 : 2), "atomdev_set_rk_variant: variant must be 0, 1, 2 (or 3, atmosphere only)");
     h->rk_variant = variant;
     return 0;
 }

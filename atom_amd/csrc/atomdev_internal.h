@@ -64,6 +64,7 @@ struct atomdev {
     double* xfer;                   // six surface planes of the atmosphere -> hydrosphere transfer (lazy)
     void* surf;                     // skewed copy of the surface fields for the 2-D sweep (lazy)
     void* ws_params;                // device copy of the wave-specialised sweep's argument block(s) (lazy)
+    void* pipe_params = nullptr;    // device copy of the pipelined atmosphere sweep's argument block (lazy)
     const double* ws_cur0;          // hyd: f[T] at the time the blocks were built (tells the buffer orientation)
     void* static_scratch;           // this GPU's copy of the library's static scratch array (k_accuracy.hip)
     size_t static_scratch_bytes;
@@ -71,7 +72,8 @@ struct atomdev {
                                     // the word kernels set on a failure they detect themselves (byte 128)
     void* stage;                    // device staging buffer of atomdev_pack_columns / _unpack_columns for host buffers (lazy)
     size_t stage_bytes;
-    int rk_variant;                 // 0: wave-specialised sweep (default), 1: one thread per theta line, 2: 0 in its tolerance form
+    int rk_variant;                 // 0: wave-specialised sweep, 1: one thread per theta line, 2: 0 in its tolerance form,
+                                    // 3 (atmosphere): the pipelined sweep (tolerance form; k_rk_atm_pipe.hip)
     int profile_rk;                 // bracket the RK sweeps with events: 1 the sweep kernel alone, 2 with the kernels that prepare it
     bool defer_files = false;         // inside a one-call slice: text files are finished by threads of their own
     std::vector<std::future<std::string>> pending_files;  // their error texts (empty: written)
@@ -98,6 +100,7 @@ inline volatile int* atomdev_kernel_error_word(atomdev* h) { return (volatile in
 // limit_before: the kernel that prepares the sweep runs Value_Limitation_Atm (and with it BC_SolidGround) on its way
 int atomdev_atm_rk3d_ws(atomdev* h, bool limit, bool limit_before);    // k_rk_atm_ws.hip
 int atomdev_atm_rk3d_ws_fast(atomdev* h, bool limit, bool limit_before);  // k_rk_atm_ws.hip compiled with -DATOMDEV_RK_FAST
+int atomdev_atm_rk3d_pipe_launch(atomdev* h, bool limit);                 // k_rk_atm_pipe.hip: the sweep kernel alone
 int atomdev_atm_limit_rest(atomdev* h);  // k_pointwise.hip: the limiter where the sweep does not store, and p_dyn on land
 int atomdev_hyd_rk3d_ws(atomdev* h);    // k_rk_hyd_ws.hip
 int atomdev_hyd_rk3d_ws_fast(atomdev* h);  // k_rk_hyd_ws.hip compiled with -DATOMDEV_RK_FAST

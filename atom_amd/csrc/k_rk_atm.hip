@@ -221,8 +221,8 @@ namespace {
 int rk3d(atomdev* h, bool limit, bool limit_before) {
     ATOMDEV_TRY(hipSetDevice(h->device));
     if (int rc = atomdev_refresh_flags(h)) return rc;
-    if (h->rk_variant == 2 || h->rk_variant == 0) {
-        if (int rc = h->rk_variant == 2 ? atomdev_atm_rk3d_ws_fast(h, limit, limit_before)
+    if (h->rk_variant == 2 || h->rk_variant == 0 || h->rk_variant == 3) {
+        if (int rc = h->rk_variant != 0 ? atomdev_atm_rk3d_ws_fast(h, limit, limit_before)
                                         : atomdev_atm_rk3d_ws(h, limit, limit_before)) return rc;
         // (after a limiter that ran just before the sweep nothing is left for the second one outside the sweep's own
         // points: the faces and p_dyn are as the first one left them, and limiting twice changes nothing)

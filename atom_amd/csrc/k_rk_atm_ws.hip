@@ -728,7 +728,9 @@ int ATM_WS_ENTRY(atomdev* h, bool limit, bool limit_before) {
     dim3 grid(8 * rounds * gx);
     ATOMDEV_REQUIRE(h->n3 * sizeof(double) < ((size_t)1 << 32), "atm_rk3d: field larger than 4 GiB");
     const size_t tab_bytes = (size_t)h->jm * 4 * sizeof(double);
-    if (limit)
+    if (h->rk_variant == 3) {  // the pipelined sweep takes the same prepared inputs
+        if (int rc = atomdev_atm_rk3d_pipe_launch(h, limit)) return rc;
+    } else if (limit)
         hipLaunchKernelGGL(k_atm_rk3d_ws<true>, grid, dim3(512), tab_bytes, h->stream, (const AtmWsParams*)h->ws_params);
     else
         hipLaunchKernelGGL(k_atm_rk3d_ws<false>, grid, dim3(512), tab_bytes, h->stream, (const AtmWsParams*)h->ws_params);

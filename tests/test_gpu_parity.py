@@ -700,11 +700,16 @@ def test_golden_small_atm():
     d.close()
 
 
-@pytest.mark.parametrize("model,tag,op", [(H.ATM, "atm", "atm_rk3d"), (H.HYD, "hyd", "hyd_rk3d")])
-def test_full_1deg_real_mask_rk3d(model, tag, op):
+@pytest.mark.parametrize("model,tag,op,variant", [(H.ATM, "atm", "atm_rk3d", None), (H.ATM, "atm", "atm_rk3d", 2),
+                                                  (H.ATM, "atm", "atm_rk3d", 3), (H.ATM, "atm", "atm_rk3d", 0),
+                                                  (H.HYD, "hyd", "hyd_rk3d", None)])
+def test_full_1deg_real_mask_rk3d(model, tag, op, variant):
     """One sweep on 41x181x361 with the real 0 Ma land mask, against the oracle
-    (whole fields) and against the planes the compiled reference left in the goldens."""
+    (whole fields) and against the planes the compiled reference left in the goldens; the atmosphere in its
+    default form and in each of the wave-specialised (0), tolerance (2) and pipelined (3) forms."""
     o, d, names = _pair(model, (41, 181, 361), 1234, "allfluid", real_mask=True)
+    if variant is not None:
+        d.set_rk_variant(variant)
     z = np.load(os.path.join(GOLD, "full_1deg_%s_rk3d.npz" % tag))
     o.op(op)
     d.op(op)
@@ -796,7 +801,8 @@ def test_rk_variants_same_bits(model, op, dims, seed):
     swaps its buffer pair in between).  Variant 2 is variant 0 in its tolerance form (reciprocal
     multiplications, fused multiply-adds): every field within 1e-12 of it."""
     out = []
-    for variant in (0, 1, 2):
+    variants = (0, 1, 2, 3) if model == H.ATM else (0, 1, 2)   # 3: the atmosphere's pipelined sweep (tolerance form)
+    for variant in variants:
         o, d, names = _pair(model, dims, seed, "blobs")
         o.close()
         d.set_rk_variant(variant)
@@ -807,7 +813,8 @@ def test_rk_variants_same_bits(model, op, dims, seed):
     for k in out[0]:
         assert H.bits_equal(out[0][k], out[1][k]), (op, k, H.max_rel_err(out[0][k], out[1][k]))
         if k != "RESIDUUM":
-            assert H.max_rel_err(out[2][k], out[0][k]) <= 1e-12, (op, k, H.max_rel_err(out[2][k], out[0][k]))
+            for n in range(2, len(variants)):
+                assert H.max_rel_err(out[n][k], out[0][k]) <= 1e-12, (op, variants[n], k, H.max_rel_err(out[n][k], out[0][k]))
 
 
 @pytest.mark.parametrize("dims,seed,real_mask", [((9, 21, 70), 51, False), ((6, 9, 131), 52, False), ((5, 7, 7), 53, False),
@@ -834,7 +841,7 @@ def test_atm_rk3d_limited_is_sweep_then_limiter(dims, seed, real_mask):
     seqs = {"two": ["atm_rk3d", "atm_value_limitation"], "two in one": ["atm_rk3d_limited"],
             "four": ["atm_value_limitation", "atm_solid_ground", "atm_rk3d", "atm_value_limitation"],
             "four in one": ["atm_limit_ground_rk3d_limit"]}
-    for variant in (0, 1, 2):
+    for variant in (0, 1, 2, 3):
         out = {}
         for name, seq in seqs.items():
             d = atom_amd.DeviceModel(H.ATM, im, jm, km, atom_amd.Params.from_buffer_copy(bytes(p)))
