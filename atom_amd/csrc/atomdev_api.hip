@@ -167,15 +167,29 @@ extern "C" int atomdev_create(int model, int im, int jm, int km, const atomdev_p
     if ((rc = atomdev_check(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking), "hipStreamCreate"))) { h->stream = nullptr; return fail(rc); }
     if ((rc = atomdev_check(hipEventCreate(&h->ev0), "hipEventCreate"))) return fail(rc);
     if ((rc = atomdev_check(hipEventCreate(&h->ev1), "hipEventCreate"))) return fail(rc);
+    // Every 3-D field starts at its own distance from the allocation's (2 MiB-aligned) start.  A sweep streams through
+    // thirty fields at the same index at once; with all of them at the same address modulo a large power of two, the
+    // requests of a row would keep landing on the same memory channel and bank.
+    size_t skew_unit = 0;
+    if (const char* e = getenv("ATOMDEV_FIELD_SKEW")) skew_unit = (size_t)atol(e) & ~(size_t)255;
+    int nalloc = 0;
+    auto alloc_field = [&](double** out) -> int {
+        void* raw = nullptr;
+        const size_t skew = skew_unit * (size_t)nalloc++;
+        if (int rc2 = atomdev_check(hipMalloc(&raw, h->n3 * sizeof(double) + skew), "hipMalloc(field)")) return rc2;
+        h->field_allocs.push_back(raw);
+        *out = (double*)((char*)raw + skew);
+        return 0;
+    };
     for (int f = 0; f < ATOMDEV_N3D; f++) {
         if (!field_used(model, f)) continue;
-        if ((rc = atomdev_check(hipMalloc(&h->f[f], h->n3 * sizeof(double)), "hipMalloc(field)"))) return fail(rc);
+        if ((rc = alloc_field(&h->f[f]))) return fail(rc);
         if ((rc = atomdev_check(hipMemsetAsync(h->f[f], 0, h->n3 * sizeof(double), h->stream), "hipMemset"))) return fail(rc);
     }
     if (model == ATOMDEV_HYD) {
         const int pp[5] = { ATOMDEV_T, ATOMDEV_U, ATOMDEV_V, ATOMDEV_W, ATOMDEV_C };
         for (int n = 0; n < 5; n++)
-            if ((rc = atomdev_check(hipMalloc(&h->alt[pp[n]], h->n3 * sizeof(double)), "hipMalloc(alt)"))) return fail(rc);
+            if ((rc = alloc_field(&h->alt[pp[n]]))) return fail(rc);
     }
     for (int g = 0; g < ATOMDEV_N2D; g++) {
         if ((rc = atomdev_check(hipMalloc(&h->g[g], h->n2 * sizeof(double)), "hipMalloc(field2d)"))) return fail(rc);
@@ -215,7 +229,7 @@ extern "C" int atomdev_destroy(atomdev_t* h) {
     if (!h) return 0;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    for (int f = 0; f < ATOMDEV_N3D; f++) { if (h->f[f]) (void)hipFree(h->f[f]); if (h->alt[f]) (void)hipFree(h->alt[f]); }
+    for (void* raw : h->field_allocs) (void)hipFree(raw);
     for (int g = 0; g < ATOMDEV_N2D; g++) if (h->g[g]) (void)hipFree(h->g[g]);
     if (h->flags) (void)hipFree(h->flags);
     if (h->plane) (void)hipFree(h->plane);
@@ -382,7 +396,8 @@ int atomdev_sync_stream(atomdev* h) {
     volatile int* err = atomdev_kernel_error_word(h);
     if (const int code = *err) {
         *err = 0;
-        atomdev_set_error(code == 2 ? "rk2d: a wave of the surface sweep gave up waiting for the row above it; the surface fields of the last sweep are not valid"
+        atomdev_set_error(code == 3 ? "atm_rk3d: a wave of the pipelined sweep gave up waiting for another wave of its workgroup; the fields of the last sweep are not valid"
+                          : code == 2 ? "rk2d: a wave of the surface sweep gave up waiting for the row above it; the surface fields of the last sweep are not valid"
                                     : "hyd_rk3d: level im-2 gave up waiting for the salinity rows of level im-3; the fields of the last sweep are not valid");
         return 1;
     }

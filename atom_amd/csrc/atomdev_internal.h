@@ -77,6 +77,7 @@ struct atomdev {
     int profile_rk;                 // bracket the RK sweeps with events: 1 the sweep kernel alone, 2 with the kernels that prepare it
     bool defer_files = false;         // inside a one-call slice: text files are finished by threads of their own
     std::vector<std::future<std::string>> pending_files;  // their error texts (empty: written)
+    std::vector<void*> field_allocs;  // what hipMalloc returned for the 3-D fields (f[] and alt[] point into these, each at its own skew)
     std::vector<hipEvent_t> prof_ev;  // pairs (start, stop), prof_used of them recorded
     size_t prof_used;
 };

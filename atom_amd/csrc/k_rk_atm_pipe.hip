@@ -13,29 +13,28 @@
 //     cB = H1 x[j-1] + H2 x[j-2] + KB        cQ = q1 x[j-1] + q2 x[j-2] + KQ
 // where cA, cP, H1, H2, q1, q2, KB, KQ depend on the mask, the geometry, the source fields and OLD field values
 // only.  So everything that needs memory or many instructions can be worked out rows ahead by waves that do
-// nothing else, and what remains on the recurrence is a handful of fused multiply-adds per variable and stage,
-// short enough for ONE wave to carry four variables through a row in a third of a microsecond.
+// nothing else, and what remains on the recurrence is a handful of fused multiply-adds per variable and stage.
 //
-// Mapping.  A workgroup owns 64 neighbouring theta lines of one level and has six live waves:
-//   four "prep" waves, taking the rows in turn (row r belongs to wave r mod 4): each loads everything its row
-//       needs (old values, base values, sources, flags, four rows of p_dyn), turns it into the row's coefficient
-//       packet in a ring of four LDS slots, and issues the loads of its next row, four rows on, before it rests -
-//       so a load has three rows' time to arrive and nobody ever waits for memory on the recurrence;
+// Mapping.  A workgroup owns 64 neighbouring theta lines of one level.  Of its sixteen waves ten live:
+//   eight "memory" waves in four pairs, taking the rows in turn (row r belongs to pair r mod 4; one wave of the pair
+//       works for chain A, the other for chain B): a wave loads what its half of the row needs (old values, base values,
+//       sources, flags, four rows of p_dyn), turns it into the row's coefficient packet in a ring of four LDS slots,
+//       stores the results of the row that stood in the slot before (which the chain wave left in LDS), and issues the
+//       loads of its next row, four rows on, before it rests - so a load has three rows' time to arrive;
 //   chain wave A carries v, u, c, t (the coupled ones: v feeds all, u feeds v, c feeds u, t feeds c on level 1)
-//       through the four stages of row j, leaves the four stage values of v in LDS, and stores its results;
-//   chain wave B carries w, cloud, ice, co2 one row behind A, with the stage values of v that A left.
-// One LDS barrier per row orders all of it: in epoch e the prep wave of row e+1 writes its packet, A works on row e,
-// B on row e-1.  The chain waves issue no loads inside the loop and the prep waves no stores, so there is no
-// vector-memory wait to place by hand anywhere.  Waves 4 and 5 of the 512-thread workgroup end at once: waves w and
-// w+4 share a SIMD, and the two chain waves are to have theirs to themselves.
+//       through the four stages of row j and leaves the four stage values of v in LDS;
+//   chain wave B carries w, cloud, ice, co2 behind A, with the stage values of v that A left.
+// The chain waves touch LDS only: a compute unit's vector-memory pipe takes about 11 bytes a cycle, the memory
+// waves keep it full, and a store issued by a chain wave would queue behind a row's worth of their loads.
+// No barrier inside the loop: the waves follow each other's progress words in LDS (which row's packet stands in a
+// slot, which row a chain has finished, which row's results have been stored), so each runs at its own pace and the
+// sweep goes at the pace of the slowest on average, not of the slowest in every row.  Waves w, w+4, w+8, w+12 share a
+// SIMD; the six that would share the chain waves' SIMDs end at once.
 #include "atomdev_internal.h"
 
 namespace {
 
 enum Var { V_T = 0, V_U = 1, V_V = 2, V_W = 3, V_C = 4, V_CLOUD = 5, V_ICE = 6, V_CO2 = 7 };
-// diffusion divisor class of a variable (re*pr, re, re*sc_WaterVapour, re*sc_CO2) and its slot among the cP columns
-__device__ constexpr int q_class(int var) { return var == V_T ? 0 : (var == V_U || var == V_V || var == V_W) ? 1 : var == V_CO2 ? 3 : 2; }
-__device__ constexpr int cp_slot(int var) { return var == V_T ? 0 : var == V_U ? 1 : var == V_V ? 2 : var == V_W ? 3 : var == V_C ? 4 : var == V_CO2 ? 6 : 5; }
 
 struct PipeArgs {
     double* x[8];
@@ -53,34 +52,43 @@ struct PipeParams {
     DevConst K;
 };
 
-// One row's packet: 64 lanes wide, everything a chain wave needs of the row besides its own last two results.  The
-// first half is written by the prep wave that works for chain B (and holds what both chains read), the second by the
-// one that works for chain A.
+// One row's packet: 64 lanes wide, everything a chain wave needs of the row besides its own last two results; one
+// half per chain wave.  On the three pole-side rows (central differences: x[j-2] does not enter, old x[j+1] does)
+// the arrays of the x[j-2] factors carry the constant terms KB of the four variables instead: q2[0..2] and, for
+// chain A, qu2, for chain B, H2.
 enum { QA_RE = 0, QA_WV = 1, QA_PR = 2 };     // diffusion classes of chain A's variables: u and v, c, t
 enum { QB_RE = 0, QB_WV = 1, QB_CO2 = 2 };    // ... and of chain B's: w, cloud and ice, co2
-struct Slot {
+struct HalfB {
     double cA[64], H1[64], H2[64];
-    double q1B[3][64], q2B[3][64];
-    double cPB[3][64];                         // w, cloud = ice, co2
-    double x0B[4][64], xnB[4][64], KQB[4][64], KBB[4][64];   // w, cloud, ice, co2 (KB, and KQ of w and co2: pole-side rows only)
-    unsigned fl[64];
-    double q1A[3][64], q2A[3][64];
-    double cPA[4][64];                         // v, u, c, t
-    double x0A[4][64], xnA[4][64], KQA[4][64], KBA[4][64];   // v, u, c, t (KB, and KQ of u: pole-side rows only)
+    double q1[3][64], q2[3][64];
+    double cP[3][64];                          // w, cloud = ice, co2
+    double x0[4][64], xn[4][64], KQ[4][64];    // w, cloud, ice, co2 (KQ of w and co2: pole-side rows only)
+};
+struct HalfA {
+    double cA[64], H1[64], H2[64];
+    double q1[3][64], q2[3][64];
+    double cP[4][64];                          // v, u, c, t
+    double x0[4][64], xn[4][64], KQ[4][64];    // v, u, c, t (KQ of u: pole-side rows only)
     double cR[64], qu1[64], qu2[64], pgv[64];
     double cFac[64], cMc[64], phk[64];         // level 1: the evaporation source of c
 };
 constexpr int NSLOT = 4;
+struct Ctl { int rdy, stored; };               // per slot and half: the row whose packet stands there, the row last stored from there
 struct PipeShared {
-    Slot ring[NSLOT];
-    double vst[2][4][64];      // stage values of v of a row, by row parity
+    HalfA ha[NSLOT];
+    HalfB hb[NSLOT];
+    double outA[NSLOT][7][64];                 // v, u, c, t, aux_u, aux_v, buoyancy of a finished row
+    double outB[NSLOT][5][64];                 // w, cloud, ice, co2, aux_w
+    double vst[2][4][64];                      // stage values of v of a row, by row parity
+    Ctl ctlA[NSLOT], ctlB[NSLOT];
+    int doneA, doneB;                          // the last row each chain wave has finished
 #ifdef ATOMDEV_EXP_PIPE_STAMP
     unsigned long long stamps[10][4][8];
     unsigned long long wall[2], cyc[2];
 #endif
 };
 
-#ifdef ATOMDEV_EXP_PIPE_STAMP  // timing experiment only: cycle stamps of four epochs of one workgroup, kept in LDS
+#ifdef ATOMDEV_EXP_PIPE_STAMP  // timing experiment only: cycle stamps of four rows of one workgroup, kept in LDS
 #define PSTAMP(wave, n)                                                                                       \
     do {                                                                                                      \
         if (e >= 60 && e < 64 && lane == 0) sh.stamps[wave][e - 60][n] = __builtin_readcyclecounter();        \
@@ -104,6 +112,35 @@ __device__ __forceinline__ void gst(double* base, unsigned off, double x) {
 // between two such constants into a per-lane choice of ADDRESS and a vector load in the middle of the loop.
 #define SPIN(x) asm volatile("" : "+s"(x))
 
+typedef volatile __attribute__((address_space(3))) int* lds_word_t;   // (typed as LDS: a generic pointer would go through the vector-memory pipe)
+#define LDS_WORD(p) ((lds_word_t)(p))
+// Progress words in LDS.  A wave's LDS operations are carried out in the order it issues them, so a word written after
+// the data it announces is seen after that data by whoever reads the word first and the data afterwards; the compiler
+// barriers keep the compiler from moving an access across the word.  Only lane 0 writes; every lane reads (one address:
+// a broadcast).  A wait gives up after about a second and says so in *err (page-locked host memory that the library's
+// next synchronising call looks at), so that every wave reaches the end of the kernel whatever happens.
+__device__ __forceinline__ void announce(int* word, int row, int lane) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) *LDS_WORD(word) = row;
+    asm volatile("" ::: "memory");
+}
+// the same without waiting for the wave's earlier LDS operations to complete: they are carried out before the word's write
+__device__ __forceinline__ void announce_in_order(int* word, int row, int lane) {
+    asm volatile("" ::: "memory");
+    if (lane == 0) *LDS_WORD(word) = row;
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void wait_for(const int* word, int need, int* err) {
+    asm volatile("" ::: "memory");
+    for (int n = 0; __builtin_amdgcn_readfirstlane(*LDS_WORD(word)) < need; n++) {
+        __builtin_amdgcn_s_sleep(2);
+        if (n > (1 << 22)) {
+            __hip_atomic_store(err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+        }
+    }
+    asm volatile("" ::: "memory");
+}
 __device__ __forceinline__ double rcp2(double b) {  // hardware estimate and two Newton steps: full precision
     double y = __builtin_amdgcn_rcp(b);
     double e = __builtin_fma(-b, y, 1.0);
@@ -126,32 +163,35 @@ __device__ __forceinline__ double limited(double x, bool land) {
     return x;
 }
 
-// ---- a prep wave: rows r = q, q + 4, ... (r >= 1), the half of the packet that chain A (FORA) or chain B reads ----
-template <bool L1, bool FORA>
-__device__ __forceinline__ void prep_wave(const PipeArgs& a, const DevConst& K, PipeShared& sh, const int q, const int i, const int bx) {
+// ---- a memory wave: rows r = q, q + 4, ... (r >= 1), the half of the row that chain A (FORA) or chain B works on ----
+template <bool L1, bool FORA, bool LIMIT>
+__device__ __forceinline__ void memory_wave(const PipeArgs& a, const DevConst& K, PipeShared& sh, const int q, const int i, const int bx, int* err) {
     const int jm = K.jm, km = K.km;
     const int lane = threadIdx.x & 63;
     const int kk = 1 + bx * 64 + lane;
     const int k = kk <= km - 2 ? kk : km - 2;  // idle lanes shadow the last line
-    const int NR = jm - 2, NE = NR + 2;
+    const int NR = jm - 2;
     const unsigned rowB = (unsigned)km * 8u;
     unsigned o_lev = (unsigned)(((size_t)i * jm * km + k) * 8);   // row 0 of the line, as a byte offset into a 3-D field
     unsigned o_sfc = (unsigned)k * 8u;                             // ... into a 2-D field
     PIN(o_lev); PIN(o_sfc);
-    Slot& S = sh.ring[q];
+    HalfA& SA = sh.ha[q];
+    HalfB& SB = sh.hb[q];
+    Ctl* ctl = FORA ? &sh.ctlA[q] : &sh.ctlB[q];
+    const int* done = FORA ? &sh.doneA : &sh.doneB;
     constexpr int VARS[4] = { FORA ? V_V : V_W, FORA ? V_U : V_CLOUD, FORA ? V_C : V_ICE, FORA ? V_T : V_CO2 };
     const int stamp_wave = 2 + 2 * q + (FORA ? 0 : 1);
     (void)stamp_wave;
 
     const double rm = a.rad[i];
     const double i_rm = 1. / rm, i_rm2 = 1. / (rm * rm);
-    const double two = 2. * i_rm2 * K.i_re;
     const double ce = K.coeff_energy, ctr = K.coeff_trans;
     const double i_phk = 1. / (K.R_Air * K.t_0);
     const double evf = K.coeff_vapour * K.i_two_dr;
     double i_dthe = K.i_dthe, i_two_dthe = K.i_two_dthe, i_dthe2 = K.i_dthe2, i_dr2 = K.i_dr2, i_dphi2 = K.i_dphi2;
     double i_re = K.i_re, i_re_sc_wv = K.i_re_sc_wv, i_re_x = FORA ? K.i_re_pr : K.i_re_sc_co2, i_r_air = K.i_r_air;
     SPIN(i_dthe); SPIN(i_two_dthe); SPIN(i_dthe2); SPIN(i_dr2); SPIN(i_dphi2); SPIN(i_re); SPIN(i_re_sc_wv); SPIN(i_re_x); SPIN(i_r_air);
+    const double two = 2. * i_rm2 * i_re;
     // diffusion divisors of this half's classes and variables
     const double idc[3] = { i_re, i_re_sc_wv, i_re_x };
     constexpr int CLS[4] = { 0, FORA ? 0 : 1, 1, 2 };   // A: v, u -> re; c -> wv; t -> pr.  B: w -> re; cloud, ice -> wv; co2
@@ -162,6 +202,9 @@ __device__ __forceinline__ void prep_wave(const PipeArgs& a, const DevConst& K, 
     double lcos, lirs, lcoefv = 0.;  // geometry of the row: one address for the whole wave, fetched with the rest of the row
     unsigned lfl;
     auto issue = [&](const int r) {
+#ifdef ATOMDEV_EXP_PIPE_NOMEM  // timing experiment only (results are wrong): no vector-memory traffic inside the loop
+        if (r > 8) return;
+#endif
         const unsigned o = o_lev + (unsigned)r * rowB;
         lfl = *(const __attribute__((address_space(1))) uint8_t*)((gcchar_t)a.flags + (o >> 3));
 #pragma unroll
@@ -190,19 +233,54 @@ __device__ __forceinline__ void prep_wave(const PipeArgs& a, const DevConst& K, 
             lph = gld(a.ph100, o);
         }
     };
+    // The results of row `rs`, which the chain wave left in the slot's output arrays: limited as the limiter that follows
+    // the sweep in the model's loop would leave them (LIMIT), side outputs zero on land (RHS_Atm.cpp:406-410, 485-492).
+    auto store_row = [&](const int rs, const bool land) {
+#ifdef ATOMDEV_EXP_PIPE_NOMEM
+        if (rs > 8) { announce(&ctl->stored, rs, lane); return; }
+#endif
+        const unsigned o = o_lev + (unsigned)rs * rowB;
+        if constexpr (FORA) {
+            const double (*out)[64] = sh.outA[q];
+            const double v = out[0][lane], u = out[1][lane], c = out[2][lane], t = out[3][lane];
+            const double au = out[4][lane], av = out[5][lane], bu = out[6][lane];
+            gst(a.x[V_V], o, LIMIT ? limited<V_V>(v, land) : v);
+            gst(a.x[V_U], o, LIMIT ? limited<V_U>(u, land) : u);
+            gst(a.x[V_C], o, LIMIT ? limited<V_C>(c, land) : c);
+            gst(a.x[V_T], o, LIMIT ? limited<V_T>(t, land) : t);
+            gst(a.aux_u, o, land ? 0. : au);
+            gst(a.aux_v, o, land ? 0. : av);
+            gst(a.buoy, o, land ? 0. : bu);
+        } else {
+            const double (*out)[64] = sh.outB[q];
+            const double w = out[0][lane], cl = out[1][lane], ic = out[2][lane], co = out[3][lane], aw = out[4][lane];
+            gst(a.x[V_W], o, LIMIT ? limited<V_W>(w, land) : w);
+            gst(a.x[V_CLOUD], o, LIMIT ? limited<V_CLOUD>(cl, land) : cl);
+            gst(a.x[V_ICE], o, LIMIT ? limited<V_ICE>(ic, land) : ic);
+            gst(a.x[V_CO2], o, LIMIT ? limited<V_CO2>(co, land) : co);
+            gst(a.aux_w, o, land ? 0. : aw);
+        }
+        announce(&ctl->stored, rs, lane);   // (waits until the values have left LDS)
+    };
     const int first = q == 0 ? 4 : q;
     if (first <= NR) issue(first);
+    bool land_prev = false;
+    int r_last = 0;
 
-    for (int e = 0; e < NE; e++) {
-        const int r = e + 1;
+    for (int r = first; r <= NR; r += 4) {
+        const int e = r;
         PSTAMP(stamp_wave, 0);
-        if ((r & 3) == q && r <= NR) {
+        // the slot is free once the chain wave has finished the row that stood in it; its results go to memory first
+        wait_for(done, r - 4, err);
+        if (r > 4) store_row(r - 4, land_prev);
+        PSTAMP(stamp_wave, 1);
+        {
             const bool window = r >= 2 && r < jm - 3;
             const double g = lcos * lirs;
             // the mask: RHS_Atm.cpp:110-149
             const unsigned fl = lfl;
-            PSTAMP(stamp_wave, 1);
             const bool land = fl & FL_LAND;
+            land_prev = land;
             const double hdj = ((fl & FL_H0J) && (fl & FL_H0K)) ? 0. : 1.;
             // which theta form stands (RHS_Atm.cpp:162-170, 192-199, 245-312), as factors of x, x[j-1], x[j-2], x[j+1]
             const int mode = !window ? 0 : ((fl & FL_ONESIDED_S) ? 2 : 1);
@@ -216,22 +294,28 @@ __device__ __forceinline__ void prep_wave(const PipeArgs& a, const DevConst& K, 
             const double G1 = __builtin_fma(f1, hEr, b1 * hDg), G2 = __builtin_fma(f2, hEr, b2 * hDg);
             const double dmp_i = lh0i * i_dr2;
             double KQ[4], KB[4] = { 0., 0., 0., 0. };
-            if constexpr (FORA) {
+            if (!window) {  // b2 = f2 = 0 on these rows: the x[j-2] arrays are free for KB
+                const double H3 = b3 * hDr;
 #pragma unroll
-                for (int c = 0; c < 3; c++) { S.q1A[c][lane] = G1 * idc[c]; S.q2A[c][lane] = G2 * idc[c]; }
+                for (int n = 0; n < 4; n++) KB[n] = H3 * lxp[n];
+            }
+            if constexpr (FORA) {
+                SA.cA[lane] = A1 * i_rm; SA.H1[lane] = b1 * hDr; SA.H2[lane] = b2 * hDr;
+#pragma unroll
+                for (int c = 0; c < 3; c++) { SA.q1[c][lane] = G1 * idc[c]; SA.q2[c][lane] = window ? G2 * idc[c] : KB[c]; }
                 // factor of the stage value outside the advection product: diffusion bracket and damping
                 const double p_re = Pb * i_re;
                 const double h0j = (fl & FL_H0J) ? 1. : 0.;
-                S.cPA[0][lane] = p_re - lcoefv * hdj * i_re - h0j * i_dthe2;
-                S.cPA[1][lane] = p_re - dmp_i;
-                S.cPA[2][lane] = Pb * i_re_sc_wv;
-                S.cPA[3][lane] = Pb * i_re_x;
+                SA.cP[0][lane] = p_re - lcoefv * hdj * i_re - h0j * i_dthe2;
+                SA.cP[1][lane] = p_re - dmp_i;
+                SA.cP[2][lane] = Pb * i_re_sc_wv;
+                SA.cP[3][lane] = Pb * i_re_x;
                 // pressure gradient of the v equation (p_dyn is not changed by the sweep)
                 const double dp = hD * (fa * lp[2] + b1 * lp[1] + b2 * lp[0] + b3 * lp[3]);
                 const double pgv = hdj * dp * i_rm * i_r_air;
-                S.pgv[lane] = pgv;
+                SA.pgv[lane] = pgv;
                 const double twoD = two * hD;
-                S.cR[lane] = two * A1; S.qu1[lane] = twoD * b1; S.qu2[lane] = twoD * b2;
+                SA.cR[lane] = two * A1; SA.qu1[lane] = twoD * b1; SA.qu2[lane] = window ? twoD * b2 : KB[3];
                 // constant terms: sources, and on the pole-side rows the old row j+1
                 KQ[0] = -pgv; KQ[1] = 0.; KQ[2] = lS[4] * ctr; KQ[3] = ce * (lS[0] + lS[1]) + ce * (lS[2] + lS[3]);
                 if (!window) KQ[0] = __builtin_fma(twoD * b3, lxp[1], KQ[0]);
@@ -239,63 +323,55 @@ __device__ __forceinline__ void prep_wave(const PipeArgs& a, const DevConst& K, 
                     double ep = lev - lpr;
                     if (ep >= 6.) ep = 6.;
                     if (ep <= -6.) ep = -6.;
-                    S.cFac[lane] = land ? 0. : evf * (1. - 2. * lc0) * ep;
-                    S.cMc[lane] = -3. * lc0 - lc3;
-                    S.phk[lane] = lph * i_phk;
+                    SA.cFac[lane] = land ? 0. : evf * (1. - 2. * lc0) * ep;
+                    SA.cMc[lane] = -3. * lc0 - lc3;
+                    SA.phk[lane] = lph * i_phk;
                 }
             } else {
-                S.cA[lane] = A1 * i_rm; S.H1[lane] = b1 * hDr; S.H2[lane] = b2 * hDr;
+                SB.cA[lane] = A1 * i_rm; SB.H1[lane] = b1 * hDr; SB.H2[lane] = window ? b2 * hDr : KB[3];
 #pragma unroll
-                for (int c = 0; c < 3; c++) { S.q1B[c][lane] = G1 * idc[c]; S.q2B[c][lane] = G2 * idc[c]; }
+                for (int c = 0; c < 3; c++) { SB.q1[c][lane] = G1 * idc[c]; SB.q2[c][lane] = window ? G2 * idc[c] : KB[c]; }
                 const double h0k = (fl & FL_H0K) ? 1. : 0.;
                 const double p_wv = Pb * i_re_sc_wv;
-                S.cPB[0][lane] = __builtin_fma(-h0k, i_dphi2, Pb * i_re);
-                S.cPB[1][lane] = p_wv - dmp_i;
-                S.cPB[2][lane] = __builtin_fma(Pb, i_re_x, -dmp_i);
+                SB.cP[0][lane] = __builtin_fma(-h0k, i_dphi2, Pb * i_re);
+                SB.cP[1][lane] = p_wv - dmp_i;
+                SB.cP[2][lane] = __builtin_fma(Pb, i_re_x, -dmp_i);
                 KQ[0] = 0.; KQ[1] = lS[0] * ctr; KQ[2] = lS[2] * ctr; KQ[3] = 0.;
-                S.fl[lane] = fl;
             }
             if (!window) {
-                const double G3 = __builtin_fma(f3, hEr, b3 * hDg), H3 = b3 * hDr;
+                const double G3 = __builtin_fma(f3, hEr, b3 * hDg);
 #pragma unroll
-                for (int n = 0; n < 4; n++) {
-                    KB[n] = H3 * lxp[n];
-                    KQ[n] = __builtin_fma(G3 * idc[CLS[n]], lxp[n], KQ[n]);
-                }
+                for (int n = 0; n < 4; n++) KQ[n] = __builtin_fma(G3 * idc[CLS[n]], lxp[n], KQ[n]);
             }
-            double (*x0)[64] = FORA ? S.x0A : S.x0B, (*xn)[64] = FORA ? S.xnA : S.xnB;
-            double (*kq)[64] = FORA ? S.KQA : S.KQB, (*kb)[64] = FORA ? S.KBA : S.KBB;
+            double (*x0)[64] = FORA ? SA.x0 : SB.x0, (*xn)[64] = FORA ? SA.xn : SB.xn, (*kq)[64] = FORA ? SA.KQ : SB.KQ;
 #pragma unroll
             for (int n = 0; n < 4; n++) {
                 x0[n][lane] = lx[n]; xn[n][lane] = lxn[n];
                 const bool zero_in_window = FORA ? n == 1 : (n == 0 || n == 3);   // u; w, co2: no source term
                 if (!window || !zero_in_window) kq[n][lane] = KQ[n];
-                if (!window) kb[n][lane] = KB[n];
             }
             PSTAMP(stamp_wave, 2);
+            announce(&ctl->rdy, r, lane);
+            r_last = r;
             if (r + 4 <= NR) issue(r + 4);
             PSTAMP(stamp_wave, 3);
         }
-        PSTAMP(stamp_wave, 4);
-        lds_barrier();
-        PSTAMP(stamp_wave, 5);
+    }
+    if (r_last) {  // the wave's last row
+        wait_for(done, r_last, err);
+        store_row(r_last, land_prev);
     }
 }
 
-// One variable's four stages need: the row's shared factors, its own packet entries, and v.
-struct RowShared { double cA, H1, H2; };
-
 // ---- chain wave A: v, u, c, t ------------------------------------------------------------------------------------
-template <bool L1, bool LIMIT>
-__device__ __forceinline__ void chain_a(const PipeArgs& a, const DevConst& K, PipeShared& sh, const int i, const int bx) {
+template <bool L1>
+__device__ __forceinline__ void chain_a(const PipeArgs& a, const DevConst& K, PipeShared& sh, const int i, const int bx, int* err) {
     const int jm = K.jm, km = K.km;
     const int lane = threadIdx.x & 63;
     const int kk = 1 + bx * 64 + lane;
     const int k = kk <= km - 2 ? kk : km - 2;
-    const int NR = jm - 2, NE = NR + 2;
-    const unsigned rowB = (unsigned)km * 8u;
-    unsigned o_lev = (unsigned)(((size_t)i * jm * km + k) * 8);
-    PIN(o_lev);
+    const int NR = jm - 2;
+    const unsigned o_lev = (unsigned)(((size_t)i * jm * km + k) * 8);
     constexpr int VARS[4] = { V_V, V_U, V_C, V_T };
     constexpr int CLS[4] = { QA_RE, QA_RE, QA_WV, QA_PR };
     enum { cV = 0, cU = 1, cC = 2, cT = 3 };
@@ -306,88 +382,101 @@ __device__ __forceinline__ void chain_a(const PipeArgs& a, const DevConst& K, Pi
 #pragma unroll
     for (int n = 0; n < 4; n++) xm1[n] = gld(a.x[VARS[n]], o_lev);
 
-    for (int e = 0; e < NE; e++) {
+    for (int j = 1; j <= NR; j++) {
+        const int e = j;
         PSTAMP(0, 0);
-        if (e >= 1 && e <= NR) {
-            const int j = e;
-            const bool window = j >= 2 && j < jm - 3;
-            const Slot& S = sh.ring[j & 3];
-            double (*vst)[64] = sh.vst[j & 1];
-            const unsigned o = o_lev + (unsigned)j * rowB;
-            const bool land = S.fl[lane] & FL_LAND;
-            const double cA = S.cA[lane], H1 = S.H1[lane], H2 = S.H2[lane];
-            double st[4], xn[4], cB[4], cQ[4], cP[4], acc[4], rhs[4];
+        // the row's packet; the slot's output arrays free (row j-4 stored); the buffer for the stage values of v free
+        // (chain B done with row j-2)
+        const bool window = j >= 2 && j < jm - 3;
+        const HalfA& S = sh.ha[j & 3];
+        double (*vst)[64] = sh.vst[j & 1];
+        double (*out)[64] = sh.outA[j & 3];
+        double cA, H1, H2, cR, pgv, qu1, qu2, cFac = 0., cMc = 0., phk = 0.;
+        double st[4], xn[4], cB[4], cQ[4], cP[4], acc[4], rhs[4], q1[3], q2[3], kq[4];
+        // The words and the packet are read in one go: the words first, so a packet read behind words that say "there" is
+        // the packet (a wave's LDS reads are carried out in order); if the words say "not yet", everything is read again.
+        for (int n = 0;; n++) {
+            asm volatile("" ::: "memory");
+            const int w_rdy = *LDS_WORD(&sh.ctlA[j & 3].rdy), w_st = *LDS_WORD(&sh.ctlA[j & 3].stored);
+            const int w_b = *LDS_WORD(&sh.doneB);
+            asm volatile("" ::: "memory");
+            cA = S.cA[lane]; H1 = S.H1[lane]; H2 = S.H2[lane]; cR = S.cR[lane]; pgv = S.pgv[lane]; qu1 = S.qu1[lane]; qu2 = S.qu2[lane];
+#pragma unroll
+            for (int c = 0; c < 3; c++) { q1[c] = S.q1[c][lane]; q2[c] = S.q2[c][lane]; }
+#pragma unroll
+            for (int m = 0; m < 4; m++) { st[m] = S.x0[m][lane]; xn[m] = S.xn[m][lane]; cP[m] = S.cP[m][lane]; kq[m] = S.KQ[m][lane]; }
+            if constexpr (L1) { cFac = S.cFac[lane]; cMc = S.cMc[lane]; phk = S.phk[lane]; }
+            asm volatile("" ::: "memory");
+            if (__builtin_amdgcn_readfirstlane(w_rdy) >= j && __builtin_amdgcn_readfirstlane(w_st) >= j - 4 &&
+                __builtin_amdgcn_readfirstlane(w_b) >= j - 2) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (n > (1 << 22)) {
+                __hip_atomic_store(err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+        }
+        PSTAMP(0, 1);
+#pragma unroll
+        for (int n = 0; n < 4; n++) {
+            const double alias = n < 3 ? q2[n] : qu2;   // pole-side rows: KB of the variable
+            const double kb = window ? 0. : alias;
+            const double q2n = window ? q2[CLS[n]] : 0.;
+            const double kqn = (window && n == cU) ? 0. : kq[n];
+            cB[n] = __builtin_fma(H1, xm1[n], __builtin_fma(window ? H2 : 0., xm2[n], kb));
+            cQ[n] = __builtin_fma(q1[CLS[n]], xm1[n], __builtin_fma(q2n, xm2[n], kqn));
+        }
+        cQ[cV] = __builtin_fma(qu1, xm1[cU], __builtin_fma(window ? qu2 : 0., xm2[cU], cQ[cV]));  // 2 du/dthe / rm^2 / re
+        double RS = 0.;
+#ifdef ATOMDEV_EXP_PIPE_NOCHAIN  // timing experiment only (results are wrong): the recurrence without its arithmetic
+#pragma unroll
+        for (int n = 0; n < 4; n++) { rhs[n] = cB[n] + cQ[n] + cP[n]; st[n] += xn[n]; }
+        if (j < 0)
+#endif
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const double v = st[cV];
+            vst[s][lane] = v;
+            // buoyancy (RHS_Atm.cpp:390-404): K g (r_humid - r_dry) / r_dry, the dry density cancels
+            const double y = rcp2(__builtin_fma(kWV, st[cC], 1.));
+            const double hod = (1. + st[cC]) * y;   // humid over dry density
+            RS = KK * (hod - 1.);
+            double lin[4];
+#pragma unroll
+            for (int n = 0; n < 4; n++) lin[n] = __builtin_fma(cP[n], st[n], cQ[n]);
+            lin[cU] -= RS;
+            lin[cV] = __builtin_fma(cR, st[cU], lin[cV]);
+            if constexpr (L1) {  // surface evaporation source of c (RHS_Atm.cpp:412-430), dry density from this stage's t
+                const double r_humid = phk * rcp2(st[cT]) * hod;
+                lin[cC] = __builtin_fma(r_humid * __builtin_fma(4., st[cC], cMc), cFac, lin[cC]);
+            }
 #pragma unroll
             for (int n = 0; n < 4; n++) {
-                st[n] = S.x0A[n][lane]; xn[n] = S.xnA[n][lane]; cP[n] = S.cPA[n][lane];
-                const double kb = window ? 0. : S.KBA[n][lane];
-                const double kq = (window && n == cU) ? 0. : S.KQA[n][lane];
-                cB[n] = __builtin_fma(H1, xm1[n], __builtin_fma(H2, xm2[n], kb));
-                cQ[n] = __builtin_fma(S.q1A[CLS[n]][lane], xm1[n], __builtin_fma(S.q2A[CLS[n]][lane], xm2[n], kq));
+                rhs[n] = __builtin_fma(-v, __builtin_fma(cA, st[n], cB[n]), lin[n]);
+                // RungeKutta_Atm.cpp:58-152
+                if (s == 0) { acc[n] = rhs[n]; st[n] = __builtin_fma(rhs[n], hdt, xn[n]); }
+                else if (s == 1) { acc[n] = __builtin_fma(2., rhs[n], acc[n]); st[n] = __builtin_fma(rhs[n], hdt, xn[n]); }
+                else if (s == 2) { acc[n] = __builtin_fma(2., rhs[n], acc[n]); st[n] = __builtin_fma(rhs[n], dt, xn[n]); }
+                else st[n] = __builtin_fma(acc[n] + rhs[n], dt6, xn[n]);
             }
-            cQ[cV] = __builtin_fma(S.qu1[lane], xm1[cU], __builtin_fma(S.qu2[lane], xm2[cU], cQ[cV]));  // 2 du/dthe / rm^2 / re
-            const double cR = S.cR[lane], pgv = S.pgv[lane];
-            double cFac = 0., cMc = 0., phk = 0.;
-            if constexpr (L1) { cFac = S.cFac[lane]; cMc = S.cMc[lane]; phk = S.phk[lane]; }
-            double RS = 0.;
-            PSTAMP(0, 1);
-#pragma unroll
-            for (int s = 0; s < 4; s++) {
-                const double v = st[cV];
-                vst[s][lane] = v;
-                // buoyancy (RHS_Atm.cpp:390-404): K g (r_humid - r_dry) / r_dry, the dry density cancels
-                const double y = rcp2(__builtin_fma(kWV, st[cC], 1.));
-                const double hod = (1. + st[cC]) * y;   // humid over dry density
-                RS = KK * (hod - 1.);
-                double lin[4];
-#pragma unroll
-                for (int n = 0; n < 4; n++) lin[n] = __builtin_fma(cP[n], st[n], cQ[n]);
-                lin[cU] -= RS;
-                lin[cV] = __builtin_fma(cR, st[cU], lin[cV]);
-                if constexpr (L1) {  // surface evaporation source of c (RHS_Atm.cpp:412-430), dry density from this stage's t
-                    const double r_humid = phk * rcp2(st[cT]) * hod;
-                    lin[cC] = __builtin_fma(r_humid * __builtin_fma(4., st[cC], cMc), cFac, lin[cC]);
-                }
-#pragma unroll
-                for (int n = 0; n < 4; n++) {
-                    rhs[n] = __builtin_fma(-v, __builtin_fma(cA, st[n], cB[n]), lin[n]);
-                    // RungeKutta_Atm.cpp:58-152
-                    if (s == 0) { acc[n] = rhs[n]; st[n] = __builtin_fma(rhs[n], hdt, xn[n]); }
-                    else if (s == 1) { acc[n] = __builtin_fma(2., rhs[n], acc[n]); st[n] = __builtin_fma(rhs[n], hdt, xn[n]); }
-                    else if (s == 2) { acc[n] = __builtin_fma(2., rhs[n], acc[n]); st[n] = __builtin_fma(rhs[n], dt, xn[n]); }
-                    else st[n] = __builtin_fma(acc[n] + rhs[n], dt6, xn[n]);
-                }
-            }
-            PSTAMP(0, 2);
-            // results and the side outputs of the fourth evaluation (RHS_Atm.cpp:406-410, 485-492)
-            gst(a.x[V_V], o, LIMIT ? limited<V_V>(st[cV], land) : st[cV]);
-            gst(a.x[V_U], o, LIMIT ? limited<V_U>(st[cU], land) : st[cU]);
-            gst(a.x[V_C], o, LIMIT ? limited<V_C>(st[cC], land) : st[cC]);
-            gst(a.x[V_T], o, LIMIT ? limited<V_T>(st[cT], land) : st[cT]);
-            gst(a.aux_u, o, land ? 0. : rhs[cU]);
-            gst(a.aux_v, o, land ? 0. : rhs[cV] + pgv);
-            gst(a.buoy, o, land ? 0. : -RS * cb1000);
-#pragma unroll
-            for (int n = 0; n < 4; n++) { xm2[n] = xm1[n]; xm1[n] = st[n]; }
-            PSTAMP(0, 3);
         }
-        PSTAMP(0, 4);
-        lds_barrier();
-        PSTAMP(0, 5);
+        PSTAMP(0, 2);
+        // results and the side outputs of the fourth evaluation, for the memory wave of the slot to store
+#pragma unroll
+        for (int n = 0; n < 4; n++) { out[n][lane] = st[n]; xm2[n] = xm1[n]; xm1[n] = st[n]; }
+        out[4][lane] = rhs[cU]; out[5][lane] = rhs[cV] + pgv; out[6][lane] = -RS * cb1000;
+        announce_in_order(&sh.doneA, j, lane);
+        PSTAMP(0, 3);
     }
 }
 
-// ---- chain wave B: w, cloud, ice, co2, one row behind A ------------------------------------------------------------
-template <bool LIMIT>
-__device__ __forceinline__ void chain_b(const PipeArgs& a, const DevConst& K, PipeShared& sh, const int i, const int bx) {
+// ---- chain wave B: w, cloud, ice, co2, behind A --------------------------------------------------------------------
+__device__ __forceinline__ void chain_b(const PipeArgs& a, const DevConst& K, PipeShared& sh, const int i, const int bx, int* err) {
     const int jm = K.jm, km = K.km;
     const int lane = threadIdx.x & 63;
     const int kk = 1 + bx * 64 + lane;
     const int k = kk <= km - 2 ? kk : km - 2;
-    const int NR = jm - 2, NE = NR + 2;
-    const unsigned rowB = (unsigned)km * 8u;
-    unsigned o_lev = (unsigned)(((size_t)i * jm * km + k) * 8);
-    PIN(o_lev);
+    const int NR = jm - 2;
+    const unsigned o_lev = (unsigned)(((size_t)i * jm * km + k) * 8);
     constexpr int VARS[4] = { V_W, V_CLOUD, V_ICE, V_CO2 };
     constexpr int CLS[4] = { QB_RE, QB_WV, QB_WV, QB_CO2 };
     constexpr int CPS[4] = { 0, 1, 1, 2 };
@@ -397,57 +486,74 @@ __device__ __forceinline__ void chain_b(const PipeArgs& a, const DevConst& K, Pi
 #pragma unroll
     for (int n = 0; n < 4; n++) xm1[n] = gld(a.x[VARS[n]], o_lev);
 
-    for (int e = 0; e < NE; e++) {
+    for (int j = 1; j <= NR; j++) {
+        const int e = j;
         PSTAMP(1, 0);
-        if (e >= 2 && e <= NR + 1) {
-            const int j = e - 1;
-            const bool window = j >= 2 && j < jm - 3;
-            const Slot& S = sh.ring[j & 3];
-            const double (*vst)[64] = sh.vst[j & 1];
-            const unsigned o = o_lev + (unsigned)j * rowB;
-            const bool land = S.fl[lane] & FL_LAND;
-            const double cA = S.cA[lane], H1 = S.H1[lane], H2 = S.H2[lane];
-            double st[4], xn[4], cB[4], cQ[4], cP[4], acc[4], rhs[4];
+        const bool window = j >= 2 && j < jm - 3;
+        const HalfB& S = sh.hb[j & 3];
+        const double (*vst)[64] = sh.vst[j & 1];
+        double (*out)[64] = sh.outB[j & 3];
+        double cA, H1, H2, vs[4];
+        double st[4], xn[4], cB[4], cQ[4], cP[4], acc[4], rhs[4], q1[3], q2[3], kq[4];
+        for (int n = 0;; n++) {   // words and packet in one go, as in chain A; here also the stage values of v of the row
+            asm volatile("" ::: "memory");
+            const int w_rdy = *LDS_WORD(&sh.ctlB[j & 3].rdy), w_st = *LDS_WORD(&sh.ctlB[j & 3].stored);
+            const int w_a = *LDS_WORD(&sh.doneA);
+            asm volatile("" ::: "memory");
+            cA = S.cA[lane]; H1 = S.H1[lane]; H2 = S.H2[lane];
+#pragma unroll
+            for (int c = 0; c < 3; c++) { q1[c] = S.q1[c][lane]; q2[c] = S.q2[c][lane]; }
+#pragma unroll
+            for (int m = 0; m < 4; m++) { st[m] = S.x0[m][lane]; xn[m] = S.xn[m][lane]; cP[m] = S.cP[CPS[m]][lane]; kq[m] = S.KQ[m][lane]; vs[m] = vst[m][lane]; }
+            asm volatile("" ::: "memory");
+            if (__builtin_amdgcn_readfirstlane(w_rdy) >= j && __builtin_amdgcn_readfirstlane(w_st) >= j - 4 &&
+                __builtin_amdgcn_readfirstlane(w_a) >= j) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (n > (1 << 22)) {
+                __hip_atomic_store(err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+        }
+        PSTAMP(1, 1);
+#pragma unroll
+        for (int n = 0; n < 4; n++) {
+            const double alias = n < 3 ? q2[n] : H2;   // pole-side rows: KB of the variable
+            const double kb = window ? 0. : alias;
+            const double q2n = window ? q2[CLS[n]] : 0.;
+            const double kqn = (window && (n == 0 || n == 3)) ? 0. : kq[n];
+            cB[n] = __builtin_fma(H1, xm1[n], __builtin_fma(window ? H2 : 0., xm2[n], kb));
+            cQ[n] = __builtin_fma(q1[CLS[n]], xm1[n], __builtin_fma(q2n, xm2[n], kqn));
+        }
+#ifdef ATOMDEV_EXP_PIPE_NOCHAIN
+#pragma unroll
+        for (int n = 0; n < 4; n++) { rhs[n] = cB[n] + cQ[n] + cP[n] + vs[n]; st[n] += xn[n]; }
+        if (j < 0)
+#endif
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const double v = vs[s];
 #pragma unroll
             for (int n = 0; n < 4; n++) {
-                st[n] = S.x0B[n][lane]; xn[n] = S.xnB[n][lane]; cP[n] = S.cPB[CPS[n]][lane];
-                const double kb = window ? 0. : S.KBB[n][lane];
-                const double kq = (window && (n == 0 || n == 3)) ? 0. : S.KQB[n][lane];
-                cB[n] = __builtin_fma(H1, xm1[n], __builtin_fma(H2, xm2[n], kb));
-                cQ[n] = __builtin_fma(S.q1B[CLS[n]][lane], xm1[n], __builtin_fma(S.q2B[CLS[n]][lane], xm2[n], kq));
+                rhs[n] = __builtin_fma(-v, __builtin_fma(cA, st[n], cB[n]), __builtin_fma(cP[n], st[n], cQ[n]));
+                if (s == 0) { acc[n] = rhs[n]; st[n] = __builtin_fma(rhs[n], hdt, xn[n]); }
+                else if (s == 1) { acc[n] = __builtin_fma(2., rhs[n], acc[n]); st[n] = __builtin_fma(rhs[n], hdt, xn[n]); }
+                else if (s == 2) { acc[n] = __builtin_fma(2., rhs[n], acc[n]); st[n] = __builtin_fma(rhs[n], dt, xn[n]); }
+                else st[n] = __builtin_fma(acc[n] + rhs[n], dt6, xn[n]);
             }
-#pragma unroll
-            for (int s = 0; s < 4; s++) {
-                const double v = vst[s][lane];
-#pragma unroll
-                for (int n = 0; n < 4; n++) {
-                    rhs[n] = __builtin_fma(-v, __builtin_fma(cA, st[n], cB[n]), __builtin_fma(cP[n], st[n], cQ[n]));
-                    if (s == 0) { acc[n] = rhs[n]; st[n] = __builtin_fma(rhs[n], hdt, xn[n]); }
-                    else if (s == 1) { acc[n] = __builtin_fma(2., rhs[n], acc[n]); st[n] = __builtin_fma(rhs[n], hdt, xn[n]); }
-                    else if (s == 2) { acc[n] = __builtin_fma(2., rhs[n], acc[n]); st[n] = __builtin_fma(rhs[n], dt, xn[n]); }
-                    else st[n] = __builtin_fma(acc[n] + rhs[n], dt6, xn[n]);
-                }
-            }
-            gst(a.x[V_W], o, LIMIT ? limited<V_W>(st[0], land) : st[0]);
-            gst(a.x[V_CLOUD], o, LIMIT ? limited<V_CLOUD>(st[1], land) : st[1]);
-            gst(a.x[V_ICE], o, LIMIT ? limited<V_ICE>(st[2], land) : st[2]);
-            gst(a.x[V_CO2], o, LIMIT ? limited<V_CO2>(st[3], land) : st[3]);
-            gst(a.aux_w, o, land ? 0. : rhs[0]);
-#pragma unroll
-            for (int n = 0; n < 4; n++) { xm2[n] = xm1[n]; xm1[n] = st[n]; }
-            PSTAMP(1, 3);
         }
-        PSTAMP(1, 4);
-        lds_barrier();
-        PSTAMP(1, 5);
+#pragma unroll
+        for (int n = 0; n < 4; n++) { out[n][lane] = st[n]; xm2[n] = xm1[n]; xm1[n] = st[n]; }
+        out[4][lane] = rhs[0];
+        announce_in_order(&sh.doneB, j, lane);
+        PSTAMP(1, 3);
     }
 }
 
 // Waves of the 1 024-thread workgroup: w and w + 4 (and w + 8, w + 12) share a SIMD.  Wave 0 is chain A, wave 1 chain B,
-// and the waves that would share their SIMDs end at once; the eight waves on the other two SIMDs are the prep waves:
+// and the waves that would share their SIMDs end at once; the eight waves on the other two SIMDs are the memory waves:
 // rows r = q mod 4 belong to the pair (2 + 4 q, 3 + 4 q), the first working for chain A, the second for chain B.
 template <bool LIMIT>
-__global__ __launch_bounds__(1024) void k_atm_rk3d_pipe(const PipeParams* __restrict__ P) {
+__global__ __launch_bounds__(1024) void k_atm_rk3d_pipe(const PipeParams* __restrict__ P, int* err) {
     const PipeArgs& a = P->a;
     const DevConst& K = P->K;
     __shared__ PipeShared sh;
@@ -458,24 +564,28 @@ __global__ __launch_bounds__(1024) void k_atm_rk3d_pipe(const PipeParams* __rest
     if (lev >= K.im - 2) return;
     const int i = 1 + lev;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (threadIdx.x < NSLOT) { sh.ctlA[threadIdx.x] = { 0, 0 }; sh.ctlB[threadIdx.x] = { 0, 0 }; }
+    if (threadIdx.x == 0) { sh.doneA = 0; sh.doneB = 0; }
+    __syncthreads();   // the only barrier: from here on the waves follow each other's progress words
 #ifdef ATOMDEV_EXP_PIPE_STAMP
     if (threadIdx.x == 0) { sh.wall[0] = wall_clock64(); sh.cyc[0] = __builtin_readcyclecounter(); }
     for (int n = threadIdx.x; n < 10 * 4 * 8; n += blockDim.x) (&sh.stamps[0][0][0])[n] = 0;
     __syncthreads();
 #endif
     if (wave == 0) {
-        if (i == 1) chain_a<true, LIMIT>(a, K, sh, i, bx);
-        else chain_a<false, LIMIT>(a, K, sh, i, bx);
+        if (i == 1) chain_a<true>(a, K, sh, i, bx, err);
+        else chain_a<false>(a, K, sh, i, bx, err);
     } else if (wave == 1) {
-        chain_b<LIMIT>(a, K, sh, i, bx);
+        chain_b(a, K, sh, i, bx, err);
     } else if ((wave & 3) == 2) {
-        if (i == 1) prep_wave<true, true>(a, K, sh, wave >> 2, i, bx);
-        else prep_wave<false, true>(a, K, sh, wave >> 2, i, bx);
+        if (i == 1) memory_wave<true, true, LIMIT>(a, K, sh, wave >> 2, i, bx, err);
+        else memory_wave<false, true, LIMIT>(a, K, sh, wave >> 2, i, bx, err);
     } else if ((wave & 3) == 3) {
-        prep_wave<false, false>(a, K, sh, wave >> 2, i, bx);
+        memory_wave<false, false, LIMIT>(a, K, sh, wave >> 2, i, bx, err);
     }
 #ifdef ATOMDEV_EXP_PIPE_STAMP
-    if (threadIdx.x == 0 && bx == 2 && i == ATOMDEV_EXP_PIPE_STAMP) {  // wave 0 leaves the loop after the last barrier: every stamp is there
+    __syncthreads();
+    if (threadIdx.x == 0 && bx == 2 && i == ATOMDEV_EXP_PIPE_STAMP) {
         sh.wall[1] = wall_clock64(); sh.cyc[1] = __builtin_readcyclecounter();
         for (int n = 0; n < 10 * 4 * 8; n++) a.aux_w[n] = (double)(long long)(&sh.stamps[0][0][0])[n];
         a.aux_w[400] = (double)(long long)(sh.wall[1] - sh.wall[0]); a.aux_w[401] = (double)(long long)(sh.cyc[1] - sh.cyc[0]);
@@ -513,9 +623,9 @@ int atomdev_atm_rk3d_pipe_launch(atomdev* h, bool limit) {
     const unsigned gx = (h->km - 2 + 63) / 64, rounds = (h->im - 2 + 7) / 8;
     dim3 grid(8 * rounds * gx);
     if (limit)
-        hipLaunchKernelGGL(k_atm_rk3d_pipe<true>, grid, dim3(1024), 0, h->stream, (const PipeParams*)h->pipe_params);
+        hipLaunchKernelGGL(k_atm_rk3d_pipe<true>, grid, dim3(1024), 0, h->stream, (const PipeParams*)h->pipe_params, (int*)atomdev_kernel_error_word(h));
     else
-        hipLaunchKernelGGL(k_atm_rk3d_pipe<false>, grid, dim3(1024), 0, h->stream, (const PipeParams*)h->pipe_params);
+        hipLaunchKernelGGL(k_atm_rk3d_pipe<false>, grid, dim3(1024), 0, h->stream, (const PipeParams*)h->pipe_params, (int*)atomdev_kernel_error_word(h));
     ATOMDEV_TRY(hipGetLastError());
     return 0;
 }
