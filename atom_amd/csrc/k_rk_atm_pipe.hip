@@ -163,9 +163,8 @@ __device__ __forceinline__ double limited(double x, bool land) {
     return x;
 }
 
-// ---- a memory wave: rows r = q, q + 4, ... (r >= 1) --------------------------------------------------------------
-// Both halves of the row's packet; what the mask and the geometry decide is worked out once.
-template <bool L1, bool LIMIT>
+// ---- a memory wave: rows r = q, q + 4, ... (r >= 1), the half of the row that chain A (FORA) or chain B works on ----
+template <bool L1, bool FORA, bool LIMIT>
 __device__ __forceinline__ void memory_wave(const PipeArgs& a, const DevConst& K, PipeShared& sh, const int q, const int i, const int bx, int* err) {
     const int jm = K.jm, km = K.km;
     const int lane = threadIdx.x & 63;
@@ -178,9 +177,11 @@ __device__ __forceinline__ void memory_wave(const PipeArgs& a, const DevConst& K
     PIN(o_lev); PIN(o_sfc);
     HalfA& SA = sh.ha[q];
     HalfB& SB = sh.hb[q];
-    const int stamp_wave = 2 + q;
+    Ctl* ctl = FORA ? &sh.ctlA[q] : &sh.ctlB[q];
+    const int* done = FORA ? &sh.doneA : &sh.doneB;
+    constexpr int VARS[4] = { FORA ? V_V : V_W, FORA ? V_U : V_CLOUD, FORA ? V_C : V_ICE, FORA ? V_T : V_CO2 };
+    const int stamp_wave = 2 + 2 * q + (FORA ? 0 : 1);
     (void)stamp_wave;
-    constexpr int VA[4] = { V_V, V_U, V_C, V_T }, VB[4] = { V_W, V_CLOUD, V_ICE, V_CO2 };
 
     const double rm = a.rad[i];
     const double i_rm = 1. / rm, i_rm2 = 1. / (rm * rm);
@@ -188,17 +189,17 @@ __device__ __forceinline__ void memory_wave(const PipeArgs& a, const DevConst& K
     const double i_phk = 1. / (K.R_Air * K.t_0);
     const double evf = K.coeff_vapour * K.i_two_dr;
     double i_dthe = K.i_dthe, i_two_dthe = K.i_two_dthe, i_dthe2 = K.i_dthe2, i_dr2 = K.i_dr2, i_dphi2 = K.i_dphi2;
-    double i_re = K.i_re, i_re_sc_wv = K.i_re_sc_wv, i_re_pr = K.i_re_pr, i_re_sc_co2 = K.i_re_sc_co2, i_r_air = K.i_r_air;
-    SPIN(i_dthe); SPIN(i_two_dthe); SPIN(i_dthe2); SPIN(i_dr2); SPIN(i_dphi2); SPIN(i_re); SPIN(i_re_sc_wv); SPIN(i_re_pr);
-    SPIN(i_re_sc_co2); SPIN(i_r_air);
+    double i_re = K.i_re, i_re_sc_wv = K.i_re_sc_wv, i_re_x = FORA ? K.i_re_pr : K.i_re_sc_co2, i_r_air = K.i_r_air;
+    SPIN(i_dthe); SPIN(i_two_dthe); SPIN(i_dthe2); SPIN(i_dr2); SPIN(i_dphi2); SPIN(i_re); SPIN(i_re_sc_wv); SPIN(i_re_x); SPIN(i_r_air);
     const double two = 2. * i_rm2 * i_re;
-    const double idA[3] = { i_re, i_re_sc_wv, i_re_pr }, idB[3] = { i_re, i_re_sc_wv, i_re_sc_co2 };
-    constexpr int CLA[4] = { 0, 0, 1, 2 }, CLB[4] = { 0, 1, 1, 2 };   // diffusion class of v, u, c, t and of w, cloud, ice, co2
+    // diffusion divisors of this half's classes and variables
+    const double idc[3] = { i_re, i_re_sc_wv, i_re_x };
+    constexpr int CLS[4] = { 0, FORA ? 0 : 1, 1, 2 };   // A: v, u -> re; c -> wv; t -> pr.  B: w -> re; cloud, ice -> wv; co2
 
     // what a row's loads leave behind until the row's turn comes
-    double ax[4], axn[4], axp[4], bx_[4], bxn[4], bxp[4], lS[5], lh0i, lp[4];
+    double lx[4], lxn[4], lxp[4], lS[5], lh0i = 0., lp[4];
     double lev = 0., lpr = 0., lc0 = 0., lc3 = 0., lph = 0.;
-    double lcos, lirs, lcoefv;  // geometry of the row: one address for the whole wave, fetched with the rest of the row
+    double lcos, lirs, lcoefv = 0.;  // geometry of the row: one address for the whole wave, fetched with the rest of the row
     unsigned lfl;
     auto issue = [&](const int r) {
 #ifdef ATOMDEV_EXP_PIPE_NOMEM  // timing experiment only (results are wrong): no vector-memory traffic inside the loop
@@ -207,60 +208,59 @@ __device__ __forceinline__ void memory_wave(const PipeArgs& a, const DevConst& K
         const unsigned o = o_lev + (unsigned)r * rowB;
         lfl = *(const __attribute__((address_space(1))) uint8_t*)((gcchar_t)a.flags + (o >> 3));
 #pragma unroll
-        for (int n = 0; n < 4; n++) { ax[n] = gld(a.x[VA[n]], o); axn[n] = gld(a.xn[VA[n]], o); }
-#pragma unroll
-        for (int n = 0; n < 4; n++) { bx_[n] = gld(a.x[VB[n]], o); bxn[n] = gld(a.xn[VB[n]], o); }
-        lcos = gld(a.costhe + r, 0u); lirs = gld(a.tab_irm2sin + (size_t)i * jm + r, 0u); lcoefv = gld(a.tab_coefv + (size_t)i * jm + r, 0u);
+        for (int n = 0; n < 4; n++) { lx[n] = gld(a.x[VARS[n]], o); lxn[n] = gld(a.xn[VARS[n]], o); }
+        lcos = gld(a.costhe + r, 0u); lirs = gld(a.tab_irm2sin + (size_t)i * jm + r, 0u);
         lh0i = gld(a.h0i, o);
-        lS[0] = gld(a.S_c, o); lS[1] = gld(a.S_r, o); lS[2] = gld(a.S_i, o); lS[3] = gld(a.S_s, o); lS[4] = gld(a.S_v, o);
-        lp[0] = r >= 2 ? gld(a.p_dyn, o - 2u * rowB) : 0.;
-        lp[1] = gld(a.p_dyn, o - rowB);
-        lp[2] = gld(a.p_dyn, o);
-        lp[3] = gld(a.p_dyn, o + rowB);
+        if constexpr (FORA) {
+            lS[0] = gld(a.S_c, o); lS[1] = gld(a.S_r, o); lS[2] = gld(a.S_i, o); lS[3] = gld(a.S_s, o); lS[4] = gld(a.S_v, o);
+            lcoefv = gld(a.tab_coefv + (size_t)i * jm + r, 0u);
+            lp[0] = r >= 2 ? gld(a.p_dyn, o - 2u * rowB) : 0.;
+            lp[1] = gld(a.p_dyn, o - rowB);
+            lp[2] = gld(a.p_dyn, o);
+            lp[3] = gld(a.p_dyn, o + rowB);
+        } else {
+            lS[0] = gld(a.S_c, o); lS[2] = gld(a.S_i, o);
+        }
         const bool window = r >= 2 && r < jm - 3;
         if (!window) {
 #pragma unroll
-            for (int n = 0; n < 4; n++) { axp[n] = gld(a.x[VA[n]], o + rowB); bxp[n] = gld(a.x[VB[n]], o + rowB); }
+            for (int n = 0; n < 4; n++) lxp[n] = gld(a.x[VARS[n]], o + rowB);
         }
-        if constexpr (L1) {
+        if constexpr (L1 && FORA) {
             const unsigned oq = o_sfc + (unsigned)r * rowB;
             lev = gld(a.evap, oq); lpr = gld(a.precip, oq);
             lc0 = gld(a.x[V_C], oq); lc3 = gld(a.c3, oq);
             lph = gld(a.ph100, o);
         }
     };
-    // The results of row `rs`, which the chain waves left in the slot's output arrays: limited as the limiter that follows
+    // The results of row `rs`, which the chain wave left in the slot's output arrays: limited as the limiter that follows
     // the sweep in the model's loop would leave them (LIMIT), side outputs zero on land (RHS_Atm.cpp:406-410, 485-492).
-    auto store_a = [&](const int rs, const bool land) {
+    auto store_row = [&](const int rs, const bool land) {
 #ifdef ATOMDEV_EXP_PIPE_NOMEM
-        if (rs > 8) { announce(&sh.ctlA[q].stored, rs, lane); return; }
+        if (rs > 8) { announce(&ctl->stored, rs, lane); return; }
 #endif
         const unsigned o = o_lev + (unsigned)rs * rowB;
-        const double (*out)[64] = sh.outA[q];
-        const double v = out[0][lane], u = out[1][lane], c = out[2][lane], t = out[3][lane];
-        const double au = out[4][lane], av = out[5][lane], bu = out[6][lane];
-        gst(a.x[V_V], o, LIMIT ? limited<V_V>(v, land) : v);
-        gst(a.x[V_U], o, LIMIT ? limited<V_U>(u, land) : u);
-        gst(a.x[V_C], o, LIMIT ? limited<V_C>(c, land) : c);
-        gst(a.x[V_T], o, LIMIT ? limited<V_T>(t, land) : t);
-        gst(a.aux_u, o, land ? 0. : au);
-        gst(a.aux_v, o, land ? 0. : av);
-        gst(a.buoy, o, land ? 0. : bu);
-        announce(&sh.ctlA[q].stored, rs, lane);   // (waits until the values have left LDS)
-    };
-    auto store_b = [&](const int rs, const bool land) {
-#ifdef ATOMDEV_EXP_PIPE_NOMEM
-        if (rs > 8) { announce(&sh.ctlB[q].stored, rs, lane); return; }
-#endif
-        const unsigned o = o_lev + (unsigned)rs * rowB;
-        const double (*out)[64] = sh.outB[q];
-        const double w = out[0][lane], cl = out[1][lane], ic = out[2][lane], co = out[3][lane], aw = out[4][lane];
-        gst(a.x[V_W], o, LIMIT ? limited<V_W>(w, land) : w);
-        gst(a.x[V_CLOUD], o, LIMIT ? limited<V_CLOUD>(cl, land) : cl);
-        gst(a.x[V_ICE], o, LIMIT ? limited<V_ICE>(ic, land) : ic);
-        gst(a.x[V_CO2], o, LIMIT ? limited<V_CO2>(co, land) : co);
-        gst(a.aux_w, o, land ? 0. : aw);
-        announce(&sh.ctlB[q].stored, rs, lane);
+        if constexpr (FORA) {
+            const double (*out)[64] = sh.outA[q];
+            const double v = out[0][lane], u = out[1][lane], c = out[2][lane], t = out[3][lane];
+            const double au = out[4][lane], av = out[5][lane], bu = out[6][lane];
+            gst(a.x[V_V], o, LIMIT ? limited<V_V>(v, land) : v);
+            gst(a.x[V_U], o, LIMIT ? limited<V_U>(u, land) : u);
+            gst(a.x[V_C], o, LIMIT ? limited<V_C>(c, land) : c);
+            gst(a.x[V_T], o, LIMIT ? limited<V_T>(t, land) : t);
+            gst(a.aux_u, o, land ? 0. : au);
+            gst(a.aux_v, o, land ? 0. : av);
+            gst(a.buoy, o, land ? 0. : bu);
+        } else {
+            const double (*out)[64] = sh.outB[q];
+            const double w = out[0][lane], cl = out[1][lane], ic = out[2][lane], co = out[3][lane], aw = out[4][lane];
+            gst(a.x[V_W], o, LIMIT ? limited<V_W>(w, land) : w);
+            gst(a.x[V_CLOUD], o, LIMIT ? limited<V_CLOUD>(cl, land) : cl);
+            gst(a.x[V_ICE], o, LIMIT ? limited<V_ICE>(ic, land) : ic);
+            gst(a.x[V_CO2], o, LIMIT ? limited<V_CO2>(co, land) : co);
+            gst(a.aux_w, o, land ? 0. : aw);
+        }
+        announce(&ctl->stored, rs, lane);   // (waits until the values have left LDS)
     };
     const int first = q == 0 ? 4 : q;
     if (first <= NR) issue(first);
@@ -270,166 +270,97 @@ __device__ __forceinline__ void memory_wave(const PipeArgs& a, const DevConst& K
     for (int r = first; r <= NR; r += 4) {
         const int e = r;
         PSTAMP(stamp_wave, 0);
-        // a half of the slot is free once its chain wave has finished the row that stood in it; that row's results go to
-        // memory first
-        wait_for(&sh.doneA, r - 4, err);
-        if (r > 4) store_a(r - 4, land_prev);
+        // the slot is free once the chain wave has finished the row that stood in it; its results go to memory first
+        wait_for(done, r - 4, err);
+        if (r > 4) store_row(r - 4, land_prev);
         PSTAMP(stamp_wave, 1);
-        const bool window = r >= 2 && r < jm - 3;
-        const double g = lcos * lirs;
-        // the mask: RHS_Atm.cpp:110-149
-        const unsigned fl = lfl;
-        const bool land = fl & FL_LAND;
-        const double hdj = ((fl & FL_H0J) && (fl & FL_H0K)) ? 0. : 1.;
-        // which theta form stands (RHS_Atm.cpp:162-170, 192-199, 245-312), as factors of x, x[j-1], x[j-2], x[j+1]
-        const int mode = !window ? 0 : ((fl & FL_ONESIDED_S) ? 2 : 1);
-        const double fa = mode == 0 ? 0. : (mode == 1 ? 1. : -3.), fe = mode == 0 ? -2. : (mode == 1 ? 0. : 2.);
-        const double b1 = mode == 2 ? 4. : -1., b2 = mode == 2 ? -1. : 0., b3 = mode == 0 ? 1. : 0.;
-        const double f1 = mode == 0 ? 1. : (mode == 1 ? 0. : -2.), f2 = mode == 2 ? 1. : 0., f3 = mode == 0 ? 1. : 0.;
-        const double hD = hdj * (mode == 1 ? i_dthe : i_two_dthe), hE = hdj * i_dthe2;
-        const double A1 = fa * hD, A2 = fe * hE;
-        const double Pb = __builtin_fma(A2, i_rm2, A1 * g);
-        const double hDr = hD * i_rm, hDg = hD * g, hEr = hE * i_rm2;
-        const double G1 = __builtin_fma(f1, hEr, b1 * hDg), G2 = __builtin_fma(f2, hEr, b2 * hDg);
-        const double G3 = __builtin_fma(f3, hEr, b3 * hDg), H3 = b3 * hDr;
-        const double dmp_i = lh0i * i_dr2;
-        const double cA = A1 * i_rm, H1 = b1 * hDr, H2 = b2 * hDr;
-        {   // ---- chain A's half: v, u, c, t ----
+        {
+            const bool window = r >= 2 && r < jm - 3;
+            const double g = lcos * lirs;
+            // the mask: RHS_Atm.cpp:110-149
+            const unsigned fl = lfl;
+            const bool land = fl & FL_LAND;
+            land_prev = land;
+            const double hdj = ((fl & FL_H0J) && (fl & FL_H0K)) ? 0. : 1.;
+            // which theta form stands (RHS_Atm.cpp:162-170, 192-199, 245-312), as factors of x, x[j-1], x[j-2], x[j+1]
+            const int mode = !window ? 0 : ((fl & FL_ONESIDED_S) ? 2 : 1);
+            const double fa = mode == 0 ? 0. : (mode == 1 ? 1. : -3.), fe = mode == 0 ? -2. : (mode == 1 ? 0. : 2.);
+            const double b1 = mode == 2 ? 4. : -1., b2 = mode == 2 ? -1. : 0., b3 = mode == 0 ? 1. : 0.;
+            const double f1 = mode == 0 ? 1. : (mode == 1 ? 0. : -2.), f2 = mode == 2 ? 1. : 0., f3 = mode == 0 ? 1. : 0.;
+            const double hD = hdj * (mode == 1 ? i_dthe : i_two_dthe), hE = hdj * i_dthe2;
+            const double A1 = fa * hD, A2 = fe * hE;
+            const double Pb = __builtin_fma(A2, i_rm2, A1 * g);
+            const double hDr = hD * i_rm, hDg = hD * g, hEr = hE * i_rm2;
+            const double G1 = __builtin_fma(f1, hEr, b1 * hDg), G2 = __builtin_fma(f2, hEr, b2 * hDg);
+            const double dmp_i = lh0i * i_dr2;
             double KQ[4], KB[4] = { 0., 0., 0., 0. };
             if (!window) {  // b2 = f2 = 0 on these rows: the x[j-2] arrays are free for KB
+                const double H3 = b3 * hDr;
 #pragma unroll
-                for (int n = 0; n < 4; n++) KB[n] = H3 * axp[n];
+                for (int n = 0; n < 4; n++) KB[n] = H3 * lxp[n];
             }
-            SA.cA[lane] = cA; SA.H1[lane] = H1; SA.H2[lane] = H2;
+            if constexpr (FORA) {
+                SA.cA[lane] = A1 * i_rm; SA.H1[lane] = b1 * hDr; SA.H2[lane] = b2 * hDr;
 #pragma unroll
-            for (int c = 0; c < 3; c++) { SA.q1[c][lane] = G1 * idA[c]; SA.q2[c][lane] = window ? G2 * idA[c] : KB[c]; }
-            // factor of the stage value outside the advection product: diffusion bracket and damping
-            const double p_re = Pb * i_re;
-            const double h0j = (fl & FL_H0J) ? 1. : 0.;
-            SA.cP[0][lane] = p_re - lcoefv * hdj * i_re - h0j * i_dthe2;
-            SA.cP[1][lane] = p_re - dmp_i;
-            SA.cP[2][lane] = Pb * i_re_sc_wv;
-            SA.cP[3][lane] = Pb * i_re_pr;
-            // pressure gradient of the v equation (p_dyn is not changed by the sweep)
-            const double dp = hD * (fa * lp[2] + b1 * lp[1] + b2 * lp[0] + b3 * lp[3]);
-            const double pgv = hdj * dp * i_rm * i_r_air;
-            SA.pgv[lane] = pgv;
-            const double twoD = two * hD;
-            SA.cR[lane] = two * A1; SA.qu1[lane] = twoD * b1; SA.qu2[lane] = window ? twoD * b2 : KB[3];
-            // constant terms: sources, and on the pole-side rows the old row j+1
-            KQ[0] = -pgv; KQ[1] = 0.; KQ[2] = lS[4] * ctr; KQ[3] = ce * (lS[0] + lS[1]) + ce * (lS[2] + lS[3]);
+                for (int c = 0; c < 3; c++) { SA.q1[c][lane] = G1 * idc[c]; SA.q2[c][lane] = window ? G2 * idc[c] : KB[c]; }
+                // factor of the stage value outside the advection product: diffusion bracket and damping
+                const double p_re = Pb * i_re;
+                const double h0j = (fl & FL_H0J) ? 1. : 0.;
+                SA.cP[0][lane] = p_re - lcoefv * hdj * i_re - h0j * i_dthe2;
+                SA.cP[1][lane] = p_re - dmp_i;
+                SA.cP[2][lane] = Pb * i_re_sc_wv;
+                SA.cP[3][lane] = Pb * i_re_x;
+                // pressure gradient of the v equation (p_dyn is not changed by the sweep)
+                const double dp = hD * (fa * lp[2] + b1 * lp[1] + b2 * lp[0] + b3 * lp[3]);
+                const double pgv = hdj * dp * i_rm * i_r_air;
+                SA.pgv[lane] = pgv;
+                const double twoD = two * hD;
+                SA.cR[lane] = two * A1; SA.qu1[lane] = twoD * b1; SA.qu2[lane] = window ? twoD * b2 : KB[3];
+                // constant terms: sources, and on the pole-side rows the old row j+1
+                KQ[0] = -pgv; KQ[1] = 0.; KQ[2] = lS[4] * ctr; KQ[3] = ce * (lS[0] + lS[1]) + ce * (lS[2] + lS[3]);
+                if (!window) KQ[0] = __builtin_fma(twoD * b3, lxp[1], KQ[0]);
+                if constexpr (L1) {  // RHS_Atm.cpp:412-430
+                    double ep = lev - lpr;
+                    if (ep >= 6.) ep = 6.;
+                    if (ep <= -6.) ep = -6.;
+                    SA.cFac[lane] = land ? 0. : evf * (1. - 2. * lc0) * ep;
+                    SA.cMc[lane] = -3. * lc0 - lc3;
+                    SA.phk[lane] = lph * i_phk;
+                }
+            } else {
+                SB.cA[lane] = A1 * i_rm; SB.H1[lane] = b1 * hDr; SB.H2[lane] = window ? b2 * hDr : KB[3];
+#pragma unroll
+                for (int c = 0; c < 3; c++) { SB.q1[c][lane] = G1 * idc[c]; SB.q2[c][lane] = window ? G2 * idc[c] : KB[c]; }
+                const double h0k = (fl & FL_H0K) ? 1. : 0.;
+                const double p_wv = Pb * i_re_sc_wv;
+                SB.cP[0][lane] = __builtin_fma(-h0k, i_dphi2, Pb * i_re);
+                SB.cP[1][lane] = p_wv - dmp_i;
+                SB.cP[2][lane] = __builtin_fma(Pb, i_re_x, -dmp_i);
+                KQ[0] = 0.; KQ[1] = lS[0] * ctr; KQ[2] = lS[2] * ctr; KQ[3] = 0.;
+            }
             if (!window) {
-                KQ[0] = __builtin_fma(twoD * b3, axp[1], KQ[0]);
+                const double G3 = __builtin_fma(f3, hEr, b3 * hDg);
 #pragma unroll
-                for (int n = 0; n < 4; n++) KQ[n] = __builtin_fma(G3 * idA[CLA[n]], axp[n], KQ[n]);
+                for (int n = 0; n < 4; n++) KQ[n] = __builtin_fma(G3 * idc[CLS[n]], lxp[n], KQ[n]);
             }
-            if constexpr (L1) {  // RHS_Atm.cpp:412-430
-                double ep = lev - lpr;
-                if (ep >= 6.) ep = 6.;
-                if (ep <= -6.) ep = -6.;
-                SA.cFac[lane] = land ? 0. : evf * (1. - 2. * lc0) * ep;
-                SA.cMc[lane] = -3. * lc0 - lc3;
-                SA.phk[lane] = lph * i_phk;
-            }
+            double (*x0)[64] = FORA ? SA.x0 : SB.x0, (*xn)[64] = FORA ? SA.xn : SB.xn, (*kq)[64] = FORA ? SA.KQ : SB.KQ;
 #pragma unroll
             for (int n = 0; n < 4; n++) {
-                SA.x0[n][lane] = ax[n]; SA.xn[n][lane] = axn[n];
-                if (!window || n != 1) SA.KQ[n][lane] = KQ[n];   // u has no source term
+                x0[n][lane] = lx[n]; xn[n][lane] = lxn[n];
+                const bool zero_in_window = FORA ? n == 1 : (n == 0 || n == 3);   // u; w, co2: no source term
+                if (!window || !zero_in_window) kq[n][lane] = KQ[n];
             }
-            announce(&sh.ctlA[q].rdy, r, lane);
+            PSTAMP(stamp_wave, 2);
+            announce(&ctl->rdy, r, lane);
+            r_last = r;
+            if (r + 4 <= NR) issue(r + 4);
+            PSTAMP(stamp_wave, 3);
         }
-        PSTAMP(stamp_wave, 2);
-        wait_for(&sh.doneB, r - 4, err);
-        if (r > 4) store_b(r - 4, land_prev);
-        {   // ---- chain B's half: w, cloud, ice, co2 ----
-            double KQ[4] = { 0., lS[0] * ctr, lS[2] * ctr, 0. }, KB[4] = { 0., 0., 0., 0. };
-            if (!window) {
-#pragma unroll
-                for (int n = 0; n < 4; n++) { KB[n] = H3 * bxp[n]; KQ[n] = __builtin_fma(G3 * idB[CLB[n]], bxp[n], KQ[n]); }
-            }
-            SB.cA[lane] = cA; SB.H1[lane] = H1; SB.H2[lane] = window ? H2 : KB[3];
-#pragma unroll
-            for (int c = 0; c < 3; c++) { SB.q1[c][lane] = G1 * idB[c]; SB.q2[c][lane] = window ? G2 * idB[c] : KB[c]; }
-            const double h0k = (fl & FL_H0K) ? 1. : 0.;
-            const double p_wv = Pb * i_re_sc_wv;
-            SB.cP[0][lane] = __builtin_fma(-h0k, i_dphi2, Pb * i_re);
-            SB.cP[1][lane] = p_wv - dmp_i;
-            SB.cP[2][lane] = __builtin_fma(Pb, i_re_sc_co2, -dmp_i);
-#pragma unroll
-            for (int n = 0; n < 4; n++) {
-                SB.x0[n][lane] = bx_[n]; SB.xn[n][lane] = bxn[n];
-                if (!window || n == 1 || n == 2) SB.KQ[n][lane] = KQ[n];   // w, co2: no source term
-            }
-            announce(&sh.ctlB[q].rdy, r, lane);
-        }
-        land_prev = land;
-        r_last = r;
-        PSTAMP(stamp_wave, 3);
-        if (r + 4 <= NR) issue(r + 4);
-        PSTAMP(stamp_wave, 4);
     }
     if (r_last) {  // the wave's last row
-        wait_for(&sh.doneA, r_last, err);
-        store_a(r_last, land_prev);
-        wait_for(&sh.doneB, r_last, err);
-        store_b(r_last, land_prev);
+        wait_for(done, r_last, err);
+        store_row(r_last, land_prev);
     }
-}
-
-// A chain wave holds two packets: the one it works on and the next one, whose reads it issues before it starts on the
-// first, so that the row's LDS latency passes behind the arithmetic.  The progress words are read in the same go, first:
-// a packet read behind words that say "there" is the packet (a wave's LDS reads are carried out in order).  Where the
-// words said "not yet", they are polled alone and the packet is read again.
-struct PktA {
-    int w_rdy, w_st, w_o;
-    double cA, H1, H2, cR, pgv, qu1, qu2, cFac, cMc, phk, q1[3], q2[3], x0[4], xn[4], cP[4], kq[4];
-};
-struct PktB {
-    int w_rdy, w_st, w_o;
-    double cA, H1, H2, q1[3], q2[3], x0[4], xn[4], cP[4], kq[4], vs[4];
-};
-template <bool L1>
-__device__ __forceinline__ void read_words_a(PipeShared& sh, int j, PktA& p) {
-    asm volatile("" ::: "memory");
-    p.w_rdy = *LDS_WORD(&sh.ctlA[j & 3].rdy); p.w_st = *LDS_WORD(&sh.ctlA[j & 3].stored); p.w_o = *LDS_WORD(&sh.doneB);
-    asm volatile("" ::: "memory");
-}
-template <bool L1>
-__device__ __forceinline__ void read_data_a(PipeShared& sh, int j, int lane, PktA& p) {
-    const HalfA& S = sh.ha[j & 3];
-    p.cA = S.cA[lane]; p.H1 = S.H1[lane]; p.H2 = S.H2[lane]; p.cR = S.cR[lane]; p.pgv = S.pgv[lane]; p.qu1 = S.qu1[lane]; p.qu2 = S.qu2[lane];
-#pragma unroll
-    for (int c = 0; c < 3; c++) { p.q1[c] = S.q1[c][lane]; p.q2[c] = S.q2[c][lane]; }
-#pragma unroll
-    for (int m = 0; m < 4; m++) { p.x0[m] = S.x0[m][lane]; p.xn[m] = S.xn[m][lane]; p.cP[m] = S.cP[m][lane]; p.kq[m] = S.KQ[m][lane]; }
-    if constexpr (L1) { p.cFac = S.cFac[lane]; p.cMc = S.cMc[lane]; p.phk = S.phk[lane]; }
-    asm volatile("" ::: "memory");
-}
-__device__ __forceinline__ bool words_ok_a(const PktA& p, int j) {
-    return __builtin_amdgcn_readfirstlane(p.w_rdy) >= j && __builtin_amdgcn_readfirstlane(p.w_st) >= j - 4 &&
-           __builtin_amdgcn_readfirstlane(p.w_o) >= j - 2;   // chain B done with row j-2: the buffer for v's stage values is free
-}
-__device__ __forceinline__ void read_words_b(PipeShared& sh, int j, PktB& p) {
-    asm volatile("" ::: "memory");
-    p.w_rdy = *LDS_WORD(&sh.ctlB[j & 3].rdy); p.w_st = *LDS_WORD(&sh.ctlB[j & 3].stored); p.w_o = *LDS_WORD(&sh.doneA);
-    asm volatile("" ::: "memory");
-}
-__device__ __forceinline__ void read_data_b(PipeShared& sh, int j, int lane, PktB& p) {
-    const HalfB& S = sh.hb[j & 3];
-    constexpr int CPS[4] = { 0, 1, 1, 2 };
-    p.cA = S.cA[lane]; p.H1 = S.H1[lane]; p.H2 = S.H2[lane];
-#pragma unroll
-    for (int c = 0; c < 3; c++) { p.q1[c] = S.q1[c][lane]; p.q2[c] = S.q2[c][lane]; }
-#pragma unroll
-    for (int m = 0; m < 4; m++) {
-        p.x0[m] = S.x0[m][lane]; p.xn[m] = S.xn[m][lane]; p.cP[m] = S.cP[CPS[m]][lane]; p.kq[m] = S.KQ[m][lane];
-        p.vs[m] = sh.vst[j & 1][m][lane];
-    }
-    asm volatile("" ::: "memory");
-}
-__device__ __forceinline__ bool words_ok_b(const PktB& p, int j) {
-    return __builtin_amdgcn_readfirstlane(p.w_rdy) >= j && __builtin_amdgcn_readfirstlane(p.w_st) >= j - 4 &&
-           __builtin_amdgcn_readfirstlane(p.w_o) >= j;       // chain A done with the row: its stage values of v are there
 }
 
 // ---- chain wave A: v, u, c, t ------------------------------------------------------------------------------------
@@ -451,42 +382,54 @@ __device__ __forceinline__ void chain_a(const PipeArgs& a, const DevConst& K, Pi
 #pragma unroll
     for (int n = 0; n < 4; n++) xm1[n] = gld(a.x[VARS[n]], o_lev);
 
-    auto row = [&](const int j, PktA& P, PktA& N) {
+    for (int j = 1; j <= NR; j++) {
         const int e = j;
         PSTAMP(0, 0);
-        if (!words_ok_a(P, j)) {   // the packet was not there (or its slot's outputs not stored, or chain B not far enough)
-            for (int n = 0;; n++) {
-                read_words_a<L1>(sh, j, P);
-                if (words_ok_a(P, j)) break;
-                __builtin_amdgcn_s_sleep(1);
-                if (n > (1 << 22)) {
-                    __hip_atomic_store(err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    break;
-                }
-            }
-            read_data_a<L1>(sh, j, lane, P);
-        }
-        if (j + 1 <= NR) { read_words_a<L1>(sh, j + 1, N); read_data_a<L1>(sh, j + 1, lane, N); }   // the next row's, ahead
-        PSTAMP(0, 1);
+        // the row's packet; the slot's output arrays free (row j-4 stored); the buffer for the stage values of v free
+        // (chain B done with row j-2)
         const bool window = j >= 2 && j < jm - 3;
+        const HalfA& S = sh.ha[j & 3];
         double (*vst)[64] = sh.vst[j & 1];
         double (*out)[64] = sh.outA[j & 3];
-        double st[4], cB[4], cQ[4], acc[4], rhs[4];
+        double cA, H1, H2, cR, pgv, qu1, qu2, cFac = 0., cMc = 0., phk = 0.;
+        double st[4], xn[4], cB[4], cQ[4], cP[4], acc[4], rhs[4], q1[3], q2[3], kq[4];
+        // The words and the packet are read in one go: the words first, so a packet read behind words that say "there" is
+        // the packet (a wave's LDS reads are carried out in order); if the words say "not yet", everything is read again.
+        for (int n = 0;; n++) {
+            asm volatile("" ::: "memory");
+            const int w_rdy = *LDS_WORD(&sh.ctlA[j & 3].rdy), w_st = *LDS_WORD(&sh.ctlA[j & 3].stored);
+            const int w_b = *LDS_WORD(&sh.doneB);
+            asm volatile("" ::: "memory");
+            cA = S.cA[lane]; H1 = S.H1[lane]; H2 = S.H2[lane]; cR = S.cR[lane]; pgv = S.pgv[lane]; qu1 = S.qu1[lane]; qu2 = S.qu2[lane];
+#pragma unroll
+            for (int c = 0; c < 3; c++) { q1[c] = S.q1[c][lane]; q2[c] = S.q2[c][lane]; }
+#pragma unroll
+            for (int m = 0; m < 4; m++) { st[m] = S.x0[m][lane]; xn[m] = S.xn[m][lane]; cP[m] = S.cP[m][lane]; kq[m] = S.KQ[m][lane]; }
+            if constexpr (L1) { cFac = S.cFac[lane]; cMc = S.cMc[lane]; phk = S.phk[lane]; }
+            asm volatile("" ::: "memory");
+            if (__builtin_amdgcn_readfirstlane(w_rdy) >= j && __builtin_amdgcn_readfirstlane(w_st) >= j - 4 &&
+                __builtin_amdgcn_readfirstlane(w_b) >= j - 2) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (n > (1 << 22)) {
+                __hip_atomic_store(err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+        }
+        PSTAMP(0, 1);
 #pragma unroll
         for (int n = 0; n < 4; n++) {
-            st[n] = P.x0[n];
-            const double alias = n < 3 ? P.q2[n] : P.qu2;   // pole-side rows: KB of the variable
+            const double alias = n < 3 ? q2[n] : qu2;   // pole-side rows: KB of the variable
             const double kb = window ? 0. : alias;
-            const double q2n = window ? P.q2[CLS[n]] : 0.;
-            const double kqn = (window && n == cU) ? 0. : P.kq[n];
-            cB[n] = __builtin_fma(P.H1, xm1[n], __builtin_fma(window ? P.H2 : 0., xm2[n], kb));
-            cQ[n] = __builtin_fma(P.q1[CLS[n]], xm1[n], __builtin_fma(q2n, xm2[n], kqn));
+            const double q2n = window ? q2[CLS[n]] : 0.;
+            const double kqn = (window && n == cU) ? 0. : kq[n];
+            cB[n] = __builtin_fma(H1, xm1[n], __builtin_fma(window ? H2 : 0., xm2[n], kb));
+            cQ[n] = __builtin_fma(q1[CLS[n]], xm1[n], __builtin_fma(q2n, xm2[n], kqn));
         }
-        cQ[cV] = __builtin_fma(P.qu1, xm1[cU], __builtin_fma(window ? P.qu2 : 0., xm2[cU], cQ[cV]));  // 2 du/dthe / rm^2 / re
+        cQ[cV] = __builtin_fma(qu1, xm1[cU], __builtin_fma(window ? qu2 : 0., xm2[cU], cQ[cV]));  // 2 du/dthe / rm^2 / re
         double RS = 0.;
 #ifdef ATOMDEV_EXP_PIPE_NOCHAIN  // timing experiment only (results are wrong): the recurrence without its arithmetic
 #pragma unroll
-        for (int n = 0; n < 4; n++) { rhs[n] = cB[n] + cQ[n] + P.cP[n]; st[n] += P.xn[n]; }
+        for (int n = 0; n < 4; n++) { rhs[n] = cB[n] + cQ[n] + cP[n]; st[n] += xn[n]; }
         if (j < 0)
 #endif
 #pragma unroll
@@ -499,36 +442,30 @@ __device__ __forceinline__ void chain_a(const PipeArgs& a, const DevConst& K, Pi
             RS = KK * (hod - 1.);
             double lin[4];
 #pragma unroll
-            for (int n = 0; n < 4; n++) lin[n] = __builtin_fma(P.cP[n], st[n], cQ[n]);
+            for (int n = 0; n < 4; n++) lin[n] = __builtin_fma(cP[n], st[n], cQ[n]);
             lin[cU] -= RS;
-            lin[cV] = __builtin_fma(P.cR, st[cU], lin[cV]);
+            lin[cV] = __builtin_fma(cR, st[cU], lin[cV]);
             if constexpr (L1) {  // surface evaporation source of c (RHS_Atm.cpp:412-430), dry density from this stage's t
-                const double r_humid = P.phk * rcp2(st[cT]) * hod;
-                lin[cC] = __builtin_fma(r_humid * __builtin_fma(4., st[cC], P.cMc), P.cFac, lin[cC]);
+                const double r_humid = phk * rcp2(st[cT]) * hod;
+                lin[cC] = __builtin_fma(r_humid * __builtin_fma(4., st[cC], cMc), cFac, lin[cC]);
             }
 #pragma unroll
             for (int n = 0; n < 4; n++) {
-                rhs[n] = __builtin_fma(-v, __builtin_fma(P.cA, st[n], cB[n]), lin[n]);
+                rhs[n] = __builtin_fma(-v, __builtin_fma(cA, st[n], cB[n]), lin[n]);
                 // RungeKutta_Atm.cpp:58-152
-                if (s == 0) { acc[n] = rhs[n]; st[n] = __builtin_fma(rhs[n], hdt, P.xn[n]); }
-                else if (s == 1) { acc[n] = __builtin_fma(2., rhs[n], acc[n]); st[n] = __builtin_fma(rhs[n], hdt, P.xn[n]); }
-                else if (s == 2) { acc[n] = __builtin_fma(2., rhs[n], acc[n]); st[n] = __builtin_fma(rhs[n], dt, P.xn[n]); }
-                else st[n] = __builtin_fma(acc[n] + rhs[n], dt6, P.xn[n]);
+                if (s == 0) { acc[n] = rhs[n]; st[n] = __builtin_fma(rhs[n], hdt, xn[n]); }
+                else if (s == 1) { acc[n] = __builtin_fma(2., rhs[n], acc[n]); st[n] = __builtin_fma(rhs[n], hdt, xn[n]); }
+                else if (s == 2) { acc[n] = __builtin_fma(2., rhs[n], acc[n]); st[n] = __builtin_fma(rhs[n], dt, xn[n]); }
+                else st[n] = __builtin_fma(acc[n] + rhs[n], dt6, xn[n]);
             }
         }
         PSTAMP(0, 2);
         // results and the side outputs of the fourth evaluation, for the memory wave of the slot to store
 #pragma unroll
         for (int n = 0; n < 4; n++) { out[n][lane] = st[n]; xm2[n] = xm1[n]; xm1[n] = st[n]; }
-        out[4][lane] = rhs[cU]; out[5][lane] = rhs[cV] + P.pgv; out[6][lane] = -RS * cb1000;
+        out[4][lane] = rhs[cU]; out[5][lane] = rhs[cV] + pgv; out[6][lane] = -RS * cb1000;
         announce_in_order(&sh.doneA, j, lane);
         PSTAMP(0, 3);
-    };
-    PktA P0, P1;
-    read_words_a<L1>(sh, 1, P0); read_data_a<L1>(sh, 1, lane, P0);
-    for (int j = 1; j <= NR; j += 2) {
-        row(j, P0, P1);
-        if (j + 1 <= NR) row(j + 1, P1, P0);
     }
 }
 
@@ -542,57 +479,66 @@ __device__ __forceinline__ void chain_b(const PipeArgs& a, const DevConst& K, Pi
     const unsigned o_lev = (unsigned)(((size_t)i * jm * km + k) * 8);
     constexpr int VARS[4] = { V_W, V_CLOUD, V_ICE, V_CO2 };
     constexpr int CLS[4] = { QB_RE, QB_WV, QB_WV, QB_CO2 };
+    constexpr int CPS[4] = { 0, 1, 1, 2 };
 
     const double hdt = .5 * K.dt, dt = K.dt, dt6 = K.dt * K.i_six;
     double xm1[4], xm2[4] = { 0., 0., 0., 0. };
 #pragma unroll
     for (int n = 0; n < 4; n++) xm1[n] = gld(a.x[VARS[n]], o_lev);
 
-    auto row = [&](const int j, PktB& P, PktB& N) {
+    for (int j = 1; j <= NR; j++) {
         const int e = j;
         PSTAMP(1, 0);
-        if (!words_ok_b(P, j)) {
-            for (int n = 0;; n++) {
-                read_words_b(sh, j, P);
-                if (words_ok_b(P, j)) break;
-                __builtin_amdgcn_s_sleep(1);
-                if (n > (1 << 22)) {
-                    __hip_atomic_store(err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    break;
-                }
-            }
-            read_data_b(sh, j, lane, P);
-        }
-        if (j + 1 <= NR) { read_words_b(sh, j + 1, N); read_data_b(sh, j + 1, lane, N); }
-        PSTAMP(1, 1);
         const bool window = j >= 2 && j < jm - 3;
+        const HalfB& S = sh.hb[j & 3];
+        const double (*vst)[64] = sh.vst[j & 1];
         double (*out)[64] = sh.outB[j & 3];
-        double st[4], cB[4], cQ[4], acc[4], rhs[4];
+        double cA, H1, H2, vs[4];
+        double st[4], xn[4], cB[4], cQ[4], cP[4], acc[4], rhs[4], q1[3], q2[3], kq[4];
+        for (int n = 0;; n++) {   // words and packet in one go, as in chain A; here also the stage values of v of the row
+            asm volatile("" ::: "memory");
+            const int w_rdy = *LDS_WORD(&sh.ctlB[j & 3].rdy), w_st = *LDS_WORD(&sh.ctlB[j & 3].stored);
+            const int w_a = *LDS_WORD(&sh.doneA);
+            asm volatile("" ::: "memory");
+            cA = S.cA[lane]; H1 = S.H1[lane]; H2 = S.H2[lane];
+#pragma unroll
+            for (int c = 0; c < 3; c++) { q1[c] = S.q1[c][lane]; q2[c] = S.q2[c][lane]; }
+#pragma unroll
+            for (int m = 0; m < 4; m++) { st[m] = S.x0[m][lane]; xn[m] = S.xn[m][lane]; cP[m] = S.cP[CPS[m]][lane]; kq[m] = S.KQ[m][lane]; vs[m] = vst[m][lane]; }
+            asm volatile("" ::: "memory");
+            if (__builtin_amdgcn_readfirstlane(w_rdy) >= j && __builtin_amdgcn_readfirstlane(w_st) >= j - 4 &&
+                __builtin_amdgcn_readfirstlane(w_a) >= j) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (n > (1 << 22)) {
+                __hip_atomic_store(err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+        }
+        PSTAMP(1, 1);
 #pragma unroll
         for (int n = 0; n < 4; n++) {
-            st[n] = P.x0[n];
-            const double alias = n < 3 ? P.q2[n] : P.H2;   // pole-side rows: KB of the variable
+            const double alias = n < 3 ? q2[n] : H2;   // pole-side rows: KB of the variable
             const double kb = window ? 0. : alias;
-            const double q2n = window ? P.q2[CLS[n]] : 0.;
-            const double kqn = (window && (n == 0 || n == 3)) ? 0. : P.kq[n];
-            cB[n] = __builtin_fma(P.H1, xm1[n], __builtin_fma(window ? P.H2 : 0., xm2[n], kb));
-            cQ[n] = __builtin_fma(P.q1[CLS[n]], xm1[n], __builtin_fma(q2n, xm2[n], kqn));
+            const double q2n = window ? q2[CLS[n]] : 0.;
+            const double kqn = (window && (n == 0 || n == 3)) ? 0. : kq[n];
+            cB[n] = __builtin_fma(H1, xm1[n], __builtin_fma(window ? H2 : 0., xm2[n], kb));
+            cQ[n] = __builtin_fma(q1[CLS[n]], xm1[n], __builtin_fma(q2n, xm2[n], kqn));
         }
 #ifdef ATOMDEV_EXP_PIPE_NOCHAIN
 #pragma unroll
-        for (int n = 0; n < 4; n++) { rhs[n] = cB[n] + cQ[n] + P.cP[n] + P.vs[n]; st[n] += P.xn[n]; }
+        for (int n = 0; n < 4; n++) { rhs[n] = cB[n] + cQ[n] + cP[n] + vs[n]; st[n] += xn[n]; }
         if (j < 0)
 #endif
 #pragma unroll
         for (int s = 0; s < 4; s++) {
-            const double v = P.vs[s];
+            const double v = vs[s];
 #pragma unroll
             for (int n = 0; n < 4; n++) {
-                rhs[n] = __builtin_fma(-v, __builtin_fma(P.cA, st[n], cB[n]), __builtin_fma(P.cP[n], st[n], cQ[n]));
-                if (s == 0) { acc[n] = rhs[n]; st[n] = __builtin_fma(rhs[n], hdt, P.xn[n]); }
-                else if (s == 1) { acc[n] = __builtin_fma(2., rhs[n], acc[n]); st[n] = __builtin_fma(rhs[n], hdt, P.xn[n]); }
-                else if (s == 2) { acc[n] = __builtin_fma(2., rhs[n], acc[n]); st[n] = __builtin_fma(rhs[n], dt, P.xn[n]); }
-                else st[n] = __builtin_fma(acc[n] + rhs[n], dt6, P.xn[n]);
+                rhs[n] = __builtin_fma(-v, __builtin_fma(cA, st[n], cB[n]), __builtin_fma(cP[n], st[n], cQ[n]));
+                if (s == 0) { acc[n] = rhs[n]; st[n] = __builtin_fma(rhs[n], hdt, xn[n]); }
+                else if (s == 1) { acc[n] = __builtin_fma(2., rhs[n], acc[n]); st[n] = __builtin_fma(rhs[n], hdt, xn[n]); }
+                else if (s == 2) { acc[n] = __builtin_fma(2., rhs[n], acc[n]); st[n] = __builtin_fma(rhs[n], dt, xn[n]); }
+                else st[n] = __builtin_fma(acc[n] + rhs[n], dt6, xn[n]);
             }
         }
 #pragma unroll
@@ -600,20 +546,14 @@ __device__ __forceinline__ void chain_b(const PipeArgs& a, const DevConst& K, Pi
         out[4][lane] = rhs[0];
         announce_in_order(&sh.doneB, j, lane);
         PSTAMP(1, 3);
-    };
-    PktB P0, P1;
-    read_words_b(sh, 1, P0); read_data_b(sh, 1, lane, P0);
-    for (int j = 1; j <= NR; j += 2) {
-        row(j, P0, P1);
-        if (j + 1 <= NR) row(j + 1, P1, P0);
     }
 }
 
-// Waves of the 512-thread workgroup: w and w + 4 share a SIMD.  Wave 0 is chain A, wave 1 chain B, and the two waves
-// that would share their SIMDs end at once; the four waves on the other two SIMDs are the memory waves: rows r = q mod 4
-// belong to wave (2, 3, 6, 7)[q].
+// Waves of the 1 024-thread workgroup: w and w + 4 (and w + 8, w + 12) share a SIMD.  Wave 0 is chain A, wave 1 chain B,
+// and the waves that would share their SIMDs end at once; the eight waves on the other two SIMDs are the memory waves:
+// rows r = q mod 4 belong to the pair (2 + 4 q, 3 + 4 q), the first working for chain A, the second for chain B.
 template <bool LIMIT>
-__global__ __launch_bounds__(512) void k_atm_rk3d_pipe(const PipeParams* __restrict__ P, int* err) {
+__global__ __launch_bounds__(1024) void k_atm_rk3d_pipe(const PipeParams* __restrict__ P, int* err) {
     const PipeArgs& a = P->a;
     const DevConst& K = P->K;
     __shared__ PipeShared sh;
@@ -637,10 +577,11 @@ __global__ __launch_bounds__(512) void k_atm_rk3d_pipe(const PipeParams* __restr
         else chain_a<false>(a, K, sh, i, bx, err);
     } else if (wave == 1) {
         chain_b(a, K, sh, i, bx, err);
-    } else if (wave != 4 && wave != 5) {
-        const int q = wave < 4 ? wave - 2 : wave - 4;   // waves 2, 3, 6, 7 -> 0, 1, 2, 3
-        if (i == 1) memory_wave<true, LIMIT>(a, K, sh, q, i, bx, err);
-        else memory_wave<false, LIMIT>(a, K, sh, q, i, bx, err);
+    } else if ((wave & 3) == 2) {
+        if (i == 1) memory_wave<true, true, LIMIT>(a, K, sh, wave >> 2, i, bx, err);
+        else memory_wave<false, true, LIMIT>(a, K, sh, wave >> 2, i, bx, err);
+    } else if ((wave & 3) == 3) {
+        memory_wave<false, false, LIMIT>(a, K, sh, wave >> 2, i, bx, err);
     }
 #ifdef ATOMDEV_EXP_PIPE_STAMP
     __syncthreads();
@@ -682,9 +623,9 @@ int atomdev_atm_rk3d_pipe_launch(atomdev* h, bool limit) {
     const unsigned gx = (h->km - 2 + 63) / 64, rounds = (h->im - 2 + 7) / 8;
     dim3 grid(8 * rounds * gx);
     if (limit)
-        hipLaunchKernelGGL(k_atm_rk3d_pipe<true>, grid, dim3(512), 0, h->stream, (const PipeParams*)h->pipe_params, (int*)atomdev_kernel_error_word(h));
+        hipLaunchKernelGGL(k_atm_rk3d_pipe<true>, grid, dim3(1024), 0, h->stream, (const PipeParams*)h->pipe_params, (int*)atomdev_kernel_error_word(h));
     else
-        hipLaunchKernelGGL(k_atm_rk3d_pipe<false>, grid, dim3(512), 0, h->stream, (const PipeParams*)h->pipe_params, (int*)atomdev_kernel_error_word(h));
+        hipLaunchKernelGGL(k_atm_rk3d_pipe<false>, grid, dim3(1024), 0, h->stream, (const PipeParams*)h->pipe_params, (int*)atomdev_kernel_error_word(h));
     ATOMDEV_TRY(hipGetLastError());
     return 0;
 }

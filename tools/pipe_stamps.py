@@ -20,7 +20,7 @@ for _ in range(3):
 raw = d.download("AUX_W").reshape(-1)
 st = raw[:10 * 32].reshape(10, 4, 8)
 print("kernel: %d wall ticks (100 MHz), %d cycles -> %.2f GHz" % (raw[400], raw[401], raw[401] / raw[400] / 10.))
-names = ["chainA", "chainB", "mem0", "mem1", "mem2", "mem3", "-", "-", "-", "-"]
+names = ["chainA", "chainB", "prep0A", "prep0B", "prep1A", "prep1B", "prep2A", "prep2B", "prep3A", "prep3B"]
 t0 = st[0, 0, 0]
 for e in range(4):
     print("epoch %d" % (60 + e))

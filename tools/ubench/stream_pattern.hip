@@ -79,10 +79,14 @@ int main() {
     for (int f = 0; f < NF_W; f++) { double* p; CHECK(hipMalloc(&p, n * 8)); CHECK(hipMemset(p, 0, n * 8)); a.w[f] = p; }
     double* big; CHECK(hipMalloc(&big, n * 8 * (NF_R + NF_W))); CHECK(hipMemset(big, 0, n * 8 * (NF_R + NF_W)));
     Args b = a; b.r[0] = big;
-    for (int nw : {8, 12, 16}) {
-        run<1, false>(a, nw, "(i,j,k) 64 lines/wg");
+    for (int nw : {8, 16}) {
+        run<1, false>(a, nw, "(i,j,k) read + write");
+        run<2, false>(a, nw, "(i,j,k) read + write");
+        run<2, false, 55>(a, nw, "(i,j,k) 55 lines a workgroup");
         run<1, false, 0, 4>(a, nw, "(i,j,k) load waves, store waves");
-        run<2, false, 0, 4>(a, nw, "(i,j,k) load waves, store waves");
+        run<1, false, 0, 2>(a, nw, "(i,j,k) read only");
+        run<1, false, 0, 3>(a, nw, "(i,j,k) write only");
+        run<1, true>(a, nw, "tiled, field by field");
         run<1, false, 0, 1>(b, nw, "one allocation, interleaved");
     }
     return 0;
