@@ -406,9 +406,14 @@ int atomdev_sync_stream(atomdev* h) {
 
 // Text files whose numbers are on the host already: inside a one-call slice (defer_files) the text is made and written
 // by a thread of its own while the slice goes on, and atomdev_join_files waits for all of them; otherwise at once.
-int atomdev_defer_file(atomdev* h, std::function<std::string()> job) {
+// Two jobs for one path run one after the other, in the order they were handed in (the reference writes its files one
+// after the other, so where a checkpoint and the final write fall on the same name the later content stands).
+int atomdev_defer_file(atomdev* h, const std::string& path, std::function<std::string()> job) {
     if (h->defer_files) {
+        for (size_t n = 0; n < h->pending_files.size(); n++)
+            if (h->pending_paths[n] == path && h->pending_files[n].valid()) h->pending_files[n].wait();
         h->pending_files.push_back(std::async(std::launch::async, std::move(job)));
+        h->pending_paths.push_back(path);
         return 0;
     }
     const std::string e = job();
@@ -423,6 +428,7 @@ int atomdev_join_files(atomdev* h) {
         if (first.empty()) first = e;
     }
     h->pending_files.clear();
+    h->pending_paths.clear();
     if (!first.empty()) { atomdev_set_error(first); return 1; }
     return 0;
 }

@@ -77,6 +77,7 @@ struct atomdev {
     int profile_rk;                 // bracket the RK sweeps with events: 1 the sweep kernel alone, 2 with the kernels that prepare it
     bool defer_files = false;         // inside a one-call slice: text files are finished by threads of their own
     std::vector<std::future<std::string>> pending_files;  // their error texts (empty: written)
+    std::vector<std::string> pending_paths;               // ... and the files they write
     std::vector<void*> field_allocs;  // what hipMalloc returned for the 3-D fields (f[] and alt[] point into these, each at its own skew)
     std::vector<hipEvent_t> prof_ev;  // pairs (start, stop), prof_used of them recorded
     size_t prof_used;
@@ -94,7 +95,7 @@ int atomdev_fill_theta_neumann(atomdev* h, int field);            // k_bc_pressu
 int atomdev_fill_phi_seam(atomdev* h, int field, int j0, int j1);  // k_bc_pressure.hip
 int atomdev_static_scratch_init(atomdev* h);  // k_accuracy.hip
 int atomdev_sync_stream(atomdev* h);          // atomdev_api.hip: hipStreamSynchronize + the kernels' own failure word
-int atomdev_defer_file(atomdev* h, std::function<std::string()> job);  // atomdev_api.hip
+int atomdev_defer_file(atomdev* h, const std::string& path, std::function<std::string()> job);  // atomdev_api.hip
 int atomdev_join_files(atomdev* h);                                   // atomdev_api.hip
 inline volatile int* atomdev_kernel_error_word(atomdev* h) { return (volatile int*)((char*)h->pinned + 128); }
 // limit: the values stored are what Value_Limitation_Atm would make of them (interior points of the eight variables);

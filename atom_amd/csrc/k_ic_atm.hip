@@ -634,8 +634,8 @@ __global__ void k_restrain_temperature(double* __restrict__ t, size_t n2, double
     t[q] = v;
 }
 
-extern "C" int atomdev_atm_restrain_temperature(atomdev_t* h, double mean_temperature) {
-    ATOMDEV_REQUIRE(h && h->model == ATOMDEV_ATM, "atomdev_atm_restrain_temperature: needs an atmosphere handle");
+extern "C" int atomdev_atm_calculate_mean_temperature(atomdev_t* h, float* mean) {
+    ATOMDEV_REQUIRE(h && mean && h->model == ATOMDEV_ATM, "atomdev_atm_calculate_mean_temperature: needs an atmosphere handle and a result");
     ATOMDEV_TRY(hipSetDevice(h->device));
     const int jm = h->jm, km = h->km;
     std::vector<double> sea(h->n2);
@@ -651,8 +651,16 @@ extern "C" int atomdev_atm_restrain_temperature(atomdev_t* h, double mean_temper
             weight += w;
         }
     }
+    *mean = (float)((ret / weight - 1) * h->p.t_0);
+    return 0;
+}
+
+extern "C" int atomdev_atm_restrain_temperature(atomdev_t* h, double mean_temperature) {
+    ATOMDEV_REQUIRE(h && h->model == ATOMDEV_ATM, "atomdev_atm_restrain_temperature: needs an atmosphere handle");
+    float mean = 0.f;
+    if (int rc = atomdev_atm_calculate_mean_temperature(h, &mean)) return rc;
     const double t_0 = h->p.t_0;
-    const double tmp_2 = (float)((ret / weight - 1) * t_0);
+    const double tmp_2 = mean;
     const double diff = tmp_2 - mean_temperature;
     hipLaunchKernelGGL(k_restrain_temperature, dim3((unsigned)((h->n2 + 255) / 256)), dim3(256), 0, h->stream, h->f[ATOMDEV_T], h->n2, diff / t_0,
                        1 + 40 / t_0);

@@ -4,6 +4,9 @@
 #include "atomdev_internal.h"
 #include "cr_math.h"
 
+#include <chrono>
+#include <thread>
+
 namespace {
 
 __global__ void k_selftest(int kind, size_t n, const double* __restrict__ x, const double* __restrict__ y, double* __restrict__ out) {
@@ -56,4 +59,25 @@ extern "C" int atomdev_selftest_math(atomdev_t* h, int kind, size_t n, const dou
     (void)hipFree(dx); (void)hipFree(dout);
     if (dy) (void)hipFree(dy);
     return rc;
+}
+
+// Two deferred writes to one path, the first held back by 300 ms: the file must end up with the second one's text.
+extern "C" int atomdev_selftest_deferred_file_order(atomdev_t* h, const char* path) {
+    ATOMDEV_REQUIRE(h && path, "atomdev_selftest_deferred_file_order: bad argument");
+    const std::string file(path);
+    auto writer = [file](const char* text, int delay_ms) {
+        return [file, text, delay_ms]() -> std::string {
+            std::this_thread::sleep_for(std::chrono::milliseconds(delay_ms));
+            FILE* f = std::fopen(file.c_str(), "w");
+            if (!f) return "could not open " + file;
+            std::fputs(text, f);
+            return std::fclose(f) == 0 ? std::string() : "write failed: " + file;
+        };
+    };
+    h->defer_files = true;
+    int rc = atomdev_defer_file(h, file, writer("first\n", 300));
+    if (!rc) rc = atomdev_defer_file(h, file, writer("second\n", 0));
+    h->defer_files = false;
+    const int rj = atomdev_join_files(h);
+    return rc ? rc : rj;
 }

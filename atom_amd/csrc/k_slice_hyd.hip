@@ -15,7 +15,27 @@ extern "C" void atomdev_default_hyd_slice(int im, atomdev_hyd_slice* s) {
     s->velocity_iter_max = 2; s->pressure_iter_max = 2;
     s->transfer_file = nullptr; s->bathymetry_file = nullptr; s->salinity_file = nullptr;
     s->queries = 1;
+    s->checkpoint = 1;  // param.py:139
+    s->paraview_panorama_vts = 0;
+    s->output_path = s->bathymetry_name = nullptr;
 }
+
+namespace {
+// The output files of cHydrosphereModel::write_file (:739-772) for the slice `s`; n: velocity iterations done so far.
+int write_files(atomdev_t* h, const atomdev_hyd_slice& s, int n, bool is_final_result) {
+    if (!s.output_path) return 0;
+    const std::string stem = std::string(s.output_path) + "/[" + s.bathymetry_name + "]";
+    const std::string count = std::to_string(n);
+    const int j_longal = 75, k_zonal = 185, i_radial = 40;
+    if (int rc = atomdev_write_vtk(h, ATOMDEV_LONGAL, j_longal, s.start.Ma, (stem + "_Hyd_longal_" + std::to_string(j_longal) + "_" + count + ".vtk").c_str())) return rc;
+    if (int rc = atomdev_write_vtk(h, ATOMDEV_ZONAL, k_zonal, s.start.Ma, (stem + "_Hyd_zonal_" + std::to_string(k_zonal) + "_" + count + ".vtk").c_str())) return rc;
+    if (int rc = atomdev_write_vtk(h, ATOMDEV_RADIAL, i_radial, s.start.Ma, (stem + "_Hyd_radial_" + std::to_string(i_radial) + "_" + count + ".vtk").c_str())) return rc;
+    if (s.paraview_panorama_vts)
+        if (int rc = atomdev_write_panorama_vts(h, (stem + "_Hyd_panorama_" + count + ".vts").c_str())) return rc;
+    const int iter_cnt = is_final_result ? -1 : n;  // PostProcess_Hyd.cpp:676-677
+    return atomdev_hyd_write_plot_data(h, (stem + "_PlotData_Hyd" + (iter_cnt > 0 ? "_" + count : "") + ".xyz").c_str());
+}
+}  // namespace
 
 // n slices advanced in lockstep: every operator is enqueued for all of them (each on its handle's stream, so the
 // slices overlap on the GPU) before the next one; the surface sweeps - one workgroup's worth of dependent diagonals
@@ -27,6 +47,7 @@ extern "C" int atomdev_hyd_run_time_slices(atomdev_t* const* handles, const atom
     for (int m = 0; m < n; m++) {
         ATOMDEV_REQUIRE(handles[m] && handles[m]->model == ATOMDEV_HYD, "atomdev_hyd_run_time_slices: needs hydrosphere handles");
         ATOMDEV_REQUIRE(slices[m].bathymetry_file, "atomdev_hyd_run_time_slices: no bathymetry file");
+        ATOMDEV_REQUIRE(!slices[m].output_path || slices[m].bathymetry_name, "atomdev_hyd_run_time_slices: output files need bathymetry_name");
         ATOMDEV_REQUIRE(slices[m].velocity_iter_max_2D == s0.velocity_iter_max_2D && slices[m].pressure_iter_max_2D == s0.pressure_iter_max_2D
                         && slices[m].velocity_iter_max == s0.velocity_iter_max && slices[m].pressure_iter_max == s0.pressure_iter_max,
                         "atomdev_hyd_run_time_slices: the slices of one call share their iteration counts");
@@ -85,6 +106,7 @@ extern "C" int atomdev_hyd_run_time_slices(atomdev_t* const* handles, const atom
     std::vector<double> before(n, 0.), after(n, 0.);
     std::vector<int> loc(3 * (size_t)n, 0);
     double steady[6]; int steady_loc[18];
+    int iter_cnt = 1;  // :411
     for (int p = 1; p <= s0.pressure_iter_max; p++) {
         for (int v = 1; v <= s0.velocity_iter_max; v++) {
             EACH(s.queries ? (before[m] = 0., atomdev_hyd_residuum3d(h, &before[m], &loc[3 * m])) : 0);
@@ -98,9 +120,12 @@ extern "C" int atomdev_hyd_run_time_slices(atomdev_t* const* handles, const atom
             EACH(s.queries ? atomdev_hyd_steady3d(h, steady, steady_loc) : 0);
             EACH(atomdev_hyd_run_data(h));
             EACH(atomdev_move_data_to_new_arrays(h, -1));
+            iter_cnt++;
         }
         EACH(atomdev_hyd_pressure3d(h));
+        EACH(s.checkpoint > 0 && p % s.checkpoint == 0 ? write_files(h, s, iter_cnt - 1, false) : 0);  // :612-614
     }
+    EACH(write_files(h, s, iter_cnt - 1, true));  // :626
     for (int m = 0; m < n; m++) {
         if (residuum) { residuum[2 * m] = before[m]; residuum[2 * m + 1] = after[m]; }
         if (residuum_loc) for (int q = 0; q < 3; q++) residuum_loc[3 * m + q] = loc[3 * m + q];

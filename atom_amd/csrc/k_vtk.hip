@@ -364,7 +364,7 @@ int write_vtk(atomdev* h, int kind, int index, int Ma, const char* path) {
     // everything the file holds is on the host now: its text can be made while the caller goes on
     auto text = std::make_shared<Text>(std::move(out));
     const std::string file(path);
-    return atomdev_defer_file(h, [text, file]() -> std::string {
+    return atomdev_defer_file(h, file, [text, file]() -> std::string {
         FILE* f = std::fopen(file.c_str(), "w");
         if (!f) return "could not open VTK file " + file;
         const bool ok = text->write(f);

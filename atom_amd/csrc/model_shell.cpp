@@ -206,12 +206,14 @@ const double cAtmosphereModel::phi0 = 0.;
 const double cAtmosphereModel::r0 = 1.;
 
 cAtmosphereModel::cAtmosphereModel() : m_curve_loaded(false), m_handle(nullptr) {
+    im_tropopause = new int[jm]();  // cAtmosphereModel.cpp:84
     SetDefaultConfig();
     memset(&m_state, 0, sizeof m_state);
     m_model = this;
 }
 
 cAtmosphereModel::~cAtmosphereModel() {
+    delete[] im_tropopause;
     if (m_handle) atomdev_destroy(m_handle);
     if (m_model == this) m_model = nullptr;
 }
@@ -320,8 +322,11 @@ void cAtmosphereModel::RunTimeSlice(int Ma) {
     P.sc_WaterVapour = sc_WaterVapour; P.sc_CO2 = sc_CO2; P.gam = gam; P.r_air = r_air; P.R_Air = R_Air; P.R_WaterVapour = R_WaterVapour;
     P.L_atm = L_atm; P.cp_l = cp_l; P.t_tropopause = t_tropopause; P.ta = ta; P.pa = pa; P.ca = ca; P.p_0 = p_0;
     P.ep = ep; P.hp = hp; P.lv = lv; P.ls = ls; P.r_water_vapour = r_water_vapour; P.co2_0 = co2_0;
-    if (!m_handle) check(atomdev_create(ATOMDEV_ATM, im, jm, km, &P, -1, &m_handle), "atomdev_create");
-    else check(atomdev_set_params(m_handle, &P), "atomdev_set_params");
+    if (!m_handle) {
+        check(atomdev_create(ATOMDEV_ATM, im, jm, km, &P, -1, &m_handle), "atomdev_create");
+        // the models' files are the reference's bytes unless the caller asks for a faster form of the sweep
+        if (!getenv("ATOMDEV_RK_VARIANT")) check(atomdev_set_rk_variant(m_handle, 0), "atomdev_set_rk_variant");
+    } else check(atomdev_set_params(m_handle, &P), "atomdev_set_params");
 
     atomdev_atm_slice S;
     atomdev_default_atm_slice(&S);
@@ -342,7 +347,8 @@ void cAtmosphereModel::RunTimeSlice(int Ma) {
     st.c_tropopause = c_tropopause; st.c_ocean = c_ocean; st.c_land = c_land;
     st.co2_average = co2_average; st.co2_equator = co2_equator; st.co2_tropopause = co2_tropopause; st.co2_pole = co2_pole;
     st.co2_cretaceous = co2_cretaceous; st.co2_vegetation = co2_vegetation; st.co2_ocean = co2_ocean; st.co2_land = co2_land;
-    st.im_tropopause = nullptr;
+    for (int j = 0; j < jm; j++) im_tropopause[j] = tropopause_equator;  // BC_Thermo::TropopauseLocation (:884-899)
+    st.im_tropopause = im_tropopause;
     atomdev_atm_loop& L = S.loop;
     L.velocity_iter_max_2D = velocity_iter_max_2D; L.pressure_iter_max_2D = pressure_iter_max_2D;
     L.velocity_iter_max = velocity_iter_max; L.pressure_iter_max = pressure_iter_max;
@@ -363,6 +369,17 @@ void cAtmosphereModel::RunTimeSlice(int Ma) {
     S.bathymetry_name = bathymetry_name.c_str();
     if (verbose) std::cout << "\n   Output is being written to " << output_path << "\n   Ma = " << Ma << "\n   bathymetry_filepath = " << bathymetry_filepath << "\n\n";
     check(atomdev_atm_run_time_slice(m_handle, &S, &m_state), "atomdev_atm_run_time_slice");
+}
+
+double cAtmosphereModel::node_weight(int j) {
+    return j <= 90 ? std::cos((90 - j) * M_PI / 180.0) : std::cos((j - 90) * M_PI / 180.0);
+}
+
+float cAtmosphereModel::calculate_mean_temperature() {
+    if (!m_handle) throw std::runtime_error("calculate_mean_temperature: no time slice has been run yet");
+    float mean = 0.f;
+    check(atomdev_atm_calculate_mean_temperature(m_handle, &mean), "atomdev_atm_calculate_mean_temperature");
+    return mean;
 }
 
 // ==== cHydrosphereModel =======================================================================================
@@ -461,18 +478,12 @@ void cHydrosphereModel::RunTimeSlice(int Ma) {
     const bool read_salinity = Ma == 0 || use_earthbyte_reconstruction;  // :273
     S.salinity_file = read_salinity ? salinity.c_str() : nullptr;
     S.queries = 1;
+    // write_file (:739-772) at the checkpoints of the loop and at the end, inside the call
+    S.checkpoint = checkpoint; S.paraview_panorama_vts = paraview_panorama_vts ? 1 : 0;
+    S.output_path = output_path.c_str(); S.bathymetry_name = bathymetry_name.c_str();
     int loc[3];
     check(atomdev_hyd_run_time_slice(h, &S, m_residuum, loc), "atomdev_hyd_run_time_slice");
 
-    // write_file with is_final_result (:739-772); n: the velocity iterations done
-    const int n = pressure_iter_max * velocity_iter_max;
-    const string stem = output_path + "/[" + bathymetry_name + "]";
-    const int j_longal = 75, k_zonal = 185, i_radial = 40;
-    check(atomdev_write_vtk(h, ATOMDEV_LONGAL, j_longal, Ma, (stem + "_Hyd_longal_" + std::to_string(j_longal) + "_" + std::to_string(n) + ".vtk").c_str()), "atomdev_write_vtk");
-    check(atomdev_write_vtk(h, ATOMDEV_ZONAL, k_zonal, Ma, (stem + "_Hyd_zonal_" + std::to_string(k_zonal) + "_" + std::to_string(n) + ".vtk").c_str()), "atomdev_write_vtk");
-    check(atomdev_write_vtk(h, ATOMDEV_RADIAL, i_radial, Ma, (stem + "_Hyd_radial_" + std::to_string(i_radial) + "_" + std::to_string(n) + ".vtk").c_str()), "atomdev_write_vtk");
-    if (paraview_panorama_vts) check(atomdev_write_panorama_vts(h, (stem + "_Hyd_panorama_" + std::to_string(n) + ".vts").c_str()), "atomdev_write_panorama_vts");
-    check(atomdev_hyd_write_plot_data(h, (stem + "_PlotData_Hyd.xyz").c_str()), "atomdev_hyd_write_plot_data");
 }
 
 // ==== the flat interface (include/atom_models_c.h) ============================================================
@@ -625,6 +636,20 @@ atomdev_t* atom_model_device_handle(atom_model_t* m) { return !m ? nullptr : m->
 double atom_model_mean_temperature_from_curve(atom_model_t* m, double time) {
     if (!m || !m->atm) return NAN;
     try { return m->atm->get_mean_temperature_from_curve((float)time); }
+    catch (const std::exception& e) { g_model_error = e.what(); return NAN; }
+}
+
+int atom_model_get_tropopause(atom_model_t* m, int* levels, int n) {
+    if (!m || !m->atm || !levels) return -1;
+    const int count = n < cAtmosphereModel::jm ? (n < 0 ? 0 : n) : cAtmosphereModel::jm;
+    const int* t = m->atm->get_tropopause();
+    for (int j = 0; j < count; j++) levels[j] = t[j];
+    return count;
+}
+
+double atom_model_calculate_mean_temperature(atom_model_t* m) {
+    if (!m || !m->atm) return NAN;
+    try { return m->atm->calculate_mean_temperature(); }
     catch (const std::exception& e) { g_model_error = e.what(); return NAN; }
 }
 

@@ -51,7 +51,9 @@ class HydSlice(C.Structure):
     """atomdev_hyd_slice: a hydrosphere time slice as cHydrosphereModel::RunTimeSlice runs it."""
     _fields_ = [("start", HydStart), ("velocity_iter_max_2D", C.c_int), ("pressure_iter_max_2D", C.c_int),
                 ("velocity_iter_max", C.c_int), ("pressure_iter_max", C.c_int), ("transfer_file", C.c_char_p),
-                ("bathymetry_file", C.c_char_p), ("salinity_file", C.c_char_p), ("queries", C.c_int)]
+                ("bathymetry_file", C.c_char_p), ("salinity_file", C.c_char_p), ("queries", C.c_int),
+                ("checkpoint", C.c_int), ("paraview_panorama_vts", C.c_int), ("output_path", C.c_char_p),
+                ("bathymetry_name", C.c_char_p)]
 
 
 class AtmStart(C.Structure):
@@ -164,6 +166,8 @@ def load_library():
     lib.atomdev_fill2d.argtypes = [vp, C.c_int, C.c_double]
     lib.atomdev_selftest_math.argtypes = [vp, C.c_int, C.c_size_t, dp, dp, dp]
     lib.atomdev_selftest_raise_kernel_error.argtypes = [vp]
+    lib.atomdev_selftest_deferred_file_order.argtypes = [vp, C.c_char_p]
+    lib.atomdev_atm_calculate_mean_temperature.argtypes = [vp, C.POINTER(C.c_float)]
     for name in ("atomdev_pack_columns", "atomdev_unpack_columns"):
         getattr(lib, name).argtypes = [vp, ip, C.c_int, C.c_int, C.c_int, vp]
     lib.atomdev_residuum3d_field.argtypes = [vp]
@@ -433,6 +437,12 @@ class DeviceModel:
             yp = y.ctypes.data_as(dp)
         self._check(self.lib.atomdev_selftest_math(self._h, kind, x.size, x.ctypes.data_as(dp), yp, out.ctypes.data_as(dp)))
         return out
+
+    def calculate_mean_temperature(self):
+        """cAtmosphereModel::calculate_mean_temperature of the handle's temperature field (C, a float)."""
+        out = C.c_float()
+        self._check(self.lib.atomdev_atm_calculate_mean_temperature(self._h, C.byref(out)))
+        return out.value
 
     def restrain_temperature(self, mean_temperature):
         """cAtmosphereModel::restrain_temperature; mean_temperature: the curve's value for the time slice in C."""

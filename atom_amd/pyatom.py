@@ -37,6 +37,10 @@ def _lib():
         lib.atom_model_device_handle.argtypes = [vp]
         lib.atom_model_mean_temperature_from_curve.restype = C.c_double
         lib.atom_model_mean_temperature_from_curve.argtypes = [vp, C.c_double]
+        lib.atom_model_get_tropopause.argtypes = [vp, C.POINTER(C.c_int), C.c_int]
+        lib.atom_model_calculate_mean_temperature.restype = C.c_double
+        lib.atom_model_calculate_mean_temperature.argtypes = [vp]
+        lib.atomdev_get_rk_variant.argtypes = [vp]
         lib._models_bound = True
     return lib
 
@@ -106,6 +110,11 @@ class _Model:
         self._check_alive()
         return self._lib.atom_model_device_handle(self._thisptr)
 
+    def device_rk_variant(self):
+        """Which form of the 3-D sweep the model's handle runs (atomdev_get_rk_variant; None before the first slice)."""
+        h = self.device_handle()
+        return None if not h else self._lib.atomdev_get_rk_variant(h)
+
     # the context manager protocol controls the lifetime of the wrapped C++ object
     def __enter__(self):
         self._check_alive()
@@ -153,6 +162,18 @@ class Atmosphere(_Model):
     def mean_temperature_from_curve(self, time):
         self._check_alive()
         return self._lib.atom_model_mean_temperature_from_curve(self._thisptr, float(time))
+
+    def get_tropopause(self):
+        """cAtmosphereModel::get_tropopause: the tropopause level of each of the 181 latitude rows."""
+        self._check_alive()
+        levels = (C.c_int * 181)()
+        n = self._lib.atom_model_get_tropopause(self._thisptr, levels, 181)
+        return list(levels)[:n]
+
+    def calculate_mean_temperature(self):
+        """cAtmosphereModel::calculate_mean_temperature of the model's own temperature field, in C."""
+        self._check_alive()
+        return self._lib.atom_model_calculate_mean_temperature(self._thisptr)
 
 
 class Hydrosphere(_Model):

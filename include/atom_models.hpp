@@ -14,7 +14,11 @@
  *    missing result is an error here instead of an abort inside the surface-file reader;
  *  - the temperature curve is read when it is first needed, from temperature_curve_file as the configuration left it (the
  *    reference reads it in the constructor, before LoadConfig can change the path);
- *  - errors are std::runtime_error exceptions with the library's message, where the reference prints and aborts.
+ *  - errors are std::runtime_error exceptions with the library's message, where the reference prints and aborts;
+ *  - the atmosphere's 3-D sweep runs in its exact form here (every quotient with the bits of the reference's division,
+ *    so that the output files carry the reference's bytes); the faster tolerance forms are chosen with the environment
+ *    variable ATOMDEV_RK_VARIANT (2 or 3) or atomdev_set_rk_variant on device_handle(): every field within 1e-10,
+ *    single numbers of the text files may then differ in their last printed digit.
  */
 #ifndef ATOM_MODELS_HPP_
 #define ATOM_MODELS_HPP_
@@ -55,6 +59,28 @@ public:
 
     float get_mean_temperature_from_curve(float time) const;
 
+    // The tropopause level of every latitude row, jm entries (cAtmosphereModel.h:80-82): what BC_Thermo::TropopauseLocation
+    // (BC_Thermo.cpp:884-899) leaves there during a time slice, tropopause_equator on every row; zeros before the first.
+    int* get_tropopause() const { return im_tropopause; }
+
+    // The cosine-of-latitude weighted mean of the temperature at sea level, in Celsius, as a float
+    // (cAtmosphereModel.cpp:952-988).  Without an argument: of the model's own temperature field, which is on the device
+    // (the reference's private overload, cAtmosphereModel.h:108-110).  With one: of any object that is indexed like the
+    // reference's Array, temp.x[0][j][k] (cAtmosphereModel.h:84) - the Array of include/atomdev_mirror.hpp or the caller's own.
+    float calculate_mean_temperature();
+    template <class ArrayLike>
+    float calculate_mean_temperature(const ArrayLike& temp) const {
+        double ret = 0., weight = 0.;
+        for (int j = 0; j < jm; j++) {
+            const double w = node_weight(j);
+            for (int k = 0; k < km; k++) {
+                ret += temp.x[0][j][k] * w;
+                weight += w;
+            }
+        }
+        return (float)((ret / weight - 1) * t_0);
+    }
+
     // the configuration parameters, as the reference's AtmosphereParams.h.inc declares them
 #define ATOM_PARAM_common(type, name) atom_detail::t_##type name;
 #define ATOM_PARAM_atmosphere(type, name) atom_detail::t_##type name;
@@ -78,6 +104,9 @@ public:
 private:
     void SetDefaultConfig();
     void load_temperature_curve() const;
+    static double node_weight(int j);   // calculate_node_weights (:971-988): the cosine of the row's latitude
+
+    int* im_tropopause;
 
     static cAtmosphereModel* m_model;
     mutable std::map<float, float> m_temperature_curve;

@@ -37,6 +37,12 @@ int atom_model_set_param(atom_model_t* m, const char* name, const char* text);
 atomdev_t* atom_model_device_handle(atom_model_t* m);
 /* cAtmosphereModel::get_mean_temperature_from_curve (atmosphere handles; NaN otherwise or outside the curve) */
 double atom_model_mean_temperature_from_curve(atom_model_t* m, double time);
+/* cAtmosphereModel::get_tropopause (cAtmosphereModel.h:80-82): copies the jm = 181 tropopause levels to levels[0 .. n-1],
+ * n <= 181; returns the number copied, -1 for a model that is no atmosphere. */
+int atom_model_get_tropopause(atom_model_t* m, int* levels, int n);
+/* cAtmosphereModel::calculate_mean_temperature (cAtmosphereModel.h:84, 108-110) of the model's own temperature field: the
+ * cosine-weighted mean of the sea-level temperature in C (NaN before the first time slice or for a hydrosphere). */
+double atom_model_calculate_mean_temperature(atom_model_t* m);
 
 #ifdef __cplusplus
 }

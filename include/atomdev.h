@@ -355,6 +355,9 @@ double atomdev_atm_co2_coeff(double CO2, double co2_factor, double co2_equator, 
  * meets mean_temperature (get_mean_temperature_from_curve of the time slice, in C), then capped at 40 C.  The mean is
  * summed on the host in the reference's order. */
 int atomdev_atm_restrain_temperature(atomdev_t* h, double mean_temperature);
+/* cAtmosphereModel::calculate_mean_temperature (atmosphere/cAtmosphereModel.cpp:952-988) of the handle's temperature
+ * field: that weighted mean of the sea-level row, in C, as the float the reference returns. */
+int atomdev_atm_calculate_mean_temperature(atomdev_t* h, float* mean);
 
 /* cAtmosphereModel::RunTimeSlice (atmosphere/cAtmosphereModel.cpp:140-341) without its printing and without the plate
  * reconstruction script (:177-189; the caller names the surface files): reset_arrays, the topography, the initial
@@ -418,6 +421,10 @@ int atomdev_selftest_math(atomdev_t* h, int kind, size_t n, const double* x, con
  * bounded wait between workgroups): the next call that waits for the handle's stream - downloads, queries, file
  * writers, atomdev_sync - must fail once, and the call after it succeed.  For tests of that path. */
 int atomdev_selftest_raise_kernel_error(atomdev_t* h);
+/* Hands the library's deferred file writer (the threads that finish a slice's text files while the slice goes on) two
+ * jobs for one path, the first of them slow: jobs for one path must run in the order given, so the file holds the second
+ * job's text afterwards ("second\n").  For tests of that path; needs no GPU work. */
+int atomdev_selftest_deferred_file_order(atomdev_t* h, const char* path);
 
 /* ---- hydrosphere ---- */
 /* BC_Hydrosphere::RB_radius / RB_theta / RB_phi (hydrosphere/BC_Hyd.cpp:38-158) */
@@ -478,8 +485,9 @@ int atomdev_hyd_bc_temperature_salinity(atomdev_t* h, const atomdev_hyd_start* s
  * salinity_file may be NULL (the surface fields are taken as they are / the salinity is not read; the reference reads
  * it when Ma == 0).  queries != 0 runs the residuum and steady-state queries where the reference does (their results
  * are printed only there); residuum[0], residuum[1] (may be NULL) receive the continuity residuum before and after
- * the last velocity iteration, residuum_loc (may be NULL) the location of the latter.  Output files: atomdev_write_vtk,
- * atomdev_write_panorama_vts, atomdev_hyd_write_plot_data afterwards. */
+ * the last velocity iteration, residuum_loc (may be NULL) the location of the latter.  Output files: with output_path
+ * set, the three VTK sections (and the panorama file) and the PlotData table at the checkpoints and at the end, under
+ * the reference's names; otherwise atomdev_write_vtk, atomdev_write_panorama_vts, atomdev_hyd_write_plot_data afterwards. */
 typedef struct atomdev_hyd_slice {
     atomdev_hyd_start start;
     int velocity_iter_max_2D, pressure_iter_max_2D, velocity_iter_max, pressure_iter_max;  /* param.py:135-138: 2, 10, 2, 2 */
@@ -487,6 +495,12 @@ typedef struct atomdev_hyd_slice {
     const char* bathymetry_file;  /* bathymetry_path/<Ma>Ma_Golonka.xyz */
     const char* salinity_file;    /* Name_SurfaceSalinity_File */
     int queries;
+    /* the output files of cHydrosphereModel::write_file (:739-772): after every checkpoint-th pressure iteration
+     * (:612-614; param.py:139) and at the end of the slice; output_path NULL: none */
+    int checkpoint;
+    int paraview_panorama_vts;    /* the whole-grid .vts file as well */
+    const char* output_path;
+    const char* bathymetry_name;  /* "<Ma>Ma_Golonka.xyz": part of every output file's name */
 } atomdev_hyd_slice;
 void atomdev_default_hyd_slice(int im, atomdev_hyd_slice* s);
 int atomdev_hyd_run_time_slice(atomdev_t* h, const atomdev_hyd_slice* s, double residuum[2], int residuum_loc[3]);

@@ -222,6 +222,38 @@ def atm_slice_case():
     print("atm_time_slice.npz", len(out), "entries")
 
 
+def hyd_slice_case():
+    """cHydrosphereModel::RunTimeSlice of the compiled reference at 0 Ma behind the compiled reference's atmosphere slice
+    (which leaves the transfer file it reads), both with the reference's default parameters and iteration counts, from
+    the input files as tests/harness.py writes them back: SHA-256 and a digest of the numbers of every file the
+    hydrosphere writes (its checkpoint files and its final ones)."""
+    import ctypes as C
+    import hashlib
+    import tempfile
+    out = {}
+    dims = (41, 181, 361)
+    with tempfile.TemporaryDirectory() as tmp:
+        _, _, curve = H.write_atm_slice_inputs(tmp)
+        p = H.default_params(H.ATM)
+        f, g = H.atm_reset_arrays(dims, p)
+        r = H.CpuModel("ref", H.ATM, *dims, p, f, g)
+        s, keep = H.atm_slice_start(0, None, curve)
+        outdir = os.path.join(tmp, "out")
+        os.makedirs(outdir)
+        H.run_ref_atm_slice(r, s, (2, 10, 2, 2), tmp, outdir)
+        before = set(os.listdir(outdir))
+        lib = H.load_ref()
+        lib.ref_hyd_run_time_slice.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
+        assert lib.ref_hyd_run_time_slice(tmp.encode(), os.path.join(tmp, "SurfaceSalinity_NASA.xyz").encode(), outdir.encode(), 0) == 0
+        for fn in sorted(set(os.listdir(outdir)) - before):
+            path = os.path.join(outdir, fn)
+            out["Ma0/file/" + fn] = np.array(hashlib.sha256(open(path, "rb").read()).hexdigest())
+            out["Ma0/numbers/" + fn] = H.text_file_numbers(path)
+            print("  ", fn, os.path.getsize(path))
+    np.savez_compressed(H.HYD_SLICE_GOLDEN, **out)
+    print("hyd_time_slice.npz", len(out), "entries")
+
+
 if __name__ == "__main__":
     assert H.have_ref(), "build oracle/_ref first: make -C oracle ref"
     os.makedirs(GOLD, exist_ok=True)

@@ -37,6 +37,7 @@
 #include "cAtmosphereModel.h"
 #include "BC_Thermo.h"
 #undef private
+#include "cHydrosphereModel.h"
 #include "AtmParameters.h"
 
 #include "ref_shim.h"
@@ -323,6 +324,28 @@ int ref_atm_run_time_slice(void* v, const atomdev_atm_start* s, const atomdev_at
     for (auto& e : f2)
         if (c->g[e.id])
             for (int j = 0; j < c->jm; j++) std::memcpy(c->g[e.id] + (size_t)j * c->km, e.a->y[j], sizeof(double) * c->km);
+    return 0;
+}
+
+/* cHydrosphereModel::RunTimeSlice (hydrosphere/cHydrosphereModel.cpp:129-632) of a model object of its own with the
+ * reference's default parameters: reads output_path/[<Ma>Ma_Golonka.xyz]_Transfer_Atm.vw, the bathymetry under
+ * bathymetry_path and the surface salinity file, and writes its output files to output_path (at the checkpoints of its
+ * loop and at the end).  The plate reconstruction is switched off. */
+int ref_hyd_run_time_slice(const char* bathymetry_path, const char* salinity_file, const char* output_path, int Ma) {
+    CoutSilencer quiet;
+    static cHydrosphereModel* hm = nullptr;
+    if (!hm) {
+        void (*old_int)(int) = std::signal(SIGINT, SIG_DFL);   // the constructor installs exit() on SIGINT
+        hm = new cHydrosphereModel();
+        std::signal(SIGINT, old_int);
+    }
+    hm->bathymetry_path = bathymetry_path;
+    hm->BathymetrySuffix = "Ma_Golonka.xyz";
+    hm->salinity_file = salinity_file;
+    hm->output_path = output_path;
+    hm->use_earthbyte_reconstruction = false;
+    hm->verbose = false; hm->debug = false; hm->paraview_panorama_vts = false;
+    hm->RunTimeSlice(Ma);
     return 0;
 }
 

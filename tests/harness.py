@@ -1015,6 +1015,16 @@ def atm_time_slice(m, s, i_trop, files, counts, mean_temperature, coast_correcti
 
 ATM_SLICE_INPUTS = os.path.join(ROOT, "tests", "golden", "atm_slice_inputs.npz")
 ATM_SLICE_GOLDEN = os.path.join(ROOT, "tests", "golden", "atm_time_slice.npz")
+HYD_SLICE_GOLDEN = os.path.join(ROOT, "tests", "golden", "hyd_time_slice.npz")
+
+
+def text_file_numbers(path, stride=53):
+    """A digest of the numbers of a text file (an ASCII VTK section, a PlotData table): how many tokens read as numbers,
+    and every stride-th of them.  Two files that agree in it up to the last printed digit hold the same table."""
+    import re
+    tokens = re.findall(r"(?<![\w.])[-+]?(?:\d+\.\d*|\.\d+|\d+)(?:[eE][-+]?\d+)?(?![\w.])", open(path).read())
+    v = np.array([float(t) for t in tokens])
+    return np.concatenate(([float(v.size)], v[::stride]))
 ATM_SLICE_CASES = [(0, None), (40, 30), (140, 130)]     # (Ma, the slice before it)
 
 

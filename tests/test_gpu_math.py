@@ -104,3 +104,14 @@ def test_a_failure_a_kernel_reports_surfaces_with_the_next_result():
                 d.sync()
         d.download("T"); d.sync()      # reported once
         d.close()
+
+
+def test_deferred_files_for_one_path_are_written_in_order(tmp_path):
+    """Inside a one-call slice the text files are finished by threads of their own.  A checkpoint and the final write can
+    fall on the same file name (the reference's defaults: 2 x 2 iterations, checkpoint 2), and the reference writes one
+    after the other, so the later content must stand: two jobs for one path, the first held back, leave the second's text."""
+    d = atom_amd.DeviceModel(H.ATM, 5, 7, 9)
+    path = str(tmp_path / "same_name.vtk")
+    d._check(d.lib.atomdev_selftest_deferred_file_order(d._h, path.encode()))
+    assert open(path).read() == "second\n"
+    d.close()
