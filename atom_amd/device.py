@@ -168,6 +168,15 @@ def load_library():
     lib.atomdev_selftest_raise_kernel_error.argtypes = [vp]
     lib.atomdev_selftest_deferred_file_order.argtypes = [vp, C.c_char_p]
     lib.atomdev_atm_calculate_mean_temperature.argtypes = [vp, C.POINTER(C.c_float)]
+    ip = C.POINTER(C.c_int)
+    lib.atomdev_slabs_local_km.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.atomdev_slabs_columns.argtypes = [C.c_int, C.c_int, C.c_int, ip, ip, ip]
+    lib.atomdev_slabs_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    lib.atomdev_slabs_destroy.argtypes = [vp]
+    lib.atomdev_slabs_begin_exchange.argtypes = [vp, ip, C.c_int]
+    lib.atomdev_slabs_finish_exchange.argtypes = [vp]
+    lib.atomdev_slabs_residuum3d.argtypes = [vp, C.POINTER(C.c_double), ip]
+    lib.atomdev_slabs_steady3d.argtypes = [vp, C.POINTER(C.c_double), ip]
     for name in ("atomdev_pack_columns", "atomdev_unpack_columns"):
         getattr(lib, name).argtypes = [vp, ip, C.c_int, C.c_int, C.c_int, vp]
     lib.atomdev_residuum3d_field.argtypes = [vp]

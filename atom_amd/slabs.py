@@ -228,7 +228,7 @@ class SlabModel:
                 w.wait()
             if on_device:
                 import torch
-                torch.cuda.current_stream().synchronize()   # wait() orders the collective against torch's stream only
+                torch.cuda.current_stream(self.xdev).synchronize()   # wait() orders the collective against torch's stream on the buffers' device only
             for buf, names, k_dst in unpack:
                 if hasattr(self.e, "unpack_columns"):
                     self.e.unpack_columns(names, k_dst, self._view(buf))
@@ -257,12 +257,14 @@ class SlabModel:
 
     # ---- queries --------------------------------------------------------------
     def _all(self, values):
-        """Every rank's list of numbers, in rank order."""
+        """Every rank's list of numbers (the same count on every rank), in rank order: one all-gather of a small tensor."""
         if self.plan.world == 1:
             return [list(values)]
-        box = [None] * self.plan.world
-        self.dist.all_gather_object(box, list(values))
-        return box
+        import torch
+        mine = torch.tensor([float(v) for v in values], dtype=torch.float64, device=self.xdev)
+        box = [torch.empty_like(mine) for _ in range(self.plan.world)]
+        self.dist.all_gather(box, mine)
+        return [b.tolist() for b in box]
 
     def residuum(self, min0=0.0, loc0=(0, 0, 0)):
         """residuumQuery_3D of the whole grid (Accuracy_Atm.cpp:82-116, Accuracy_Hyd.cpp:88-116): (value, location)."""
@@ -357,6 +359,129 @@ class SlabModel:
             self.begin_exchange(["P_DYNN"])
             self.finish_exchange()
             self.e.op(pre + "pressure3d")
+        return log
+
+
+class LocalSlabs:
+    """One model split into phi-slabs over several handles of THIS process - one per GPU of the node, or several on one
+    GPU - with the exchange and the whole-grid queries done by the library (atomdev_slabs_*: a second stream per handle,
+    events, peer copies between persistent device buffers; the host never waits).  A thin caller: layout, exchange and
+    queries are the C side's."""
+
+    def __init__(self, model, im, jm, km_global, params, world, devices=None):
+        import ctypes as C
+        from .device import DeviceModel, F3, load_library
+        self.lib = load_library()
+        self.model, self.im, self.jm, self.km, self.world = model, im, jm, km_global, world
+        self.F3 = F3
+        devices = list(devices) if devices is not None else [-1] * world
+        self.e, self.cols, self.owned = [], [], []
+        for r in range(world):
+            kml = self.lib.atomdev_slabs_local_km(km_global, world, r)
+            if kml < 0:
+                raise ValueError("slabs of %d columns over %d handles are too narrow" % (km_global, world))
+            cols = (C.c_int * kml)()
+            first, count = C.c_int(), C.c_int()
+            if self.lib.atomdev_slabs_columns(km_global, world, r, cols, C.byref(first), C.byref(count)):
+                raise RuntimeError(self.lib.atomdev_last_error().decode())
+            self.cols.append(np.array(cols[:], dtype=np.int64))
+            self.owned.append((first.value, count.value))
+            self.e.append(DeviceModel(model, im, jm, kml, params, device=devices[r]))
+        handles = (C.c_void_p * world)(*[e._h for e in self.e])
+        self._g = C.c_void_p()
+        self._check(self.lib.atomdev_slabs_create(handles, world, km_global, C.byref(self._g)))
+
+    def _check(self, rc):
+        if rc:
+            raise RuntimeError(self.lib.atomdev_last_error().decode())
+
+    def close(self):
+        if self._g:
+            self.lib.atomdev_slabs_destroy(self._g)
+            self._g = None
+        for e in self.e:
+            e.close()
+        self.e = []
+
+    def upload_all(self, fields3d, fields2d):
+        """Every slab's columns (ghosts and seam copies included) of whole-grid arrays."""
+        for r, e in enumerate(self.e):
+            e.upload_all({k: np.ascontiguousarray(v[..., self.cols[r]]) for k, v in fields3d.items()},
+                         {k: np.ascontiguousarray(v[..., self.cols[r]]) for k, v in fields2d.items()})
+
+    def collect(self, name):
+        """A 3-D field of the whole grid from the slabs' owned columns."""
+        a = np.empty((self.im, self.jm, self.km))
+        for r, e in enumerate(self.e):
+            first, count = self.owned[r]
+            g0 = int(self.cols[r][first])
+            a[:, :, g0:g0 + count] = e.get_columns(name, first, count)
+        return a
+
+    def op(self, name):
+        for e in self.e:
+            e.op(name)
+
+    def move_data_to_new_arrays(self, level=-1):
+        for e in self.e:
+            e.move_data_to_new_arrays(level)
+
+    def sync(self):
+        for e in self.e:
+            e.sync()
+
+    def begin_exchange(self, names):
+        import ctypes as C
+        ids = (C.c_int * len(names))(*[self.F3[n] for n in names])
+        self._check(self.lib.atomdev_slabs_begin_exchange(self._g, ids, len(names)))
+
+    def finish_exchange(self):
+        self._check(self.lib.atomdev_slabs_finish_exchange(self._g))
+
+    def residuum(self, min0=0.0, loc0=(0, 0, 0)):
+        import ctypes as C
+        m, loc = C.c_double(min0), (C.c_int * 3)(*loc0)
+        self._check(self.lib.atomdev_slabs_residuum3d(self._g, C.byref(m), loc))
+        return m.value, tuple(loc)
+
+    def steady(self):
+        import ctypes as C
+        nf = 9 if self.model == 0 else 6
+        v, loc = (C.c_double * nf)(), (C.c_int * (3 * nf))()
+        self._check(self.lib.atomdev_slabs_steady3d(self._g, v, loc))
+        return list(v), [tuple(loc[3 * f:3 * f + 3]) for f in range(nf)]
+
+    def run_3d_loop(self, pressure_iters=2, velocity_iters=2, queries=True):
+        """The pressure / velocity iterations of run_3D_loop without the column physics (as SlabModel.run_3d_loop), the
+        exchanges posted as early as their data is final."""
+        atm = self.model == 0
+        pre = "atm_" if atm else "hyd_"
+        log = []
+        if atm:
+            self.move_data_to_new_arrays(-1)
+        for _ in range(pressure_iters):
+            for v in range(1, velocity_iters + 1):
+                if queries:
+                    first = self.residuum()
+                    log.append(first)
+                if atm:
+                    ops = ["bc_radius", "bc_theta", "bc_phi", "value_limitation", "solid_ground", "rk3d", "value_limitation"]
+                else:
+                    ops = ["bc_radius", "bc_theta", "bc_phi", "pressure_density", "value_limitation", "rk3d", "solid_ground"]
+                for op in ops:
+                    self.op(pre + op)
+                    if op == "rk3d" and v == velocity_iters:
+                        self.begin_exchange(["AUX_U", "AUX_V", "AUX_W"])
+                if queries:
+                    log.append(self.residuum(*first) if atm else self.residuum())
+                    log.append(self.steady())
+                if atm:
+                    for e in self.e:
+                        e.msl_data(1)
+                self.move_data_to_new_arrays(-1)
+            self.begin_exchange(["P_DYNN"])
+            self.finish_exchange()
+            self.op(pre + "pressure3d")
         return log
 
 

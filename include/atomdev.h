@@ -407,6 +407,35 @@ int atomdev_residuum3d_field(atomdev_t* h);
 int atomdev_residuum3d_suffix(atomdev_t* h, int k0, int nk, int kg0, int km_global, double from, double out[7]);
 int atomdev_steady3d_part(atomdev_t* h, int k0, int nk, int kg0, int km_global, double* values, double* positions);
 
+/* ---- one model split into phi-slabs over several handles of ONE process (one handle per GPU) ----
+ * No counterpart in the reference, which has one domain.  Slab r of n holds, as an ordinary smaller model of
+ * km = atomdev_slabs_local_km(km_global, n, r) columns: [5 copies of the columns behind the phi seam: last slab only]
+ * [3 ghost columns of its left neighbour] [its owned columns] [3 ghost columns of its right neighbour] [5 seam copies:
+ * slab 0 only], and runs the unmodified operators on it; atomdev_slabs_columns names the global column of every local
+ * one (for scattering the fields and the mask) and the owned range.  The 3-D Runge-Kutta sweeps, the limiters and the
+ * r / theta / phi fills need no exchange (no phi coupling: RHS_Atm.cpp:146-149, RHS_Hyd.cpp:136-139); the pressure step
+ * reads p_dynn and aux_u / aux_v / aux_w at the ghost and seam columns (Pressure_Atm.cpp:57-66, 140-155, 170-176), the
+ * continuity residuum reads w (Accuracy_Atm.cpp:82-116).
+ *   atomdev_slabs_begin_exchange: the owners' columns of the named fields set out for the slabs that hold copies of them -
+ *     on a second stream per handle, behind an event on its compute stream (so: call it right after the operator that
+ *     makes the fields final), packed by one kernel per message and carried by hipMemcpyPeerAsync between persistent
+ *     device buffers.  Returns at once; up to four exchanges may be in flight.
+ *   atomdev_slabs_finish_exchange: every holder's compute stream waits (on the device: hipStreamWaitEvent, the host goes
+ *     on) for its messages and stores them into its ghost and seam columns.  Call it just before the operator that reads.
+ *   atomdev_slabs_residuum3d / _steady3d: the accuracy queries of the whole grid (Accuracy_Atm.cpp:82-116, 192-337,
+ *     Accuracy_Hyd.cpp:88-184) with the single domain's values and locations; *min carries the atmosphere's scan state
+ *     from call to call as atomdev_atm_residuum3d does; values: 9 (atmosphere) or 6 numbers, loc: 3 per value.
+ * A C++ caller with one process per node drives all its GPUs this way; one process per GPU: atom_amd/slabs.py. */
+typedef struct atomdev_slabs atomdev_slabs_t;
+int atomdev_slabs_local_km(int km_global, int world, int rank);   /* -1: no such plan */
+int atomdev_slabs_columns(int km_global, int world, int rank, int* global_columns, int* owned_first_local, int* owned_count);
+int atomdev_slabs_create(atomdev_t* const* handles, int n, int km_global, atomdev_slabs_t** out);
+int atomdev_slabs_destroy(atomdev_slabs_t* g);
+int atomdev_slabs_begin_exchange(atomdev_slabs_t* g, const int* fields3d, int nf);
+int atomdev_slabs_finish_exchange(atomdev_slabs_t* g);
+int atomdev_slabs_residuum3d(atomdev_slabs_t* g, double* min, int loc[3]);
+int atomdev_slabs_steady3d(atomdev_slabs_t* g, double* values, int* loc);
+
 /* The library's arithmetic helpers evaluated on the device for n caller-supplied operands (host pointers): the
  * double-double exp / pow / x^4 / fourth root the column physics uses in place of the device library's functions, and the
  * sweeps' division by a known reciprocal beside the hardware's IEEE division.  For property tests; no counterpart in the

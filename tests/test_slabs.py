@@ -256,6 +256,11 @@ class _ThreadDist:
     def all_gather_object(self, box, obj):
         box[:] = self._exchange("ag", obj)
 
+    def all_gather(self, box, tensor):
+        tensor.device.type == "cuda" and __import__("torch").cuda.current_stream().synchronize()
+        for b, t in zip(box, self._exchange("agt", tensor.clone())):
+            b.copy_(t)
+
     def scatter_object_list(self, box, parts, src=0):
         box[0] = self._exchange("sc", parts)[src][self.rank]
 
@@ -316,3 +321,54 @@ def test_slab_loop_device_resident_exchange(model, dims, seed):
     _same_log(got_log, log, exact=model == "hyd")
     assert results[1][1] == got_log         # every rank sees the same query results
     full.close(); o.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,model,dims,seed", [(2, "hyd", (7, 13, 70), 71), (3, "hyd", (6, 11, 80), 72), (2, "atm", (9, 21, 70), 73),
+                                                   (3, "atm", (7, 13, 80), 74)])
+def test_slab_group_in_one_process(world, model, dims, seed):
+    """The slabs as handles of ONE process, exchange and queries by the library (atomdev_slabs_*: a second stream per
+    handle, events, device-to-device copies between persistent buffers, no host wait): 2 x 2 iterations of the 3-D loop,
+    fields and queries of the single domain."""
+    import atom_amd
+    im, jm, km = dims
+    m = H.ATM if model == "atm" else H.HYD
+    p = H.default_params(m, im, jm, km)
+    if m == H.ATM:
+        f, g = H.make_msl_inputs(im, jm, km, seed, p)
+    else:
+        f, g = H.make_inputs(m, im, jm, km, seed, "blobs", p)
+        f = {k: f[k] for k in H.HYD_FIELDS}
+    ls = slabs.LocalSlabs(m, im, jm, km, atom_amd.Params.from_buffer_copy(bytes(p)), world, devices=[0] * world)
+    plan = slabs.SlabPlan(km, world)
+    for r in range(world):   # the library's layout is the plan of atom_amd/slabs.py
+        assert list(ls.cols[r]) == list(plan.columns(r)) and ls.owned[r] == plan.owned_local(r)
+    ls.upload_all(f, g)
+    got_log = ls.run_3d_loop(2, 2, queries=True)
+    o, log = _single_domain_loop(model, dims, seed)
+    for k in f:
+        if k in ("H", "RESIDUUM"):
+            continue
+        got = ls.collect(k)
+        if model == "hyd":
+            assert H.bits_equal(got, o.f[k]), (k, H.max_rel_err(got, o.f[k]))
+        else:
+            assert H.max_rel_err(got, o.f[k]) <= 1e-10, (k, H.max_rel_err(got, o.f[k]))
+    _same_log(got_log, log, exact=model == "hyd")
+    ls.close(); o.close()
+
+
+@pytest.mark.gpu
+def test_slab_group_refuses_what_it_cannot_do():
+    import atom_amd
+    p = H.default_params(H.HYD, 5, 7, 40)
+    a = atom_amd.DeviceModel(H.HYD, 5, 7, 28, atom_amd.Params.from_buffer_copy(bytes(p)))
+    lib = a.lib
+    import ctypes as C
+    assert lib.atomdev_slabs_local_km(40, 2, 0) == 28 and lib.atomdev_slabs_local_km(40, 2, 1) == 28
+    assert lib.atomdev_slabs_local_km(20, 4, 0) == -1            # slabs narrower than ghosts + seam copies
+    handles, g = (C.c_void_p * 2)(a._h, a._h), C.c_void_p()
+    b = atom_amd.DeviceModel(H.HYD, 5, 7, 30, atom_amd.Params.from_buffer_copy(bytes(p)))
+    handles[1] = b._h
+    assert lib.atomdev_slabs_create(handles, 2, 40, C.byref(g)) != 0 and b"must have km = 28" in lib.atomdev_last_error()
+    a.close(); b.close()
