@@ -11,14 +11,22 @@ and computePressure_3D after every second step (velocity_iter_max = 2).
 One step advances 39*179*359 = 2,506,179 grid points through all four RK stages of
 all eight prognostic variables.  Fields are resident in HBM before the timed
 region.  With N > 1 every rank runs an independent slice on its own GPU (the
-140->0 Ma sweep of independent time slices): weak scaling, no data-path collective.
+140->0 Ma sweep of independent time slices): weak scaling, no data-path collective;
+the same run then times ONE 0.25-degree atmosphere split into N phi-slabs (strong
+scaling, halo exchange around the pressure step) and reports it as `slabs_0p25`.
+
+The timed region of K steps is repeated (--windows, default 5, each bracketed by the same barrier + synchronize);
+`value` and `ms_per_step` are the median window's, the fastest and slowest are reported beside them.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu]
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py --mode slabs --grid 0.25 --slabs 2          one model as 2 phi-slabs of this process (library-side exchange)
+  python bench.py --mode slabs --grid 0.1 --slab-of 16        rank 0's slab of the 81x1801x3601 grid split 16 ways, alone
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -26,10 +34,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 IM, JM, KM = 41, 181, 361
-GRIDS = {"1": (41, 181, 361), "0.25": (41, 721, 1441)}   # degrees -> grid; the refined one takes the 0 Ma mask upsampled by 4
+# degrees -> grid; the refined ones take the 0 Ma mask upsampled (nearest neighbour; 0.1 degree: 81 levels)
+GRIDS = {"1": (41, 181, 361), "0.25": (41, 721, 1441), "0.1": (81, 1801, 3601)}
 UPDATES = (IM - 2) * (JM - 2) * (KM - 2)
 ATM_BYTES_PER_UPDATE = 280   # reads 9 state + 8 xn + h + 5 sources, writes 8 state + 3 aux + buoyancy
 HYD_BYTES_PER_UPDATE = 208
@@ -42,57 +50,43 @@ ATM_STEP = ["atm_bc_radius", "atm_bc_theta", "atm_bc_phi", "atm_value_limitation
 ATM_DEV_STEP = ["atm_bc_radius_theta_phi", "atm_limit_ground_rk3d_limit", "move3d"]
 HYD_STEP = ["hyd_bc_radius_theta_phi", "hyd_pressure_density", "hyd_value_limitation", "hyd_rk3d",
             "hyd_solid_ground", "move3d"]   # (the three boundary fills as one call: same bits)
+SWEEP_KERNEL = {0: "k_atm_rk3d_ws<true>", 1: "k_atm_rk3d", 2: "k_atm_rk3d_wsf<true>", 3: "k_atm_rk3d_pipe<true>"}
+SWEEP_FORM = {0: "exact form", 1: "one thread per line, exact form", 2: "tolerance form", 3: "pipelined tolerance form"}
 
 
-def make_slab(H, atom_amd, dist, rank, world, device, seed, backend):
-    """This rank's phi-slab of the atmosphere on the global grid (atom_amd/slabs.py): the mask columns it holds, seeded fields."""
-    from atom_amd import slabs
-    p = atom_amd.default_params(H.ATM, IM, JM, KM)
-    sm = slabs.create_device_slab(H.ATM, IM, JM, KM, p, rank, world, dist, device=device, xdev=None if backend == "nccl" else "cpu")
-    kml = sm.e.km
-    f, g = H.make_inputs(H.ATM, IM, JM, kml, seed, "allfluid", p)
-    f = {k: f[k] for k in H.ATM_FIELDS}
-    h, topo = H.load_mask_0Ma(H.ATM)
+def set_grid(name):
+    global IM, JM, KM, UPDATES
+    IM, JM, KM = GRIDS[name]
+    UPDATES = (IM - 2) * (JM - 2) * (KM - 2)
+
+
+def grid_mask(S, model, columns=None):
+    """The real 0 Ma mask of the 1-degree grid at the points of the current grid (nearest neighbour in all three
+    directions), restricted to the given global columns."""
+    h, topo = S.load_mask_0Ma(model)
+    if (IM, JM, KM) == GRIDS["1"] and columns is None:
+        return h, topo
+    ii = np.rint(np.arange(IM) * 40. / (IM - 1)).astype(int)
     jj = np.rint(np.arange(JM) * 180. / (JM - 1)).astype(int)
-    kk = np.rint(sm.cols * 360. / (KM - 1)).astype(int)
-    f["H"], g["TOPOGRAPHY"] = np.ascontiguousarray(h[:, jj][:, :, kk]), np.ascontiguousarray(topo[jj][:, kk])
+    kk = np.rint((np.arange(KM) if columns is None else np.asarray(columns)) * 360. / (KM - 1)).astype(int)
+    return np.ascontiguousarray(h[ii][:, jj][:, :, kk]), np.ascontiguousarray(topo[jj][:, kk])
+
+
+def slab_fields(S, model, columns, seed, p):
+    """Seeded fields of a model that holds the given global columns (every slab its own seed), the mask at those columns."""
+    f, g = S.make_inputs(model, IM, JM, len(columns), seed, "allfluid", p)
+    f = {k: f[k] for k in (S.ATM_FIELDS if model == S.ATM else S.HYD_FIELDS)}
+    full = (IM, JM, KM) == GRIDS["1"] and len(columns) == KM
+    f["H"], g["TOPOGRAPHY"] = grid_mask(S, model, None if full else columns)
     if (IM, JM, KM) != GRIDS["1"]:
-        H.shrink_noise(f, 256.)
-    sm.e.upload_all(f, g)
-    sm.e.sync()
-    return sm
+        # the 1-degree noise at 1/256 of its amplitude: second differences as on the 1-degree grid next to the poles
+        S.shrink_noise(f, 256.)
+    return f, g
 
 
-def slab_step(sm, s):
-    """One velocity iteration of the slab; the exchange for the pressure step is posted as soon as its data is final."""
-    pressure = (s + 1) % 2 == 0
-    for op in ATM_DEV_STEP:
-        if op == "move3d":
-            sm.e.move_data_to_new_arrays(-1)
-        else:
-            sm.e.op(op)
-            if op == "atm_limit_ground_rk3d_limit" and pressure:
-                sm.begin_exchange(["AUX_U", "AUX_V", "AUX_W"])
-    if pressure:
-        sm.begin_exchange(["P_DYNN"])
-        sm.finish_exchange()
-        sm.e.op("atm_pressure3d")
-
-
-def make_model(H, atom_amd, model, device, seed):
+def make_model(S, atom_amd, model, device, seed):
     p = atom_amd.default_params(model, IM, JM, KM)   # the product's own defaults (param.py), no checker involved
-    f, g = H.make_inputs(model, IM, JM, KM, seed, "allfluid", p)
-    names = H.ATM_FIELDS if model == H.ATM else H.HYD_FIELDS
-    f = {k: f[k] for k in names}
-    f["H"], g["TOPOGRAPHY"] = H.load_mask_0Ma(model)
-    if (IM, JM, KM) != GRIDS["1"]:
-        jj = np.rint(np.arange(JM) * 180. / (JM - 1)).astype(int)
-        kk = np.rint(np.arange(KM) * 360. / (KM - 1)).astype(int)
-        f["H"], g["TOPOGRAPHY"] = np.ascontiguousarray(f["H"][:, jj][:, :, kk]), np.ascontiguousarray(g["TOPOGRAPHY"][jj][:, kk])
-        for k in names:   # the 1-degree noise at 1/256 of its amplitude: second differences as on the 1-degree grid next to the poles
-            if k not in ("H", "RESIDUUM", "R_WATER", "R_SALT_WATER", "P_STAT"):
-                m = f[k].mean()
-                f[k] = m + (f[k] - m) / 256.
+    f, g = slab_fields(S, model, np.arange(KM), seed, p)
     d = atom_amd.DeviceModel(model, IM, JM, KM, p, device=device)
     d.upload_all(f, g)
     d.sync()
@@ -109,11 +103,53 @@ def dev_step(d, seq, s, pressure_op):
         d.op(pressure_op)
 
 
-def cpu_baseline(H, p, f, g, budget_s=12.0):
+def slab_step(sm, s):
+    """One velocity iteration of a slabbed atmosphere (atom_amd.slabs.SlabModel: this process's slab among the ranks';
+    LocalSlabs: all slabs in this process); the exchange for the pressure step is posted as soon as its data is final."""
+    pressure = (s + 1) % 2 == 0
+    target = sm if isinstance(getattr(sm, "e", None), list) else sm.e
+    for op in ATM_DEV_STEP:
+        if op == "move3d":
+            target.move_data_to_new_arrays(-1)
+        else:
+            target.op(op)
+            if op == "atm_limit_ground_rk3d_limit" and pressure:
+                sm.begin_exchange(["AUX_U", "AUX_V", "AUX_W"])
+    if pressure:
+        sm.begin_exchange(["P_DYNN"])
+        sm.finish_exchange()
+        target.op("atm_pressure3d")
+
+
+def timed_windows(step, sync, barrier, reduce_max, steps, windows, first_step=0):
+    """`windows` timed regions of exactly `steps` steps each, every one bracketed by barrier + synchronize on both sides;
+    returns the regions' wall times (the maximum over the ranks of each)."""
+    out = []
+    s = first_step
+    for _ in range(windows):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(s)
+            s += 1
+        sync()
+        barrier()
+        out.append(reduce_max(time.perf_counter() - t0))
+    return out
+
+
+def window_stats(times, units_per_window):
+    med = statistics.median(times)
+    return med, {"n": len(times), "seconds": times, "value_min": units_per_window / max(times), "value_max": units_per_window / min(times)}
+
+
+def cpu_baseline(p, f, g, budget_s=12.0):
     """The same step on the host, 1 thread, with the C restatement of the reference
-    (oracle/atom_oracle.c, bit-identical to the compiled reference).  Where the
-    compiled reference itself travelled with the tree (oracle/_ref), its own
-    solveRungeKutta_3D_Atmosphere is timed once as well."""
+    (oracle/atom_oracle.c, bit-identical to the compiled reference; loaded through the tests' harness: checker code,
+    used here as the reported baseline only).  Where the compiled reference itself travelled with the tree
+    (oracle/_ref), its own solveRungeKutta_3D_Atmosphere is timed once as well."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import harness as H
     m = H.CpuModel("oracle", H.ATM, IM, JM, KM, H.Params.from_buffer_copy(bytes(p)), f, g)
     n, t0 = 0, time.perf_counter()
     rk_s = 0.0
@@ -146,51 +182,72 @@ def cpu_baseline(H, p, f, g, budget_s=12.0):
     return out
 
 
-def run_slabs(args, H, atom_amd, torch, dist, rank, world, local_rank, barrier):
-    """Strong scaling: one atmosphere on the chosen grid, its longitudes split over the ranks."""
-    sm = make_slab(H, atom_amd, dist, rank, world, local_rank, 1234 + rank, args.backend)
-    for s in range(args.warmup + args.warmup % 2):
+def measure_slabs(args, S, atom_amd, dist, rank, world, local_rank, barrier, reduce_max, steps, warmup, windows):
+    """Strong scaling: ONE atmosphere on the current grid, its longitudes split into phi-slabs.  world > 1: one slab per
+    rank (atom_amd.slabs.SlabModel over torch.distributed); world == 1: --slabs N slabs as N handles of this process with
+    the library's own exchange (atomdev_slabs_*), or --slab-of W: slab 0 of a W-way split alone (what one GPU of W would
+    hold and compute; nothing to exchange with).  Returns rank 0's record (None elsewhere)."""
+    from atom_amd import slabs
+    p = atom_amd.default_params(S.ATM, IM, JM, KM)
+    nslabs, alone, local = world, False, None
+    if world > 1:
+        sm = slabs.create_device_slab(S.ATM, IM, JM, KM, p, rank, world, dist, device=local_rank, xdev=None if args.backend == "nccl" else "cpu")
+        f, g = slab_fields(S, S.ATM, sm.cols, 1234 + rank, p)
+        sm.e.upload_all(f, g)
+        engines, own = [sm.e], sm.plan.owned[0][1] - sm.plan.owned[0][0]
+        mode = "one slab per process over torch.distributed (%s)" % args.backend
+    elif args.slab_of > 1:
+        alone, nslabs = True, args.slab_of
+        plan = slabs.SlabPlan(KM, args.slab_of)
+        cols = plan.columns(0)
+        e = atom_amd.DeviceModel(S.ATM, IM, JM, len(cols), p, device=local_rank)
+        f, g = slab_fields(S, S.ATM, cols, 1234, p)
+        e.upload_all(f, g)
+        sm = slabs.SlabModel(e, slabs.SlabPlan(len(cols), 1), 0, None, "cpu", S.ATM)   # a single domain of the slab's width
+        engines, own = [e], plan.owned[0][1] - plan.owned[0][0]
+        mode = "slab 0 of %d alone on one GPU (%d owned + %d ghost and seam columns), no exchange partner" % (args.slab_of, own, len(cols) - own)
+    else:
+        nslabs = max(1, args.slabs)
+        local = sm = slabs.LocalSlabs(S.ATM, IM, JM, KM, p, nslabs, devices=[local_rank] * nslabs)
+        for r, e in enumerate(sm.e):
+            f, g = slab_fields(S, S.ATM, sm.cols[r], 1234 + r, p)
+            e.upload_all(f, g)
+        engines, own = list(sm.e), sm.owned[0][1]
+        mode = "%d slabs as handles of one process on one GPU, exchange by the library (second stream, events, device-to-device copies)" % nslabs
+    del f, g
+
+    def sync():
+        for e in engines:
+            e.sync()
+
+    for s in range(warmup + warmup % 2):
         slab_step(sm, s)
-    sm.e.sync()
-    sm.e.profile_rk(True)
-    barrier()
-    t0 = time.perf_counter()
-    for s in range(args.steps):
-        slab_step(sm, s)
-    sm.e.sync()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    rk_ms, rk_n = sm.e.profile_read()
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    if rank == 0:
-        own = sm.plan.owned[0][1] - sm.plan.owned[0][0]
-        slab_updates = (IM - 2) * (JM - 2) * own
-        rk_s = rk_ms / rk_n * 1e-3
-        achieved = slab_updates * ATM_BYTES_PER_UPDATE / rk_s / 1e9
+    sync()
+    engines[0].profile_rk(True)
+    times = timed_windows(lambda s: slab_step(sm, s), sync, barrier, reduce_max, steps, windows)
+    rk_ms, rk_n = engines[0].profile_read()
+    variant = engines[0].rk_variant()
+    exchanged = None
+    if world > 1:
         exchanged = sum(n for o, hd, a, b2, n in sm._transfers if o == 0) * IM * JM * 8 * 4   # four fields per pressure step
-        print(json.dumps({
-            "metric": "grid-point RK updates/s (%dx%dx%d fp64)" % (IM, JM, KM),
-            "value": UPDATES * args.steps / elapsed, "unit": "grid-point RK updates/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic fields (numpy PCG64 seed 1234+rank per slab), real 0 Ma land mask" + ("" if args.grid == "1" else " upsampled"),
-            "config": {"workload": "ONE atmosphere, 3-D hot-path iteration, %dx%dx%d split into %d phi-slabs (3 ghost columns per edge, "
-                                   "5 seam copies on the edge ranks); per pressure step every rank sends p_dynn, aux_u, aux_v, aux_w at its "
-                                   "neighbours' ghost columns" % (IM, JM, KM, world),
-                       "grid": [IM, JM, KM], "updates_per_step": UPDATES, "parallelism": "phi-slabs x%d" % world,
-                       "backend": args.backend, "exchange_bytes_per_pressure_step_rank0": exchanged},
-            "roofline": {"bound": "hbm", "kernel": "k_atm_rk3d_ws (rank 0's slab of %d owned columns)" % own, "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "bytes_per_update": ATM_BYTES_PER_UPDATE, "kernel_ms": rk_s * 1e3, "launches": rk_n,
-                         "rk_variant": sm.e.rk_variant()},
-            "cpu_baseline": None}))
-    sm.e.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if local is not None:
+        local.close()
+    else:
+        for e in engines:
+            e.close()
+    if rank != 0:
+        return None
+    units = (IM - 2) * (JM - 2) * (own if alone else KM - 2) * steps
+    med, stats = window_stats(times, units)
+    slab_updates = (IM - 2) * (JM - 2) * own
+    rk_s = rk_ms / rk_n * 1e-3
+    achieved = slab_updates * ATM_BYTES_PER_UPDATE / rk_s / 1e9
+    return {"value": units / med, "ms_per_step": 1e3 * med / steps, "windows": stats, "slabs": nslabs, "mode": mode, "alone": alone,
+            "grid": [IM, JM, KM], "owned_columns_slab0": own, "exchange_bytes_per_pressure_step_rank0": exchanged,
+            "roofline": {"bound": "hbm", "kernel": "%s (slab 0: %d owned columns)" % (SWEEP_KERNEL.get(variant, "?"), own),
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "bytes_per_update": ATM_BYTES_PER_UPDATE, "kernel_ms": rk_s * 1e3, "launches": rk_n,
+                         "rk_variant": variant}}
 
 
 def main():
@@ -198,17 +255,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--windows", type=int, default=5, help="how many times the timed region of --steps steps is repeated (median reported)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo to rehearse "
                                                       "several ranks on one GPU)")
     ap.add_argument("--grid", default="1", choices=sorted(GRIDS), help="horizontal resolution in degrees (default 1: the metric's grid)")
     ap.add_argument("--mode", default="slices", choices=["slices", "slabs"],
-                    help="slices (default): every GPU its own time slice, weak scaling; slabs: ONE model split into phi-slabs over "
-                         "the GPUs with halo exchange around the pressure step, strong scaling (meant for --grid 0.25)")
+                    help="slices (default): every GPU its own time slice, weak scaling; slabs: ONE model split into phi-slabs "
+                         "with halo exchange around the pressure step, strong scaling (meant for --grid 0.25 and 0.1)")
+    ap.add_argument("--slabs", type=int, default=2, help="--mode slabs in one process: how many slabs (handles) share this GPU")
+    ap.add_argument("--slab-of", type=int, default=0, help="--mode slabs in one process: run slab 0 of a split this many ways, alone "
+                                                           "(the grids that do not fit one GPU)")
+    ap.add_argument("--no-slabs", action="store_true", help="N > 1: skip the 0.25-degree slab measurement behind the slices")
     args = ap.parse_args()
-    global IM, JM, KM, UPDATES
-    IM, JM, KM = GRIDS[args.grid]
-    UPDATES = (IM - 2) * (JM - 2) * (KM - 2)
+    set_grid(args.grid)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -220,7 +280,7 @@ def main():
 
     import torch
     import atom_amd
-    import harness as H
+    from atom_amd import synthetic as S
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (there is no CPU fallback for the product path)")
@@ -241,28 +301,53 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def reduce_max(seconds):
+        if dist is None:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def finish():
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+
     if args.mode == "slabs":
-        run_slabs(args, H, atom_amd, torch, dist, rank, world, local_rank, barrier)
+        if args.grid == "0.1" and world == 1 and args.slab_of < 2:
+            sys.exit("the 0.1-degree grid (4.2 GB a field) does not fit one GPU: --slab-of W runs one slab of a W-way split")
+        rec = measure_slabs(args, S, atom_amd, dist, rank, world, local_rank, barrier, reduce_max, args.steps, args.warmup, args.windows)
+        if rank == 0:
+            alone = rec["alone"]
+            print(json.dumps({
+                "metric": "grid-point RK updates/s (%dx%dx%d fp64)" % (IM, JM, KM),
+                "value": rec["value"], "unit": "grid-point RK updates/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": rec["ms_per_step"], "windows": rec["windows"],
+                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+                "data": "synthetic fields (numpy PCG64 seed 1234+slab per slab), real 0 Ma land mask" + ("" if args.grid == "1" else " upsampled"),
+                "config": {"workload": ("ONE slab of an atmosphere" if alone else "ONE atmosphere") + ", 3-D hot-path iteration, %dx%dx%d split into %d "
+                                       "phi-slabs (3 ghost columns per edge, 5 seam copies on the edge slabs); per pressure step every slab receives "
+                                       "p_dynn, aux_u, aux_v, aux_w at its ghost columns; %s" % (IM, JM, KM, rec["slabs"], rec["mode"])
+                                       + ("; value counts the slab's own updates" if alone else ""),
+                           "grid": [IM, JM, KM], "updates_per_step": UPDATES, "parallelism": "phi-slabs x%d" % rec["slabs"],
+                           "backend": args.backend if world > 1 else "in-process", "owned_columns_slab0": rec["owned_columns_slab0"],
+                           "exchange_bytes_per_pressure_step_rank0": rec["exchange_bytes_per_pressure_step_rank0"]},
+                "roofline": rec["roofline"], "cpu_baseline": None}))
+        finish()
         return
-    atm, p, f, g = make_model(H, atom_amd, H.ATM, local_rank, 1234 + rank)
 
-    for s in range(args.warmup):
+    atm, p, f, g = make_model(S, atom_amd, S.ATM, local_rank, 1234 + rank)
+    for s in range(args.warmup + args.warmup % 2):
         dev_step(atm, ATM_DEV_STEP, s, "atm_pressure3d")
     atm.sync()
-
     atm.profile_rk(True)
-    barrier()
-    t0 = time.perf_counter()
-    for s in range(args.steps):
-        dev_step(atm, ATM_DEV_STEP, s, "atm_pressure3d")
-    atm.sync()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    times = timed_windows(lambda s: dev_step(atm, ATM_DEV_STEP, s, "atm_pressure3d"), atm.sync, barrier, reduce_max, args.steps, args.windows)
     rk_ms, rk_n = atm.profile_read()
     atm.profile_rk(False)
     variant = atm.rk_variant()
+    elapsed, stats = window_stats(times, UPDATES * args.steps * world)
 
-    # outside the timed region: the sweep with the kernel that prepares its inputs in one bracket, and the exact form
+    # outside the timed region: the sweep with the kernel that prepares its inputs in one bracket, and the other forms
     # (operator by operator, so that the bracket of the operator holds atomdev_atm_rk3d and nothing else)
     def sweep_ms(profile_mode, rk_variant, steps=40):
         atm.set_rk_variant(rk_variant)
@@ -278,16 +363,12 @@ def main():
 
     operator_ms = sweep_ms(2, variant) if rank == 0 else None
     exact_ms = sweep_ms(1, 0) if rank == 0 else None
-
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    pipelined_ms = sweep_ms(1, 3) if rank == 0 else None
 
     # hydrosphere sweep, reported beside the headline (not part of `value`)
     hyd_info = None
     if rank == 0:
-        hyd, _, _, _ = make_model(H, atom_amd, H.HYD, local_rank, 4321)
+        hyd, _, _, _ = make_model(S, atom_amd, S.HYD, local_rank, 4321)
         for s in range(3):
             dev_step(hyd, HYD_STEP, s, "hyd_pressure3d")
         hyd.profile_rk(True)
@@ -320,6 +401,7 @@ def main():
                     "rk_sweep_ms_tolerance_form": hms2 / hn2,
                     "rk_hbm_frac_tolerance_form": UPDATES * HYD_BYTES_PER_UPDATE / (hms2 / hn2 * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
+    out = None
     if rank == 0:
         rk_avg_s = rk_ms / rk_n * 1e-3
         achieved = UPDATES * ATM_BYTES_PER_UPDATE / rk_avg_s / 1e9
@@ -345,14 +427,15 @@ def main():
             "value": UPDATES * args.steps * world / elapsed,
             "unit": "grid-point RK updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_step": 1e3 * elapsed / args.steps, "windows": stats,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic fields (numpy PCG64 seed 1234+rank), real 0 Ma land mask",
             "config": {"workload": "atmosphere 3-D hot-path iteration (BC fills - one call -, limiter, solid ground, fused RK4+RHS sweep, "
                                    "limiter - the four as one call: first limiter in the sweep's preparing kernel, last one in its stores -, "
-                                   "old->new copy; pressure Jacobi every 2nd step), %dx%dx%d, one slice per GPU" % (IM, JM, KM),
+                                   "old->new copy; pressure Jacobi every 2nd step), %dx%dx%d, one slice per GPU; sweep in its %s "
+                                   "(rk_variant %d: every field within 1e-10 of the reference)" % (IM, JM, KM, SWEEP_FORM.get(variant, "?"), variant),
                        "grid": [IM, JM, KM], "updates_per_step_per_gpu": UPDATES, "parallelism": "independent slices"},
-            "roofline": {"bound": "hbm", "kernel": ("k_atm_rk3d_wsf<true>" if variant == 2 else "k_atm_rk3d_ws<true>") if variant != 1 else "k_atm_rk3d",
+            "roofline": {"bound": "hbm", "kernel": SWEEP_KERNEL.get(variant, "?"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": "profiles/pmc_atm_rk3d.json (offline PMC pass, not measured in this run)",
@@ -361,18 +444,31 @@ def main():
                          "operator_ms": operator_ms,    # the sweep and the kernel that prepares its pressure-height term
                          "frac_operator": UPDATES * ATM_BYTES_PER_UPDATE / (operator_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "exact_form_kernel_ms": exact_ms,
+                         "pipelined_form_kernel_ms": pipelined_ms,
+                         # what a kernel that only moves the sweep's bytes in the sweep's pattern reaches (profiles/r03_stream_pattern.txt)
+                         "pattern_bound_note": "35 row-strided streams read and written together by 234 workgroups reach 3.75 TB/s = 0.47 of "
+                                               "peak whatever the kernel does between load and store (tools/ubench/stream_pattern.hip; offline measurement)",
                          "fp64_issue": issue},
             "hydrosphere": hyd_info,
         }
-        if not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(H, p, f, g)
-        else:
-            out["cpu_baseline"] = None
-        print(json.dumps(out))
     atm.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+
+    # N > 1: the strong-scaling figure of the same run - one 0.25-degree atmosphere split into N phi-slabs
+    if world > 1 and not args.no_slabs:
+        rec = None
+        try:
+            set_grid("0.25")
+            rec = measure_slabs(args, S, atom_amd, dist, rank, world, local_rank, barrier, reduce_max, steps=20, warmup=4, windows=3)
+        except Exception as exc:   # the slices' line must not be lost to a failure here
+            rec = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        set_grid(args.grid)
+        if rank == 0:
+            out["slabs_0p25"] = rec
+
+    if rank == 0:
+        out["cpu_baseline"] = None if args.no_cpu else cpu_baseline(p, f, g)
+        print(json.dumps(out))
+    finish()
 
 
 if __name__ == "__main__":
