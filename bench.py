@@ -79,13 +79,23 @@ def slab_fields(S, model, columns, seed, p):
     full = (IM, JM, KM) == GRIDS["1"] and len(columns) == KM
     f["H"], g["TOPOGRAPHY"] = grid_mask(S, model, None if full else columns)
     if (IM, JM, KM) != GRIDS["1"]:
-        # the 1-degree noise at 1/256 of its amplitude: second differences as on the 1-degree grid next to the poles
-        S.shrink_noise(f, 256.)
+        # the 1-degree noise shrunk by (refinement)^4 (1/256 at 0.25 degree): second differences as on the 1-degree grid next to the poles
+        S.shrink_noise(f, ((JM - 1) / 180.) ** 4)
     return f, g
 
 
+def grid_params(atom_amd, model):
+    """The product's own defaults (param.py; no checker involved) with the steps of the current grid.  On the 0.1-degree
+    grid the time step goes with dthe^2 (1e-7): the reference's 1e-5 belongs to its 1-degree grid, and with it the
+    coastal damping term dt v / dthe^2 is beyond the four-stage scheme's stability limit there (a sweep overflows)."""
+    p = atom_amd.default_params(model, IM, JM, KM)
+    if (IM, JM, KM) == GRIDS["0.1"]:
+        p.dt = 1e-7
+    return p
+
+
 def make_model(S, atom_amd, model, device, seed):
-    p = atom_amd.default_params(model, IM, JM, KM)   # the product's own defaults (param.py), no checker involved
+    p = grid_params(atom_amd, model)
     f, g = slab_fields(S, model, np.arange(KM), seed, p)
     d = atom_amd.DeviceModel(model, IM, JM, KM, p, device=device)
     d.upload_all(f, g)
@@ -188,7 +198,7 @@ def measure_slabs(args, S, atom_amd, dist, rank, world, local_rank, barrier, red
     the library's own exchange (atomdev_slabs_*), or --slab-of W: slab 0 of a W-way split alone (what one GPU of W would
     hold and compute; nothing to exchange with).  Returns rank 0's record (None elsewhere)."""
     from atom_amd import slabs
-    p = atom_amd.default_params(S.ATM, IM, JM, KM)
+    p = grid_params(atom_amd, S.ATM)
     nslabs, alone, local = world, False, None
     if world > 1:
         sm = slabs.create_device_slab(S.ATM, IM, JM, KM, p, rank, world, dist, device=local_rank, xdev=None if args.backend == "nccl" else "cpu")
