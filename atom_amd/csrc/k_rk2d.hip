@@ -239,7 +239,7 @@ struct Chain {
 };
 constexpr unsigned long long BND_EMPTY = 0xFFF4A70DA70DA70Dull;  // "not written yet" (a NaN no arithmetic produces)
 
-struct BatchItem { Rk2dArgs a; Chain c; DevConst K; };
+struct BatchItem { Rk2dArgs a; Chain c; DevConst K; int* err; };   // err: the item's own handle's failure word
 
 __global__ __launch_bounds__(256) void k_rk2d_prepare(Rk2dArgs a, Chain c, DevConst K, int groups,
                                                       const BatchItem* __restrict__ items) {
@@ -328,7 +328,7 @@ struct Packet { pair_t e[PK]; };
 // where adding a negated value is the subtraction the reference writes, bit for bit.
 __global__ __launch_bounds__(64) void k_rk2d_chain(Rk2dArgs a, Chain c, DevConst K, const BatchItem* __restrict__ items,
                                                    int* __restrict__ err) {
-    if (items) { a = items[blockIdx.y].a; c = items[blockIdx.y].c; K = items[blockIdx.y].K; }
+    if (items) { a = items[blockIdx.y].a; c = items[blockIdx.y].c; K = items[blockIdx.y].K; err = items[blockIdx.y].err; }
     const int jm = K.jm, km = K.km;
     const int g = blockIdx.x, lane = threadIdx.x, r = lane >> 1, x = lane & 1;
     const int j0 = 1 + g * CH_ROWS, j = j0 + r;
@@ -504,8 +504,10 @@ extern "C" int atomdev_rk2d_batch(atomdev_t* const* handles, int n) {
     }
     ATOMDEV_TRY(hipSetDevice(h0->device));
     std::vector<BatchItem> items(n);
-    for (int m = 0; m < n; m++)
+    for (int m = 0; m < n; m++) {
         if (int rc = rk2d_item(handles[m], items[m])) return rc;
+        items[m].err = (int*)atomdev_kernel_error_word(handles[m]);   // a give-up is reported on the model it happened in
+    }
     const size_t bytes = (size_t)n * sizeof(BatchItem);
     if (h0->batch_bytes < bytes) {
         ATOMDEV_TRY(hipStreamSynchronize(h0->stream));

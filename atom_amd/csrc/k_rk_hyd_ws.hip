@@ -123,6 +123,9 @@ __device__ __forceinline__ int ld_progress(const int* progress) {
 // memory system has acknowledged them (vmcnt(0), issued by the caller), then the progress word.  Consumer: the progress
 // word, then sc1 loads of the rows.  The hardware issues a wave's memory instructions in program order; the two
 // compiler barriers keep the compiler from moving an access across the word, which relaxed atomics alone would allow.
+// (Release / acquire orderings at agent scope would be the portable spelling; on gfx950 they lower to a write-back of
+// the whole L2 (buffer_wbl2) and an invalidate of the L1 (buffer_inv) per hand-off, microseconds each, where the rows
+// handed over here are a few hundred bytes that bypass both caches already: every store and load of them carries sc1.)
 __device__ __forceinline__ void announce_rows(int* progress, int rows, int lane) {
     asm volatile("" ::: "memory");
     if (lane == 0) __hip_atomic_store(progress, rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
