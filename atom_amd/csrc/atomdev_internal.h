@@ -64,7 +64,8 @@ struct atomdev {
     double* xfer;                   // six surface planes of the atmosphere -> hydrosphere transfer (lazy)
     void* surf;                     // skewed copy of the surface fields for the 2-D sweep (lazy)
     void* ws_params;                // device copy of the wave-specialised sweep's argument block(s) (lazy)
-    void* pipe_params = nullptr;    // device copy of the pipelined atmosphere sweep's argument block (lazy)
+    void* pipe_params = nullptr;    // device copy of the pipelined sweep's argument block(s) (lazy)
+    const double* pipe_cur0 = nullptr;  // hyd: f[T] at the time the pipelined sweep's blocks were built
     const double* ws_cur0;          // hyd: f[T] at the time the blocks were built (tells the buffer orientation)
     void* static_scratch;           // this GPU's copy of the library's static scratch array (k_accuracy.hip)
     size_t static_scratch_bytes;
@@ -73,7 +74,7 @@ struct atomdev {
     void* stage;                    // device staging buffer of atomdev_pack_columns / _unpack_columns for host buffers (lazy)
     size_t stage_bytes;
     int rk_variant;                 // 0: wave-specialised sweep, 1: one thread per theta line, 2: 0 in its tolerance form,
-                                    // 3 (atmosphere): the pipelined sweep (tolerance form; k_rk_atm_pipe.hip)
+                                    // 3: the pipelined sweep (tolerance form; k_rk_atm_pipe.hip, k_rk_hyd_pipe.hip)
     int profile_rk;                 // bracket the RK sweeps with events: 1 the sweep kernel alone, 2 with the kernels that prepare it
     bool defer_files = false;         // inside a one-call slice: text files are finished by threads of their own
     std::vector<std::future<std::string>> pending_files;  // their error texts (empty: written)
@@ -106,6 +107,7 @@ int atomdev_atm_rk3d_pipe_launch(atomdev* h, bool limit);                 // k_r
 int atomdev_atm_limit_rest(atomdev* h);  // k_pointwise.hip: the limiter where the sweep does not store, and p_dyn on land
 int atomdev_hyd_rk3d_ws(atomdev* h);    // k_rk_hyd_ws.hip
 int atomdev_hyd_rk3d_ws_fast(atomdev* h);  // k_rk_hyd_ws.hip compiled with -DATOMDEV_RK_FAST
+int atomdev_hyd_rk3d_pipe(atomdev* h);     // k_rk_hyd_pipe.hip
 
 #define ATOMDEV_TRY(expr)                                   \
     do {                                                    \

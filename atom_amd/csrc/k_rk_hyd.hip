@@ -222,6 +222,7 @@ extern "C" int atomdev_hyd_rk3d(atomdev_t* h) {
     ATOMDEV_REQUIRE(h && h->model == ATOMDEV_HYD, "atomdev_hyd_rk3d: not a hydrosphere handle");
     ATOMDEV_TRY(hipSetDevice(h->device));
     if (int rc = atomdev_refresh_flags(h)) return rc;
+    if (h->rk_variant == 3) return atomdev_hyd_rk3d_pipe(h);
     if (h->rk_variant == 2) return atomdev_hyd_rk3d_ws_fast(h);
     if (h->rk_variant == 0) return atomdev_hyd_rk3d_ws(h);
     static const int X[5] = { ATOMDEV_T, ATOMDEV_U, ATOMDEV_V, ATOMDEV_W, ATOMDEV_C };

@@ -433,8 +433,11 @@ void cHydrosphereModel::RunTimeSlice(int Ma) {
     P.dt = 0.00001; P.dr = 0.025; P.dthe = 1. / pi180; P.dphi = 1. / pi180; P.r0 = 1.; P.the0 = 0.; P.phi0 = 0.;
     P.re = re; P.pr = pr; P.g = g; P.Buoyancy = Buoyancy; P.u_0 = u_0; P.t_0 = t_0; P.c_0 = c_0;
     P.sc = sc; P.L_hyd = L_hyd; P.r_0_water = r_0_water; P.ta = ta; P.pa = pa; P.ca = ca; P.p_0 = p_0;
-    if (!m_handle) check(atomdev_create(ATOMDEV_HYD, im, jm, km, &P, -1, &m_handle), "atomdev_create");
-    else check(atomdev_set_params(m_handle, &P), "atomdev_set_params");
+    if (!m_handle) {
+        check(atomdev_create(ATOMDEV_HYD, im, jm, km, &P, -1, &m_handle), "atomdev_create");
+        // the models' files are the reference's bytes unless the caller asks for a faster form of the sweep
+        if (!getenv("ATOMDEV_RK_VARIANT")) check(atomdev_set_rk_variant(m_handle, 0), "atomdev_set_rk_variant");
+    } else check(atomdev_set_params(m_handle, &P), "atomdev_set_params");
     atomdev_t* h = m_handle;
 
     // reset_arrays (:636-694): t and c at ta and ca, the velocities at ua, va, wa, the pressures at pa, the rest 0

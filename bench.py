@@ -374,6 +374,7 @@ def main():
     operator_ms = sweep_ms(2, variant) if rank == 0 else None
     exact_ms = sweep_ms(1, 0) if rank == 0 else None
     pipelined_ms = sweep_ms(1, 3) if rank == 0 else None
+    tolerance_ms = sweep_ms(1, 2) if rank == 0 else None
 
     # hydrosphere sweep, reported beside the headline (not part of `value`)
     hyd_info = None
@@ -390,14 +391,20 @@ def main():
         hyd.sync()
         th = time.perf_counter() - th
         hms, hn = hyd.profile_read()
-        # the same sweep in its tolerance form (ATOMDEV_RK_VARIANT=2; the hydrosphere's default is the exact form)
-        hyd.set_rk_variant(2)
-        for s in range(3):
-            dev_step(hyd, HYD_STEP, s, "hyd_pressure3d")
-        hyd.profile_read()
-        for s in range(40):
-            dev_step(hyd, HYD_STEP, s, "hyd_pressure3d")
-        hms2, hn2 = hyd.profile_read()
+        hyd_variant = hyd.rk_variant()
+        # the same sweep in its other forms: 0 exact (the reference's bits), 2 wave-specialised tolerance form, 3 pipelined
+        other = {}
+        for v in (0, 2, 3):
+            if v == hyd_variant:
+                other[v] = (hms, hn)
+                continue
+            hyd.set_rk_variant(v)
+            for s in range(4):
+                dev_step(hyd, HYD_STEP, s, "hyd_pressure3d")
+            hyd.profile_read()
+            for s in range(40):
+                dev_step(hyd, HYD_STEP, s, "hyd_pressure3d")
+            other[v] = hyd.profile_read()
         hyd.close()
         hyd_traffic = None
         try:
@@ -406,10 +413,13 @@ def main():
             pass
         hyd_info = {"updates_per_s": UPDATES * nh / th, "ms_per_step": 1e3 * th / nh, "rk_traffic": hyd_traffic,
                     "rk_traffic_source": "profiles/pmc_hyd_rk3d.json (offline PMC pass, not measured in this run)",
+                    "rk_variant": hyd_variant, "rk_form": SWEEP_FORM.get(hyd_variant, "?"),
                     "rk_sweep_ms": hms / hn,
-                    "rk_hbm_frac": UPDATES * HYD_BYTES_PER_UPDATE / (hms / hn * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    "rk_sweep_ms_tolerance_form": hms2 / hn2,
-                    "rk_hbm_frac_tolerance_form": UPDATES * HYD_BYTES_PER_UPDATE / (hms2 / hn2 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                    "rk_hbm_frac": UPDATES * HYD_BYTES_PER_UPDATE / (hms / hn * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        for v, tag in ((0, "exact_form"), (2, "tolerance_form"), (3, "pipelined_form")):
+            ms, n = other[v]
+            hyd_info["rk_sweep_ms_" + tag] = ms / n
+            hyd_info["rk_hbm_frac_" + tag] = UPDATES * HYD_BYTES_PER_UPDATE / (ms / n * 1e-3) / 1e9 / HBM_PEAK_GBS
 
     out = None
     if rank == 0:
@@ -455,6 +465,7 @@ def main():
                          "frac_operator": UPDATES * ATM_BYTES_PER_UPDATE / (operator_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "exact_form_kernel_ms": exact_ms,
                          "pipelined_form_kernel_ms": pipelined_ms,
+                         "wave_specialised_tolerance_form_kernel_ms": tolerance_ms,
                          # what a kernel that only moves the sweep's bytes in the sweep's pattern reaches (profiles/r03_stream_pattern.txt)
                          "pattern_bound_note": "35 row-strided streams read and written together by 234 workgroups reach 3.75 TB/s = 0.47 of "
                                                "peak whatever the kernel does between load and store (tools/ubench/stream_pattern.hip; offline measurement)",

@@ -15,7 +15,7 @@
  *  - the temperature curve is read when it is first needed, from temperature_curve_file as the configuration left it (the
  *    reference reads it in the constructor, before LoadConfig can change the path);
  *  - errors are std::runtime_error exceptions with the library's message, where the reference prints and aborts;
- *  - the atmosphere's 3-D sweep runs in its exact form here (every quotient with the bits of the reference's division,
+ *  - the 3-D sweeps of both models run in their exact form here (every quotient with the bits of the reference's division,
  *    so that the output files carry the reference's bytes); the faster tolerance forms are chosen with the environment
  *    variable ATOMDEV_RK_VARIANT (2 or 3) or atomdev_set_rk_variant on device_handle(): every field within 1e-10,
  *    single numbers of the text files may then differ in their last printed digit.

@@ -598,10 +598,18 @@ int atomdev_timer_stop(atomdev_t* h, float* milliseconds);
  * one multiplication by its reciprocal and products feeding sums are fused - which costs up
  * to one unit in the last place per operation (measured on the 1-degree grid: every field
  * of a sweep within 3e-14 of variant 0, a whole time slice with the column physics as far from
- * the reference as with variant 0) and about a fifth less time.  Initial value: 2 for an
- * atmosphere handle (its sweep calls pow() per point and is held to a tolerance in any form),
- * 0 for a hydrosphere handle (bit-exact against the reference); the environment variable
- * ATOMDEV_RK_VARIANT overrides both.  atomdev_get_rk_variant returns the current value. */
+ * the reference as with variant 0) and about a fifth less time.  3: the pipelined sweep -
+ * the arithmetic of 2 restated as affine recurrences along the theta line, two waves of a
+ * workgroup carrying the recurrences through LDS while eight others do all loads, stores and
+ * per-row coefficients rows ahead (within 1e-12 of variant 0 per sweep; the 1-degree
+ * hydrosphere time slice ends 1.5e-13 from the reference; the atmosphere's, whose column
+ * physics amplifies last-place differences, 4e-10 in c, against 2e-11 with variant 2).
+ * Initial value: 3 for a hydrosphere handle, 2 for an atmosphere handle (the stated bound is
+ * 1e-10 per field after a time slice with identical iteration counts); the hydrosphere's
+ * variants 0 and 1 carry the reference's bits, and the models' outer interfaces
+ * (atom_models.hpp, atomdev_mirror.hpp) select 0 so that their results and files carry the
+ * reference's bits and bytes.  The environment variable ATOMDEV_RK_VARIANT overrides the initial
+ * value and the outer interface's choice.  atomdev_get_rk_variant returns the current value. */
 int atomdev_set_rk_variant(atomdev_t* h, int variant);
 int atomdev_get_rk_variant(const atomdev_t* h);
 

@@ -57,6 +57,9 @@ public:
     atomdev_t* handle() {
         if (!h_) {
             if (atomdev_create(model_, im_, jm_, km_, &params(), -1, &h_)) die("atomdev_create");
+            // drop-in classes: the sweeps in their exact form (the hydrosphere's results carry the reference's bits)
+            // unless the caller asks for a faster one
+            if (!std::getenv("ATOMDEV_RK_VARIANT") && atomdev_set_rk_variant(h_, 0)) die("atomdev_set_rk_variant");
             stage_.resize((size_t)im_ * jm_ * km_);
             std::memcpy(&sent_, &p_, sizeof(p_));
         } else if (std::memcmp(&sent_, &p_, sizeof(p_)) != 0) {

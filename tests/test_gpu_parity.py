@@ -21,7 +21,10 @@ TOL = 1e-10
 GOLD = os.path.join(H.ROOT, "tests", "golden")
 
 
-def _pair(model, dims, seed, mask, real_mask=False):
+def _pair(model, dims, seed, mask, real_mask=False, variant=None):
+    """Oracle and device model on the same inputs.  variant: the form of the device's 3-D sweep; None is the handle's
+    default for the atmosphere and the exact form for the hydrosphere, whose comparisons here are bit for bit;
+    "default" leaves the hydrosphere on its default (the pipelined tolerance form) as well."""
     im, jm, km = dims
     p = H.default_params(model, im, jm, km)
     f, g = H.make_inputs(model, im, jm, km, seed, mask, p)
@@ -33,6 +36,10 @@ def _pair(model, dims, seed, mask, real_mask=False):
     dp = atom_amd.Params.from_buffer_copy(bytes(p))
     d = atom_amd.DeviceModel(model, im, jm, km, dp)
     d.upload_all(f, g)
+    if variant is None and model == H.HYD:
+        variant = 0
+    if variant not in (None, "default"):
+        d.set_rk_variant(variant)
     return o, d, names
 
 
@@ -702,18 +709,19 @@ def test_golden_small_atm():
 
 @pytest.mark.parametrize("model,tag,op,variant", [(H.ATM, "atm", "atm_rk3d", None), (H.ATM, "atm", "atm_rk3d", 2),
                                                   (H.ATM, "atm", "atm_rk3d", 3), (H.ATM, "atm", "atm_rk3d", 0),
-                                                  (H.HYD, "hyd", "hyd_rk3d", None)])
+                                                  (H.HYD, "hyd", "hyd_rk3d", None), (H.HYD, "hyd", "hyd_rk3d", 0),
+                                                  (H.HYD, "hyd", "hyd_rk3d", 2), (H.HYD, "hyd", "hyd_rk3d", 3)])
 def test_full_1deg_real_mask_rk3d(model, tag, op, variant):
     """One sweep on 41x181x361 with the real 0 Ma land mask, against the oracle
     (whole fields) and against the planes the compiled reference left in the goldens; the atmosphere in its
-    default form and in each of the wave-specialised (0), tolerance (2) and pipelined (3) forms."""
-    o, d, names = _pair(model, (41, 181, 361), 1234, "allfluid", real_mask=True)
-    if variant is not None:
-        d.set_rk_variant(variant)
+    default form and in each of the wave-specialised (0), tolerance (2) and pipelined (3) forms; the hydrosphere in its
+    default form (the pipelined one) and in its tolerance form within the tolerance, in its exact form bit for bit."""
+    o, d, names = _pair(model, (41, 181, 361), 1234, "allfluid", real_mask=True, variant="default" if variant is None else variant)
+    assert d.rk_variant() == ((2 if model == H.ATM else 3) if variant is None else variant) or "ATOMDEV_RK_VARIANT" in os.environ
     z = np.load(os.path.join(GOLD, "full_1deg_%s_rk3d.npz" % tag))
     o.op(op)
     d.op(op)
-    exact = model == H.HYD
+    exact = model == H.HYD and variant == 0
     nbits = 0
     for k in names:
         if k == "RESIDUUM":
@@ -801,7 +809,7 @@ def test_rk_variants_same_bits(model, op, dims, seed):
     swaps its buffer pair in between).  Variant 2 is variant 0 in its tolerance form (reciprocal
     multiplications, fused multiply-adds): every field within 1e-12 of it."""
     out = []
-    variants = (0, 1, 2, 3) if model == H.ATM else (0, 1, 2)   # 3: the atmosphere's pipelined sweep (tolerance form)
+    variants = (0, 1, 2, 3)   # 3: the pipelined sweep (tolerance form)
     for variant in variants:
         o, d, names = _pair(model, dims, seed, "blobs")
         o.close()

@@ -59,6 +59,7 @@ def test_hyd_loop_device_bitexact(dims, seed):
     o = H.CpuModel("oracle", H.HYD, *dims, p, f, g)
     d = atom_amd.DeviceModel(H.HYD, *dims, atom_amd.Params.from_buffer_copy(bytes(p)))
     d.upload_all(f, g)
+    d.set_rk_variant(0)   # the exact form of the sweep
     _same_queries(H.hyd_3d_loop(d, run_data=True), H.hyd_3d_loop(o, run_data=True), exact=True)
     for k in H.HYD_FIELDS:
         if k != "RESIDUUM":
@@ -210,13 +211,14 @@ def test_hyd_time_slice_device(tmp_path):
 
 @pytest.mark.gpu
 def test_hyd_time_slice_device_bitexact_after_ekman(tmp_path):
-    """The same slice with the Ekman step's v and w taken from the oracle (the only operator whose bits may differ):
+    """The same slice with the sweep in its exact form and the Ekman step's v and w taken from the oracle (the only operator whose bits may differ):
     every field of the surface loop and of the volume loop must then carry the oracle's bits - level im-2 of the volume
     sweep included, which takes its salinity rows from another workgroup's stores while both are running."""
     dims, p, f, g, bath, salt = _hyd_slice_inputs(tmp_path, 185, 82)
     o = H.CpuModel("oracle", H.HYD, *dims, p, f, g)
     d = atom_amd.DeviceModel(H.HYD, *dims, atom_amd.Params.from_buffer_copy(bytes(p)))
     d.upload_all(f, g)
+    d.set_rk_variant(0)   # the exact form of the sweep
     st = H.hyd_start(dims[0])
     H.hyd_start_of_slice(o, st, bath, salt)
     H.hyd_start_of_slice(d, atom_amd.HydStart.from_buffer_copy(bytes(st)), bath, salt)

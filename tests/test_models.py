@@ -234,6 +234,7 @@ def test_models_through_pyatom(tmp_path, monkeypatch):
     mean = m.atmosphere.calculate_mean_temperature()
     assert abs(mean - m.atmosphere.mean_temperature_from_curve(0)) < 0.05, mean
     m.run_hyd(0, str(output), str(cfg))
+    assert m.hydrosphere.device_rk_variant() == 0
     _check_hyd_files(str(output), set(got))
     # a second slice in the same objects: the time list now has a previous slice
     m.atmosphere.run_time_slice(40)

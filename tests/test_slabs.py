@@ -27,6 +27,8 @@ HYD_OPS = ["hyd_bc_radius", "hyd_bc_theta", "hyd_bc_phi", "hyd_value_limitation"
 
 def _launch(world, engine, model, dims, seed, mask, ops, out, port, timeout=600):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), OMP_NUM_THREADS="1")
+    if model == "hyd":   # the slabs must reproduce the single domain bit for bit: the hydrosphere's sweep in its exact form
+        env["ATOMDEV_RK_VARIANT"] = "0"
     procs = []
     for r in range(world):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
@@ -297,6 +299,8 @@ def test_slab_loop_device_resident_exchange(model, dims, seed):
             torch.cuda.set_device(0)
             sm = slabs.create_device_slab(m, im, jm, km, atom_amd.Params.from_buffer_copy(bytes(p)), rank, 2, _ThreadDist(shared, rank), device=-1)
             assert sm.xdev == "cuda:0"
+            if model == "hyd":
+                sm.e.set_rk_variant(0)   # the exact form: the comparison below is bit for bit
             sm.distribute(full if rank == 0 else None, list(f), list(g))
             log = sm.run_3d_loop(2, 2, queries=True)
             results[rank] = (sm.collect([k for k in f if k not in ("H", "RESIDUUM")]), log)
@@ -344,6 +348,9 @@ def test_slab_group_in_one_process(world, model, dims, seed):
     for r in range(world):   # the library's layout is the plan of atom_amd/slabs.py
         assert list(ls.cols[r]) == list(plan.columns(r)) and ls.owned[r] == plan.owned_local(r)
     ls.upload_all(f, g)
+    if model == "hyd":
+        for e in ls.e:
+            e.set_rk_variant(0)   # the exact form: the comparison below is bit for bit
     got_log = ls.run_3d_loop(2, 2, queries=True)
     o, log = _single_domain_loop(model, dims, seed)
     for k in f:
