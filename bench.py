@@ -408,7 +408,8 @@ def main():
         hyd.close()
         hyd_traffic = None
         try:
-            hyd_traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_hyd_rk3d.json"))).get("hbm_bytes_per_launch") if args.grid == "1" else None
+            rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_hyd_rk3d.json")))   # (of the pipelined form's kernel)
+            hyd_traffic = rec.get("hbm_bytes_per_launch") if args.grid == "1" and hyd_variant == 3 and "pipe" in rec.get("kernel", "") else None
         except Exception:
             pass
         hyd_info = {"updates_per_s": UPDATES * nh / th, "ms_per_step": 1e3 * th / nh, "rk_traffic": hyd_traffic,
