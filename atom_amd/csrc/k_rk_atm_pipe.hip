@@ -43,8 +43,8 @@ struct PipeArgs {
     const double *S_v, *S_c, *S_i, *S_r, *S_s;
     double *aux_u, *aux_v, *aux_w, *buoy;
     const uint8_t* flags;
-    const double *evap, *precip, *c3;          // 2-D
-    const double *ph100, *h0i;                 // 3-D, from the preparing kernel of k_rk_atm_ws.hip
+    const double *evap, *precip, *c3, *topo;   // 2-D
+    const double* ph100;                       // 3-D, from the preparing kernel of k_rk_atm_ws.hip (level 1 is read)
     const double *rad, *costhe, *tab_irm2sin, *tab_coefv;
 };
 struct PipeParams {
@@ -187,6 +187,9 @@ __device__ __forceinline__ void memory_wave(const PipeArgs& a, const DevConst& K
     const double i_rm = 1. / rm, i_rm2 = 1. / (rm * rm);
     const double ce = K.coeff_energy, ctr = K.coeff_trans;
     const double i_phk = 1. / (K.R_Air * K.t_0);
+    const double hight = (double)i * K.topo_step;
+    double topo_step = K.topo_step, i_topo_step = K.i_topo_step;
+    SPIN(topo_step); SPIN(i_topo_step);
     const double evf = K.coeff_vapour * K.i_two_dr;
     double i_dthe = K.i_dthe, i_two_dthe = K.i_two_dthe, i_dthe2 = K.i_dthe2, i_dr2 = K.i_dr2, i_dphi2 = K.i_dphi2;
     double i_re = K.i_re, i_re_sc_wv = K.i_re_sc_wv, i_re_x = FORA ? K.i_re_pr : K.i_re_sc_co2, i_r_air = K.i_r_air;
@@ -197,7 +200,7 @@ __device__ __forceinline__ void memory_wave(const PipeArgs& a, const DevConst& K
     constexpr int CLS[4] = { 0, FORA ? 0 : 1, 1, 2 };   // A: v, u -> re; c -> wv; t -> pr.  B: w -> re; cloud, ice -> wv; co2
 
     // what a row's loads leave behind until the row's turn comes
-    double lx[4], lxn[4], lxp[4], lS[5], lh0i = 0., lp[4];
+    double lx[4], lxn[4], lxp[4], lS[5], ltopo = 0., lp[4];
     double lev = 0., lpr = 0., lc0 = 0., lc3 = 0., lph = 0.;
     double lcos, lirs, lcoefv = 0.;  // geometry of the row: one address for the whole wave, fetched with the rest of the row
     unsigned lfl;
@@ -210,7 +213,7 @@ __device__ __forceinline__ void memory_wave(const PipeArgs& a, const DevConst& K
 #pragma unroll
         for (int n = 0; n < 4; n++) { lx[n] = gld(a.x[VARS[n]], o); lxn[n] = gld(a.xn[VARS[n]], o); }
         lcos = gld(a.costhe + r, 0u); lirs = gld(a.tab_irm2sin + (size_t)i * jm + r, 0u);
-        lh0i = gld(a.h0i, o);
+        ltopo = gld(a.topo, o_sfc + (unsigned)r * rowB);   // (a 2-D field: stays in the L2)
         if constexpr (FORA) {
             lS[0] = gld(a.S_c, o); lS[1] = gld(a.S_r, o); lS[2] = gld(a.S_i, o); lS[3] = gld(a.S_s, o); lS[4] = gld(a.S_v, o);
             lcoefv = gld(a.tab_coefv + (size_t)i * jm + r, 0u);
@@ -292,7 +295,13 @@ __device__ __forceinline__ void memory_wave(const PipeArgs& a, const DevConst& K
             const double Pb = __builtin_fma(A2, i_rm2, A1 * g);
             const double hDr = hD * i_rm, hDg = hD * g, hEr = hE * i_rm2;
             const double G1 = __builtin_fma(f1, hEr, b1 * hDg), G2 = __builtin_fma(f2, hEr, b2 * hDg);
-            const double dmp_i = lh0i * i_dr2;
+            // h_0_i (RHS_Atm.cpp:110-124): 1 over fluid, the relative height above the ground over land
+            double h0i = 1.;
+            if (land) {
+                const double topo_diff = hight - ltopo;
+                if (!(topo_diff == topo_step)) h0i = div_by(topo_diff, topo_step, i_topo_step);
+            }
+            const double dmp_i = h0i * i_dr2;
             double KQ[4], KB[4] = { 0., 0., 0., 0. };
             if (!window) {  // b2 = f2 = 0 on these rows: the x[j-2] arrays are free for KB
                 const double H3 = b3 * hDr;
@@ -551,7 +560,9 @@ __device__ __forceinline__ void chain_b(const PipeArgs& a, const DevConst& K, Pi
 
 // Waves of the 1 024-thread workgroup: w and w + 4 (and w + 8, w + 12) share a SIMD.  Wave 0 is chain A, wave 1 chain B,
 // and the waves that would share their SIMDs end at once; the eight waves on the other two SIMDs are the memory waves:
-// rows r = q mod 4 belong to the pair (2 + 4 q, 3 + 4 q), the first working for chain A, the second for chain B.
+// rows r = q mod 4 belong to the pair (2 + 4 q, 3 + 4 q).  One wave of a pair works for chain A, the other for chain B;
+// chain A's half of a row is about twice the instructions of chain B's, so which is which alternates with q and each of
+// the two SIMDs carries two waves of either kind.
 template <bool LIMIT>
 __global__ __launch_bounds__(1024) void k_atm_rk3d_pipe(const PipeParams* __restrict__ P, int* err) {
     const PipeArgs& a = P->a;
@@ -572,15 +583,16 @@ __global__ __launch_bounds__(1024) void k_atm_rk3d_pipe(const PipeParams* __rest
     for (int n = threadIdx.x; n < 10 * 4 * 8; n += blockDim.x) (&sh.stamps[0][0][0])[n] = 0;
     __syncthreads();
 #endif
+    const bool fora = ((wave & 3) == 2) != (((wave >> 2) & 1) != 0);   // (see above: the two kinds alternate on a SIMD)
     if (wave == 0) {
         if (i == 1) chain_a<true>(a, K, sh, i, bx, err);
         else chain_a<false>(a, K, sh, i, bx, err);
     } else if (wave == 1) {
         chain_b(a, K, sh, i, bx, err);
-    } else if ((wave & 3) == 2) {
+    } else if ((wave & 3) >= 2 && fora) {
         if (i == 1) memory_wave<true, true, LIMIT>(a, K, sh, wave >> 2, i, bx, err);
         else memory_wave<false, true, LIMIT>(a, K, sh, wave >> 2, i, bx, err);
-    } else if ((wave & 3) == 3) {
+    } else if ((wave & 3) >= 2) {
         memory_wave<false, false, LIMIT>(a, K, sh, wave >> 2, i, bx, err);
     }
 #ifdef ATOMDEV_EXP_PIPE_STAMP
@@ -610,7 +622,7 @@ int atomdev_atm_rk3d_pipe_launch(atomdev* h, bool limit) {
         a.flags = h->flags;
         a.evap = h->g[ATOMDEV_EVAPORATION_DALTON]; a.precip = h->g[ATOMDEV_PRECIPITATION];
         a.c3 = h->plane;
-        a.ph100 = h->scr[0]; a.h0i = h->scr[1];
+        a.ph100 = h->scr[0]; a.topo = h->g[ATOMDEV_TOPOGRAPHY];
         a.rad = h->rad; a.costhe = h->costhe;
         a.tab_irm2sin = h->tab_irm2sin; a.tab_coefv = h->tab_coefv;
         P.K = h->k;

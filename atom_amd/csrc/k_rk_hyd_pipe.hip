@@ -581,7 +581,9 @@ __device__ void copy_shell(const PipeArgs& a, unsigned part, unsigned parts, int
 
 // Waves of the 1 024-thread workgroup: w and w + 4 (and w + 8, w + 12) share a SIMD.  Wave 0 is chain A, wave 1 chain B,
 // and the waves that would share their SIMDs end at once; the eight waves on the other two SIMDs are the memory waves:
-// rows r = q mod 4 belong to the pair (2 + 4 q, 3 + 4 q), the first working for chain A, the second for chain B.
+// rows r = q mod 4 belong to the pair (2 + 4 q, 3 + 4 q).  One wave of a pair works for chain A, the other for chain B;
+// chain A's half of a row is about twice the instructions of chain B's, so which is which alternates with q and each of
+// the two SIMDs carries two waves of either kind.
 __global__ __launch_bounds__(1024) void k_hyd_rk3d_pipe(const PipeParams* __restrict__ P, int* __restrict__ progress, int* err, int ncopy) {
     const PipeArgs& a = P->a;
     const DevConst& K = P->K;
@@ -607,17 +609,18 @@ __global__ __launch_bounds__(1024) void k_hyd_rk3d_pipe(const PipeParams* __rest
     if (threadIdx.x == 0) { sh.doneA = 0; sh.doneB = 0; }
     __syncthreads();   // the only barrier: from here on the waves follow each other's progress words
     const bool top = i == K.im - 2, feeds = i == K.im - 3;
+    const bool fora = ((wave & 3) == 2) != (((wave >> 2) & 1) != 0);   // (see above: the two kinds alternate on a SIMD)
     if (wave == 0) {
         if (top) chain_a<true>(a, K, sh, i, bx, err);
         else chain_a<false>(a, K, sh, i, bx, err);
     } else if (wave == 1) {
         if (top) chain_b<true>(a, K, sh, i, bx, err);
         else chain_b<false>(a, K, sh, i, bx, err);
-    } else if ((wave & 3) == 2) {
+    } else if ((wave & 3) >= 2 && fora) {
         if (top) memory_wave<true, false, true>(a, K, sh, wave >> 2, i, bx, progress, err);
         else if (feeds) memory_wave<false, true, true>(a, K, sh, wave >> 2, i, bx, progress, err);
         else memory_wave<false, false, true>(a, K, sh, wave >> 2, i, bx, progress, err);
-    } else if ((wave & 3) == 3) {
+    } else if ((wave & 3) >= 2) {
         if (top) memory_wave<true, false, false>(a, K, sh, wave >> 2, i, bx, progress, err);
         else memory_wave<false, false, false>(a, K, sh, wave >> 2, i, bx, progress, err);
     }
