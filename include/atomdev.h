@@ -166,8 +166,9 @@ int atomdev_atm_pressure2d(atomdev_t* h);
  * field is left in ATOMDEV_RESIDUUM. loc = {i, j, k} ({0, j, k} for 2-D). */
 int atomdev_atm_residuum3d(atomdev_t* h, double* min, int loc[3]);
 int atomdev_atm_residuum2d(atomdev_t* h, double* min, int loc[3]);
-/* atomdev_atm_residuum3d for callers that must not allocate device memory while they run (code under HIP graph
- * capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  The query's
+/* atomdev_atm_residuum3d for callers that must not allocate device memory while they run (tight serving loops,
+ * harnesses that forbid hipMalloc; the call still synchronises the handle's stream to hand its result back, so it is
+ * not itself something to record into a HIP graph).  No counterpart in the reference.  The query's
  * intermediate results (the compact residuum sequence, its per-chunk summaries, the result words) live in a
  * static array of the library's device image, 20 MiB per GPU for as long as the process lives, instead of the
  * handle's reduction buffer that atomdev_atm_residuum3d grows on demand; the result comes back through page-locked

@@ -11,15 +11,22 @@ step() {  # step <seconds> <log> <command...>
   local rc=$?
   if [ $rc -ne 0 ]; then echo "FAILED rc=$rc: $*"; tail -30 $log; exit $rc; fi
 }
-step 1150 gpurun_out/final/pytest.log python -u -m pytest tests -m gpu -x -q --timeout 900 --timeout-method thread
+# usage: tools/gpu_final.sh tests | measure   (two calls: a call on the GPU box is limited to 20 minutes)
+if [ "${1:-tests}" = tests ]; then
+step 1000 gpurun_out/final/pytest.log python -u -m pytest tests -m gpu -x -q --timeout 900 --timeout-method thread
 tail -3 gpurun_out/final/pytest.log
-step 200 gpurun_out/final/smoke.log python -u -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')"
-tail -1 gpurun_out/final/smoke.log
+step 150 gpurun_out/final/smoke.log python -u -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')"
+tail -3 gpurun_out/final/smoke.log
+echo "ALL STEPS PASSED"
+exit 0
+fi
 step 300 gpurun_out/final/bench.json python -u bench.py
 tail -1 gpurun_out/final/bench.json
 cd /tmp && export TMPDIR=/tmp
 step 300 $R/gpurun_out/final/rocprof.log rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/prof -o bench -- python3 $R/bench.py --steps 200 --warmup 20
 cd $R
+step 300 gpurun_out/final/bench_quarter_degree.json python -u bench.py --grid 0.25 --steps 40 --warmup 6 --no-cpu
+tail -c 600 gpurun_out/final/bench_quarter_degree.json
 step 400 gpurun_out/final/op_table.md python -u tools/op_table.py 20
 tail -36 gpurun_out/final/op_table.md
 step 300 gpurun_out/final/loop_time.txt python -u tools/loop_time.py 4
