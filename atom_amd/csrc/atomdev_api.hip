@@ -239,6 +239,7 @@ extern "C" int atomdev_destroy(atomdev_t* h) {
     if (h->red) (void)hipFree(h->red);
     if (h->pinned) (void)hipHostFree(h->pinned);
     if (h->stage) (void)hipFree(h->stage);
+    if (h->stage_host) (void)hipHostFree(h->stage_host);
     if (h->rad) (void)hipFree(h->rad);
     if (h->sinthe) (void)hipFree(h->sinthe);
     if (h->costhe) (void)hipFree(h->costhe);

@@ -73,6 +73,8 @@ struct atomdev {
                                     // the word kernels set on a failure they detect themselves (byte 128)
     void* stage;                    // device staging buffer of atomdev_pack_columns / _unpack_columns for host buffers (lazy)
     size_t stage_bytes;
+    void* stage_host = nullptr;     // page-locked host mirror of `stage` for the text writers' section fetches (lazy)
+    size_t stage_host_bytes = 0;
     int rk_variant;                 // 0: wave-specialised sweep, 1: one thread per theta line, 2: 0 in its tolerance form,
                                     // 3: the pipelined sweep (tolerance form; k_rk_atm_pipe.hip, k_rk_hyd_pipe.hip)
     int profile_rk;                 // bracket the RK sweeps with events: 1 the sweep kernel alone, 2 with the kernels that prepare it

@@ -5,6 +5,8 @@
 
 #include "atomdev_internal.h"
 #include "fixed4.h"
+#include <memory>
+
 #include "host_parallel.h"
 
 namespace {
@@ -109,7 +111,8 @@ int write_plot_data(atomdev* h, const char* path, bool atm) {
     ATOMDEV_TRY(hipSetDevice(h->device));
     const int jm = h->jm, km = h->km, L = atm ? 0 : h->im - 1;
     const size_t n2 = h->n2;
-    std::vector<double> s(8 * n2);
+    auto values = std::make_shared<std::vector<double>>(8 * n2);
+    std::vector<double>& s = *values;
     const int f3[5] = { ATOMDEV_H, ATOMDEV_V, ATOMDEV_W, ATOMDEV_T, ATOMDEV_C };
     const int f2a[2] = { ATOMDEV_PRECIPITATION, ATOMDEV_PRECIPITABLE_WATER };
     const int f2h[3] = { ATOMDEV_BOTTOM_WATER, ATOMDEV_UPWELLING, ATOMDEV_DOWNWELLING };
@@ -119,41 +122,47 @@ int write_plot_data(atomdev* h, const char* path, bool atm) {
     for (int n = 0; n < n2d; n++)
         ATOMDEV_TRY(hipMemcpyAsync(&s[(5 + n) * n2], h->g[atm ? f2a[n] : f2h[n]], n2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (int rc__ = atomdev_sync_stream(h)) return rc__;
-    FILE* f = std::fopen(path, "w");
-    ATOMDEV_REQUIRE(f, std::string("could not open PlotData file ") + path);
-    std::string out = atm ? "lons(deg), lats(deg), topography, v-velocity(m/s), w-velocity(m/s), velocity-mag(m/s), "
-                            "temperature(Celsius), water_vapour(g/kg), precipitation(mm), precipitable water(mm)\n"
-                          : "lons(deg), lats(deg), topography, v-velocity(m/s), w-velocity(m/s), velocity-mag(m/s), "
-                            "temperature(Celsius), salinity(psu), bottom_water(m/s), upwelling(m/s), downwelling(m/s)\n";
     const double u_0 = h->p.u_0, t_0 = h->p.t_0;
-    std::fwrite(out.data(), 1, out.size(), f);
-    // the rows of a longitude are a piece of text of their own; a few host threads make the pieces side by side
-    std::vector<std::string> piece(km);
-    host_parallel_run((size_t)km, [&](size_t kk) {
-        const int k = (int)kk;
-        std::string& o = piece[kk];
-        o.reserve((size_t)jm * 96);
-        char b[400 * 9 + 64];
-        for (int j = 0; j < jm; j++) {
-            const size_t q = (size_t)j * km + k;
-            const double v = s[n2 + q] * u_0, w = s[2 * n2 + q] * u_0;
-            const double vel_mag = std::sqrt(v * v + w * w);  // pow(x, 2) is x * x, correctly rounded either way
-            char* e = b + std::snprintf(b, 64, "%d %d ", k, 90 - j);
-            auto num = [&e](double x, const char* after) { e = put_fixed4(e, x); while (*after) *e++ = *after++; };
-            num(s[q], " "); num(v, " "); num(w, " "); num(vel_mag, " ");
-            if (atm) {
-                num(s[3 * n2 + q] * t_0 - t_0, " "); num(s[4 * n2 + q] * 1000., " "); num(s[5 * n2 + q], " "); num(s[6 * n2 + q], " \n");
-            } else {
-                num(s[3 * n2 + q] * 273.15 - 273.15, " "); num(s[4 * n2 + q] * 35., " "); num(s[5 * n2 + q], " ");
-                num(s[6 * n2 + q], "   "); num(s[7 * n2 + q], " \n");
+    const std::string file(path);
+    // The values are on the host: inside a one-call slice the text is made and written by a thread of its own while the
+    // slice goes on (the call that ends the slice waits for it).
+    return atomdev_defer_file(h, file, [values, file, atm, jm, km, n2, u_0, t_0]() -> std::string {
+        const std::vector<double>& s = *values;
+        FILE* f = std::fopen(file.c_str(), "w");
+        if (!f) return "could not open PlotData file " + file;
+        std::string out = atm ? "lons(deg), lats(deg), topography, v-velocity(m/s), w-velocity(m/s), velocity-mag(m/s), "
+                                "temperature(Celsius), water_vapour(g/kg), precipitation(mm), precipitable water(mm)\n"
+                              : "lons(deg), lats(deg), topography, v-velocity(m/s), w-velocity(m/s), velocity-mag(m/s), "
+                                "temperature(Celsius), salinity(psu), bottom_water(m/s), upwelling(m/s), downwelling(m/s)\n";
+        std::fwrite(out.data(), 1, out.size(), f);
+        // the rows of a longitude are a piece of text of their own; a few host threads make the pieces side by side
+        std::vector<std::string> piece(km);
+        host_parallel_run((size_t)km, [&](size_t kk) {
+            const int k = (int)kk;
+            std::string& o = piece[kk];
+            o.reserve((size_t)jm * 96);
+            char b[400 * 9 + 64];
+            for (int j = 0; j < jm; j++) {
+                const size_t q = (size_t)j * km + k;
+                const double v = s[n2 + q] * u_0, w = s[2 * n2 + q] * u_0;
+                const double vel_mag = std::sqrt(v * v + w * w);  // pow(x, 2) is x * x, correctly rounded either way
+                char* e = b + std::snprintf(b, 64, "%d %d ", k, 90 - j);
+                auto num = [&e](double x, const char* after) { e = put_fixed4(e, x); while (*after) *e++ = *after++; };
+                num(s[q], " "); num(v, " "); num(w, " "); num(vel_mag, " ");
+                if (atm) {
+                    num(s[3 * n2 + q] * t_0 - t_0, " "); num(s[4 * n2 + q] * 1000., " "); num(s[5 * n2 + q], " "); num(s[6 * n2 + q], " \n");
+                } else {
+                    num(s[3 * n2 + q] * 273.15 - 273.15, " "); num(s[4 * n2 + q] * 35., " "); num(s[5 * n2 + q], " ");
+                    num(s[6 * n2 + q], "   "); num(s[7 * n2 + q], " \n");
+                }
+                o.append(b, (size_t)(e - b));
             }
-            o.append(b, (size_t)(e - b));
-        }
+        });
+        for (const std::string& o : piece) std::fwrite(o.data(), 1, o.size(), f);
+        const bool bad = std::ferror(f) != 0;
+        if (std::fclose(f) != 0 || bad) return "write failed: " + file;
+        return std::string();
     });
-    for (const std::string& o : piece) std::fwrite(o.data(), 1, o.size(), f);
-    const bool bad = std::ferror(f) != 0;
-    ATOMDEV_REQUIRE(std::fclose(f) == 0 && !bad, std::string("write failed: ") + path);
-    return 0;
 }
 
 }  // namespace

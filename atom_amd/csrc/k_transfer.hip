@@ -10,6 +10,8 @@
 
 #include "atomdev_internal.h"
 #include "fixed4.h"
+#include <memory>
+
 #include "host_parallel.h"
 #include "text_numbers.h"
 
@@ -88,26 +90,32 @@ extern "C" int atomdev_atm_write_transfer_file(atomdev_t* atm, const char* path)
     ATOMDEV_REQUIRE(atm && atm->model == ATOMDEV_ATM && path, "atomdev_atm_write_transfer_file: bad argument");
     if (int rc = planes(atm, 0)) return rc;
     const size_t n2 = atm->n2;
-    std::vector<double> x(6 * n2);
-    ATOMDEV_TRY(hipMemcpy(x.data(), atm->xfer, 6 * n2 * sizeof(double), hipMemcpyDeviceToHost));
-    // the text an ofstream with ios::fixed and precision(4) writes: six numbers a line, one space between them
-    FILE* f = std::fopen(path, "w");
-    ATOMDEV_REQUIRE(f, std::string("atomdev_atm_write_transfer_file: could not open ") + path);
-    const size_t rows = 4096, pieces = (n2 + rows - 1) / rows;   // a few host threads make the text side by side
-    std::vector<std::string> piece(pieces);
-    host_parallel_run(pieces, [&](size_t c) {
-        std::string& out = piece[c];
-        out.reserve(rows * 60);
-        for (size_t q = c * rows; q < n2 && q < (c + 1) * rows; q++)
-            for (int n = 0; n < 6; n++) {
-                append_fixed4(out, x[(size_t)n * n2 + q]);
-                out += n < 5 ? ' ' : '\n';
-            }
+    auto xs = std::make_shared<std::vector<double>>(6 * n2);
+    ATOMDEV_TRY(hipMemcpy(xs->data(), atm->xfer, 6 * n2 * sizeof(double), hipMemcpyDeviceToHost));
+    // The values are on the host: inside a one-call slice the text is made and written by a thread of its own while the
+    // slice goes on (the call that ends the slice waits for it).
+    const std::string file(path);
+    return atomdev_defer_file(atm, file, [xs, n2, file]() -> std::string {
+        const std::vector<double>& x = *xs;
+        // the text an ofstream with ios::fixed and precision(4) writes: six numbers a line, one space between them
+        FILE* f = std::fopen(file.c_str(), "w");
+        if (!f) return "atomdev_atm_write_transfer_file: could not open " + file;
+        const size_t rows = 4096, pieces = (n2 + rows - 1) / rows;   // a few host threads make the text side by side
+        std::vector<std::string> piece(pieces);
+        host_parallel_run(pieces, [&](size_t c) {
+            std::string& out = piece[c];
+            out.reserve(rows * 60);
+            for (size_t q = c * rows; q < n2 && q < (c + 1) * rows; q++)
+                for (int n = 0; n < 6; n++) {
+                    append_fixed4(out, x[(size_t)n * n2 + q]);
+                    out += n < 5 ? ' ' : '\n';
+                }
+        });
+        bool ok = true;
+        for (const std::string& out : piece) ok = ok && std::fwrite(out.data(), 1, out.size(), f) == out.size();
+        if (std::fclose(f) != 0 || !ok) return "atomdev_atm_write_transfer_file: write failed: " + file;
+        return std::string();
     });
-    bool ok = true;
-    for (const std::string& out : piece) ok = ok && std::fwrite(out.data(), 1, out.size(), f) == out.size();
-    ATOMDEV_REQUIRE(std::fclose(f) == 0 && ok, std::string("atomdev_atm_write_transfer_file: write failed: ") + path);
-    return 0;
 }
 
 extern "C" int atomdev_hyd_read_transfer_file(atomdev_t* hyd, const char* path) {

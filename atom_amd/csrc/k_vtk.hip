@@ -23,6 +23,13 @@ __global__ void k_section_column(double* __restrict__ buf, double* __restrict__ 
     if (scatter) field[r * pitch] = buf[r]; else buf[r] = field[r * pitch];
 }
 
+// rows of `width` doubles, `pitch` doubles apart, as one dense run (a section of a 3-D field in the writers' order)
+__global__ void k_section_gather(double* __restrict__ dst, const double* __restrict__ src, size_t width, size_t pitch, size_t count) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= count) return;
+    dst[e] = src[(e / width) * pitch + e % width];
+}
+
 // one section of a 3-D field in the order the writers walk it: radial [j][k], longal [i][k], zonal [i][j]
 struct Section {
     atomdev* h;
@@ -69,6 +76,46 @@ struct Section {
         ATOMDEV_TRY(hipMemcpy2DAsync(out.data(), width, h->f[field] + off, pitch, width, rows, hipMemcpyDeviceToHost, h->stream));
         return 0;
     }
+    // Several columns of a file at once: every section (or 2-D field, `two_d`) is gathered into its slot of the device
+    // staging buffer, the slots come over in ONE copy into page-locked memory, and the stream is waited for once -
+    // instead of a strided copy into pageable memory and a wait per column.
+    struct Want { int field; bool two_d; std::vector<double>* out; };
+    int get_many(const std::vector<Want>& list) const {
+        if (list.empty()) return 0;
+        const size_t n = size(), n2 = h->n2, per = std::max(n, n2), bytes = list.size() * per * sizeof(double);
+        if (bytes > h->stage_bytes) {
+            ATOMDEV_TRY(hipStreamSynchronize(h->stream));
+            if (h->stage) ATOMDEV_TRY(hipFree(h->stage));
+            h->stage = nullptr; h->stage_bytes = 0;
+            ATOMDEV_TRY(hipMalloc(&h->stage, bytes));
+            h->stage_bytes = bytes;
+        }
+        if (bytes > h->stage_host_bytes) {
+            if (h->stage_host) ATOMDEV_TRY(hipHostFree(h->stage_host));
+            h->stage_host = nullptr; h->stage_host_bytes = 0;
+            ATOMDEV_TRY(hipHostMalloc(&h->stage_host, bytes, hipHostMallocDefault));
+            h->stage_host_bytes = bytes;
+        }
+        double* dev = (double*)h->stage;
+        const double* host = (const double*)h->stage_host;
+        size_t off, width, pitch, rows;
+        geometry(off, width, pitch, rows);
+        for (size_t c = 0; c < list.size(); c++) {
+            double* d = dev + c * per;
+            if (list[c].two_d) {
+                ATOMDEV_TRY(hipMemcpyAsync(d, h->g[list[c].field], n2 * 8, hipMemcpyDeviceToDevice, h->stream));
+            } else {
+                hipLaunchKernelGGL(k_section_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, d,
+                                   (const double*)(h->f[list[c].field] + off), width / 8, pitch / 8, n);
+                ATOMDEV_TRY(hipGetLastError());
+            }
+        }
+        ATOMDEV_TRY(hipMemcpyAsync(h->stage_host, dev, bytes, hipMemcpyDeviceToHost, h->stream));
+        if (int rc = atomdev_sync_stream(h)) return rc;
+        for (size_t c = 0; c < list.size(); c++)
+            list[c].out->assign(host + c * per, host + c * per + (list[c].two_d ? n2 : n));
+        return 0;
+    }
     int put(int field, const std::vector<double>& in) const {
         size_t off, width, pitch, rows;
         geometry(off, width, pitch, rows);
@@ -105,6 +152,11 @@ struct Text {
         scalars(name);
         pieces.emplace_back();
         pieces.back().kind = 1; pieces.back().a = a; pieces.back().multiplier = multiplier;
+    }
+    void column(const char* name, std::vector<double>&& a, double multiplier) {
+        scalars(name);
+        pieces.emplace_back();
+        pieces.back().kind = 1; pieces.back().a = std::move(a); pieces.back().multiplier = multiplier;
     }
     void triples(const std::vector<double>& a, const std::vector<double>& b, const std::vector<double>& c) {
         pieces.emplace_back();
@@ -183,17 +235,20 @@ int write_vtk(atomdev* h, int kind, int index, int Ma, const char* path) {
     }
     const std::string point_data = "POINT_DATA " + std::to_string(sec.n_outer * sec.n_inner) + "\n";
 
-    std::vector<double> u, v, w, t, tmp;
-    if (int rc = slice(ATOMDEV_U, u)) return rc;
-    if (int rc = slice(ATOMDEV_V, v)) return rc;
-    if (int rc = slice(ATOMDEV_W, w)) return rc;
-    if (int rc = slice(ATOMDEV_T, t)) return rc;
+    std::vector<double> u, v, w, t, c, cloud, ice;
+    {
+        std::vector<Section::Want> first = { { ATOMDEV_U, false, &u }, { ATOMDEV_V, false, &v }, { ATOMDEV_W, false, &w }, { ATOMDEV_T, false, &t } };
+        if (atm) { first.push_back({ ATOMDEV_C, false, &c }); first.push_back({ ATOMDEV_CLOUD, false, &cloud }); first.push_back({ ATOMDEV_ICE, false, &ice }); }
+        if (int rc = sec.get_many(first)) return rc;
+    }
     auto columns = [&](std::initializer_list<Column> list) {
-        for (const Column& c : list) {
-            if (int rc = c.two_d ? surface(c.field, tmp) : slice(c.field, tmp)) return rc;
-            if (int rc = sync()) return rc;
-            out.column(c.name, tmp, c.multiplier);
-        }
+        std::vector<std::vector<double>> got(list.size());
+        std::vector<Section::Want> want;
+        size_t q = 0;
+        for (const Column& col : list) want.push_back({ col.field, col.two_d, &got[q++] });
+        if (int rc = sec.get_many(want)) return rc;
+        q = 0;
+        for (const Column& col : list) out.column(col.name, std::move(got[q++]), col.multiplier);
         return 0;
     };
     auto temperature_celsius = [&]() {
@@ -201,15 +256,9 @@ int write_vtk(atomdev* h, int kind, int index, int Ma, const char* path) {
         for (size_t q = 0; q < t.size(); q++) celsius[q] = t[q] * P.t_0 - P.t_0;
         out.column("Temperature", celsius, 1.);
     };
-    if (int rc = sync()) return rc;
 
     if (atm) {
         const double p_scale = P.u_0 * P.u_0 * P.r_air * .01;
-        std::vector<double> c, cloud, ice;
-        if (int rc = slice(ATOMDEV_C, c)) return rc;
-        if (int rc = slice(ATOMDEV_CLOUD, cloud)) return rc;
-        if (int rc = slice(ATOMDEV_ICE, ice)) return rc;
-        if (int rc = sync()) return rc;
         if (kind == ATOMDEV_RADIAL) {
             if (Ma == 0) {  // :287-309: Celsius copy of the NASA temperature, its difference to t, evaporation - precipitation
                 std::vector<double> t_nasa, t0, evap, precip, aux_v, aux_w;
