@@ -51,6 +51,7 @@ ATM_DEV_STEP = ["atm_bc_radius_theta_phi", "atm_limit_ground_rk3d_limit", "move3
 HYD_STEP = ["hyd_bc_radius_theta_phi", "hyd_pressure_density", "hyd_value_limitation", "hyd_rk3d",
             "hyd_solid_ground", "move3d"]   # (the three boundary fills as one call: same bits)
 SWEEP_KERNEL = {0: "k_atm_rk3d_ws<true>", 1: "k_atm_rk3d", 2: "k_atm_rk3d_wsf<true>", 3: "k_atm_rk3d_pipe<true>"}
+SLAB_LEG_LIMIT_S = 300   # N > 1: how long the slab measurement behind the slices may take before the line is printed without it
 SWEEP_FORM = {0: "exact form", 1: "one thread per line, exact form", 2: "tolerance form", 3: "pipelined tolerance form"}
 
 
@@ -475,21 +476,47 @@ def main():
         }
     atm.close()
 
-    # N > 1: the strong-scaling figure of the same run - one 0.25-degree atmosphere split into N phi-slabs
+    if rank == 0:
+        out["cpu_baseline"] = None if args.no_cpu else cpu_baseline(p, f, g)
+
+    # N > 1: the strong-scaling figure of the same run - one 0.25-degree atmosphere split into N phi-slabs.  The slices'
+    # line is complete at this point and must not be lost to this leg: an exception is reported in the leg's field, and
+    # a leg (or a closing barrier) that does not come back - a rank that failed alone leaves the others waiting in a
+    # collective - is ended by a watchdog that prints the line as it stands and ends the process.
+    import threading
+    printed = threading.Lock()
+
+    def emit():
+        if printed.acquire(blocking=False) and rank == 0:
+            print(json.dumps(out), flush=True)
+
+    def give_up(what):
+        if rank == 0 and out is not None and "slabs_0p25" not in out and world > 1 and not args.no_slabs:
+            out["slabs_0p25"] = {"error": "%s did not finish within %d s" % (what, SLAB_LEG_LIMIT_S)}
+        emit()
+        sys.stdout.flush()
+        os._exit(0)
+
     if world > 1 and not args.no_slabs:
+        watchdog = threading.Timer(SLAB_LEG_LIMIT_S, give_up, args=("the 0.25-degree slab leg",))
+        watchdog.daemon = True
+        watchdog.start()
         rec = None
         try:
             set_grid("0.25")
             rec = measure_slabs(args, S, atom_amd, dist, rank, world, local_rank, barrier, reduce_max, steps=20, warmup=4, windows=3)
-        except Exception as exc:   # the slices' line must not be lost to a failure here
+        except Exception as exc:
             rec = {"error": "%s: %s" % (type(exc).__name__, exc)}
         set_grid(args.grid)
+        watchdog.cancel()
         if rank == 0:
             out["slabs_0p25"] = rec
 
-    if rank == 0:
-        out["cpu_baseline"] = None if args.no_cpu else cpu_baseline(p, f, g)
-        print(json.dumps(out))
+    emit()
+    if world > 1:
+        closing = threading.Timer(60, give_up, args=("the closing barrier",))
+        closing.daemon = True
+        closing.start()
     finish()
 
 

@@ -67,3 +67,18 @@ for v in variants:
         pt = np.abs(a - b) / np.maximum(np.abs(b), 1e-30 + 1e-12 * scale)
         line.append("%s %.1e (field) %.1e (point)" % (k, np.abs(a - b).max() / scale, pt.max()))
     print("one sweep from that state, variant %d against 0: %s" % (v, "; ".join(line)))
+
+# where the largest point-by-point differences of one sweep are
+H_mask = base["H"]
+for v in variants:
+    for k in ("CLOUD", "ICE", "V"):
+        a, b = one[v][k], one[0][k]
+        scale = np.abs(b).max()
+        pt = np.abs(a - b) / np.maximum(np.abs(b), 1e-30 + 1e-12 * scale)
+        order = np.argsort(pt.reshape(-1))[::-1][:5]
+        txt = []
+        for o in order:
+            i, j, kk = np.unravel_index(o, pt.shape)
+            txt.append("(%d,%d,%d) %.1e x=%.3e xm1=%.3e land=%d landm1=%d" % (i, j, kk, pt[i, j, kk], b[i, j, kk], b[i, j - 1, kk],
+                                                                             int(H_mask[i, j, kk] == 1.), int(H_mask[i, j - 1, kk] == 1.)))
+        print("variant %d %s worst points: %s" % (v, k, "; ".join(txt)))
