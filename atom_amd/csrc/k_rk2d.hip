@@ -220,6 +220,7 @@ __global__ __launch_bounds__(256) void k_rk2d(Rk2dArgs a, DevConst K) {
 // ---- the sweep as a pipeline of narrow waves ----
 constexpr int CH_ROWS = 32;   // rows of a chain wave (two lanes per row: v and w)
 constexpr int PK = 13;        // 16-byte entries of a lane's packet for one point
+constexpr int PKF = 8;        // ... in the tolerance form (the packets keep the stride of PK entries)
 
 // Packet of lane x (0: v, 1: w) for point (j, k), as doubles:
 //   0 xc   1 xn                                  old centre value, "new"-array value
@@ -241,6 +242,8 @@ constexpr unsigned long long BND_EMPTY = 0xFFF4A70DA70DA70Dull;  // "not written
 
 struct BatchItem { Rk2dArgs a; Chain c; DevConst K; int* err; };   // err: the item's own handle's failure word
 
+// FAST: the packet of the tolerance form (below, at k_rk2d_chain)
+template <bool FAST>
 __global__ __launch_bounds__(256) void k_rk2d_prepare(Rk2dArgs a, Chain c, DevConst K, int groups,
                                                       const BatchItem* __restrict__ items) {
     if (items) { a = items[blockIdx.y].a; c = items[blockIdx.y].c; K = items[blockIdx.y].K; }
@@ -277,6 +280,31 @@ __global__ __launch_bounds__(256) void k_rk2d_prepare(Rk2dArgs a, Chain c, DevCo
         const double x_tp = f[q + R], x_pp = f[q + 1];
         double e[2 * PK];
         e[0] = f[q]; e[1] = fn[q];
+        if constexpr (FAST) {
+            // dx/dthe / rm = A_th x + B_th0 + B_th1 x(j-1,k);  dx/dphi / (rm sin) = A_ph x + B_ph0 + B_ph1 x(j,k-1)
+            const double tf = C.T1.h * C.T1.idiv * a.i_rm, pf = C.P1.h * C.P1.idiv * G.i_rmsin;
+            const double A_th = tf * C.T1.cc, A_ph = pf * C.P1.cc;
+            e[2] = A_th; e[3] = tf * (C.T1.c1 * x_tp); e[4] = tf * C.T1.c2;
+            e[5] = A_ph; e[6] = pf * (C.P1.c1 * x_pp); e[7] = pf * C.P1.c2;
+            // what multiplies the lane's own stage value outside the advection products, and the partner's
+            const double sgn = x ? 1. : -1.;
+            const double t2f = C.T2.h * C.T2.idiv * a.i_rm2;
+            const double gth = G.costhe * G.i_rmsin;                    // dx/dthe cos / (rm2 sin) = (dx/dthe / rm) gth
+            const double coefh = G.coef * (x ? C.h_d_k : C.h_d_j), h0 = x ? C.h_0_k : C.h_0_j;
+            e[8] = sgn * K.i_re * (t2f * C.T2.cc + gth * A_th - coefh) - h0 * (x ? K.i_dphi2 : K.i_dthe2);
+            e[9] = K.i_re * 2. * gth * A_ph;                            // d other/dphi 2 cos / (rm2 sin2) / re
+            e[10] = x ? C.pg_w : C.pg_v;
+            e[11] = sgn * K.i_re * t2f * C.T2.c1; e[12] = sgn * K.i_re * t2f * C.T2.c2;
+            e[13] = C.o_fwd ? x_pp : x_tp; e[14] = x_pp2[x];
+            e[15] = __longlong_as_double(sel);
+            const int lane = 2 * r + x;
+#pragma unroll
+            for (int n2 = 0; n2 < PKF; n2++) {
+                out[((size_t)n2 * 64 + lane) * 2] = e[2 * n2];
+                out[((size_t)n2 * 64 + lane) * 2 + 1] = e[2 * n2 + 1];
+            }
+            continue;
+        }
         e[2] = C.T1.cc; e[3] = C.T1.c1 * x_tp; e[4] = C.T1.c2; e[5] = C.T1.h; e[6] = C.T1.div; e[7] = C.T1.idiv;
         e[8] = C.P1.cc; e[9] = C.P1.c1 * x_pp; e[10] = C.P1.c2; e[11] = C.P1.h; e[12] = C.P1.div; e[13] = C.P1.idiv;
         e[14] = C.T2.cc; e[15] = C.T2.c1; e[16] = C.T2.c2; e[17] = C.T2.h; e[18] = C.T2.div; e[19] = C.T2.idiv;
@@ -326,6 +354,12 @@ struct Packet { pair_t e[PK]; };
 //   k_x = -(v dx/dthe / rm + w dx/dphi / (rm sin)) - pg_x + s ( (d2x / rm2 + dx/dthe / (rm2 sin) cos - coef h x)
 //          + s (d other/dphi 2 cos / (rm2 sin2)) ) / re - h0 x / d2,       s = -1 for v, +1 for w
 // where adding a negated value is the subtraction the reference writes, bit for bit.
+// FAST, the tolerance form (about 1e-15 from the exact one per sweep): with the neighbours fixed during the four
+// stages, both right-hand sides are
+//   k_x = -v (A_th x + B_th) - w (A_ph x + B_ph) + C x + F x' + D        (x' the partner's stage value)
+// where A_th, A_ph, C, F come ready in the packet and B_th, B_ph, D take this sweep's neighbour values once per
+// step: a stage is six fused multiply-adds and one lane swap instead of ~65 instructions.
+template <bool FAST>
 __global__ __launch_bounds__(64) void k_rk2d_chain(Rk2dArgs a, Chain c, DevConst K, const BatchItem* __restrict__ items,
                                                    int* __restrict__ err) {
     if (items) { a = items[blockIdx.y].a; c = items[blockIdx.y].c; K = items[blockIdx.y].K; err = items[blockIdx.y].err; }
@@ -337,6 +371,9 @@ __global__ __launch_bounds__(64) void k_rk2d_chain(Rk2dArgs a, Chain c, DevConst
     const bool feeds = r == rlast && g + 1 < (int)gridDim.x, polls = r == 0;
     const RowGeo G = row_geometry(a, row ? j : 1);
     const double rm = a.rm, rm2 = rm * rm, dt = K.dt;
+    const double hdt = .5 * K.dt, dt6 = K.dt * K.i_six;
+    // tolerance form: what the theta difference and the partner's phi difference are multiplied by in the viscous bracket
+    const double e_th = (x ? 1. : -1.) * K.i_re * G.costhe * G.i_rmsin, g_ph = K.i_re * 2. * G.costhe * G.i_rmsin;
     const double d2 = x ? K.dphi2 : K.dthe2, i_d2 = x ? K.i_dphi2 : K.i_dthe2;
     const int smask = x ? 0 : (int)0x80000000;
     const gcpair_t pk = (gcpair_t)(c.pk + (size_t)g * c.ndd * PK * 64 + lane);
@@ -353,7 +390,7 @@ __global__ __launch_bounds__(64) void k_rk2d_chain(Rk2dArgs a, Chain c, DevConst
         Packet P;
         const gcpair_t p = pk + (size_t)n * PK * 64;
 #pragma unroll
-        for (int e = 0; e < PK; e++) P.e[e] = p[e * 64];
+        for (int e = 0; e < (FAST ? PKF : PK); e++) P.e[e] = p[e * 64];
         return P;
     };
     const int nlast = km - 3 + rlast;
@@ -382,6 +419,41 @@ __global__ __launch_bounds__(64) void k_rk2d_chain(Rk2dArgs a, Chain c, DevConst
             if (polls) x_tm = b;
         }
         b_nx = ld_agent(bin + min(max(k + 1, 0), km - 1));  // every lane, so that nothing has to wait for it here
+        if constexpr (FAST) {
+            const double xn = cur.e[0].y;
+            const double A_th = cur.e[1].x, B_th0 = cur.e[1].y, B_th1 = cur.e[2].x, A_ph = cur.e[2].y, B_ph0 = cur.e[3].x, B_ph1 = cur.e[3].y;
+            const double Cx = cur.e[4].x, F = cur.e[4].y, pg = cur.e[5].x, S_A = cur.e[5].y, S_B = cur.e[6].x;
+            const double sA = cur.e[6].y, sB = cur.e[7].x;
+            const bool own = __double2loint(cur.e[7].y) != 0, above = __double2hiint(cur.e[7].y) != 0;
+            const double x2A = own ? x_m1 : sA;
+            const double x2B = own ? x_m2 : (above ? x_tm : sB);
+            const double B_th = __builtin_fma(B_th1, x_tm, B_th0), B_ph = __builtin_fma(B_ph1, x_m1, B_ph0);
+            const double oB_ph = pair_swap(B_ph);
+            double D = __builtin_fma(e_th, B_th, -pg);
+            D = __builtin_fma(g_ph, oB_ph, D);
+            D = __builtin_fma(S_A, x2A, D);
+            D = __builtin_fma(S_B, x2B, D);
+            // lane v: v is the lane's own value, w the partner's; lane w: the other way round
+            const double A_own = x ? A_ph : A_th, B_own = x ? B_ph : B_th, A_oth = x ? A_th : A_ph, B_oth = x ? B_th : B_ph;
+            double xc = cur.e[0].x, acc = 0., kx = 0.;
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const double oc = pair_swap(xc);
+                kx = __builtin_fma(Cx, xc, D);
+                kx = __builtin_fma(F, oc, kx);
+                kx = __builtin_fma(-xc, __builtin_fma(A_own, xc, B_own), kx);
+                kx = __builtin_fma(-oc, __builtin_fma(A_oth, xc, B_oth), kx);
+                if (s == 0) { acc = kx; xc = __builtin_fma(kx, hdt, xn); }
+                else if (s == 1) { acc = __builtin_fma(2., kx, acc); xc = __builtin_fma(kx, hdt, xn); }
+                else if (s == 2) { acc = __builtin_fma(2., kx, acc); xc = __builtin_fma(kx, dt, xn); }
+            }
+            const double x_new = __builtin_fma(acc + kx, dt6, xn);
+            out[active ? k : 0] = active ? x_new : xb;
+            out_aux[active ? k : 0] = active ? kx + pg : aux_b;
+            st_agent(active && feeds ? bout + k : idle, x_new);
+            if (active) { x_m2 = x_m1; x_m1 = x_new; }
+            return;
+        }
         const double xn = cur.e[0].y;
         const double t1_cc = cur.e[1].x, t1_a = cur.e[1].y, t1_c2 = cur.e[2].x, t1_h = cur.e[2].y, t1_div = cur.e[3].x, t1_idiv = cur.e[3].y;
         const double p1_cc = cur.e[4].x, p1_a = cur.e[4].y, p1_c2 = cur.e[5].x, p1_h = cur.e[5].y, p1_div = cur.e[6].x, p1_idiv = cur.e[6].y;
@@ -462,12 +534,15 @@ int rk2d_item(atomdev* h, BatchItem& it) {
 }
 
 // prepare + chain for n models (items == nullptr: one model, arguments of `one` by value) on `stream`
-int rk2d_launch(const BatchItem& one, const BatchItem* items, int n, int jm, int km, hipStream_t stream, int* err) {
+// fast: the tolerance form (the handles' rk_variant 2 and 3)
+int rk2d_launch(const BatchItem& one, const BatchItem* items, int n, int jm, int km, hipStream_t stream, int* err, bool fast) {
     const int groups = (jm - 2 + CH_ROWS - 1) / CH_ROWS;
     const unsigned nb = (unsigned)(((size_t)jm * km + 255) / 256);
-    hipLaunchKernelGGL(k_rk2d_prepare, dim3(nb, n), dim3(256), 0, stream, one.a, one.c, one.K, groups, items);
+    if (fast) hipLaunchKernelGGL(k_rk2d_prepare<true>, dim3(nb, n), dim3(256), 0, stream, one.a, one.c, one.K, groups, items);
+    else hipLaunchKernelGGL(k_rk2d_prepare<false>, dim3(nb, n), dim3(256), 0, stream, one.a, one.c, one.K, groups, items);
     ATOMDEV_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_rk2d_chain, dim3(groups, n), dim3(64), 0, stream, one.a, one.c, one.K, items, err);
+    if (fast) hipLaunchKernelGGL(k_rk2d_chain<true>, dim3(groups, n), dim3(64), 0, stream, one.a, one.c, one.K, items, err);
+    else hipLaunchKernelGGL(k_rk2d_chain<false>, dim3(groups, n), dim3(64), 0, stream, one.a, one.c, one.K, items, err);
     return atomdev_check(hipGetLastError(), "k_rk2d_chain");
 }
 
@@ -479,7 +554,7 @@ int rk2d(atomdev* h, bool hyd) {
         hipLaunchKernelGGL(k_rk2d, dim3(1), dim3(256), (size_t)h->jm * sizeof(RowGeo), h->stream, it.a, h->k);
         return atomdev_check(hipGetLastError(), "k_rk2d");
     }
-    return rk2d_launch(it, nullptr, 1, h->jm, h->km, h->stream, (int*)atomdev_kernel_error_word(h));
+    return rk2d_launch(it, nullptr, 1, h->jm, h->km, h->stream, (int*)atomdev_kernel_error_word(h), h->rk_variant >= 2);
 }
 
 }  // namespace
@@ -500,6 +575,7 @@ extern "C" int atomdev_rk2d_batch(atomdev_t* const* handles, int n) {
         ATOMDEV_REQUIRE(h->jm == h0->jm && h->km == h0->km, "atomdev_rk2d_batch: surfaces of different size");
         ATOMDEV_REQUIRE(h->model != ATOMDEV_HYD || h->im == 41,
                         "atomdev_rk2d_batch: the reference hard-codes im = 41 for the hydrosphere surface sweep");
+        ATOMDEV_REQUIRE((h->rk_variant >= 2) == (h0->rk_variant >= 2), "atomdev_rk2d_batch: handles with the exact and the tolerance form of the sweep in one batch");
         for (int q = 0; q < m; q++) ATOMDEV_REQUIRE(handles[q] != h, "atomdev_rk2d_batch: a handle appears twice");
     }
     ATOMDEV_TRY(hipSetDevice(h0->device));
@@ -524,7 +600,7 @@ extern "C" int atomdev_rk2d_batch(atomdev_t* const* handles, int n) {
     ATOMDEV_TRY(hipMemcpyAsync(h0->batch, items.data(), bytes, hipMemcpyHostToDevice, h0->stream));
     ATOMDEV_TRY(hipStreamSynchronize(h0->stream));  // `items` is host memory that goes out of scope
     if (int rc = rk2d_launch(items[0], (const BatchItem*)h0->batch, n, h0->jm, h0->km, h0->stream,
-                             (int*)atomdev_kernel_error_word(h0))) return rc;
+                             (int*)atomdev_kernel_error_word(h0), h0->rk_variant >= 2)) return rc;
     ATOMDEV_TRY(hipEventRecord(h0->ev1, h0->stream));
     for (int m = 1; m < n; m++) ATOMDEV_TRY(hipStreamWaitEvent(handles[m]->stream, h0->ev1, 0));
     return 0;

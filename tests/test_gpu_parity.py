@@ -67,8 +67,12 @@ def _compare(o, d, names, op, exact):
     return worst
 
 
-def _run_sequence(model, dims, seed, mask, seq, pow_ops=("atm_rk3d",)):
-    o, d, names = _pair(model, dims, seed, mask)
+def _run_sequence(model, dims, seed, mask, seq, pow_ops=("atm_rk3d",), variant=None):
+    """variant: see _pair.  With the sweeps in a tolerance form (variants 2 and 3: the 3-D and the surface sweeps alike)
+    the fields are held to the tolerance from the first sweep on."""
+    o, d, names = _pair(model, dims, seed, mask, variant=variant)
+    if d.rk_variant() >= 2:
+        pow_ops = tuple(pow_ops) + ("atm_rk2d", "hyd_rk2d", "hyd_rk3d")
     tainted = False  # once a pow-dependent op ran, later fields inherit its last-place differences
     for op in seq:
         H.run_op(o, op)
@@ -100,30 +104,38 @@ def test_hyd_sequence_two_blocks_per_group_bitexact(dims, seed, mask, monkeypatc
     _run_sequence(H.HYD, dims, seed, mask, H.HYD_SEQ)
 
 
-def test_hyd_surface_sequence_bitexact():
-    _run_sequence(H.HYD, (41, 43, 19), 13, "blobs", H.HYD_SURFACE_SEQ + ["hyd_pressure2d"])
+@pytest.mark.parametrize("variant", [0, "default"])
+def test_hyd_surface_sequence_bitexact(variant):
+    """The hydrosphere's surface sequence: bit for bit with the sweeps in their exact form, within the tolerance in the
+    handle's default form (the surface sweep follows the same knob as the 3-D sweep)."""
+    _run_sequence(H.HYD, (41, 43, 19), 13, "blobs", H.HYD_SURFACE_SEQ + ["hyd_pressure2d"], variant=variant)
 
 
-def test_atm_everything_but_rk3d_bitexact():
-    """The same operators with the pow-dependent sweep left out: bit-exact."""
+@pytest.mark.parametrize("variant", [0, "default"])
+def test_atm_everything_but_rk3d_bitexact(variant):
+    """The same operators with the pow-dependent sweep left out: bit-exact with the surface sweep in its exact form,
+    within the tolerance in the handle's default form."""
     seq = ["atm_bc_radius", "atm_bc_theta", "atm_bc_phi", "atm_value_limitation", "atm_solid_ground",
            "atm_rk2d", "atm_pressure2d", "move2d", "atm_rk2d", "atm_pressure3d", "move3d", "atm_pressure3d"]
-    _run_sequence(H.ATM, (9, 23, 67), 31, "blobs", seq)
+    _run_sequence(H.ATM, (9, 23, 67), 31, "blobs", seq, variant=variant)
 
 
+@pytest.mark.parametrize("variant", [0, "default"])
 @pytest.mark.parametrize("dims", [(5, 7, 7), (5, 8, 7), (5, 34, 7), (5, 35, 40), (5, 66, 9), (5, 7, 130)])
-def test_atm_surface_sweep_small_and_ragged_bitexact(dims):
+def test_atm_surface_sweep_small_and_ragged_bitexact(dims, variant):
     """The surface sweep on surfaces around its block sizes: fewer rows than a wave holds (32), one row more than a
-    wave holds, one more than two waves hold, the smallest grids the library takes, a long thin one."""
-    _run_sequence(H.ATM, dims, 60 + dims[1], "blobs", ["atm_rk2d", "move2d", "atm_rk2d"])
+    wave holds, one more than two waves hold, the smallest grids the library takes, a long thin one; in its exact form
+    (bit for bit) and in its tolerance form."""
+    _run_sequence(H.ATM, dims, 60 + dims[1], "blobs", ["atm_rk2d", "move2d", "atm_rk2d"], variant=variant)
 
 
+@pytest.mark.parametrize("variant", [0, "default"])
 @pytest.mark.parametrize("jm", [301, 801, 1101])
-def test_atm_surface_sweep_many_rows_bitexact(jm):
+def test_atm_surface_sweep_many_rows_bitexact(jm, variant):
     """The surface sweep runs as a pipeline of waves of 32 rows each: 10, 25 and 35 waves here (the 1-degree grid has
-    six); variant 1 is the plain form, one workgroup walking the diagonals."""
+    six), in its exact and in its tolerance form; variant 1 is the plain form, one workgroup walking the diagonals."""
     seq = ["atm_rk2d", "move2d", "atm_rk2d"]
-    _run_sequence(H.ATM, (5, jm, 11), 40 + jm, "blobs", seq)
+    _run_sequence(H.ATM, (5, jm, 11), 40 + jm, "blobs", seq, variant=variant)
     o, d, names = _pair(H.ATM, (5, 45, 37), 47, "blobs")
     d.set_rk_variant(1)  # the looping form on a small grid as well
     H.run_op(o, "atm_rk2d"); _dev_op(d, "atm_rk2d")
@@ -274,15 +286,18 @@ def test_minmax_searches(model):
     d.close()
 
 
-def test_rk2d_batch_same_bits():
+@pytest.mark.parametrize("variant", [0, 2])
+def test_rk2d_batch_same_bits(variant):
     """Surface sweeps of five independent models (three atmospheres, two hydrospheres) in one launch: each gets
-    the bits of its own single-model sweep; work enqueued before and after the batch keeps its order."""
+    the bits of its own single-model sweep; work enqueued before and after the batch keeps its order.  In the exact form
+    of the sweep those are the oracle's bits, in the tolerance form the fields are within the tolerance of it."""
     dims = (41, 43, 19)
     singles, batched, oracles = [], [], []
     for n, model in enumerate([H.ATM, H.HYD, H.ATM, H.ATM, H.HYD]):
-        o, d1, names = _pair(model, dims, 100 + n, "blobs")
+        o, d1, names = _pair(model, dims, 100 + n, "blobs", variant=variant)
         d2 = atom_amd.DeviceModel(model, *dims, atom_amd.Params.from_buffer_copy(bytes(o.params)))
         d2.upload_all(o.f, o.g)
+        d2.set_rk_variant(variant)
         singles.append(d1); batched.append(d2); oracles.append((o, names))
     pre = lambda m: "atm" if m.model == atom_amd.ATM else "hyd"
     for rep in range(2):
@@ -301,9 +316,15 @@ def test_rk2d_batch_same_bits():
             if k != "RESIDUUM":
                 a, b = d1.download(k), d2.download(k)
                 assert H.bits_equal(a, b), k
-                assert H.bits_equal(a, o.f[k]), k
+                if variant == 0:
+                    assert H.bits_equal(a, o.f[k]), k
+                else:
+                    assert H.max_rel_err(a, o.f[k]) <= TOL, (k, H.max_rel_err(a, o.f[k]))
     with pytest.raises(atom_amd.AtomDevError):
         atom_amd.rk2d_batch([batched[0], batched[0]])
+    batched[1].set_rk_variant(2 - variant)   # the two forms of the sweep do not go into one batch
+    with pytest.raises(atom_amd.AtomDevError):
+        atom_amd.rk2d_batch(batched)
     for d in singles + batched:
         d.close()
 

@@ -23,7 +23,7 @@ for model, pre in ((H.ATM, "atm"), (H.HYD, "hyd")):
         f["H"], g["TOPOGRAPHY"] = H.load_mask_0Ma(model)
     d = atom_amd.DeviceModel(model, im, jm, km, atom_amd.Params.from_buffer_copy(bytes(p)))
     d.upload_all(f, g)
-    for variant in (0, 1):
+    for variant in (0, 1, 2):
         d.set_rk_variant(variant)
         for _ in range(3):
             d.op(pre + "_rk2d")
