@@ -395,12 +395,15 @@ __global__ __launch_bounds__(64) void k_rk2d_chain(Rk2dArgs a, Chain c, DevConst
     };
     const int nlast = km - 3 + rlast;
     double b_nx = polls ? ld_agent(bin + 1) : 0.;
-    auto step = [&](const Packet& cur, int n) {
+    // tolerance form: a step is shorter than a trip to memory, so the row above is asked for four to seven steps ahead,
+    // with the packets (a value that was not there yet when asked for is asked for again when its step comes)
+    auto load_above = [&](int n) { return ld_agent(bin + min(max(n + 1 - r, 0), km - 1)); };
+    auto step = [&](const Packet& cur, int n, double b_ahead = 0.) {
         const int k = n + 1 - r;
         const bool active = row && k >= 1 && k <= km - 2;
         double x_tm = __shfl_up(x_m1, 2);
         {
-            double b = b_nx;
+            double b = FAST ? b_ahead : b_nx;
             // the row above belongs to another wave: its value was asked for a step ago and is nearly always there
             const bool missing = polls && active && !dead && __double_as_longlong(b) == (long long)BND_EMPTY;
             if (__builtin_expect(__any(missing), 0)) {
@@ -418,7 +421,7 @@ __global__ __launch_bounds__(64) void k_rk2d_chain(Rk2dArgs a, Chain c, DevConst
             }
             if (polls) x_tm = b;
         }
-        b_nx = ld_agent(bin + min(max(k + 1, 0), km - 1));  // every lane, so that nothing has to wait for it here
+        if constexpr (!FAST) b_nx = ld_agent(bin + min(max(k + 1, 0), km - 1));  // every lane, so that nothing has to wait for it here
         if constexpr (FAST) {
             const double xn = cur.e[0].y;
             const double A_th = cur.e[1].x, B_th0 = cur.e[1].y, B_th1 = cur.e[2].x, A_ph = cur.e[2].y, B_ph0 = cur.e[3].x, B_ph1 = cur.e[3].y;
@@ -490,6 +493,29 @@ __global__ __launch_bounds__(64) void k_rk2d_chain(Rk2dArgs a, Chain c, DevConst
     };
     // two steps per trip, each with packet registers of its own: the loads of a step are issued a whole step
     // before their first use and nothing waits for the stores (a step beyond the last one has no active lane)
+    if constexpr (FAST) {
+        // Eight steps per trip, in two halves with packet registers of their own: what a half needs is asked for behind
+        // the first step of the half before, three to six steps ahead.  (The compiler waits for everything outstanding
+        // at the first use of a value loaded before the loop's back edge: loads issued just before that use, or a step
+        // before the end of a trip, would cost a whole trip to memory per trip.)
+        Packet X0 = load(0), X1 = load(1), X2 = load(2), X3 = load(3);
+        double bx0 = load_above(0), bx1 = load_above(1), bx2 = load_above(2), bx3 = load_above(3);
+        // (Holding the results of a half back and storing them behind the next half's wait, so that it is never a wait for
+        // a store's acknowledgement, was slower: the row handed to the next wave left four steps later.)
+        for (int n = 0; n <= nlast; n += 8) {
+            // (every value that was asked for before the back edge is declared used here, where nothing newer is under way)
+            asm volatile("" :: "v"(bx0), "v"(bx1), "v"(bx2), "v"(bx3), "v"(X0.e[PKF - 1].y), "v"(X1.e[PKF - 1].y), "v"(X2.e[PKF - 1].y), "v"(X3.e[PKF - 1].y));
+            step(X0, n, bx0);
+            const Packet Y0 = load(n + 4), Y1 = load(n + 5), Y2 = load(n + 6), Y3 = load(n + 7);
+            const double by0 = load_above(n + 4), by1 = load_above(n + 5), by2 = load_above(n + 6), by3 = load_above(n + 7);
+            step(X1, n + 1, bx1); step(X2, n + 2, bx2); step(X3, n + 3, bx3);
+            step(Y0, n + 4, by0);
+            X0 = load(n + 8); X1 = load(n + 9); X2 = load(n + 10); X3 = load(n + 11);
+            bx0 = load_above(n + 8); bx1 = load_above(n + 9); bx2 = load_above(n + 10); bx3 = load_above(n + 11);
+            step(Y1, n + 5, by1); step(Y2, n + 6, by2); step(Y3, n + 7, by3);
+        }
+        return;
+    }
     Packet A = load(0);
     for (int n = 0; n <= nlast; n += 2) {
         const Packet B = load(n + 1);
@@ -520,7 +546,7 @@ int rk2d_item(atomdev* h, BatchItem& it) {
     a.i_two_dphi = 1. / h->k.two_dphi; a.i_dphi = 1. / h->k.dphi;
     it.K = h->k;
     const int groups = (h->jm - 2 + CH_ROWS - 1) / CH_ROWS;
-    const int ndd = h->km + CH_ROWS + 4;   // steps 0 .. km - 3 + 31, and up to three more that are loaded ahead
+    const int ndd = h->km + CH_ROWS + 12;   // steps 0 .. km - 3 + 31, and up to eleven more that are loaded ahead
     const size_t pk_bytes = (size_t)groups * ndd * PK * 64 * sizeof(double2);
     const size_t bnd_bytes = ((size_t)groups * 2 * h->km + (size_t)groups * 64) * sizeof(double);  // and a slot per lane
     if (!h->surf) {
