@@ -609,7 +609,10 @@ int atomdev_timer_stop(atomdev_t* h, float* milliseconds);
  * 1e-10 per field after a time slice with identical iteration counts); the hydrosphere's
  * variants 0 and 1 carry the reference's bits, and the models' outer interfaces
  * (atom_models.hpp, atomdev_mirror.hpp) select 0 so that their results and files carry the
- * reference's bits and bytes.  The environment variable ATOMDEV_RK_VARIANT overrides the initial
+ * reference's bits and bytes.  The surface sweeps (atomdev_*_rk2d, atomdev_rk2d_batch) follow the
+ * same knob: exact form for 0 (1: the plain one-workgroup form, same bits), tolerance form for 2
+ * and 3 (1e-16 per field and sweep, 0.24 ms instead of 0.55 ms on the 1-degree surface); the handles
+ * of one batch must agree on the form.  The environment variable ATOMDEV_RK_VARIANT overrides the initial
  * value and the outer interface's choice.  atomdev_get_rk_variant returns the current value. */
 int atomdev_set_rk_variant(atomdev_t* h, int variant);
 int atomdev_get_rk_variant(const atomdev_t* h);
