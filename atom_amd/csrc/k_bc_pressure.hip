@@ -338,16 +338,30 @@ __global__ void k_pressure3d(double* __restrict__ p_dyn, const double* __restric
     const int im = K.im, jm = K.jm, km = K.km;
     const int k = 1 + blockIdx.x * blockDim.x + threadIdx.x;
     const int j = 1 + blockIdx.y, i = 1 + blockIdx.z;
+    // What depends on the row (i, j) only - ten divisions of the reference's statements - is worked out by one thread of
+    // the block; every quotient by one of these divisors is then div_by with the divisor's correctly rounded reciprocal
+    // (the bits of the division, atomdev_internal.h).  2 dphi rm sin (Pressure_Hyd) and 2 rm sin dphi (Pressure_Atm) are
+    // the same number: doubling is exact and the product commutes.
+    __shared__ double rc[12];
+    if (threadIdx.x == 0) {
+        const double rm = rad[i], rm2 = rm * rm;
+        const double sinthe = sinthe_t[j];
+        const double rmsinthe = rm * sinthe;
+        const double rm2sinthe2 = rmsinthe * rmsinthe;
+        const double denom = 2. / K.dr2 + 2. / (rm2 * K.dthe2) + 2. / (rm2sinthe2 * K.dphi2);
+        rc[0] = denom; rc[1] = 1. / denom;
+        rc[2] = 1. / (rm2 * K.dthe2); rc[3] = 1. / (rm2sinthe2 * K.dphi2);
+        const double t2 = 2. * K.dthe * rm, t1 = K.dthe * rm, w2 = 2. * K.dphi * rmsinthe, w1 = K.dphi * rmsinthe;
+        rc[4] = t2; rc[5] = 1. / t2; rc[6] = t1; rc[7] = 1. / t1;
+        rc[8] = w2; rc[9] = 1. / w2; rc[10] = w1; rc[11] = 1. / w1;
+    }
+    __syncthreads();
     if (k > km - 2) return;
     const size_t row = km, lvl = (size_t)jm * km;
     const size_t p = idx3(jm, km, i, j, k);
-    const double dr = K.dr, dthe = K.dthe, dphi = K.dphi;
-    const double rm = rad[i], rm2 = rm * rm;
-    const double sinthe = sinthe_t[j];
-    const double rmsinthe = rm * sinthe;
-    const double rm2sinthe2 = rmsinthe * rmsinthe;
-    const double denom = 2. / K.dr2 + 2. / (rm2 * K.dthe2) + 2. / (rm2sinthe2 * K.dphi2);
-    const double num1 = 1. / K.dr2, num2 = 1. / (rm2 * K.dthe2), num3 = 1. / (rm2sinthe2 * K.dphi2);
+    const double denom = rc[0], i_denom = rc[1], num1 = K.i_dr2, num2 = rc[2], num3 = rc[3];
+    const double t2 = rc[4], i_t2 = rc[5], t1 = rc[6], i_t1 = rc[7], w2 = rc[8], i_w2 = rc[9], w1 = rc[10], i_w1 = rc[11];
+    const double two_dr = K.two_dr, i_two_dr = K.i_two_dr, dr = K.dr, i_dr = K.i_dr;
 
     double r;
     if constexpr (HYD) {
@@ -368,73 +382,73 @@ __global__ void k_pressure3d(double* __restrict__ p_dyn, const double* __restric
         auto is_land = [](uint8_t f) { return (f & FL_LAND) != 0; };
         const bool lc = is_land(f_c);
 
-        double drhs_udr = (au_p - au_m) / (2. * dr);
+        double drhs_udr = div_by(au_p - au_m, two_dr, i_two_dr);
         if (iwin) {
             const bool above_fluid = HYD ? ((f_up & FL_HZERO) != 0) : !is_land(f_up);
-            if (lc && above_fluid) drhs_udr = (-3. * au_c + 4. * au_p - au_p2) / (2. * dr);
+            if (lc && above_fluid) drhs_udr = div_by(-3. * au_c + 4. * au_p - au_p2, two_dr, i_two_dr);
         } else {
-            drhs_udr = (au_p - au_c) / dr;
+            drhs_udr = div_by(au_p - au_c, dr, i_dr);
         }
 
-        double drhs_vdthe = (av_p - av_m) / (2. * dthe * rm);
-        if (lc && !is_land(f_jp)) drhs_vdthe = (av_p - av_c) / (dthe * rm);
-        if (lc && !is_land(f_jm)) drhs_vdthe = (av_m - av_c) / (dthe * rm);
+        double drhs_vdthe = div_by(av_p - av_m, t2, i_t2);
+        if (lc && !is_land(f_jp)) drhs_vdthe = div_by(av_p - av_c, t1, i_t1);
+        if (lc && !is_land(f_jm)) drhs_vdthe = div_by(av_m - av_c, t1, i_t1);
         if (jwin) {
-            if (lc && (!is_land(f_jp) && !is_land(f_jp2))) drhs_vdthe = (-3. * av_c + 4. * av_p - av_p2) / (2. * dthe * rm);
-            if (lc && !is_land(f_jm) && !is_land(f_jm2)) drhs_vdthe = (-3. * av_c + 4. * av_m - av_m2) / (2. * dthe * rm);
+            if (lc && (!is_land(f_jp) && !is_land(f_jp2))) drhs_vdthe = div_by(-3. * av_c + 4. * av_p - av_p2, t2, i_t2);
+            if (lc && !is_land(f_jm) && !is_land(f_jm2)) drhs_vdthe = div_by(-3. * av_c + 4. * av_m - av_m2, t2, i_t2);
         }
 
-        double drhs_wdphi = HYD ? (aw_p - aw_m) / (2. * dphi * rmsinthe) : (aw_p - aw_m) / (2. * rmsinthe * dphi);
+        double drhs_wdphi = div_by(aw_p - aw_m, w2, i_w2);
         if (lc && !is_land(f_kp))
-            drhs_wdphi = HYD ? (aw_p - aw_c) / (dphi * rmsinthe) : (aw_p - aw_c) / (rmsinthe * dphi);
+            drhs_wdphi = div_by(aw_p - aw_c, w1, i_w1);
         if (HYD ? (lc && !is_land(f_km)) : (!lc && is_land(f_km)))
-            drhs_wdphi = HYD ? (aw_m - aw_c) / (dphi * rmsinthe) : (aw_m - aw_c) / (rmsinthe * dphi);
+            drhs_wdphi = div_by(aw_m - aw_c, w1, i_w1);
         if (kwin) {
-            if (lc && !is_land(f_kp) && !is_land(f_kp2)) drhs_wdphi = (-3. * aw_c + 4. * aw_p - aw_p2) / (2. * rmsinthe * dphi);
-            if (lc && !is_land(f_km) && !is_land(f_km2)) drhs_wdphi = (-3. * aw_c + 4. * aw_m - aw_m2) / (2. * rmsinthe * dphi);
+            if (lc && !is_land(f_kp) && !is_land(f_kp2)) drhs_wdphi = div_by(-3. * aw_c + 4. * aw_p - aw_p2, w2, i_w2);
+            if (lc && !is_land(f_km) && !is_land(f_km2)) drhs_wdphi = div_by(-3. * aw_c + 4. * aw_m - aw_m2, w2, i_w2);
         }
 
-        r = ((pn_ip + pn_im) * num1 + (pn_jp + pn_jm) * num2 + (pn_kp + pn_km) * num3
-                    - rho * (drhs_udr + drhs_vdthe + drhs_wdphi)) / denom;
+        r = div_by((pn_ip + pn_im) * num1 + (pn_jp + pn_jm) * num2 + (pn_kp + pn_km) * num3
+                   - rho * (drhs_udr + drhs_vdthe + drhs_wdphi), denom, i_denom);
         if (!HYD && lc) r = .0;
     } else {
         auto land = [&](size_t q) { return (flags[q] & FL_LAND) != 0; };
         const bool lc = land(p);
 
-        double drhs_udr = (au[p + lvl] - au[p - lvl]) / (2. * dr);
+        double drhs_udr = div_by(au[p + lvl] - au[p - lvl], two_dr, i_two_dr);
         if (i <= im - 3) {
             bool above_fluid = HYD ? ((flags[p + lvl] & FL_HZERO) != 0) : !land(p + lvl);
-            if (lc && above_fluid) drhs_udr = (-3. * au[p] + 4. * au[p + lvl] - au[p + 2 * lvl]) / (2. * dr);
+            if (lc && above_fluid) drhs_udr = div_by(-3. * au[p] + 4. * au[p + lvl] - au[p + 2 * lvl], two_dr, i_two_dr);
         } else {
-            drhs_udr = (au[p + lvl] - au[p]) / dr;
+            drhs_udr = div_by(au[p + lvl] - au[p], dr, i_dr);
         }
 
         // aux_v / aux_w base: own level (atm) or level im-1 (hyd)
         const size_t a = HYD ? idx3(jm, km, im - 1, j, k) : p;
-        double drhs_vdthe = (av[a + row] - av[a - row]) / (2. * dthe * rm);
-        if (lc && !land(p + row)) drhs_vdthe = (av[a + row] - av[a]) / (dthe * rm);
-        if (lc && !land(p - row)) drhs_vdthe = (av[a - row] - av[a]) / (dthe * rm);
+        double drhs_vdthe = div_by(av[a + row] - av[a - row], t2, i_t2);
+        if (lc && !land(p + row)) drhs_vdthe = div_by(av[a + row] - av[a], t1, i_t1);
+        if (lc && !land(p - row)) drhs_vdthe = div_by(av[a - row] - av[a], t1, i_t1);
         if ((j >= 2) && (j <= jm - 3)) {
             if (lc && (!land(p + row) && !land(p + 2 * row)))
-                drhs_vdthe = (-3. * av[a] + 4. * av[a + row] - av[a + 2 * row]) / (2. * dthe * rm);
+                drhs_vdthe = div_by(-3. * av[a] + 4. * av[a + row] - av[a + 2 * row], t2, i_t2);
             if (lc && !land(p - row) && !land(p - 2 * row))
-                drhs_vdthe = (-3. * av[a] + 4. * av[a - row] - av[a - 2 * row]) / (2. * dthe * rm);
+                drhs_vdthe = div_by(-3. * av[a] + 4. * av[a - row] - av[a - 2 * row], t2, i_t2);
         }
 
-        double drhs_wdphi = HYD ? (aw[a + 1] - aw[a - 1]) / (2. * dphi * rmsinthe) : (aw[a + 1] - aw[a - 1]) / (2. * rmsinthe * dphi);
+        double drhs_wdphi = div_by(aw[a + 1] - aw[a - 1], w2, i_w2);
         if (lc && !land(p + 1))
-            drhs_wdphi = HYD ? (aw[a + 1] - aw[a]) / (dphi * rmsinthe) : (aw[a + 1] - aw[a]) / (rmsinthe * dphi);
+            drhs_wdphi = div_by(aw[a + 1] - aw[a], w1, i_w1);
         if (HYD ? (lc && !land(p - 1)) : (!lc && land(p - 1)))
-            drhs_wdphi = HYD ? (aw[a - 1] - aw[a]) / (dphi * rmsinthe) : (aw[a - 1] - aw[a]) / (rmsinthe * dphi);
+            drhs_wdphi = div_by(aw[a - 1] - aw[a], w1, i_w1);
         if ((k >= 2) && (k <= km - 3)) {
             if (lc && !land(p + 1) && !land(p + 2))
-                drhs_wdphi = (-3. * aw[a] + 4. * aw[a + 1] - aw[a + 2]) / (2. * rmsinthe * dphi);
+                drhs_wdphi = div_by(-3. * aw[a] + 4. * aw[a + 1] - aw[a + 2], w2, i_w2);
             if (lc && !land(p - 1) && !land(p - 2))
-                drhs_wdphi = (-3. * aw[a] + 4. * aw[a - 1] - aw[a - 2]) / (2. * rmsinthe * dphi);
+                drhs_wdphi = div_by(-3. * aw[a] + 4. * aw[a - 1] - aw[a - 2], w2, i_w2);
         }
 
-        r = ((pn[p + lvl] + pn[p - lvl]) * num1 + (pn[p + row] + pn[p - row]) * num2 + (pn[p + 1] + pn[p - 1]) * num3
-                    - rho * (drhs_udr + drhs_vdthe + drhs_wdphi)) / denom;
+        r = div_by((pn[p + lvl] + pn[p - lvl]) * num1 + (pn[p + row] + pn[p - row]) * num2 + (pn[p + 1] + pn[p - 1]) * num3
+                   - rho * (drhs_udr + drhs_vdthe + drhs_wdphi), denom, i_denom);
         if (!HYD && lc) r = .0;
     }
     p_dyn[p] = r;
