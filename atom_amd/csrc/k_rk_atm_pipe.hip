@@ -73,6 +73,7 @@ struct HalfA {
     double cFac[64], cMc[64], phk[64];         // level 1: the evaporation source of c
 };
 constexpr int NSLOT = 4;
+constexpr int GEO_ROWS = 768;                  // grids with more rows fetch the geometry with the row's other loads
 struct Ctl { int rdy, stored; };               // per slot and half: the row whose packet stands there, the row last stored from there
 struct PipeShared {
     HalfA ha[NSLOT];
@@ -80,6 +81,7 @@ struct PipeShared {
     double outA[NSLOT][7][64];                 // v, u, c, t, aux_u, aux_v, buoyancy of a finished row
     double outB[NSLOT][5][64];                 // w, cloud, ice, co2, aux_w
     double vst[2][4][64];                      // stage values of v of a row, by row parity
+    double geo[GEO_ROWS][2];                   // the level's geometry by row: cos(the) / (rm^2 sin(the)), the viscous v coefficient
     Ctl ctlA[NSLOT], ctlB[NSLOT];
     int doneA, doneB;                          // the last row each chain wave has finished
 #ifdef ATOMDEV_EXP_PIPE_STAMP
@@ -166,6 +168,7 @@ __device__ __forceinline__ double limited(double x, bool land) {
 // ---- a memory wave: rows r = q, q + 4, ... (r >= 1), the half of the row that chain A (FORA) or chain B works on ----
 template <bool L1, bool FORA, bool LIMIT>
 __device__ __forceinline__ void memory_wave(const PipeArgs& a, const DevConst& K, PipeShared& sh, const int q, const int i, const int bx, int* err) {
+    const bool geo_lds = K.jm <= GEO_ROWS;
     const int jm = K.jm, km = K.km;
     const int lane = threadIdx.x & 63;
     const int kk = 1 + bx * 64 + lane;
@@ -202,7 +205,7 @@ __device__ __forceinline__ void memory_wave(const PipeArgs& a, const DevConst& K
     // what a row's loads leave behind until the row's turn comes
     double lx[4], lxn[4], lxp[4], lS[5], ltopo = 0., lp[4];
     double lev = 0., lpr = 0., lc0 = 0., lc3 = 0., lph = 0.;
-    double lcos, lirs, lcoefv = 0.;  // geometry of the row: one address for the whole wave, fetched with the rest of the row
+    double lcos = 0., lirs = 0., lcoefv = 0.;  // geometry of the row where the level's table is not in LDS: one address for the whole wave
     unsigned lfl;
     auto issue = [&](const int r) {
 #ifdef ATOMDEV_EXP_PIPE_NOMEM  // timing experiment only (results are wrong): no vector-memory traffic inside the loop
@@ -212,11 +215,11 @@ __device__ __forceinline__ void memory_wave(const PipeArgs& a, const DevConst& K
         lfl = *(const __attribute__((address_space(1))) uint8_t*)((gcchar_t)a.flags + (o >> 3));
 #pragma unroll
         for (int n = 0; n < 4; n++) { lx[n] = gld(a.x[VARS[n]], o); lxn[n] = gld(a.xn[VARS[n]], o); }
-        lcos = gld(a.costhe + r, 0u); lirs = gld(a.tab_irm2sin + (size_t)i * jm + r, 0u);
+        if (!geo_lds) { lcos = gld(a.costhe + r, 0u); lirs = gld(a.tab_irm2sin + (size_t)i * jm + r, 0u); }
         ltopo = gld(a.topo, o_sfc + (unsigned)r * rowB);   // (a 2-D field: stays in the L2)
         if constexpr (FORA) {
             lS[0] = gld(a.S_c, o); lS[1] = gld(a.S_r, o); lS[2] = gld(a.S_i, o); lS[3] = gld(a.S_s, o); lS[4] = gld(a.S_v, o);
-            lcoefv = gld(a.tab_coefv + (size_t)i * jm + r, 0u);
+            if (!geo_lds) lcoefv = gld(a.tab_coefv + (size_t)i * jm + r, 0u);
             lp[0] = r >= 2 ? gld(a.p_dyn, o - 2u * rowB) : 0.;
             lp[1] = gld(a.p_dyn, o - rowB);
             lp[2] = gld(a.p_dyn, o);
@@ -279,7 +282,8 @@ __device__ __forceinline__ void memory_wave(const PipeArgs& a, const DevConst& K
         PSTAMP(stamp_wave, 1);
         {
             const bool window = r >= 2 && r < jm - 3;
-            const double g = lcos * lirs;
+            const double g = geo_lds ? sh.geo[r][0] : lcos * lirs;
+            const double coefv = geo_lds ? sh.geo[r][1] : lcoefv;
             // the mask: RHS_Atm.cpp:110-149
             const unsigned fl = lfl;
             const bool land = fl & FL_LAND;
@@ -315,7 +319,7 @@ __device__ __forceinline__ void memory_wave(const PipeArgs& a, const DevConst& K
                 // factor of the stage value outside the advection product: diffusion bracket and damping
                 const double p_re = Pb * i_re;
                 const double h0j = (fl & FL_H0J) ? 1. : 0.;
-                SA.cP[0][lane] = p_re - lcoefv * hdj * i_re - h0j * i_dthe2;
+                SA.cP[0][lane] = p_re - coefv * hdj * i_re - h0j * i_dthe2;
                 SA.cP[1][lane] = p_re - dmp_i;
                 SA.cP[2][lane] = Pb * i_re_sc_wv;
                 SA.cP[3][lane] = Pb * i_re_x;
@@ -577,6 +581,11 @@ __global__ __launch_bounds__(1024) void k_atm_rk3d_pipe(const PipeParams* __rest
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (threadIdx.x < NSLOT) { sh.ctlA[threadIdx.x] = { 0, 0 }; sh.ctlB[threadIdx.x] = { 0, 0 }; }
     if (threadIdx.x == 0) { sh.doneA = 0; sh.doneB = 0; }
+    if (K.jm <= GEO_ROWS)
+        for (int j = threadIdx.x; j < K.jm; j += (int)blockDim.x) {
+            sh.geo[j][0] = a.costhe[j] * a.tab_irm2sin[(size_t)i * K.jm + j];
+            sh.geo[j][1] = a.tab_coefv[(size_t)i * K.jm + j];
+        }
     __syncthreads();   // the only barrier: from here on the waves follow each other's progress words
 #ifdef ATOMDEV_EXP_PIPE_STAMP
     if (threadIdx.x == 0) { sh.wall[0] = wall_clock64(); sh.cyc[0] = __builtin_readcyclecounter(); }

@@ -72,6 +72,7 @@ struct HalfB {
     double cP[2][64], x0[2][64], xn[2][64], KQ[2][64], cBr[2][64];   // t, w
 };
 constexpr int NSLOT = 4;
+constexpr int GEO_ROWS = 768;                  // grids with more rows fetch the geometry with the row's other loads
 struct Ctl { int rdy, stored; };
 struct PipeShared {
     HalfA ha[NSLOT];
@@ -79,6 +80,7 @@ struct PipeShared {
     double outA[NSLOT][7][64];                 // v, u, c, aux_u, aux_v, buoyancy, salt balance of a finished row
     double outB[NSLOT][3][64];                 // t, w, aux_w
     double ust[2][4][64], vst[2][4][64];       // stage values of u and v of a row, by row parity
+    double geo[GEO_ROWS][2];                   // the level's geometry by row: cos(the) / (rm^2 sin(the)), the viscous v coefficient
     Ctl ctlA[NSLOT], ctlB[NSLOT];
     int doneA, doneB;
 };
@@ -158,7 +160,8 @@ __device__ __forceinline__ double rcp2(double b) {  // hardware estimate and two
 // ---- a memory wave: rows r = q, q + 4, ... (r >= 1), the half of the row that chain A (FORA) or chain B works on ----
 // TOP: level im-2 (no radial differences; chain A's half carries the evaporation source and waits for level im-3);
 // FEEDS: level im-3 (chain A's half publishes its rows of c for level im-2).
-template <bool TOP, bool FEEDS, bool FORA>
+// GEO: the level's geometry table is in LDS (grids of up to GEO_ROWS rows).
+template <bool TOP, bool FEEDS, bool FORA, bool GEO>
 __device__ __forceinline__ void memory_wave(const PipeArgs& a, const DevConst& K, PipeShared& sh, const int q, const int i, const int bx,
                                             int* progress, int* err) {
     const int jm = K.jm, km = K.km;
@@ -196,7 +199,8 @@ __device__ __forceinline__ void memory_wave(const PipeArgs& a, const DevConst& K
 
     // what a row's loads leave behind until the row's turn comes
     double lx[3], lxn[3], lxa[3], lxp[3], lp[4], lbathy = 0., lrw = 0., lrsw = 0., lev = 0., lpr = 0.;
-    double lcos, lirs, lcoefv = 0.;
+    constexpr bool geo_lds = GEO;
+    double lcos = 0., lirs = 0., lcoefv = 0.;
     unsigned lfl;
     auto issue = [&](const int r) {
         const unsigned o = o_lev + (unsigned)r * rowB;
@@ -211,10 +215,10 @@ __device__ __forceinline__ void memory_wave(const PipeArgs& a, const DevConst& K
             lxa[n] = gld(a.x[VARS[n]], o + lvlB);   // level i+1 <= im-1 always exists
 #endif
         }
-        lcos = gld(a.costhe + r, 0u); lirs = gld(a.tab_irm2sin + (size_t)i * jm + r, 0u);
+        if constexpr (!geo_lds) { lcos = gld(a.costhe + r, 0u); lirs = gld(a.tab_irm2sin + (size_t)i * jm + r, 0u); }
         lbathy = gld(a.bathy, oq);
         if constexpr (FORA) {
-            lcoefv = gld(a.tab_coefv + (size_t)i * jm + r, 0u);
+            if constexpr (!geo_lds) lcoefv = gld(a.tab_coefv + (size_t)i * jm + r, 0u);
             lrw = gld(a.r_water, o); lrsw = gld(a.r_salt_water, o);
             lp[0] = r >= 2 ? gld(a.p_dyn, o - 2u * rowB) : 0.;
             lp[1] = gld(a.p_dyn, o - rowB);
@@ -282,7 +286,8 @@ __device__ __forceinline__ void memory_wave(const PipeArgs& a, const DevConst& K
         wait_for(done, r - 4, err);
         if (r > 4) store_row(r - 4, land_prev);
         const bool window = r >= 2 && r < jm - 3;
-        const double g = lcos * lirs;
+        const double g = geo_lds ? sh.geo[r][0] : lcos * lirs;
+        const double coefv = geo_lds ? sh.geo[r][1] : lcoefv;
         // the mask: RHS_Hyd.cpp:96-139, 191-214, 296-300, 326-330
         const unsigned fl = lfl;
         const bool land = fl & FL_LAND;
@@ -324,7 +329,7 @@ __device__ __forceinline__ void memory_wave(const PipeArgs& a, const DevConst& K
         // damping of the variable (RHS_Hyd.cpp:406-437: u is damped with 1 / dthe^2)
         double dmp[3];
         if constexpr (FORA) {
-            dmp[0] = ((fl & FL_H0J) ? 1. : 0.) * i_dthe2 + lcoefv * hdj * i_re;
+            dmp[0] = ((fl & FL_H0J) ? 1. : 0.) * i_dthe2 + coefv * hdj * i_re;
             dmp[1] = h0i * i_dthe2;
             dmp[2] = h0i * i_dr2;
         } else {
@@ -607,6 +612,11 @@ __global__ __launch_bounds__(1024) void k_hyd_rk3d_pipe(const PipeParams* __rest
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (threadIdx.x < NSLOT) { sh.ctlA[threadIdx.x] = { 0, 0 }; sh.ctlB[threadIdx.x] = { 0, 0 }; }
     if (threadIdx.x == 0) { sh.doneA = 0; sh.doneB = 0; }
+    if (K.jm <= GEO_ROWS)
+        for (int j = threadIdx.x; j < K.jm; j += (int)blockDim.x) {
+            sh.geo[j][0] = a.costhe[j] * a.tab_irm2sin[(size_t)i * K.jm + j];
+            sh.geo[j][1] = a.tab_coefv[(size_t)i * K.jm + j];
+        }
     __syncthreads();   // the only barrier: from here on the waves follow each other's progress words
     const bool top = i == K.im - 2, feeds = i == K.im - 3;
     const bool fora = ((wave & 3) == 2) != (((wave >> 2) & 1) != 0);   // (see above: the two kinds alternate on a SIMD)
@@ -616,13 +626,27 @@ __global__ __launch_bounds__(1024) void k_hyd_rk3d_pipe(const PipeParams* __rest
     } else if (wave == 1) {
         if (top) chain_b<true>(a, K, sh, i, bx, err);
         else chain_b<false>(a, K, sh, i, bx, err);
-    } else if ((wave & 3) >= 2 && fora) {
-        if (top) memory_wave<true, false, true>(a, K, sh, wave >> 2, i, bx, progress, err);
-        else if (feeds) memory_wave<false, true, true>(a, K, sh, wave >> 2, i, bx, progress, err);
-        else memory_wave<false, false, true>(a, K, sh, wave >> 2, i, bx, progress, err);
     } else if ((wave & 3) >= 2) {
-        if (top) memory_wave<true, false, false>(a, K, sh, wave >> 2, i, bx, progress, err);
-        else memory_wave<false, false, false>(a, K, sh, wave >> 2, i, bx, progress, err);
+        const int q = wave >> 2;
+        if (K.jm <= GEO_ROWS) {
+            if (fora) {
+                if (top) memory_wave<true, false, true, true>(a, K, sh, q, i, bx, progress, err);
+                else if (feeds) memory_wave<false, true, true, true>(a, K, sh, q, i, bx, progress, err);
+                else memory_wave<false, false, true, true>(a, K, sh, q, i, bx, progress, err);
+            } else {
+                if (top) memory_wave<true, false, false, true>(a, K, sh, q, i, bx, progress, err);
+                else memory_wave<false, false, false, true>(a, K, sh, q, i, bx, progress, err);
+            }
+        } else {
+            if (fora) {
+                if (top) memory_wave<true, false, true, false>(a, K, sh, q, i, bx, progress, err);
+                else if (feeds) memory_wave<false, true, true, false>(a, K, sh, q, i, bx, progress, err);
+                else memory_wave<false, false, true, false>(a, K, sh, q, i, bx, progress, err);
+            } else {
+                if (top) memory_wave<true, false, false, false>(a, K, sh, q, i, bx, progress, err);
+                else memory_wave<false, false, false, false>(a, K, sh, q, i, bx, progress, err);
+            }
+        }
     }
 }
 
