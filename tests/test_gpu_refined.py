@@ -21,7 +21,9 @@ def _upsampled_mask(model):
     return np.ascontiguousarray(h[:, jj][:, :, kk]), np.ascontiguousarray(topo[jj][:, kk])
 
 
-def _pair(model, seed):
+def _pair(model, seed, variants):
+    """The oracle and one device model per sweep variant on the same inputs (the oracle's sweeps take most of the time
+    here: they are run once for all variants)."""
     p = H.default_params(model, *DIMS)
     f, g = H.make_inputs(model, *DIMS, seed, "allfluid", p)
     names = H.ATM_FIELDS if model == H.ATM else H.HYD_FIELDS
@@ -35,50 +37,52 @@ def _pair(model, seed):
             f[k] = m + (f[k] - m) / 256.
     f["H"], g["TOPOGRAPHY"] = _upsampled_mask(model)
     o = H.CpuModel("oracle", model, *DIMS, p, f, g)
-    d = atom_amd.DeviceModel(model, *DIMS, atom_amd.Params.from_buffer_copy(bytes(p)))
-    d.upload_all(f, g)
-    return o, d, names
+    devices = []
+    for v in variants:
+        d = atom_amd.DeviceModel(model, *DIMS, atom_amd.Params.from_buffer_copy(bytes(p)))
+        d.upload_all(f, g)
+        if v is None:
+            assert d.rk_variant() == (2 if model == H.ATM else 3)     # the handle's default
+        else:
+            d.set_rk_variant(v)
+        devices.append(d)
+    return o, devices, names
 
 
-def test_hyd_sweeps_and_pressure_quarter_degree_bitexact():
-    o, d, names = _pair(H.HYD, 301)
-    d.set_rk_variant(0)
-    for op in ("hyd_rk3d", "hyd_rk3d", "hyd_pressure3d"):       # two sweeps: both orientations of the buffer pair
-        o.op(op); d.op(op)
+def test_hyd_sweeps_and_pressure_quarter_degree():
+    """Two sweeps (both orientations of the buffer pair) and a pressure step: the oracle's bits with the sweep in its
+    exact form, every field within 1e-10 in the handle's default form (the pipelined one)."""
+    o, (exact, default), names = _pair(H.HYD, 301, (0, None))
+    worst = 0.0
+    for op in ("hyd_rk3d", "hyd_rk3d", "hyd_pressure3d"):
+        o.op(op); exact.op(op); default.op(op)
         for k in names:
             if k != "RESIDUUM":
                 assert np.isfinite(o.f[k]).all(), (op, k)
-                assert H.bits_equal(d.download(k), o.f[k]), (op, k, H.max_rel_err(d.download(k), o.f[k]))
-    d.close()
-
-
-def test_hyd_sweeps_and_pressure_quarter_degree_default_form():
-    """The same in the handle's default form of the sweep (the pipelined one): every field within 1e-10."""
-    o, d, names = _pair(H.HYD, 301)
-    assert d.rk_variant() == 3
-    worst = 0.0
-    for op in ("hyd_rk3d", "hyd_rk3d", "hyd_pressure3d"):
-        o.op(op); d.op(op)
-        for k in names:
-            if k != "RESIDUUM":
-                e = H.max_rel_err(d.download(k), o.f[k])
+                got = exact.download(k)
+                assert H.bits_equal(got, o.f[k]), (op, k, H.max_rel_err(got, o.f[k]))
+                e = H.max_rel_err(default.download(k), o.f[k])
                 worst = max(worst, e)
                 assert e <= 1e-10, (op, k, e)
     print("hydrosphere sweeps + pressure at 0.25 degrees, pipelined form: max rel err %.3e" % worst)
-    d.close()
+    exact.close(); default.close()
 
 
-@pytest.mark.parametrize("variant", [3, 2, 0])
-def test_atm_sweep_and_pressure_quarter_degree(variant):
-    o, d, names = _pair(H.ATM, 302)
-    d.set_rk_variant(variant)
-    worst = 0.0
+def test_atm_sweep_and_pressure_quarter_degree():
+    """A sweep and a pressure step with the sweep in its pipelined (3), wave-specialised tolerance (2, the default) and
+    exact (0) forms: every field within 1e-10 of the oracle."""
+    variants = (3, 2, 0)
+    o, devices, names = _pair(H.ATM, 302, variants)
+    worst = dict.fromkeys(variants, 0.0)
     for op in ("atm_rk3d", "atm_pressure3d"):
-        o.op(op); d.op(op)
-        for k in names:
-            if k != "RESIDUUM":
-                e = H.max_rel_err(d.download(k), o.f[k])
-                worst = max(worst, e)
-                assert e <= 1e-10, (op, k, e)
-    print("atmosphere sweep + pressure at 0.25 degrees, variant %d: max rel err %.3e" % (variant, worst))
-    d.close()
+        o.op(op)
+        for v, d in zip(variants, devices):
+            d.op(op)
+            for k in names:
+                if k != "RESIDUUM":
+                    e = H.max_rel_err(d.download(k), o.f[k])
+                    worst[v] = max(worst[v], e)
+                    assert e <= 1e-10, (v, op, k, e)
+    print("atmosphere sweep + pressure at 0.25 degrees: max rel err by sweep variant %r" % worst)
+    for d in devices:
+        d.close()
