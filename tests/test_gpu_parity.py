@@ -668,34 +668,51 @@ def test_hyd_start_needs_the_one_degree_rows():
     d.close()
 
 
-def test_hyd_sweeps_of_concurrent_handles_same_bits():
+@pytest.mark.parametrize("variant", [None, 0])
+def test_hyd_sweeps_of_concurrent_handles_same_bits(variant):
     """Volume sweeps of four hydrosphere handles enqueued side by side on their streams (the slices of a series share
     one GPU this way): level im-2 of each waits for rows another workgroup of its own launch stores, while the
-    launches compete for the compute units.  Every handle must end with the bits a handle running alone gets, and
-    no wait may give up (sync reports that)."""
+    launches compete for the compute units - with each other and with the surface sweeps of two more models, whose
+    waves wait for each other's rows in the same way and are enqueued first.  Every handle must end with the bits a
+    handle running alone gets, and no wait may give up (sync reports that).  In the handle's default form of the sweep
+    (the pipelined one) and in the exact form."""
     im, jm, km = 41, 181, 361
     p = H.default_params(H.HYD, im, jm, km)
     f, g = H.make_inputs(H.HYD, im, jm, km, 77, "allfluid", p)
     f = {k: f[k] for k in H.HYD_FIELDS}
     f["H"], g["TOPOGRAPHY"] = H.load_mask_0Ma(H.HYD)
     models = []
-    for _ in range(4):
+    for _ in range(6):
         d = atom_amd.DeviceModel(H.HYD, im, jm, km, atom_amd.Params.from_buffer_copy(bytes(p)))
         d.upload_all(f, g)
+        if variant is not None:
+            d.set_rk_variant(variant)
         models.append(d)
+    models, others = models[:4], models[4:]
     for _ in range(3):
         models[0].op("hyd_rk3d")
     models[0].sync()
     alone = {k: models[0].download(k) for k in ("T", "U", "V", "W", "C", "AUX_U", "SALT_BALANCE")}
-    models[0].upload_all(f, g)
     for _ in range(3):
+        others[0].op("hyd_rk2d")
+    others[0].sync()
+    surface_alone = {k: others[0].download(k) for k in ("V", "W")}
+    models[0].upload_all(f, g)
+    others[0].upload_all(f, g)
+    for _ in range(3):
+        for d in others:
+            d.op("hyd_rk2d")
         for d in models:
             d.op("hyd_rk3d")
-    for d in models:
+    for d in models + others:
         d.sync()
     for n, d in enumerate(models):
         for k, ref in alone.items():
             assert H.bits_equal(d.download(k), ref), (n, k)
+        d.close()
+    for n, d in enumerate(others):
+        for k, ref in surface_alone.items():
+            assert H.bits_equal(d.download(k), ref), ("surface", n, k)
         d.close()
 
 
