@@ -597,14 +597,16 @@ __global__ __launch_bounds__(1024) void k_hyd_rk3d_pipe(const PipeParams* __rest
         return;
     }
     __shared__ PipeShared sh;
-    // workgroup -> (level, longitude block): the host's table gives every XCD a chunk of consecutive levels, all blocks of
-    // a level together (see the launch)
+    // workgroup -> (level, longitude block): the host's table gives every XCD a chunk of consecutive levels (see the launch)
     const int gx = (K.km - 2 + 63) / 64;
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     const int bx = idx % gx;
 #ifdef ATOMDEV_EXP_HP_OLDMAP  // timing experiment only: levels dealt round robin to the XCDs
     const int lev = xcd + 8 * (idx / gx) < K.im - 2 ? xcd + 8 * (idx / gx) : -1;
 #else
+    // (all blocks of a level, then the next level of the chunk; the chunk's levels block by block instead - so that the
+    // workgroups of levels i and i+1 of a block run side by side where a launch takes several rounds - was no faster
+    // on the 0.25-degree grid)
     const int lev = P->level_of_slot[xcd * P->chunk + idx / gx];
 #endif
     if (lev < 0) return;
