@@ -30,6 +30,22 @@ __global__ void k_section_gather(double* __restrict__ dst, const double* __restr
     dst[e] = src[(e / width) * pitch + e % width];
 }
 
+// What the radial writer of the atmosphere leaves behind at Ma = 0 (PostProcess_Atm.cpp:287-309), one thread per column:
+// the Celsius copy of the NASA temperature, its difference to the ground temperature where the column has air at the
+// ground or a land cell below an air cell (in aux_v at the section's level), evaporation - precipitation (in aux_w).
+__global__ void k_radial_nasa_terms(const double* __restrict__ t_nasa, const double* __restrict__ t, const double* __restrict__ evap,
+                                    const double* __restrict__ precip, const uint8_t* __restrict__ flags, double* __restrict__ celsius,
+                                    double* __restrict__ aux_v, double* __restrict__ aux_w, double t_0, int im, size_t n2) {
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n2) return;
+    celsius[q] = t_nasa[q] * t_0 - t_0;
+    bool assigned = !(flags[q] & FL_LAND);  // is_air(h, 0, j, k)
+    for (int i = im - 2; i >= 0 && !assigned; i--)
+        if (!(flags[(size_t)(i + 1) * n2 + q] & FL_LAND) && (flags[(size_t)i * n2 + q] & FL_LAND)) assigned = true;
+    if (assigned) aux_v[q] = (t[q] - t_nasa[q]) * t_0;
+    aux_w[q] = evap[q] - precip[q];
+}
+
 // one section of a 3-D field in the order the writers walk it: radial [j][k], longal [i][k], zonal [i][j]
 struct Section {
     atomdev* h;
@@ -261,30 +277,13 @@ int write_vtk(atomdev* h, int kind, int index, int Ma, const char* path) {
         const double p_scale = P.u_0 * P.u_0 * P.r_air * .01;
         if (kind == ATOMDEV_RADIAL) {
             if (Ma == 0) {  // :287-309: Celsius copy of the NASA temperature, its difference to t, evaporation - precipitation
-                std::vector<double> t_nasa, t0, evap, precip, aux_v, aux_w;
-                std::vector<uint8_t> flags((size_t)im * n2);
                 if (int rc = atomdev_refresh_flags(h)) return rc;
-                if (int rc = surface(ATOMDEV_TEMPERATURE_NASA, t_nasa)) return rc;
-                if (int rc = surface(ATOMDEV_EVAPORATION_DALTON, evap)) return rc;
-                if (int rc = surface(ATOMDEV_PRECIPITATION, precip)) return rc;
-                if (int rc = slice(ATOMDEV_AUX_V, aux_v)) return rc;
-                t0.resize(n2); aux_w.resize(n2);
-                ATOMDEV_TRY(hipMemcpyAsync(t0.data(), h->f[ATOMDEV_T], n2 * 8, hipMemcpyDeviceToHost, h->stream));
-                ATOMDEV_TRY(hipMemcpyAsync(flags.data(), h->flags, flags.size(), hipMemcpyDeviceToHost, h->stream));
-                if (int rc = sync()) return rc;
-                std::vector<double> celsius(n2);
-                for (size_t q = 0; q < n2; q++) {
-                    celsius[q] = t_nasa[q] * P.t_0 - P.t_0;
-                    bool assigned = !(flags[q] & FL_LAND);  // is_air(h, 0, j, k)
-                    for (int i = im - 2; i >= 0 && !assigned; i--)
-                        if (!(flags[(size_t)(i + 1) * n2 + q] & FL_LAND) && (flags[(size_t)i * n2 + q] & FL_LAND)) assigned = true;
-                    if (assigned) aux_v[q] = (t0[q] - t_nasa[q]) * P.t_0;
-                    aux_w[q] = evap[q] - precip[q];
-                }
-                ATOMDEV_TRY(hipMemcpyAsync(h->g[ATOMDEV_TEMP_NASA_CELSIUS], celsius.data(), n2 * 8, hipMemcpyHostToDevice, h->stream));
-                if (int rc = sec.put(ATOMDEV_AUX_V, aux_v)) return rc;
-                if (int rc = sec.put(ATOMDEV_AUX_W, aux_w)) return rc;
-                if (int rc = sync()) return rc;
+                hipLaunchKernelGGL(k_radial_nasa_terms, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, h->stream,
+                                   (const double*)h->g[ATOMDEV_TEMPERATURE_NASA], (const double*)h->f[ATOMDEV_T],
+                                   (const double*)h->g[ATOMDEV_EVAPORATION_DALTON], (const double*)h->g[ATOMDEV_PRECIPITATION],
+                                   (const uint8_t*)h->flags, h->g[ATOMDEV_TEMP_NASA_CELSIUS], h->f[ATOMDEV_AUX_V] + (size_t)index * n2,
+                                   h->f[ATOMDEV_AUX_W] + (size_t)index * n2, P.t_0, im, n2);
+                ATOMDEV_TRY(hipGetLastError());
             }
             out.lit(point_data);
             out.column("u-Component", u, 1.); out.column("v-Component", v, 1.); out.column("w-Component", w, 1.);
