@@ -132,9 +132,15 @@ __device__ __forceinline__ void announce_in_order(int* word, int row, int lane) 
     if (lane == 0) *LDS_WORD(word) = row;
     asm volatile("" ::: "memory");
 }
-__device__ __forceinline__ void wait_for(const int* word, int need, int* err) {
+#ifdef ATOMDEV_EXP_PIPE_COUNT  // experiment only: how often each kind of wave found its input not there yet
+#define PCOUNT(x) ((x)++)
+#else
+#define PCOUNT(x) do {} while (0)
+#endif
+__device__ __forceinline__ void wait_for(const int* word, int need, int* err, int& spins) {
     asm volatile("" ::: "memory");
     for (int n = 0; __builtin_amdgcn_readfirstlane(*LDS_WORD(word)) < need; n++) {
+        PCOUNT(spins);
         __builtin_amdgcn_s_sleep(2);
         if (n > (1 << 22)) {
             __hip_atomic_store(err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -271,13 +277,13 @@ __device__ __forceinline__ void memory_wave(const PipeArgs& a, const DevConst& K
     const int first = q == 0 ? 4 : q;
     if (first <= NR) issue(first);
     bool land_prev = false;
-    int r_last = 0;
+    int r_last = 0, spins = 0;
 
     for (int r = first; r <= NR; r += 4) {
         const int e = r;
         PSTAMP(stamp_wave, 0);
         // the slot is free once the chain wave has finished the row that stood in it; its results go to memory first
-        wait_for(done, r - 4, err);
+        wait_for(done, r - 4, err, spins);
         if (r > 4) store_row(r - 4, land_prev);
         PSTAMP(stamp_wave, 1);
         {
@@ -371,9 +377,12 @@ __device__ __forceinline__ void memory_wave(const PipeArgs& a, const DevConst& K
         }
     }
     if (r_last) {  // the wave's last row
-        wait_for(done, r_last, err);
+        wait_for(done, r_last, err, spins);
         store_row(r_last, land_prev);
     }
+#ifdef ATOMDEV_EXP_PIPE_COUNT
+    if (lane == 0 && bx == 2 && i == ATOMDEV_EXP_PIPE_COUNT) a.aux_w[16 + 2 * q + (FORA ? 0 : 1)] = (double)spins;
+#endif
 }
 
 // ---- chain wave A: v, u, c, t ------------------------------------------------------------------------------------
@@ -394,6 +403,8 @@ __device__ __forceinline__ void chain_a(const PipeArgs& a, const DevConst& K, Pi
     double xm1[4], xm2[4] = { 0., 0., 0., 0. };
 #pragma unroll
     for (int n = 0; n < 4; n++) xm1[n] = gld(a.x[VARS[n]], o_lev);
+    int retries = 0, why[3] = { 0, 0, 0 };
+    (void)retries; (void)why;
 
     for (int j = 1; j <= NR; j++) {
         const int e = j;
@@ -422,6 +433,10 @@ __device__ __forceinline__ void chain_a(const PipeArgs& a, const DevConst& K, Pi
             asm volatile("" ::: "memory");
             if (__builtin_amdgcn_readfirstlane(w_rdy) >= j && __builtin_amdgcn_readfirstlane(w_st) >= j - 4 &&
                 __builtin_amdgcn_readfirstlane(w_b) >= j - 2) break;
+            PCOUNT(retries);
+#ifdef ATOMDEV_EXP_PIPE_COUNT
+            if (__builtin_amdgcn_readfirstlane(w_rdy) < j) why[0]++; else if (__builtin_amdgcn_readfirstlane(w_st) < j - 4) why[1]++; else why[2]++;
+#endif
             __builtin_amdgcn_s_sleep(1);
             if (n > (1 << 22)) {
                 __hip_atomic_store(err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -480,6 +495,9 @@ __device__ __forceinline__ void chain_a(const PipeArgs& a, const DevConst& K, Pi
         announce_in_order(&sh.doneA, j, lane);
         PSTAMP(0, 3);
     }
+#ifdef ATOMDEV_EXP_PIPE_COUNT
+    if (lane == 0 && bx == 2 && i == ATOMDEV_EXP_PIPE_COUNT) { a.aux_w[0] = retries; a.aux_w[1] = why[0]; a.aux_w[2] = why[1]; a.aux_w[3] = why[2]; }
+#endif
 }
 
 // ---- chain wave B: w, cloud, ice, co2, behind A --------------------------------------------------------------------
@@ -498,6 +516,8 @@ __device__ __forceinline__ void chain_b(const PipeArgs& a, const DevConst& K, Pi
     double xm1[4], xm2[4] = { 0., 0., 0., 0. };
 #pragma unroll
     for (int n = 0; n < 4; n++) xm1[n] = gld(a.x[VARS[n]], o_lev);
+    int retries = 0, why[3] = { 0, 0, 0 };
+    (void)retries; (void)why;
 
     for (int j = 1; j <= NR; j++) {
         const int e = j;
@@ -521,6 +541,10 @@ __device__ __forceinline__ void chain_b(const PipeArgs& a, const DevConst& K, Pi
             asm volatile("" ::: "memory");
             if (__builtin_amdgcn_readfirstlane(w_rdy) >= j && __builtin_amdgcn_readfirstlane(w_st) >= j - 4 &&
                 __builtin_amdgcn_readfirstlane(w_a) >= j) break;
+            PCOUNT(retries);
+#ifdef ATOMDEV_EXP_PIPE_COUNT
+            if (__builtin_amdgcn_readfirstlane(w_rdy) < j) why[0]++; else if (__builtin_amdgcn_readfirstlane(w_st) < j - 4) why[1]++; else why[2]++;
+#endif
             __builtin_amdgcn_s_sleep(1);
             if (n > (1 << 22)) {
                 __hip_atomic_store(err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -560,6 +584,9 @@ __device__ __forceinline__ void chain_b(const PipeArgs& a, const DevConst& K, Pi
         announce_in_order(&sh.doneB, j, lane);
         PSTAMP(1, 3);
     }
+#ifdef ATOMDEV_EXP_PIPE_COUNT
+    if (lane == 0 && bx == 2 && i == ATOMDEV_EXP_PIPE_COUNT) { a.aux_w[4] = retries; a.aux_w[5] = why[0]; a.aux_w[6] = why[1]; a.aux_w[7] = why[2]; }
+#endif
 }
 
 // Waves of the 1 024-thread workgroup: w and w + 4 (and w + 8, w + 12) share a SIMD.  Wave 0 is chain A, wave 1 chain B,
