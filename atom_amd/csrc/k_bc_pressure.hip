@@ -336,8 +336,13 @@ __global__ void k_pressure3d(double* __restrict__ p_dyn, const double* __restric
                              const uint8_t* __restrict__ flags, const double* __restrict__ rad,
                              const double* __restrict__ sinthe_t, double rho, DevConst K) {
     const int im = K.im, jm = K.jm, km = K.km;
-    const int k = 1 + blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = 1 + blockIdx.y, i = 1 + blockIdx.z;
+    // Workgroups go to the eight XCDs in turn; each XCD gets one contiguous run of (level, row, segment) triples, so the
+    // neighbour rows and levels a workgroup reads are, most of the time, already in its XCD's L2.
+    const unsigned gx = (unsigned)(km - 2 + (int)blockDim.x - 1) / blockDim.x, nblk = gx * (unsigned)(jm - 2) * (unsigned)(im - 2);
+    const unsigned per = (nblk + 7) / 8, L = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= per || L >= nblk) return;
+    const int k = 1 + (int)(L % gx) * (int)blockDim.x + (int)threadIdx.x;
+    const int j = 1 + (int)((L / gx) % (unsigned)(jm - 2)), i = 1 + (int)(L / (gx * (unsigned)(jm - 2)));
     // What depends on the row (i, j) only - ten divisions of the reference's statements - is worked out by one thread of
     // the block; every quotient by one of these divisors is then div_by with the divisor's correctly rounded reciprocal
     // (the bits of the division, atomdev_internal.h).  2 dphi rm sin (Pressure_Hyd) and 2 rm sin dphi (Pressure_Atm) are
@@ -541,7 +546,8 @@ int pressure3d(atomdev* h, bool hyd) {
         if (int rc = fill_theta(h, AUX, NE3, 3, 0, h->im)) return rc;
         if (int rc = fill_phi(h, AUX, 3, 0, h->im, 0, h->jm)) return rc;
     }
-    dim3 grid((h->km - 2 + 127) / 128, h->jm - 2, h->im - 2);
+    const unsigned nblk3 = (unsigned)((h->km - 2 + 127) / 128) * (unsigned)(h->jm - 2) * (unsigned)(h->im - 2);
+    dim3 grid(8 * ((nblk3 + 7) / 8));
     const double rho = hyd ? h->p.r_0_water : h->p.r_air;
     if (hyd)
         hipLaunchKernelGGL(k_pressure3d<true>, grid, dim3(128), 0, h->stream, h->f[ATOMDEV_P_DYN], h->f[ATOMDEV_P_DYNN],

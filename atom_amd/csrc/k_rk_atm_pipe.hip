@@ -282,10 +282,9 @@ __device__ __forceinline__ void memory_wave(const PipeArgs& a, const DevConst& K
     for (int r = first; r <= NR; r += 4) {
         const int e = r;
         PSTAMP(stamp_wave, 0);
-        // the slot is free once the chain wave has finished the row that stood in it; its results go to memory first
-        wait_for(done, r - 4, err, spins);
-        if (r > 4) store_row(r - 4, land_prev);
-        PSTAMP(stamp_wave, 1);
+        // The row's packet is worked out in registers first (its loads were issued a turn ago); only writing it needs the
+        // slot, which is free once the chain wave has finished the row that stood in it.  That row's results go to memory
+        // after the packet has been announced: the chain wave looks at `stored` only when it is about to write results.
         {
             const bool window = r >= 2 && r < jm - 3;
             const double g = geo_lds ? sh.geo[r][0] : lcos * lirs;
@@ -293,7 +292,6 @@ __device__ __forceinline__ void memory_wave(const PipeArgs& a, const DevConst& K
             // the mask: RHS_Atm.cpp:110-149
             const unsigned fl = lfl;
             const bool land = fl & FL_LAND;
-            land_prev = land;
             const double hdj = ((fl & FL_H0J) && (fl & FL_H0K)) ? 0. : 1.;
             // which theta form stands (RHS_Atm.cpp:162-170, 192-199, 245-312), as factors of x, x[j-1], x[j-2], x[j+1]
             const int mode = !window ? 0 : ((fl & FL_ONESIDED_S) ? 2 : 1);
@@ -313,28 +311,29 @@ __device__ __forceinline__ void memory_wave(const PipeArgs& a, const DevConst& K
             }
             const double dmp_i = h0i * i_dr2;
             double KQ[4], KB[4] = { 0., 0., 0., 0. };
+            double o_cA, o_H1, o_H2, o_q1[3], o_q2[3], o_cP[4] = { 0., 0., 0., 0. }, o_pgv = 0., o_cR = 0., o_qu1 = 0., o_qu2 = 0., o_cFac = 0., o_cMc = 0., o_phk = 0.;
             if (!window) {  // b2 = f2 = 0 on these rows: the x[j-2] arrays are free for KB
                 const double H3 = b3 * hDr;
 #pragma unroll
                 for (int n = 0; n < 4; n++) KB[n] = H3 * lxp[n];
             }
             if constexpr (FORA) {
-                SA.cA[lane] = A1 * i_rm; SA.H1[lane] = b1 * hDr; SA.H2[lane] = b2 * hDr;
+                o_cA = A1 * i_rm; o_H1 = b1 * hDr; o_H2 = b2 * hDr;
 #pragma unroll
-                for (int c = 0; c < 3; c++) { SA.q1[c][lane] = G1 * idc[c]; SA.q2[c][lane] = window ? G2 * idc[c] : KB[c]; }
+                for (int c = 0; c < 3; c++) { o_q1[c] = G1 * idc[c]; o_q2[c] = window ? G2 * idc[c] : KB[c]; }
                 // factor of the stage value outside the advection product: diffusion bracket and damping
                 const double p_re = Pb * i_re;
                 const double h0j = (fl & FL_H0J) ? 1. : 0.;
-                SA.cP[0][lane] = p_re - coefv * hdj * i_re - h0j * i_dthe2;
-                SA.cP[1][lane] = p_re - dmp_i;
-                SA.cP[2][lane] = Pb * i_re_sc_wv;
-                SA.cP[3][lane] = Pb * i_re_x;
+                o_cP[0] = p_re - coefv * hdj * i_re - h0j * i_dthe2;
+                o_cP[1] = p_re - dmp_i;
+                o_cP[2] = Pb * i_re_sc_wv;
+                o_cP[3] = Pb * i_re_x;
                 // pressure gradient of the v equation (p_dyn is not changed by the sweep)
                 const double dp = hD * (fa * lp[2] + b1 * lp[1] + b2 * lp[0] + b3 * lp[3]);
                 const double pgv = hdj * dp * i_rm * i_r_air;
-                SA.pgv[lane] = pgv;
+                o_pgv = pgv;
                 const double twoD = two * hD;
-                SA.cR[lane] = two * A1; SA.qu1[lane] = twoD * b1; SA.qu2[lane] = window ? twoD * b2 : KB[3];
+                o_cR = two * A1; o_qu1 = twoD * b1; o_qu2 = window ? twoD * b2 : KB[3];
                 // constant terms: sources, and on the pole-side rows the old row j+1
                 KQ[0] = -pgv; KQ[1] = 0.; KQ[2] = lS[4] * ctr; KQ[3] = ce * (lS[0] + lS[1]) + ce * (lS[2] + lS[3]);
                 if (!window) KQ[0] = __builtin_fma(twoD * b3, lxp[1], KQ[0]);
@@ -342,25 +341,47 @@ __device__ __forceinline__ void memory_wave(const PipeArgs& a, const DevConst& K
                     double ep = lev - lpr;
                     if (ep >= 6.) ep = 6.;
                     if (ep <= -6.) ep = -6.;
-                    SA.cFac[lane] = land ? 0. : evf * (1. - 2. * lc0) * ep;
-                    SA.cMc[lane] = -3. * lc0 - lc3;
-                    SA.phk[lane] = lph * i_phk;
+                    o_cFac = land ? 0. : evf * (1. - 2. * lc0) * ep;
+                    o_cMc = -3. * lc0 - lc3;
+                    o_phk = lph * i_phk;
                 }
             } else {
-                SB.cA[lane] = A1 * i_rm; SB.H1[lane] = b1 * hDr; SB.H2[lane] = window ? b2 * hDr : KB[3];
+                o_cA = A1 * i_rm; o_H1 = b1 * hDr; o_H2 = window ? b2 * hDr : KB[3];
 #pragma unroll
-                for (int c = 0; c < 3; c++) { SB.q1[c][lane] = G1 * idc[c]; SB.q2[c][lane] = window ? G2 * idc[c] : KB[c]; }
+                for (int c = 0; c < 3; c++) { o_q1[c] = G1 * idc[c]; o_q2[c] = window ? G2 * idc[c] : KB[c]; }
                 const double h0k = (fl & FL_H0K) ? 1. : 0.;
                 const double p_wv = Pb * i_re_sc_wv;
-                SB.cP[0][lane] = __builtin_fma(-h0k, i_dphi2, Pb * i_re);
-                SB.cP[1][lane] = p_wv - dmp_i;
-                SB.cP[2][lane] = __builtin_fma(Pb, i_re_x, -dmp_i);
+                o_cP[0] = __builtin_fma(-h0k, i_dphi2, Pb * i_re);
+                o_cP[1] = p_wv - dmp_i;
+                o_cP[2] = __builtin_fma(Pb, i_re_x, -dmp_i);
                 KQ[0] = 0.; KQ[1] = lS[0] * ctr; KQ[2] = lS[2] * ctr; KQ[3] = 0.;
             }
             if (!window) {
                 const double G3 = __builtin_fma(f3, hEr, b3 * hDg);
 #pragma unroll
                 for (int n = 0; n < 4; n++) KQ[n] = __builtin_fma(G3 * idc[CLS[n]], lxp[n], KQ[n]);
+            }
+            // (kept from moving below the wait)
+            PIN(o_cA); PIN(o_H1); PIN(o_H2); PIN(o_cP[0]); PIN(o_cP[1]); PIN(o_cP[2]);
+#pragma unroll
+            for (int c = 0; c < 3; c++) { PIN(o_q1[c]); PIN(o_q2[c]); }
+#pragma unroll
+            for (int n = 0; n < 4; n++) PIN(KQ[n]);
+            if constexpr (FORA) { PIN(o_cP[3]); PIN(o_pgv); PIN(o_cR); PIN(o_qu1); PIN(o_qu2); }
+            PSTAMP(stamp_wave, 1);
+            wait_for(done, r - 4, err, spins);
+            if constexpr (FORA) {
+                SA.cA[lane] = o_cA; SA.H1[lane] = o_H1; SA.H2[lane] = o_H2; SA.cR[lane] = o_cR; SA.pgv[lane] = o_pgv;
+                SA.qu1[lane] = o_qu1; SA.qu2[lane] = o_qu2;
+#pragma unroll
+                for (int c = 0; c < 3; c++) { SA.q1[c][lane] = o_q1[c]; SA.q2[c][lane] = o_q2[c]; }
+#pragma unroll
+                for (int n = 0; n < 4; n++) SA.cP[n][lane] = o_cP[n];
+                if constexpr (L1) { SA.cFac[lane] = o_cFac; SA.cMc[lane] = o_cMc; SA.phk[lane] = o_phk; }
+            } else {
+                SB.cA[lane] = o_cA; SB.H1[lane] = o_H1; SB.H2[lane] = o_H2;
+#pragma unroll
+                for (int c = 0; c < 3; c++) { SB.q1[c][lane] = o_q1[c]; SB.q2[c][lane] = o_q2[c]; SB.cP[c][lane] = o_cP[c]; }
             }
             double (*x0)[64] = FORA ? SA.x0 : SB.x0, (*xn)[64] = FORA ? SA.xn : SB.xn, (*kq)[64] = FORA ? SA.KQ : SB.KQ;
 #pragma unroll
@@ -371,6 +392,8 @@ __device__ __forceinline__ void memory_wave(const PipeArgs& a, const DevConst& K
             }
             PSTAMP(stamp_wave, 2);
             announce(&ctl->rdy, r, lane);
+            if (r > 4) store_row(r - 4, land_prev);
+            land_prev = land;
             r_last = r;
             if (r + 4 <= NR) issue(r + 4);
             PSTAMP(stamp_wave, 3);
@@ -409,16 +432,17 @@ __device__ __forceinline__ void chain_a(const PipeArgs& a, const DevConst& K, Pi
     for (int j = 1; j <= NR; j++) {
         const int e = j;
         PSTAMP(0, 0);
-        // the row's packet; the slot's output arrays free (row j-4 stored); the buffer for the stage values of v free
-        // (chain B done with row j-2)
+        // the row's packet; the buffer for the stage values of v free (chain B done with row j-2)
         const bool window = j >= 2 && j < jm - 3;
         const HalfA& S = sh.ha[j & 3];
         double (*vst)[64] = sh.vst[j & 1];
         double (*out)[64] = sh.outA[j & 3];
         double cA, H1, H2, cR, pgv, qu1, qu2, cFac = 0., cMc = 0., phk = 0.;
+        int stored_seen = 0;
         double st[4], xn[4], cB[4], cQ[4], cP[4], acc[4], rhs[4], q1[3], q2[3], kq[4];
         // The words and the packet are read in one go: the words first, so a packet read behind words that say "there" is
-        // the packet (a wave's LDS reads are carried out in order); if the words say "not yet", everything is read again.
+        // the packet (a wave's LDS reads are carried out in order); if the words say "not yet", the words are waited for and
+        // everything is read again.
         for (int n = 0;; n++) {
             asm volatile("" ::: "memory");
             const int w_rdy = *LDS_WORD(&sh.ctlA[j & 3].rdy), w_st = *LDS_WORD(&sh.ctlA[j & 3].stored);
@@ -431,14 +455,16 @@ __device__ __forceinline__ void chain_a(const PipeArgs& a, const DevConst& K, Pi
             for (int m = 0; m < 4; m++) { st[m] = S.x0[m][lane]; xn[m] = S.xn[m][lane]; cP[m] = S.cP[m][lane]; kq[m] = S.KQ[m][lane]; }
             if constexpr (L1) { cFac = S.cFac[lane]; cMc = S.cMc[lane]; phk = S.phk[lane]; }
             asm volatile("" ::: "memory");
-            if (__builtin_amdgcn_readfirstlane(w_rdy) >= j && __builtin_amdgcn_readfirstlane(w_st) >= j - 4 &&
-                __builtin_amdgcn_readfirstlane(w_b) >= j - 2) break;
+            stored_seen = __builtin_amdgcn_readfirstlane(w_st);
+            if (__builtin_amdgcn_readfirstlane(w_rdy) >= j && __builtin_amdgcn_readfirstlane(w_b) >= j - 2) break;
             PCOUNT(retries);
 #ifdef ATOMDEV_EXP_PIPE_COUNT
-            if (__builtin_amdgcn_readfirstlane(w_rdy) < j) why[0]++; else if (__builtin_amdgcn_readfirstlane(w_st) < j - 4) why[1]++; else why[2]++;
+            if (__builtin_amdgcn_readfirstlane(w_rdy) < j) why[0]++; else why[2]++;
 #endif
-            __builtin_amdgcn_s_sleep(1);
-            if (n > (1 << 22)) {
+            // not there: the words alone are polled (the LDS stays free for the other waves), then everything is read again
+            wait_for(&sh.ctlA[j & 3].rdy, j, err, why[0]);
+            wait_for(&sh.doneB, j - 2, err, why[2]);
+            if (n > 2) {
                 __hip_atomic_store(err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 break;
             }
@@ -488,7 +514,10 @@ __device__ __forceinline__ void chain_a(const PipeArgs& a, const DevConst& K, Pi
             }
         }
         PSTAMP(0, 2);
-        // results and the side outputs of the fourth evaluation, for the memory wave of the slot to store
+        // results and the side outputs of the fourth evaluation, for the memory wave of the slot to store; the slot's
+        // output arrays are free once row j-4 has been stored (looked at here, not at the top: the memory wave stores a
+        // row after it has announced the packet of the row four on)
+        if (stored_seen < j - 4) { wait_for(&sh.ctlA[j & 3].stored, j - 4, err, why[1]); }
 #pragma unroll
         for (int n = 0; n < 4; n++) { out[n][lane] = st[n]; xm2[n] = xm1[n]; xm1[n] = st[n]; }
         out[4][lane] = rhs[cU]; out[5][lane] = rhs[cV] + pgv; out[6][lane] = -RS * cb1000;
@@ -527,30 +556,33 @@ __device__ __forceinline__ void chain_b(const PipeArgs& a, const DevConst& K, Pi
         const double (*vst)[64] = sh.vst[j & 1];
         double (*out)[64] = sh.outB[j & 3];
         double cA, H1, H2, vs[4];
+        int stored_seen = 0;
         double st[4], xn[4], cB[4], cQ[4], cP[4], acc[4], rhs[4], q1[3], q2[3], kq[4];
-        for (int n = 0;; n++) {   // words and packet in one go, as in chain A; here also the stage values of v of the row
+        // The packet is nearly always there long before chain A has done the row: it is read together with its word (and
+        // again if the word says "not yet"); then chain A's word alone is polled, and the four stage values of v are read
+        // once it says "done".  (Reading the whole packet at every poll would keep the LDS busy while chain A needs it.)
+        for (int n = 0;; n++) {
             asm volatile("" ::: "memory");
             const int w_rdy = *LDS_WORD(&sh.ctlB[j & 3].rdy), w_st = *LDS_WORD(&sh.ctlB[j & 3].stored);
-            const int w_a = *LDS_WORD(&sh.doneA);
             asm volatile("" ::: "memory");
             cA = S.cA[lane]; H1 = S.H1[lane]; H2 = S.H2[lane];
 #pragma unroll
             for (int c = 0; c < 3; c++) { q1[c] = S.q1[c][lane]; q2[c] = S.q2[c][lane]; }
 #pragma unroll
-            for (int m = 0; m < 4; m++) { st[m] = S.x0[m][lane]; xn[m] = S.xn[m][lane]; cP[m] = S.cP[CPS[m]][lane]; kq[m] = S.KQ[m][lane]; vs[m] = vst[m][lane]; }
+            for (int m = 0; m < 4; m++) { st[m] = S.x0[m][lane]; xn[m] = S.xn[m][lane]; cP[m] = S.cP[CPS[m]][lane]; kq[m] = S.KQ[m][lane]; }
             asm volatile("" ::: "memory");
-            if (__builtin_amdgcn_readfirstlane(w_rdy) >= j && __builtin_amdgcn_readfirstlane(w_st) >= j - 4 &&
-                __builtin_amdgcn_readfirstlane(w_a) >= j) break;
-            PCOUNT(retries);
-#ifdef ATOMDEV_EXP_PIPE_COUNT
-            if (__builtin_amdgcn_readfirstlane(w_rdy) < j) why[0]++; else if (__builtin_amdgcn_readfirstlane(w_st) < j - 4) why[1]++; else why[2]++;
-#endif
+            stored_seen = __builtin_amdgcn_readfirstlane(w_st);
+            if (__builtin_amdgcn_readfirstlane(w_rdy) >= j) break;
+            PCOUNT(retries); PCOUNT(why[0]);
             __builtin_amdgcn_s_sleep(1);
             if (n > (1 << 22)) {
                 __hip_atomic_store(err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 break;
             }
         }
+        wait_for(&sh.doneA, j, err, why[2]);
+#pragma unroll
+        for (int m = 0; m < 4; m++) vs[m] = vst[m][lane];
         PSTAMP(1, 1);
 #pragma unroll
         for (int n = 0; n < 4; n++) {
@@ -578,6 +610,7 @@ __device__ __forceinline__ void chain_b(const PipeArgs& a, const DevConst& K, Pi
                 else st[n] = __builtin_fma(acc[n] + rhs[n], dt6, xn[n]);
             }
         }
+        if (stored_seen < j - 4) { wait_for(&sh.ctlB[j & 3].stored, j - 4, err, why[1]); }
 #pragma unroll
         for (int n = 0; n < 4; n++) { out[n][lane] = st[n]; xm2[n] = xm1[n]; xm1[n] = st[n]; }
         out[4][lane] = rhs[0];
@@ -591,9 +624,10 @@ __device__ __forceinline__ void chain_b(const PipeArgs& a, const DevConst& K, Pi
 
 // Waves of the 1 024-thread workgroup: w and w + 4 (and w + 8, w + 12) share a SIMD.  Wave 0 is chain A, wave 1 chain B,
 // and the waves that would share their SIMDs end at once; the eight waves on the other two SIMDs are the memory waves:
-// rows r = q mod 4 belong to the pair (2 + 4 q, 3 + 4 q).  One wave of a pair works for chain A, the other for chain B;
-// chain A's half of a row is about twice the instructions of chain B's, so which is which alternates with q and each of
-// the two SIMDs carries two waves of either kind.
+// rows r = q mod 4 belong to pair q.  One wave of a pair works for chain A, the other for chain B; chain A's half of a row
+// is about twice the instructions of chain B's, so which is which alternates with q and each of the two SIMDs carries
+// two waves of either kind.  (Spreading the memory waves over the chain waves' SIMDs too - rows 1 to 3 of the table
+// below - changed the sweep's time by 2 per cent at most.)
 template <bool LIMIT>
 __global__ __launch_bounds__(1024) void k_atm_rk3d_pipe(const PipeParams* __restrict__ P, int* err) {
     const PipeArgs& a = P->a;
@@ -619,17 +653,27 @@ __global__ __launch_bounds__(1024) void k_atm_rk3d_pipe(const PipeParams* __rest
     for (int n = threadIdx.x; n < 10 * 4 * 8; n += blockDim.x) (&sh.stamps[0][0][0])[n] = 0;
     __syncthreads();
 #endif
-    const bool fora = ((wave & 3) == 2) != (((wave >> 2) & 1) != 0);   // (see above: the two kinds alternate on a SIMD)
-    if (wave == 0) {
+    // role of a wave: 0 chain A, 1 chain B, 2 + 2 q memory wave of pair q for chain A, 3 + 2 q for chain B, -1 none
+#ifndef ATOMDEV_EXP_ROLEMAP
+#define ATOMDEV_EXP_ROLEMAP 0
+#endif
+    static constexpr signed char ROLE[4][16] = {
+        // SIMD:   0   1   2   3    0   1   2   3    0   1   2   3    0   1   2   3
+        {          0,  1,  2,  3,  -1, -1,  5,  4,  -1, -1,  6,  7,  -1, -1,  9,  8 },
+        {          0,  1,  2,  4,   3,  5,  6,  8,  -1, -1,  7,  9,  -1, -1, -1, -1 },
+        {          0,  1,  2,  4,  -1,  3,  6,  8,  -1,  5,  7,  9,  -1, -1, -1, -1 },
+        {          0,  1,  2,  4,   3,  5,  6,  8,   7,  9, -1, -1,  -1, -1, -1, -1 } };
+    const int role = ROLE[ATOMDEV_EXP_ROLEMAP][wave];
+    if (role == 0) {
         if (i == 1) chain_a<true>(a, K, sh, i, bx, err);
         else chain_a<false>(a, K, sh, i, bx, err);
-    } else if (wave == 1) {
+    } else if (role == 1) {
         chain_b(a, K, sh, i, bx, err);
-    } else if ((wave & 3) >= 2 && fora) {
-        if (i == 1) memory_wave<true, true, LIMIT>(a, K, sh, wave >> 2, i, bx, err);
-        else memory_wave<false, true, LIMIT>(a, K, sh, wave >> 2, i, bx, err);
-    } else if ((wave & 3) >= 2) {
-        memory_wave<false, false, LIMIT>(a, K, sh, wave >> 2, i, bx, err);
+    } else if (role >= 2 && !(role & 1)) {
+        if (i == 1) memory_wave<true, true, LIMIT>(a, K, sh, (role - 2) >> 1, i, bx, err);
+        else memory_wave<false, true, LIMIT>(a, K, sh, (role - 2) >> 1, i, bx, err);
+    } else if (role >= 2) {
+        memory_wave<false, false, LIMIT>(a, K, sh, (role - 2) >> 1, i, bx, err);
     }
 #ifdef ATOMDEV_EXP_PIPE_STAMP
     __syncthreads();

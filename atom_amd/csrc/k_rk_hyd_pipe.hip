@@ -10,7 +10,7 @@
 //     cB = H1 x[j-1] + H2 x[j-2] + KB        cQ = q1 x[j-1] + q2 x[j-2] + KQ
 // where everything else depends on the mask, the geometry, the level above and OLD values only.
 //
-// Mapping.  A workgroup owns 64 neighbouring theta lines of one level.  Of its sixteen waves ten live:
+// Mapping.  A workgroup owns 64 neighbouring theta lines of one level.  Of its twelve waves ten live:
 //   eight "memory" waves in four pairs that take the rows in turn (row r belongs to pair r mod 4; one wave of the pair
 //       works for chain A, the other for chain B): loads, the row's coefficient packet into a ring of four LDS slots,
 //       the stores of the row that stood in the slot before, the loads of the row four on;
@@ -149,6 +149,12 @@ __device__ __forceinline__ void wait_rows(const int* progress, int need, int* er
     }
     asm volatile("" ::: "memory");
 }
+// a value every lane holds alike, moved to scalar registers
+__device__ __forceinline__ double uniform(double x) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, x);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ double rcp2(double b) {  // hardware estimate and two Newton steps: full precision
     double y = __builtin_amdgcn_rcp(b);
     double e = __builtin_fma(-b, y, 1.0);
@@ -203,6 +209,9 @@ __device__ __forceinline__ void memory_wave(const PipeArgs& a, const DevConst& K
     double lcos = 0., lirs = 0., lcoefv = 0.;
     unsigned lfl;
     auto issue = [&](const int r) {
+#ifdef ATOMDEV_EXP_HP_NOMEM  // timing experiment only (results are wrong): no vector-memory traffic inside the loop
+        if (r > 8) return;
+#endif
         const unsigned o = o_lev + (unsigned)r * rowB;
         const unsigned oq = o_sfc + (unsigned)r * rowB;
         lfl = *(const __attribute__((address_space(1))) uint8_t*)((gcchar_t)a.flags + (o >> 3));
@@ -247,6 +256,9 @@ __device__ __forceinline__ void memory_wave(const PipeArgs& a, const DevConst& K
     // The results of row `rs`, which the chain wave left in the slot's output arrays; side outputs zero on land, where
     // the two densities are rewritten instead (RHS_Hyd.cpp:379-402, 440-446).
     auto store_row = [&](const int rs, const bool land) {
+#ifdef ATOMDEV_EXP_HP_NOMEM
+        if (rs > 8) { announce(&ctl->stored, rs, lane); return; }
+#endif
         const unsigned o = o_lev + (unsigned)rs * rowB;
         if constexpr (FORA) {
             const double (*out)[64] = sh.outA[q];
@@ -399,90 +411,128 @@ __device__ __forceinline__ void chain_a(const PipeArgs& a, const DevConst& K, Pi
     constexpr int CLS[3] = { 0, 0, 1 };
     enum { cV = 0, cU = 1, cC = 2 };
 
-    const double c07 = .7 * K.c_0, KK = K.buoy_g, hdt = .5 * K.dt, dt = K.dt, dt6 = K.dt * K.i_six;
-    const double cb1000 = K.coeff_buoy * 1000.;
+    // (wave-uniform constants, kept in scalar registers: the vector registers are needed for two packets)
+    double c07 = uniform(.7 * K.c_0), KK = K.buoy_g, hdt = uniform(.5 * K.dt), dt = K.dt, dt6 = uniform(K.dt * K.i_six);
+    double cb1000 = uniform(K.coeff_buoy * 1000.);
+    SPIN(KK); SPIN(dt);
     double xm1[3], xm2[3] = { 0., 0., 0. };
 #pragma unroll
     for (int n = 0; n < 3; n++) xm1[n] = gld(a.x[n], o_lev);
 
-    for (int j = 1; j <= NR; j++) {
-        const bool window = j >= 2 && j < jm - 3;
+    // A row's packet in registers.  The packet of row j+1 is fetched while row j is worked on (its slot was written rows
+    // ago), so two of these are alive at a time and the loop below takes the rows in twos.
+    struct Packet {
+        int w_rdy, w_st;
+        double cA, H1, H2, cAr, cR, pgn, qu1, qu2, rw, rsw, rw2, rsw2, cFac4, cMF;
+        double q1[2], q2[2], st[3], xn[3], cP[3], kq[3], cBr[3];
+    };
+    // Words first, then the packet: a packet read behind a word that says "there" is the packet (a wave's LDS reads are
+    // carried out in order); nothing is waited for here.  In two parts: one is fetched while the row before is in its
+    // stages, the other (what the top of a row needs: the factors of the two rows before, then the coefficients the
+    // stages do not change) when the registers of that row's stages are free again.
+    auto fetch_main = [&](Packet& P, const int j) {
         const HalfA& S = sh.ha[j & 3];
+        asm volatile("" ::: "memory");
+        P.w_rdy = *LDS_WORD(&sh.ctlA[j & 3].rdy); P.w_st = *LDS_WORD(&sh.ctlA[j & 3].stored);
+        asm volatile("" ::: "memory");
+        P.cA = S.cA[lane]; P.pgn = S.pgn[lane];
+        P.rw = S.rw[lane]; P.rsw = S.rsw[lane]; P.rw2 = S.rw2[lane]; P.rsw2 = S.rsw2[lane];
+#pragma unroll
+        for (int m = 0; m < 3; m++) { P.st[m] = S.x0[m][lane]; P.xn[m] = S.xn[m][lane]; }
+        if constexpr (TOP) { P.cFac4 = S.cFac4[lane]; P.cMF = S.cMF[lane]; } else { P.cFac4 = 0.; P.cMF = 0.; }
+        asm volatile("" ::: "memory");
+    };
+    auto fetch_top = [&](Packet& P, const int j) {
+        const HalfA& S = sh.ha[j & 3];
+        asm volatile("" ::: "memory");
+        P.H1 = S.H1[lane]; P.H2 = S.H2[lane]; P.qu1 = S.qu1[lane]; P.qu2 = S.qu2[lane];
+#pragma unroll
+        for (int c = 0; c < 2; c++) { P.q1[c] = S.q1[c][lane]; P.q2[c] = S.q2[c][lane]; }
+#pragma unroll
+        for (int m = 0; m < 3; m++) P.kq[m] = S.KQ[m][lane];
+        P.cAr = S.cAr[lane]; P.cR = S.cR[lane];   // (first needed a little later: by the first evaluation)
+#pragma unroll
+        for (int m = 0; m < 3; m++) { P.cP[m] = S.cP[m][lane]; P.cBr[m] = S.cBr[m][lane]; }
+        asm volatile("" ::: "memory");
+    };
+    auto row = [&](const int j, Packet& P, Packet& N) {
+        const bool window = j >= 2 && j < jm - 3;
         double (*vst)[64] = sh.vst[j & 1];
         double (*ust)[64] = sh.ust[j & 1];
         double (*out)[64] = sh.outA[j & 3];
-        double cA, H1, H2, cAr, cR, pgn, qu1, qu2, rw, rsw, rw2, rsw2, cFac4 = 0., cMF = 0.;
-        double st[3], xn[3], cB[3], cQ[3], cP[3], cBr[3], acc[3], rhs[3], q1[2], q2[2], kq[3];
-        // words first, then the packet, in one go; read again if the words say "not yet" (see k_rk_atm_pipe.hip)
-        for (int n = 0;; n++) {
-            asm volatile("" ::: "memory");
-            const int w_rdy = *LDS_WORD(&sh.ctlA[j & 3].rdy), w_st = *LDS_WORD(&sh.ctlA[j & 3].stored);
-            const int w_b = *LDS_WORD(&sh.doneB);
-            asm volatile("" ::: "memory");
-            cA = S.cA[lane]; H1 = S.H1[lane]; H2 = S.H2[lane]; cAr = S.cAr[lane];
-            cR = S.cR[lane]; pgn = S.pgn[lane]; qu1 = S.qu1[lane]; qu2 = S.qu2[lane];
-            rw = S.rw[lane]; rsw = S.rsw[lane]; rw2 = S.rw2[lane]; rsw2 = S.rsw2[lane];
-#pragma unroll
-            for (int c = 0; c < 2; c++) { q1[c] = S.q1[c][lane]; q2[c] = S.q2[c][lane]; }
-#pragma unroll
-            for (int m = 0; m < 3; m++) { st[m] = S.x0[m][lane]; xn[m] = S.xn[m][lane]; cP[m] = S.cP[m][lane]; kq[m] = S.KQ[m][lane]; cBr[m] = S.cBr[m][lane]; }
-            if constexpr (TOP) { cFac4 = S.cFac4[lane]; cMF = S.cMF[lane]; }
-            asm volatile("" ::: "memory");
-            if (__builtin_amdgcn_readfirstlane(w_rdy) >= j && __builtin_amdgcn_readfirstlane(w_st) >= j - 4 &&
-                __builtin_amdgcn_readfirstlane(w_b) >= j - 2) break;
-            __builtin_amdgcn_s_sleep(1);
-            if (n > (1 << 22)) {
-                __hip_atomic_store(err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                break;
-            }
+        // the packet was fetched a row ago; if its word said "not yet" then, the word is waited for and it is read again
+        if (__builtin_amdgcn_readfirstlane(P.w_rdy) < j) {
+            wait_for(&sh.ctlA[j & 3].rdy, j, err);
+            fetch_main(P, j);
         }
+        fetch_top(P, j);
+        const int w_b = *LDS_WORD(&sh.doneB);   // (looked at below, before the first stage value is written)
+        double cB[3], cQ[3], acc[3], rhs[3];
 #pragma unroll
         for (int n = 0; n < 3; n++) {
-            const double alias = n < 2 ? q2[n] : qu2;   // pole-side rows: KB of the variable
+            const double alias = n < 2 ? P.q2[n] : P.qu2;   // pole-side rows: KB of the variable
             const double kb = window ? 0. : alias;
-            const double q2n = window ? q2[CLS[n]] : 0.;
-            cB[n] = __builtin_fma(H1, xm1[n], __builtin_fma(window ? H2 : 0., xm2[n], kb));
-            cQ[n] = __builtin_fma(q1[CLS[n]], xm1[n], __builtin_fma(q2n, xm2[n], kq[n]));
+            const double q2n = window ? P.q2[CLS[n]] : 0.;
+            cB[n] = __builtin_fma(P.H1, xm1[n], __builtin_fma(window ? P.H2 : 0., xm2[n], kb));
+            cQ[n] = __builtin_fma(P.q1[CLS[n]], xm1[n], __builtin_fma(q2n, xm2[n], P.kq[n]));
         }
-        cQ[cV] = __builtin_fma(qu1, xm1[cU], __builtin_fma(window ? qu2 : 0., xm2[cU], cQ[cV]));  // 2 du/dthe / rm^2 / re
+        cQ[cV] = __builtin_fma(P.qu1, xm1[cU], __builtin_fma(window ? P.qu2 : 0., xm2[cU], cQ[cV]));  // 2 du/dthe / rm^2 / re
+#pragma unroll
+        for (int n = 0; n < 3; n++) { PIN(cB[n]); PIN(cQ[n]); }
+        // the next row's packet, read while this row's stages are worked out
+        if (j + 1 <= NR) fetch_main(N, j + 1);
+        // the buffer of the stage values is free once chain B has done row j-2
+        if (__builtin_amdgcn_readfirstlane(w_b) < j - 2) wait_for(&sh.doneB, j - 2, err);
+        double rw = P.rw, rsw = P.rsw;
         double RS = 0., sb = 0., pgv = 0.;
 #pragma unroll
         for (int s = 0; s < 4; s++) {
-            const double v = st[cV], u = st[cU];
+            const double v = P.st[cV], u = P.st[cU];
             vst[s][lane] = v; ust[s][lane] = u;
             // RHS_Hyd.cpp:345, 374-377: density of the salt water, buoyancy, pressure gradient
-            const double swr = __builtin_fma(c07, st[cC], rw);
+            const double swr = __builtin_fma(c07, P.st[cC], rw);
             const double y = rcp2(swr);
             RS = KK * __builtin_fma(rsw, y, -1.);
             sb = swr - rsw;
-            pgv = pgn * y;
+            pgv = P.pgn * y;
             double lin[3];
 #pragma unroll
-            for (int n = 0; n < 3; n++) lin[n] = __builtin_fma(cP[n], st[n], cQ[n]);
+            for (int n = 0; n < 3; n++) lin[n] = __builtin_fma(P.cP[n], P.st[n], cQ[n]);
             lin[cU] += RS;
-            lin[cV] = __builtin_fma(cR, u, lin[cV]) - pgv;
+            lin[cV] = __builtin_fma(P.cR, u, lin[cV]) - pgv;
             if constexpr (TOP) {  // surface evaporation source of c (RHS_Hyd.cpp:355-372)
-                double sal = swr * __builtin_fma(cFac4, st[cC], cMF);
+                double sal = swr * __builtin_fma(P.cFac4, P.st[cC], P.cMF);
                 sal = fmin(fmax(sal, -20.), 20.);
                 lin[cC] += sal;
             }
-            if (s == 0) { rw = rw2; rsw = rsw2; }   // on land the following evaluations see the rewritten densities
+            if (s == 0) { rw = P.rw2; rsw = P.rsw2; }   // on land the following evaluations see the rewritten densities
 #pragma unroll
             for (int n = 0; n < 3; n++) {
-                const double tv = __builtin_fma(-v, __builtin_fma(cA, st[n], cB[n]), lin[n]);
-                rhs[n] = TOP ? tv : __builtin_fma(-u, __builtin_fma(cAr, st[n], cBr[n]), tv);
+                const double tv = __builtin_fma(-v, __builtin_fma(P.cA, P.st[n], cB[n]), lin[n]);
+                rhs[n] = TOP ? tv : __builtin_fma(-u, __builtin_fma(P.cAr, P.st[n], P.cBr[n]), tv);
                 // RungeKutta_Hyd.cpp:56-120
-                if (s == 0) { acc[n] = rhs[n]; st[n] = __builtin_fma(rhs[n], hdt, xn[n]); }
-                else if (s == 1) { acc[n] = __builtin_fma(2., rhs[n], acc[n]); st[n] = __builtin_fma(rhs[n], hdt, xn[n]); }
-                else if (s == 2) { acc[n] = __builtin_fma(2., rhs[n], acc[n]); st[n] = __builtin_fma(rhs[n], dt, xn[n]); }
-                else st[n] = __builtin_fma(acc[n] + rhs[n], dt6, xn[n]);
+                if (s == 0) { acc[n] = rhs[n]; P.st[n] = __builtin_fma(rhs[n], hdt, P.xn[n]); }
+                else if (s == 1) { acc[n] = __builtin_fma(2., rhs[n], acc[n]); P.st[n] = __builtin_fma(rhs[n], hdt, P.xn[n]); }
+                else if (s == 2) { acc[n] = __builtin_fma(2., rhs[n], acc[n]); P.st[n] = __builtin_fma(rhs[n], dt, P.xn[n]); }
+                else P.st[n] = __builtin_fma(acc[n] + rhs[n], dt6, P.xn[n]);
             }
         }
-        // results and the side outputs of the fourth evaluation, for the memory wave of the slot to store
 #pragma unroll
-        for (int n = 0; n < 3; n++) { out[n][lane] = st[n]; xm2[n] = xm1[n]; xm1[n] = st[n]; }
+        for (int n = 0; n < 3; n++) { PIN(P.st[n]); PIN(rhs[n]); }
+        PIN(RS); PIN(sb); PIN(pgv);
+        // results and the side outputs of the fourth evaluation, for the memory wave of the slot to store; the slot's
+        // output arrays are free once row j-4 has been stored
+        if (__builtin_amdgcn_readfirstlane(P.w_st) < j - 4) wait_for(&sh.ctlA[j & 3].stored, j - 4, err);
+#pragma unroll
+        for (int n = 0; n < 3; n++) { out[n][lane] = P.st[n]; xm2[n] = xm1[n]; xm1[n] = P.st[n]; }
         out[3][lane] = rhs[cU]; out[4][lane] = rhs[cV] + pgv; out[5][lane] = RS * cb1000; out[6][lane] = sb;
         announce_in_order(&sh.doneA, j, lane);
+    };
+    Packet X, Y;
+    fetch_main(X, 1);
+    for (int j = 1; j <= NR; j += 2) {
+        row(j, X, Y);
+        if (j + 1 <= NR) row(j + 1, Y, X);
     }
 }
 
@@ -584,12 +634,15 @@ __device__ void copy_shell(const PipeArgs& a, unsigned part, unsigned parts, int
     }
 }
 
-// Waves of the 1 024-thread workgroup: w and w + 4 (and w + 8, w + 12) share a SIMD.  Wave 0 is chain A, wave 1 chain B,
-// and the waves that would share their SIMDs end at once; the eight waves on the other two SIMDs are the memory waves:
-// rows r = q mod 4 belong to the pair (2 + 4 q, 3 + 4 q).  One wave of a pair works for chain A, the other for chain B;
-// chain A's half of a row is about twice the instructions of chain B's, so which is which alternates with q and each of
-// the two SIMDs carries two waves of either kind.
-__global__ __launch_bounds__(1024) void k_hyd_rk3d_pipe(const PipeParams* __restrict__ P, int* __restrict__ progress, int* err, int ncopy) {
+// Waves of the 768-thread workgroup: w, w + 4 and w + 8 share a SIMD, and with three waves a SIMD a wave may hold 168
+// vector registers (chain A holds two packets).  Wave 0 is chain A and has its SIMD to itself (waves 4 and 8 end at once);
+// wave 1 is chain B.  Rows r = q mod 4 belong to pair q of the memory waves; the wave of a pair that works for chain A
+// has about twice the instructions of the one that works for chain B: two of the former and one of the latter on each
+// of SIMDs 2 and 3, the other two beside chain B.
+constexpr int WG = 768;
+// role of a wave: 0 chain A, 1 chain B, 2 + 2 q memory wave of pair q for chain A, 3 + 2 q for chain B, -1 none
+__constant__ const signed char ROLE[WG / 64] = { 0, 1, 2, 4,  -1, 3, 6, 8,  -1, 5, 7, 9 };
+__global__ __launch_bounds__(WG) void k_hyd_rk3d_pipe(const PipeParams* __restrict__ P, int* __restrict__ progress, int* err, int ncopy) {
     const PipeArgs& a = P->a;
     const DevConst& K = P->K;
     if (blockIdx.x >= gridDim.x - (unsigned)ncopy) {  // before anything a workgroup does together
@@ -621,15 +674,16 @@ __global__ __launch_bounds__(1024) void k_hyd_rk3d_pipe(const PipeParams* __rest
         }
     __syncthreads();   // the only barrier: from here on the waves follow each other's progress words
     const bool top = i == K.im - 2, feeds = i == K.im - 3;
-    const bool fora = ((wave & 3) == 2) != (((wave >> 2) & 1) != 0);   // (see above: the two kinds alternate on a SIMD)
-    if (wave == 0) {
+    const int role = ROLE[wave];
+    const bool fora = !(role & 1);
+    if (role == 0) {
         if (top) chain_a<true>(a, K, sh, i, bx, err);
         else chain_a<false>(a, K, sh, i, bx, err);
-    } else if (wave == 1) {
+    } else if (role == 1) {
         if (top) chain_b<true>(a, K, sh, i, bx, err);
         else chain_b<false>(a, K, sh, i, bx, err);
-    } else if ((wave & 3) >= 2) {
-        const int q = wave >> 2;
+    } else if (role >= 2) {
+        const int q = (role - 2) >> 1;
         if (K.jm <= GEO_ROWS) {
             if (fora) {
                 if (top) memory_wave<true, false, true, true>(a, K, sh, q, i, bx, progress, err);
@@ -710,19 +764,19 @@ int atomdev_hyd_rk3d_pipe(atomdev* h) {
     Blocks* D = (Blocks*)h->pipe_params;
     if (int rc = atomdev_prof_begin(h)) return rc;
     const size_t shell = (size_t)5 * (2 * h->n2 + (size_t)(h->im - 2) * 2 * (h->km + h->jm));
-    ATOMDEV_REQUIRE(shell + (size_t)256 * 1024 < ((size_t)1 << 31), "hyd_rk3d: boundary shell too large for 32-bit indices");
+    ATOMDEV_REQUIRE(shell + (size_t)256 * WG < ((size_t)1 << 31), "hyd_rk3d: boundary shell too large for 32-bit indices");
     const unsigned chunk = (h->im - 2 + 7) / 8;
     const unsigned sweep_blocks = 8 * chunk * gx;
     // the shell copy: about 32 points a thread, but on a grid that fits the chip in one go no more workgroups than the
     // sweep leaves compute units for (a workgroup of either kind takes a whole compute unit)
     int cus = 0;
     ATOMDEV_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
-    unsigned ncopy = (unsigned)std::min<size_t>(256, std::max<size_t>(16, shell / ((size_t)1024 * 32)));
+    unsigned ncopy = (unsigned)std::min<size_t>(256, std::max<size_t>(16, shell / ((size_t)WG * 32)));
     if (sweep_blocks < (unsigned)cus && sweep_blocks + ncopy > (unsigned)cus) ncopy = std::max(8u, (unsigned)cus - sweep_blocks);
 #ifdef ATOMDEV_EXP_HP_NOSHELL  // timing experiment only (results are wrong after the first sweep)
     ncopy = 0;
 #endif
-    hipLaunchKernelGGL(k_hyd_rk3d_pipe, dim3(sweep_blocks + ncopy), dim3(1024), 0, h->stream, (const PipeParams*)&D->p[o], D->progress,
+    hipLaunchKernelGGL(k_hyd_rk3d_pipe, dim3(sweep_blocks + ncopy), dim3(WG), 0, h->stream, (const PipeParams*)&D->p[o], D->progress,
                        (int*)atomdev_kernel_error_word(h), (int)ncopy);
     ATOMDEV_TRY(hipGetLastError());
     if (int rc = atomdev_prof_end(h)) return rc;
