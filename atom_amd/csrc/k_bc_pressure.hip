@@ -336,11 +336,13 @@ __global__ void k_pressure3d(double* __restrict__ p_dyn, const double* __restric
                              const uint8_t* __restrict__ flags, const double* __restrict__ rad,
                              const double* __restrict__ sinthe_t, double rho, DevConst K) {
     const int im = K.im, jm = K.jm, km = K.km;
-    // Workgroups go to the eight XCDs in turn; each XCD gets one contiguous run of (level, row, segment) triples, so the
-    // neighbour rows and levels a workgroup reads are, most of the time, already in its XCD's L2.
+    // Workgroups go to the eight XCDs in turn.  Hydrosphere: each XCD gets one contiguous run of (level, row, segment)
+    // triples, so the neighbour rows and levels a workgroup reads are, most of the time, already in its XCD's L2 (42 ->
+    // 39 us).  The atmosphere's form, which fetches most operands only where a branch needs them, is faster dealt round
+    // robin (41 us; 57 us in runs).
     const unsigned gx = (unsigned)(km - 2 + (int)blockDim.x - 1) / blockDim.x, nblk = gx * (unsigned)(jm - 2) * (unsigned)(im - 2);
-    const unsigned per = (nblk + 7) / 8, L = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    if ((blockIdx.x >> 3) >= per || L >= nblk) return;
+    const unsigned per = (nblk + 7) / 8, L = HYD ? (blockIdx.x & 7) * per + (blockIdx.x >> 3) : blockIdx.x;
+    if ((HYD && (blockIdx.x >> 3) >= per) || L >= nblk) return;
     const int k = 1 + (int)(L % gx) * (int)blockDim.x + (int)threadIdx.x;
     const int j = 1 + (int)((L / gx) % (unsigned)(jm - 2)), i = 1 + (int)(L / (gx * (unsigned)(jm - 2)));
     // What depends on the row (i, j) only - ten divisions of the reference's statements - is worked out by one thread of
