@@ -105,11 +105,15 @@ extern "C" int atomdev_atm_write_transfer_file(atomdev_t* atm, const char* path)
         host_parallel_run(pieces, [&](size_t c) {
             std::string& out = piece[c];
             out.reserve(rows * 60);
-            for (size_t q = c * rows; q < n2 && q < (c + 1) * rows; q++)
+            char line[6 * 400 + 8];   // a row at a time: one append per row, not per number
+            for (size_t q = c * rows; q < n2 && q < (c + 1) * rows; q++) {
+                char* e = line;
                 for (int n = 0; n < 6; n++) {
-                    append_fixed4(out, x[(size_t)n * n2 + q]);
-                    out += n < 5 ? ' ' : '\n';
+                    e = put_fixed4(e, x[(size_t)n * n2 + q]);
+                    *e++ = n < 5 ? ' ' : '\n';
                 }
+                out.append(line, (size_t)(e - line));
+            }
         });
         bool ok = true;
         for (const std::string& out : piece) ok = ok && std::fwrite(out.data(), 1, out.size(), f) == out.size();

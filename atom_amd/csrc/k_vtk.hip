@@ -183,9 +183,14 @@ struct Text {
         const size_t n = p.kind == 1 ? p.a.size() : std::max(p.a.size(), std::max(p.b.size(), p.c.size()));
         p.text.clear();
         p.text.reserve(n * (p.kind == 1 ? 12 : 36));
-        char b[1300];
+        // (the digits go into a local buffer that is appended when it is nearly full: one append per value costs more
+        // than the value's digits; a value may take up to 400 bytes)
+        std::vector<char> buf(1 << 16);
+        char* const b0 = buf.data();
+        char* const high = b0 + buf.size() - 1300;
+        char* e = b0;
         for (size_t q = 0; q < n; q++) {
-            char* e = b;
+            if (e > high) { p.text.append(b0, (size_t)(e - b0)); e = b0; }
             if (p.kind == 1) e = put_fixed4(e, p.a[q] * p.multiplier);  // precision(4), ios::fixed
             else {
                 e = put_fixed4(e, p.a.empty() ? 0. : p.a[q]); *e++ = ' ';
@@ -193,8 +198,8 @@ struct Text {
                 e = put_fixed4(e, p.c.empty() ? 0. : p.c[q]);
             }
             *e++ = '\n';
-            p.text.append(b, (size_t)(e - b));
         }
+        p.text.append(b0, (size_t)(e - b0));
         p.a = std::vector<double>(); p.b = std::vector<double>(); p.c = std::vector<double>();
     }
     bool write(FILE* f) {
