@@ -66,6 +66,9 @@
 #ifndef ATM_WS_AFFINE
 #define ATM_WS_AFFINE 0
 #endif
+#ifndef ATM_WS_TOPO
+#define ATM_WS_TOPO 0
+#endif
 
 namespace {
 
@@ -80,6 +83,7 @@ struct AtmWsArgs {
     const uint8_t* flags;
     const double *evap, *precip, *c3;
     const double *ph100, *h0i;                 // k_atm_prep outputs (3-D)
+    const double* topo;                        // 2-D (read by the ATM_WS_TOPO build only)
     const double *rad, *costhe;
     const double *tab_rm2sin, *tab_irm2sin, *tab_coefv;   // [i*jm + j]
 };
@@ -135,7 +139,8 @@ __global__ void k_atm_prep(const double* __restrict__ t, const double* __restric
     const size_t p = (size_t)i * jm * km + q;
     if (c3 && i == 3) c3[q] = c[p];
     const double hight = (double)i * K.topo_step;
-    ph100[p] = ph100_of(t[q], hight, K);
+    // (the tolerance form reads 100 p_h on level 1 only - the dry density has dropped out of the buoyancy - and no h_0_i array)
+    if (!ATM_WS_AFFINE || i == 1) ph100[p] = ph100_of(t[q], hight, K);
     if constexpr (WITH_H0I) h0i[p] = h0i_of(flags[p], hight, topo[q], K);
 }
 
@@ -253,12 +258,12 @@ __global__ __launch_bounds__(256) void k_atm_limit_prep(LimitFields f, const dou
     // every load first, then the pressure power (which needs the ground temperature only) while they are on their way
     const uint8_t fl = flags[p];
     const bool inner = i >= 1 && i <= K.im - 2;
-    const double t_ground = inner ? f.t[q] : 1.;
+    const double t_ground = (inner && (!ATM_WS_AFFINE || i == 1)) ? f.t[q] : 1.;
     const double topo_q = (WITH_H0I && inner) ? topo[q] : 0.;
     const double u0 = f.u[p], v0 = f.v[p], w0 = f.w[p], t0 = f.t[p], c0 = f.c[p], cl0 = f.cloud[p], ic0 = f.ice[p], co0 = f.co2[p];
     const double hight = (double)i * K.topo_step;
     if (inner) {
-        ph100[p] = ph100_of(limited<R_T>(t_ground, false), hight, K);
+        if (!ATM_WS_AFFINE || i == 1) ph100[p] = ph100_of(limited<R_T>(t_ground, false), hight, K);
         if constexpr (WITH_H0I) h0i[p] = h0i_of(fl, hight, topo_q, K);
     }
     const bool land = fl & FL_LAND;
@@ -291,6 +296,11 @@ __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K
     // the sweep itself goes on with the value it computed, as it does when the limiter runs afterwards.
     constexpr bool isV = ROLE == R_V, isU = ROLE == R_U, isT = ROLE == R_T, isC = ROLE == R_C, isW = ROLE == R_W;
     constexpr bool hasH0I = ROLE == R_U || ROLE == R_CO2 || ROLE == R_ICE || ROLE == R_CLOUD;
+    // (Tried in the tolerance form: these roles fetching the column's topography, a 2-D field that stays in the L2, and
+    // working h_0_i out themselves instead of reading a 3-D array of it.  8 bytes a point less traffic, and slower: 0.187
+    // -> 0.189 ms; the few instructions stand in the row's dependent chain.  ATM_WS_TOPO=1 builds that form.)
+    constexpr bool AFFINE_TOPO = ATM_WS_TOPO != 0;
+    constexpr bool needs_ph = isT && (!ATM_WS_AFFINE || L1);   // 100 p_h: tolerance form on level 1 only
     const int jm = K.jm, km = K.km;
     const int lane = threadIdx.x & 63;
     const int kk = 1 + bx * 64 + lane;
@@ -334,7 +344,7 @@ __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K
     // source-term fields of the role (bases stay scalar)
     const double *E1 = nullptr, *E2 = nullptr, *E3 = nullptr, *E4 = nullptr, *E5 = nullptr;
     if constexpr (isT) { E1 = a.ph100; E2 = a.S_c; E3 = a.S_r; E4 = a.S_i; E5 = a.S_s; }
-    if constexpr (hasH0I) E1 = a.h0i;
+    if constexpr (hasH0I) E1 = AFFINE_TOPO ? a.topo : a.h0i;
     if constexpr (ROLE == R_ICE) E2 = a.S_i;
     if constexpr (ROLE == R_CLOUD) E2 = a.S_c;
     if constexpr (isC) { E2 = a.S_v; E1 = a.evap; E3 = a.precip; E4 = a.c; E5 = a.c3; }
@@ -362,7 +372,7 @@ __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K
     };
     auto load_sources = [&](unsigned o, unsigned q) {
         if constexpr (isT) { n_r2 = ldg(E2, o); n_r3 = ldg(E3, o); n_r4 = ldg(E4, o); n_r5 = ldg(E5, o); }
-        if constexpr (hasH0I) n_r1 = ldg(E1, o);
+        if constexpr (hasH0I) n_r1 = ldg(E1, AFFINE_TOPO ? q : o);
         if constexpr (ROLE == R_ICE || ROLE == R_CLOUD || isC) n_r2 = ldg(E2, o);
         if constexpr (isC) {
             if (lvl1) { n_r1 = ldg(E1, q); n_r3 = ldg(E3, q); n_r4 = ldg(E4, q); n_r5 = ldg(E5, q); }
@@ -378,7 +388,7 @@ __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K
     load_table(1);
     // t wave: 100 p_h of rows j and j+1; row j+2 is fetched at the top of step j
     double ph_cur = 0., ph_nxt = 0., n_ph2 = 0.;
-    if constexpr (isT) { ph_cur = ldg(E1, o0); ph_nxt = ldg(E1, o1); }
+    if constexpr (needs_ph) { ph_cur = ldg(E1, o0); ph_nxt = ldg(E1, o1); }
 
     // what the other waves need of a new t or c value (RHS_Atm.cpp:385, 390-404)
     constexpr bool AFFINE = ATM_WS_AFFINE;
@@ -449,7 +459,7 @@ __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K
         double xp2 = 0., yp2 = 0., up2 = 0.;
         if (exp_mem && j + 2 < jm) {
             xp2 = ldg(X, o2);
-            if constexpr (isT) n_ph2 = ldg(E1, o2);
+            if constexpr (needs_ph) n_ph2 = ldg(E1, o2);
             if constexpr (isV) { yp2 = ldg(E1, o2); up2 = ldg(E2, o2); }
         }
         if (exp_mem) load_sources(o1, q1);
@@ -474,7 +484,7 @@ __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K
             theta_terms(mode, um2, um1, up1, uB, uC, pF, pG);
         }
         if constexpr (isW) h_0 = (fl & FL_H0K) ? 1. : 0.;
-        if constexpr (hasH0I) h_0 = e_a;  // h_0_i
+        if constexpr (hasH0I) h_0 = AFFINE_TOPO ? h0i_of(fl, (double)i * K.topo_step, e_a, K) : e_a;  // h_0_i
 
         double st = x0, acc = 0., rhs = 0., RS = 0.;
         // ---- affine form: coefficients of the row ----
@@ -688,7 +698,7 @@ int ATM_WS_ENTRY(atomdev* h, bool limit, bool limit_before) {
     a.flags = h->flags;
     a.evap = h->g[ATOMDEV_EVAPORATION_DALTON]; a.precip = h->g[ATOMDEV_PRECIPITATION];
     a.c3 = h->plane;
-    a.ph100 = h->scr[0]; a.h0i = h->scr[1];
+    a.ph100 = h->scr[0]; a.h0i = h->scr[1]; a.topo = h->g[ATOMDEV_TOPOGRAPHY];
     a.rad = h->rad; a.costhe = h->costhe;
     a.tab_rm2sin = h->tab_rm2sin; a.tab_irm2sin = h->tab_irm2sin; a.tab_coefv = h->tab_coefv;
     P.K = h->k;
@@ -708,20 +718,20 @@ int ATM_WS_ENTRY(atomdev* h, bool limit, bool limit_before) {
         LimitFields lf = { h->f[ATOMDEV_U], h->f[ATOMDEV_V], h->f[ATOMDEV_W], h->f[ATOMDEV_T], h->f[ATOMDEV_C],
                            h->f[ATOMDEV_CLOUD], h->f[ATOMDEV_ICE], h->f[ATOMDEV_CO2], h->f[ATOMDEV_P_DYN] };
         const unsigned nb = (unsigned)((h->n3 + 255) / 256);
-        if (h->h0i_valid)
+        if (ATM_WS_TOPO || h->h0i_valid)
             hipLaunchKernelGGL(k_atm_limit_prep<false>, dim3(nb), dim3(256), 0, h->stream, lf, h->g[ATOMDEV_TOPOGRAPHY], h->flags,
                                h->scr[0], h->scr[1], c3, h->k, h->n3);
         else
             hipLaunchKernelGGL(k_atm_limit_prep<true>, dim3(nb), dim3(256), 0, h->stream, lf, h->g[ATOMDEV_TOPOGRAPHY], h->flags,
                                h->scr[0], h->scr[1], c3, h->k, h->n3);
-    } else if (h->h0i_valid)
+    } else if (ATM_WS_TOPO || h->h0i_valid)
         hipLaunchKernelGGL(k_atm_prep<false>, pg, dim3(128), 0, h->stream, h->f[ATOMDEV_T], h->g[ATOMDEV_TOPOGRAPHY], h->flags,
                            h->scr[0], h->scr[1], h->f[ATOMDEV_C], c3, h->k);
     else
         hipLaunchKernelGGL(k_atm_prep<true>, pg, dim3(128), 0, h->stream, h->f[ATOMDEV_T], h->g[ATOMDEV_TOPOGRAPHY], h->flags,
                            h->scr[0], h->scr[1], h->f[ATOMDEV_C], c3, h->k);
     ATOMDEV_TRY(hipGetLastError());
-    h->h0i_valid = true;
+    if (!ATM_WS_TOPO) h->h0i_valid = true;
     if (h->profile_rk == 1)
         if (int rc = atomdev_prof_begin(h)) return rc;  // the bracket of the sweep kernel alone
     const unsigned gx = (h->km - 2 + 63) / 64, rounds = (h->im - 2 + 7) / 8;
