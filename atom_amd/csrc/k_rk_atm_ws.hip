@@ -35,6 +35,8 @@
 // stage, only runs the three-instruction quotient step.  The instruction sequence, and therefore
 // every bit of the quotient, is the one the compiler emits for a / b on operands that need no
 // range scaling, which holds for densities and mixing ratios.
+#include <cstdlib>
+
 #include "atomdev_internal.h"
 
 // This file is compiled twice.  As it stands: every quotient carries the bits of the reference's division
@@ -245,7 +247,10 @@ __device__ __forceinline__ double limited(double x, bool land) {
 // already limited changes nothing).  BC_SolidGround (BC_Bath_Atm.cpp:94-119) right after this limiter would write
 // what the limiter's land rule has just written, so the pass stands for both.
 struct LimitFields { double *u, *v, *w, *t, *c, *cloud, *ice, *co2, *p_dyn; };
-template <bool WITH_H0I>
+// SHELL: the form for a sweep that limits the old values of its own points as it loads them (tolerance form): only the
+// points on the six faces, which the sweep reads but does not store, are limited here; of the others p_dyn is zeroed on
+// land, and level 3's c goes to the plane as the limiter would leave it.
+template <bool WITH_H0I, bool SHELL = false>
 __global__ __launch_bounds__(256) void k_atm_limit_prep(LimitFields f, const double* __restrict__ topo,
                                                         const uint8_t* __restrict__ flags, double* __restrict__ ph100,
                                                         double* __restrict__ h0i, double* __restrict__ c3, DevConst K, size_t n) {
@@ -258,10 +263,19 @@ __global__ __launch_bounds__(256) void k_atm_limit_prep(LimitFields f, const dou
     // every load first, then the pressure power (which needs the ground temperature only) while they are on their way
     const uint8_t fl = flags[p];
     const bool inner = i >= 1 && i <= K.im - 2;
+    const double hight = (double)i * K.topo_step;
+    if constexpr (SHELL) {
+        const int j = (int)(q / (size_t)km), k = (int)(q - (size_t)j * km);
+        if (inner && j >= 1 && j <= jm - 2 && k >= 1 && k <= km - 2) {
+            if (i == 1) ph100[p] = ph100_of(limited<R_T>(f.t[q], false), hight, K);
+            if (fl & FL_LAND) f.p_dyn[p] = 0.;
+            if (c3 && i == 3) c3[q] = limited<R_C>(f.c[p], (fl & FL_LAND) != 0);
+            return;
+        }
+    }
     const double t_ground = (inner && (!ATM_WS_AFFINE || i == 1)) ? f.t[q] : 1.;
     const double topo_q = (WITH_H0I && inner) ? topo[q] : 0.;
     const double u0 = f.u[p], v0 = f.v[p], w0 = f.w[p], t0 = f.t[p], c0 = f.c[p], cl0 = f.cloud[p], ic0 = f.ice[p], co0 = f.co2[p];
-    const double hight = (double)i * K.topo_step;
     if (inner) {
         if (!ATM_WS_AFFINE || i == 1) ph100[p] = ph100_of(limited<R_T>(t_ground, false), hight, K);
         if constexpr (WITH_H0I) h0i[p] = h0i_of(fl, hight, topo_q, K);
@@ -289,7 +303,10 @@ __global__ __launch_bounds__(256) void k_atm_limit_prep(LimitFields f, const dou
 // of row j+1 is read from LDS in stage 4.  Nothing loaded in a step is used before the next step.
 // L1: the instantiation for level 1 (the t and c waves only: the evaporation source of c and the dry density it needs),
 // so that the other levels carry no test for it inside their stages.
-template <int ROLE, bool limit, bool L1 = false>
+// LOADLIM: the old values of the sweep's own points (the variable's rows 1 .. jm-2, and for the v wave the rows of p_dyn
+// and u it reads) pass through the limiter as they are taken over - what a limiter and BC_SolidGround run just before
+// the sweep would have left in memory; the rows 0 and jm-1 have been limited in memory by k_atm_limit_prep<.., true>.
+template <int ROLE, bool limit, bool L1 = false, bool LOADLIM = false>
 __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K, Shared& sh, const double* tab,
                                            int bx, int i, double* __restrict__ X, const double* __restrict__ XN) {
     // limit: what goes to memory is the value as the limiter that follows the sweep in the model's loop would leave it;
@@ -361,6 +378,18 @@ __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K
         ym1 = ldg(E1, o0 - rowB); y0 = ldg(E1, o0); yp1 = ldg(E1, o1);
         um1 = ldg(E2, o0 - rowB); up1 = ldg(E2, o1);
     }
+    // LOADLIM: the mask byte of row j+2, whose old values are taken over at the end of step j (a step then loads that
+    // byte instead of the one of row j+1, which it already has), and the byte of row j+1
+    unsigned n_fl2 = 0, fl_nn = 0;
+    if constexpr (LOADLIM) {
+        fl_nn = ldg_u8(FL, o1 >> 3);
+        const bool land1 = ldg_u8(FL, o0 >> 3) & FL_LAND, land2 = fl_nn & FL_LAND;
+        x0 = limited<ROLE>(x0, land1); xp1 = limited<ROLE>(xp1, land2);
+        if constexpr (isV) {
+            y0 = land1 ? 0. : y0; yp1 = land2 ? 0. : yp1;
+            up1 = limited<R_U>(up1, land2);
+        }
+    }
 
     // raw inputs of the next step, loaded during this one
     double n_xn, n_r1 = 0., n_r2 = 0., n_r3 = 0., n_r4 = 0., n_r5 = 0.;
@@ -368,7 +397,7 @@ __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K
     uint8_t n_fl;
     auto load_top = [&](unsigned o) {  // xn, flags
         n_xn = ldg(XN, o);
-        n_fl = ldg_u8(FL, o >> 3);
+        if constexpr (!LOADLIM) n_fl = ldg_u8(FL, o >> 3);
     };
     auto load_sources = [&](unsigned o, unsigned q) {
         if constexpr (isT) { n_r2 = ldg(E2, o); n_r3 = ldg(E3, o); n_r4 = ldg(E4, o); n_r5 = ldg(E5, o); }
@@ -384,6 +413,7 @@ __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K
         if constexpr (isV) n_coefv = row[3];
     };
     load_top(o0);
+    if constexpr (LOADLIM) n_fl = ldg_u8(FL, o0 >> 3);
     load_sources(o0, q1 - rowB);
     load_table(1);
     // t wave: 100 p_h of rows j and j+1; row j+2 is fetched at the top of step j
@@ -433,6 +463,13 @@ __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K
     for (int j = 1; j < jm - 1; j++) {
         // (Idle lanes shadow the last line: they load what its owner loads and store the same bits.)
         STAMP(0);
+        if constexpr (LOADLIM) {
+            if (j > 1) {   // (rows 1 and 2 were limited before the loop)
+                const bool land_p1 = fl_nn & FL_LAND;
+                xp1 = limited<ROLE>(xp1, land_p1);
+                if constexpr (isV) { yp1 = land_p1 ? 0. : yp1; up1 = limited<R_U>(up1, land_p1); }
+            }
+        }
         // ---- take over the prefetched inputs of this step, start loading the next step's ----
         const double xn = n_xn;
         const uint8_t fl = n_fl;
@@ -459,6 +496,7 @@ __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K
         double xp2 = 0., yp2 = 0., up2 = 0.;
         if (exp_mem && j + 2 < jm) {
             xp2 = ldg(X, o2);
+            if constexpr (LOADLIM) n_fl2 = ldg_u8(FL, o2 >> 3);
             if constexpr (needs_ph) n_ph2 = ldg(E1, o2);
             if constexpr (isV) { yp2 = ldg(E1, o2); up2 = ldg(E2, o2); }
         }
@@ -620,6 +658,14 @@ __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K
         if (j > 1) __builtin_amdgcn_s_waitcnt(0x0F70 | NST);  // vmcnt(NST)
         else __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0): the first step stores nothing
         STAMP(10);
+        if constexpr (LOADLIM) {
+            // (the loaded values are taken as they are here, behind the wait: worked on any earlier, the compiler waits
+            // for the step's loads in the middle of the stages; the limiting itself is the next step's, which has room
+            // for it - inside the window of backward differences row j+1 is not needed before the step's last stage)
+            asm volatile("" : "+v"(xp2), "+v"(n_fl2));
+            if constexpr (isV) asm volatile("" : "+v"(yp2), "+v"(up2));
+            n_fl = (uint8_t)fl_nn; fl_nn = n_fl2;
+        }
         xm2 = xm1; xm1 = st; x0 = xp1; xp1 = xp2;
         land_prev = land;
         if constexpr (isV) { ym2 = ym1; ym1 = y0; y0 = yp1; yp1 = yp2; um2 = um1; up1 = up2; }
@@ -631,7 +677,7 @@ __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K
     if constexpr (isV || isW) stg(O1, o0 - rowB, so1);
 }
 
-template <bool LIMIT>
+template <bool LIMIT, bool LOADLIM = false>
 __global__ __launch_bounds__(512) void k_atm_rk3d_ws(const AtmWsParams* __restrict__ P) {
     const AtmWsArgs& a = P->a;
     const DevConst& K = P->K;
@@ -660,19 +706,19 @@ __global__ __launch_bounds__(512) void k_atm_rk3d_ws(const AtmWsParams* __restri
         __syncthreads();
     }
     switch (threadIdx.x >> 6) {
-        case R_U: sweep_role<R_U, LIMIT>(a, K, sh, tab, bx, i, a.u, a.un); break;
-        case R_V: sweep_role<R_V, LIMIT>(a, K, sh, tab, bx, i, a.v, a.vn); break;
+        case R_U: sweep_role<R_U, LIMIT, false, LOADLIM>(a, K, sh, tab, bx, i, a.u, a.un); break;
+        case R_V: sweep_role<R_V, LIMIT, false, LOADLIM>(a, K, sh, tab, bx, i, a.v, a.vn); break;
         case R_T:
-            if (ATM_WS_AFFINE && i == 1) sweep_role<R_T, LIMIT, ATM_WS_AFFINE != 0>(a, K, sh, tab, bx, i, a.t, a.tn);
-            else sweep_role<R_T, LIMIT>(a, K, sh, tab, bx, i, a.t, a.tn);
+            if (ATM_WS_AFFINE && i == 1) sweep_role<R_T, LIMIT, ATM_WS_AFFINE != 0, LOADLIM>(a, K, sh, tab, bx, i, a.t, a.tn);
+            else sweep_role<R_T, LIMIT, false, LOADLIM>(a, K, sh, tab, bx, i, a.t, a.tn);
             break;
-        case R_W: sweep_role<R_W, LIMIT>(a, K, sh, tab, bx, i, a.w, a.wn); break;
-        case R_CO2: sweep_role<R_CO2, LIMIT>(a, K, sh, tab, bx, i, a.co2, a.co2n); break;
-        case R_ICE: sweep_role<R_ICE, LIMIT>(a, K, sh, tab, bx, i, a.ice, a.icen); break;
-        case R_CLOUD: sweep_role<R_CLOUD, LIMIT>(a, K, sh, tab, bx, i, a.cloud, a.cloudn); break;
+        case R_W: sweep_role<R_W, LIMIT, false, LOADLIM>(a, K, sh, tab, bx, i, a.w, a.wn); break;
+        case R_CO2: sweep_role<R_CO2, LIMIT, false, LOADLIM>(a, K, sh, tab, bx, i, a.co2, a.co2n); break;
+        case R_ICE: sweep_role<R_ICE, LIMIT, false, LOADLIM>(a, K, sh, tab, bx, i, a.ice, a.icen); break;
+        case R_CLOUD: sweep_role<R_CLOUD, LIMIT, false, LOADLIM>(a, K, sh, tab, bx, i, a.cloud, a.cloudn); break;
         default:
-            if (ATM_WS_AFFINE && i == 1) sweep_role<R_C, LIMIT, ATM_WS_AFFINE != 0>(a, K, sh, tab, bx, i, a.c, a.cn);
-            else sweep_role<R_C, LIMIT>(a, K, sh, tab, bx, i, a.c, a.cn);
+            if (ATM_WS_AFFINE && i == 1) sweep_role<R_C, LIMIT, ATM_WS_AFFINE != 0, LOADLIM>(a, K, sh, tab, bx, i, a.c, a.cn);
+            else sweep_role<R_C, LIMIT, false, LOADLIM>(a, K, sh, tab, bx, i, a.c, a.cn);
             break;
     }
 #ifdef ATOMDEV_EXP_WGTIME
@@ -714,11 +760,17 @@ int ATM_WS_ENTRY(atomdev* h, bool limit, bool limit_before) {
     else ATOMDEV_TRY(hipMemcpyAsync(h->plane, h->f[ATOMDEV_C] + 3 * h->n2, h->n2 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     if (h->profile_rk == 2)
         if (int rc = atomdev_prof_begin(h)) return rc;  // the bracket of the whole operator
+    // tolerance form, wave-specialised sweep: the limiter in front of the sweep touches the six faces only and the sweep
+    // limits the old values of its own points as it takes them over (same bits; the pass over all points is 36 us)
+    const bool load_limited = ATM_WS_AFFINE && limit_before && limit && h->rk_variant == 2 && !getenv("ATOMDEV_NO_LOAD_LIMIT");
     if (limit_before) {
         LimitFields lf = { h->f[ATOMDEV_U], h->f[ATOMDEV_V], h->f[ATOMDEV_W], h->f[ATOMDEV_T], h->f[ATOMDEV_C],
                            h->f[ATOMDEV_CLOUD], h->f[ATOMDEV_ICE], h->f[ATOMDEV_CO2], h->f[ATOMDEV_P_DYN] };
         const unsigned nb = (unsigned)((h->n3 + 255) / 256);
-        if (ATM_WS_TOPO || h->h0i_valid)
+        if (load_limited && (ATM_WS_TOPO || h->h0i_valid))
+            hipLaunchKernelGGL((k_atm_limit_prep<false, ATM_WS_AFFINE != 0>), dim3(nb), dim3(256), 0, h->stream, lf, h->g[ATOMDEV_TOPOGRAPHY], h->flags,
+                               h->scr[0], h->scr[1], c3, h->k, h->n3);
+        else if (ATM_WS_TOPO || h->h0i_valid)
             hipLaunchKernelGGL(k_atm_limit_prep<false>, dim3(nb), dim3(256), 0, h->stream, lf, h->g[ATOMDEV_TOPOGRAPHY], h->flags,
                                h->scr[0], h->scr[1], c3, h->k, h->n3);
         else
@@ -731,6 +783,7 @@ int ATM_WS_ENTRY(atomdev* h, bool limit, bool limit_before) {
         hipLaunchKernelGGL(k_atm_prep<true>, pg, dim3(128), 0, h->stream, h->f[ATOMDEV_T], h->g[ATOMDEV_TOPOGRAPHY], h->flags,
                            h->scr[0], h->scr[1], h->f[ATOMDEV_C], c3, h->k);
     ATOMDEV_TRY(hipGetLastError());
+    const bool h0i_was_valid = h->h0i_valid;   // (the first call of a mask takes the pass that also prepares h_0_i)
     if (!ATM_WS_TOPO) h->h0i_valid = true;
     if (h->profile_rk == 1)
         if (int rc = atomdev_prof_begin(h)) return rc;  // the bracket of the sweep kernel alone
@@ -740,7 +793,9 @@ int ATM_WS_ENTRY(atomdev* h, bool limit, bool limit_before) {
     const size_t tab_bytes = (size_t)h->jm * 4 * sizeof(double);
     if (h->rk_variant == 3) {  // the pipelined sweep takes the same prepared inputs
         if (int rc = atomdev_atm_rk3d_pipe_launch(h, limit)) return rc;
-    } else if (limit)
+    } else if (load_limited && (ATM_WS_TOPO || h0i_was_valid))
+        hipLaunchKernelGGL((k_atm_rk3d_ws<true, ATM_WS_AFFINE != 0>), grid, dim3(512), tab_bytes, h->stream, (const AtmWsParams*)h->ws_params);
+    else if (limit)
         hipLaunchKernelGGL(k_atm_rk3d_ws<true>, grid, dim3(512), tab_bytes, h->stream, (const AtmWsParams*)h->ws_params);
     else
         hipLaunchKernelGGL(k_atm_rk3d_ws<false>, grid, dim3(512), tab_bytes, h->stream, (const AtmWsParams*)h->ws_params);

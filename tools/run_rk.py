@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Runs a few RK sweeps on the full 1-degree grid (for rocprofv3 passes).
-usage: python3 tools/run_rk.py atm|hyd [sweeps]"""
+usage: python3 tools/run_rk.py atm|hyd [sweeps] [IMxJMxKM]"""
 import os
 import sys
 
@@ -24,7 +24,7 @@ d = atom_amd.DeviceModel(model, im, jm, km, atom_amd.Params.from_buffer_copy(byt
 d.upload_all(f, g)
 d.profile_rk(2 if os.environ.get("RUN_RK_OPERATOR") else True)  # RUN_RK_OPERATOR: the preparing kernel is timed too
 for _ in range(n):
-    d.op("atm_rk3d" if model == H.ATM else "hyd_rk3d")
+    d.op(os.environ.get("RUN_RK_OP") or ("atm_rk3d" if model == H.ATM else "hyd_rk3d"))  # RUN_RK_OP: another call that holds the sweep
     if os.environ.get("RUN_RK_MOVE"):  # a streaming copy of known size, to calibrate byte counters against
         d.move_data_to_new_arrays(-1)
 ms, cnt = d.profile_read()
