@@ -108,16 +108,29 @@ struct Shared {
 
 // ---- prep: everything per point that does not change during the sweep -------------------------
 // ph100 = 100 * p_h, p_h from RHS_Atm.cpp:384-389 (t0jk: t at the ground of the column)
+#if ATM_WS_AFFINE
+// Tolerance form: x^y as exp(y log x), a few units in the last place off and half the instructions.  Three kernels work
+// this value out for the same points (the preparing pass, the limiting pass and its faces-and-rows form) and must agree
+// to the bit, while what the compiler fuses - inside an inlined exp or log, or of a product that one kernel finds to be
+// the same for a whole loop and another does not - depends on the code around it: so this is one function that is
+// called, not inlined.  The tolerance form needs the value on level 1 only; the call costs nothing there.
+__device__ __attribute__((noinline)) double ph100_called(double t0jk, double hight, double t_0, double p_SL_factor, double gam,
+                                                         double exp_pressure) {
+    const double t0K = t0jk * t_0;
+    const double p_SL = .01 * (p_SL_factor * t0jk * t_0);
+    return 100. * (exp(exp_pressure * log((t0K - gam * hight * 1.e-2) / t0K)) * p_SL);
+}
+__device__ __forceinline__ double ph100_of(double t0jk, double hight, const DevConst& K) {
+    return ph100_called(t0jk, hight, K.t_0, K.p_SL_factor, K.gam, K.exp_pressure);
+}
+#else
 __device__ __forceinline__ double ph100_of(double t0jk, double hight, const DevConst& K) {
     const double t0K = t0jk * K.t_0;
     const double p_SL = .01 * (K.p_SL_factor * t0jk * K.t_0);
-#if ATM_WS_AFFINE  // tolerance form: x^y as exp(y log x), a few units in the last place off and half the instructions
-    const double p_h = exp(K.exp_pressure * log((t0K - K.gam * hight * 1.e-2) / t0K)) * p_SL;
-#else
     const double p_h = pow((t0K - K.gam * hight * 1.e-2) / t0K, K.exp_pressure) * p_SL;
-#endif
     return 100. * p_h;
 }
+#endif
 // h_0_i from RHS_Atm.cpp:110-124: static, depends on the mask and the topography only
 __device__ __forceinline__ double h0i_of(uint8_t fl, double hight, double topo, const DevConst& K) {
     double h_0_i = 1.;
@@ -247,35 +260,17 @@ __device__ __forceinline__ double limited(double x, bool land) {
 // already limited changes nothing).  BC_SolidGround (BC_Bath_Atm.cpp:94-119) right after this limiter would write
 // what the limiter's land rule has just written, so the pass stands for both.
 struct LimitFields { double *u, *v, *w, *t, *c, *cloud, *ice, *co2, *p_dyn; };
-// SHELL: the form for a sweep that limits the old values of its own points as it loads them (tolerance form): only the
-// points on the six faces, which the sweep reads but does not store, are limited here; of the others p_dyn is zeroed on
-// land, and level 3's c goes to the plane as the limiter would leave it.
-template <bool WITH_H0I, bool SHELL = false>
-__global__ __launch_bounds__(256) void k_atm_limit_prep(LimitFields f, const double* __restrict__ topo,
-                                                        const uint8_t* __restrict__ flags, double* __restrict__ ph100,
-                                                        double* __restrict__ h0i, double* __restrict__ c3, DevConst K, size_t n) {
-    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    const int jm = K.jm, km = K.km;
-    const size_t n2 = (size_t)jm * km;
-    const int i = (int)(p / n2);
-    const size_t q = p - (size_t)i * n2;
+template <bool WITH_H0I>
+__device__ __forceinline__ void limit_prep_point(const LimitFields& f, const double* __restrict__ topo, const uint8_t* __restrict__ flags,
+                                                 double* __restrict__ ph100, double* __restrict__ h0i, double* __restrict__ c3,
+                                                 const DevConst& K, size_t p, size_t q, int i) {
     // every load first, then the pressure power (which needs the ground temperature only) while they are on their way
     const uint8_t fl = flags[p];
     const bool inner = i >= 1 && i <= K.im - 2;
-    const double hight = (double)i * K.topo_step;
-    if constexpr (SHELL) {
-        const int j = (int)(q / (size_t)km), k = (int)(q - (size_t)j * km);
-        if (inner && j >= 1 && j <= jm - 2 && k >= 1 && k <= km - 2) {
-            if (i == 1) ph100[p] = ph100_of(limited<R_T>(f.t[q], false), hight, K);
-            if (fl & FL_LAND) f.p_dyn[p] = 0.;
-            if (c3 && i == 3) c3[q] = limited<R_C>(f.c[p], (fl & FL_LAND) != 0);
-            return;
-        }
-    }
     const double t_ground = (inner && (!ATM_WS_AFFINE || i == 1)) ? f.t[q] : 1.;
     const double topo_q = (WITH_H0I && inner) ? topo[q] : 0.;
     const double u0 = f.u[p], v0 = f.v[p], w0 = f.w[p], t0 = f.t[p], c0 = f.c[p], cl0 = f.cloud[p], ic0 = f.ice[p], co0 = f.co2[p];
+    const double hight = (double)i * K.topo_step;
     if (inner) {
         if (!ATM_WS_AFFINE || i == 1) ph100[p] = ph100_of(limited<R_T>(t_ground, false), hight, K);
         if constexpr (WITH_H0I) h0i[p] = h0i_of(fl, hight, topo_q, K);
@@ -292,6 +287,57 @@ __global__ __launch_bounds__(256) void k_atm_limit_prep(LimitFields f, const dou
     put(f.co2, co0, limited<R_CO2>(co0, land));
     if (land) f.p_dyn[p] = 0.;
     if (c3 && i == 3) c3[q] = c_now;
+}
+template <bool WITH_H0I>
+__global__ __launch_bounds__(256) void k_atm_limit_prep(LimitFields f, const double* __restrict__ topo,
+                                                        const uint8_t* __restrict__ flags, double* __restrict__ ph100,
+                                                        double* __restrict__ h0i, double* __restrict__ c3, DevConst K, size_t n) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const size_t n2 = (size_t)K.jm * K.km;
+    const int i = (int)(p / n2);
+    limit_prep_point<WITH_H0I>(f, topo, flags, ph100, h0i, c3, K, p, p - (size_t)i * n2, i);
+}
+// The form for a sweep that limits the old values of its own points as it takes them over (tolerance form): only the
+// points on the six faces, which the sweep reads but does not store, are limited here (the first nb_faces workgroups:
+// levels 0 and im-1, then of every other level the rows j = 0, jm-1 and the columns k = 0, km-1); of the others (a
+// workgroup a row) p_dyn is zeroed on land, level 1 gets its pressure term and level 3's c goes to the plane as the
+// limiter would leave it.
+__global__ __launch_bounds__(256) void k_atm_limit_faces_prep(LimitFields f, const uint8_t* __restrict__ flags,
+                                                              double* __restrict__ ph100, double* __restrict__ c3, DevConst K,
+                                                              unsigned nb_faces) {
+    const int im = K.im, jm = K.jm, km = K.km;
+    const size_t n2 = (size_t)jm * km;
+    if (blockIdx.x < nb_faces) {
+        const unsigned rim = 2u * (unsigned)km + 2u * (unsigned)(jm - 2), total = 2u * (unsigned)n2 + (unsigned)(im - 2) * rim;
+        const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
+        if (idx >= total) return;
+        int i, j, k;
+        if (idx < 2u * (unsigned)n2) {
+            i = idx < (unsigned)n2 ? 0 : im - 1;
+            const unsigned q = idx < (unsigned)n2 ? idx : idx - (unsigned)n2;
+            j = (int)(q / (unsigned)km); k = (int)(q - (unsigned)j * (unsigned)km);
+        } else {
+            const unsigned r = idx - 2u * (unsigned)n2, e = r % rim;
+            i = 1 + (int)(r / rim);
+            if (e < (unsigned)km) { j = 0; k = (int)e; }
+            else if (e < 2u * (unsigned)km) { j = jm - 1; k = (int)e - km; }
+            else { j = 1 + (int)((e - 2u * (unsigned)km) >> 1); k = (e & 1u) ? km - 1 : 0; }
+        }
+        const size_t q = (size_t)j * km + k;
+        limit_prep_point<false>(f, nullptr, flags, ph100, nullptr, c3, K, (size_t)i * n2 + q, q, i);
+        return;
+    }
+    const unsigned row = blockIdx.x - nb_faces;   // (level, row) of interior points
+    const int i = 1 + (int)(row / (unsigned)(jm - 2)), j = 1 + (int)(row % (unsigned)(jm - 2));
+    const double hight = (double)i * K.topo_step;
+    for (int k = 1 + (int)threadIdx.x; k <= km - 2; k += (int)blockDim.x) {
+        const size_t q = (size_t)j * km + k, p = (size_t)i * n2 + q;
+        const bool land = flags[p] & FL_LAND;
+        if (i == 1) ph100[p] = ph100_of(limited<R_T>(f.t[q], false), hight, K);
+        if (land) f.p_dyn[p] = 0.;
+        if (c3 && i == 3) c3[q] = limited<R_C>(f.c[p], land);
+    }
 }
 
 // The whole sweep of one wave.  ROLE is a template parameter so that every wave runs
@@ -768,8 +814,13 @@ int ATM_WS_ENTRY(atomdev* h, bool limit, bool limit_before) {
                            h->f[ATOMDEV_CLOUD], h->f[ATOMDEV_ICE], h->f[ATOMDEV_CO2], h->f[ATOMDEV_P_DYN] };
         const unsigned nb = (unsigned)((h->n3 + 255) / 256);
         if (load_limited && (ATM_WS_TOPO || h->h0i_valid))
-            hipLaunchKernelGGL((k_atm_limit_prep<false, ATM_WS_AFFINE != 0>), dim3(nb), dim3(256), 0, h->stream, lf, h->g[ATOMDEV_TOPOGRAPHY], h->flags,
-                               h->scr[0], h->scr[1], c3, h->k, h->n3);
+        {
+            const size_t faces = 2 * h->n2 + (size_t)(h->im - 2) * (2 * (size_t)h->km + 2 * (size_t)(h->jm - 2));
+            ATOMDEV_REQUIRE(faces < ((size_t)1 << 31), "atm_rk3d: the six faces hold more than 2^31 points");
+            const unsigned nb_faces = (unsigned)((faces + 255) / 256);
+            hipLaunchKernelGGL(k_atm_limit_faces_prep, dim3(nb_faces + (unsigned)(h->im - 2) * (unsigned)(h->jm - 2)), dim3(256), 0, h->stream, lf,
+                               h->flags, h->scr[0], c3, h->k, nb_faces);
+        }
         else if (ATM_WS_TOPO || h->h0i_valid)
             hipLaunchKernelGGL(k_atm_limit_prep<false>, dim3(nb), dim3(256), 0, h->stream, lf, h->g[ATOMDEV_TOPOGRAPHY], h->flags,
                                h->scr[0], h->scr[1], c3, h->k, h->n3);
