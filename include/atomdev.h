@@ -152,7 +152,10 @@ int atomdev_atm_rk3d_limited(atomdev_t* h);
  * every field ends with the bits atomdev_atm_value_limitation, atomdev_atm_solid_ground, atomdev_atm_rk3d and
  * atomdev_atm_value_limitation leave.  The first limiter runs in the kernel that prepares the sweep's per-point
  * inputs (BC_SolidGround after it writes what the limiter's land rule has just written), the last one in the sweep's
- * stores (outside the sweep's points the first limiter has left it nothing to do). */
+ * stores (outside the sweep's points the first limiter has left it nothing to do).  With the handle's default form of
+ * the sweep (rk_variant 2) the first limiter touches memory on the six faces only and the sweep passes the old values
+ * of its own points - which it overwrites anyway - through the limiter as it loads them: same bits, one pass over the
+ * fields less.  ATOMDEV_NO_LOAD_LIMIT=1 in the environment keeps the pass over all points. */
 int atomdev_atm_limit_ground_rk3d_limit(atomdev_t* h);
 /* solveRungeKutta_2D_Atmosphere + RK_RHS_2D_Atmosphere
  * (atmosphere/RungeKutta_Atm.cpp:163-217, RHS_Atm.cpp:498-678) */
