@@ -349,8 +349,8 @@ __global__ __launch_bounds__(256) void k_atm_limit_faces_prep(LimitFields f, con
 // of row j+1 is read from LDS in stage 4.  Nothing loaded in a step is used before the next step.
 // L1: the instantiation for level 1 (the t and c waves only: the evaporation source of c and the dry density it needs),
 // so that the other levels carry no test for it inside their stages.
-// LOADLIM: the old values of the sweep's own points (the variable's rows 1 .. jm-2, and for the v wave the rows of p_dyn
-// and u it reads) pass through the limiter as they are taken over - what a limiter and BC_SolidGround run just before
+// LOADLIM: the old values of the sweep's own points (the variable's rows 1 .. jm-2, and for the v wave the rows of u it
+// reads; p_dyn, which the sweep does not store, has been zeroed on land in memory) pass through the limiter as they are taken over - what a limiter and BC_SolidGround run just before
 // the sweep would have left in memory; the rows 0 and jm-1 have been limited in memory by k_atm_limit_prep<.., true>.
 template <int ROLE, bool limit, bool L1 = false, bool LOADLIM = false>
 __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K, Shared& sh, const double* tab,
@@ -431,10 +431,7 @@ __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K
         fl_nn = ldg_u8(FL, o1 >> 3);
         const bool land1 = ldg_u8(FL, o0 >> 3) & FL_LAND, land2 = fl_nn & FL_LAND;
         x0 = limited<ROLE>(x0, land1); xp1 = limited<ROLE>(xp1, land2);
-        if constexpr (isV) {
-            y0 = land1 ? 0. : y0; yp1 = land2 ? 0. : yp1;
-            up1 = limited<R_U>(up1, land2);
-        }
+        if constexpr (isV) up1 = limited<R_U>(up1, land2);   // (p_dyn has been zeroed on land in memory: the sweep does not store it)
     }
 
     // raw inputs of the next step, loaded during this one
@@ -513,7 +510,7 @@ __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K
             if (j > 1) {   // (rows 1 and 2 were limited before the loop)
                 const bool land_p1 = fl_nn & FL_LAND;
                 xp1 = limited<ROLE>(xp1, land_p1);
-                if constexpr (isV) { yp1 = land_p1 ? 0. : yp1; up1 = limited<R_U>(up1, land_p1); }
+                if constexpr (isV) up1 = limited<R_U>(up1, land_p1);
             }
         }
         // ---- take over the prefetched inputs of this step, start loading the next step's ----
@@ -709,7 +706,7 @@ __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K
             // for the step's loads in the middle of the stages; the limiting itself is the next step's, which has room
             // for it - inside the window of backward differences row j+1 is not needed before the step's last stage)
             asm volatile("" : "+v"(xp2), "+v"(n_fl2));
-            if constexpr (isV) asm volatile("" : "+v"(yp2), "+v"(up2));
+            if constexpr (isV) asm volatile("" : "+v"(up2));
             n_fl = (uint8_t)fl_nn; fl_nn = n_fl2;
         }
         xm2 = xm1; xm1 = st; x0 = xp1; xp1 = xp2;
