@@ -86,7 +86,7 @@ def load_ref():
 
 
 def default_params(model, im=41, jm=181, km=361):
-    """Reference defaults; dr/dthe/dphi follow the grid like the survey's synthetic configs."""
+    """Reference defaults; dr/dthe/dphi follow the grid as on the refined grids: dthe = dphi = pi / (jm - 1), dr = 1 / (im - 1)."""
     p = Params()
     load_oracle().oracle_default_params(C.c_int(model), C.byref(p))
     if (im, jm, km) != (41, 181, 361):
