@@ -54,7 +54,7 @@ def synthetic_mask(model, im, jm, km, L, rng, kind="blobs"):
 
 
 def make_inputs(model, im, jm, km, seed=1234, mask="blobs", params=None):
-    """Fields drawn inside the limiter bounds (uniform draws; S_* zero or within 1e-6; the hydrosphere's densities 1000 / 1028)."""
+    """Fields drawn inside the limiter bounds (uniform draws; the source terms within 1e-6; the hydrosphere's two densities around 1000 and 1028)."""
     rng = np.random.default_rng(seed)
     shp = (im, jm, km)
     U = lambda lo, hi: rng.uniform(lo, hi, shp)
