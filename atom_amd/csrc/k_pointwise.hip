@@ -2,6 +2,8 @@
 // All are pure streaming kernels over the flat phi-fastest arrays (HBM-bound).
 #include <float.h>
 
+#include <cstdlib>
+
 #include "atomdev_internal.h"
 
 namespace {
@@ -54,6 +56,20 @@ __global__ void k_copy_lists(CPtrList src, PtrList dst, int nf, size_t off, size
     size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= n) return;
     for (int f = 0; f < nf; f++) dst.p[f][off + id] = 1. * src.p[f][off + id];
+}
+// the same for whole fields (16-byte aligned, as every allocation of the library is), two neighbouring points a thread
+__global__ void k_copy_lists_pairs(CPtrList src, PtrList dst, int nf, size_t n) {
+    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x, pairs = n >> 1;
+    if (id < pairs) {
+        for (int f = 0; f < nf; f++) {
+            typedef double pair_t __attribute__((ext_vector_type(2)));
+            const pair_t v = __builtin_nontemporal_load(reinterpret_cast<const pair_t*>(src.p[f]) + id);
+            const pair_t w = { 1. * v.x, 1. * v.y };
+            __builtin_nontemporal_store(w, reinterpret_cast<pair_t*>(dst.p[f]) + id);
+        }
+    } else if (id == pairs && (n & 1)) {
+        for (int f = 0; f < nf; f++) dst.p[f][n - 1] = 1. * src.p[f][n - 1];
+    }
 }
 
 // Stores x only where its bits differ from what the field holds: a limiter changes few points, and the
@@ -192,7 +208,10 @@ extern "C" int atomdev_move_data_to_new_arrays(atomdev_t* h, int level) {
         nf = 3; off = (size_t)level * h->n2; n = h->n2;
         for (int f = 0; f < nf; f++) { s.p[f] = h->f[O2[f]]; d.p[f] = h->f[O2[f] + 9]; }
     }
-    hipLaunchKernelGGL(k_copy_lists, dim3(blocks_for(n)), dim3(TPB), 0, h->stream, s, d, nf, off, n);
+    if (level < 0 && !getenv("ATOMDEV_COPY_ONE_BY_ONE"))
+        hipLaunchKernelGGL(k_copy_lists_pairs, dim3(blocks_for((n >> 1) + 1)), dim3(TPB), 0, h->stream, s, d, nf, n);
+    else
+        hipLaunchKernelGGL(k_copy_lists, dim3(blocks_for(n)), dim3(TPB), 0, h->stream, s, d, nf, off, n);
     ATOMDEV_TRY(hipGetLastError());
     return 0;
 }
