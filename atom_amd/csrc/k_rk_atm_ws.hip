@@ -191,6 +191,14 @@ __device__ __forceinline__ uint8_t ldg_u8(const uint8_t* base, unsigned idx) {
 __device__ __forceinline__ void stg(double* base, unsigned off, double x) {
     *(__attribute__((address_space(1))) double*)((gchar_t)base + off) = x;
 }
+// The same with the non-temporal hint, for what a step touches once: the old-time-level fields and the source terms
+// (read), the side outputs (written).  The last-level cache then keeps the fields the next kernels read again.
+__device__ __forceinline__ double ldg_once(const double* base, unsigned off) {
+    return __builtin_nontemporal_load((const __attribute__((address_space(1))) double*)((gcchar_t)base + off));
+}
+__device__ __forceinline__ void stg_once(double* base, unsigned off, double x) {
+    __builtin_nontemporal_store(x, (__attribute__((address_space(1))) double*)((gchar_t)base + off));
+}
 
 // 1/b to the accuracy the fp64 division sequence uses: hardware estimate plus two Newton steps.
 __device__ __forceinline__ double rcp_refined(double b) {
@@ -439,13 +447,13 @@ __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K
     double n_cos, n_rm2sin, n_irm2sin, n_coefv = 0.;
     uint8_t n_fl;
     auto load_top = [&](unsigned o) {  // xn, flags
-        n_xn = ldg(XN, o);
+        n_xn = ldg_once(XN, o);
         if constexpr (!LOADLIM) n_fl = ldg_u8(FL, o >> 3);
     };
     auto load_sources = [&](unsigned o, unsigned q) {
-        if constexpr (isT) { n_r2 = ldg(E2, o); n_r3 = ldg(E3, o); n_r4 = ldg(E4, o); n_r5 = ldg(E5, o); }
+        if constexpr (isT) { n_r2 = ldg_once(E2, o); n_r3 = ldg_once(E3, o); n_r4 = ldg_once(E4, o); n_r5 = ldg_once(E5, o); }
         if constexpr (hasH0I) n_r1 = ldg(E1, AFFINE_TOPO ? q : o);
-        if constexpr (ROLE == R_ICE || ROLE == R_CLOUD || isC) n_r2 = ldg(E2, o);
+        if constexpr (ROLE == R_ICE || ROLE == R_CLOUD || isC) n_r2 = ldg_once(E2, o);
         if constexpr (isC) {
             if (lvl1) { n_r1 = ldg(E1, q); n_r3 = ldg(E3, q); n_r4 = ldg(E4, q); n_r5 = ldg(E5, q); }
         }
@@ -606,8 +614,8 @@ __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K
         }
         auto store_prev = [&]() {  // results of the previous row
             stg(X, o0 - rowB, limit ? limited<ROLE>(xm1, land_prev) : xm1);
-            if constexpr (isU) { stg(O1, o0 - rowB, so1); stg(O2, o0 - rowB, so2); }
-            if constexpr (isV || isW) stg(O1, o0 - rowB, so1);
+            if constexpr (isU) { stg_once(O1, o0 - rowB, so1); stg_once(O2, o0 - rowB, so2); }
+            if constexpr (isV || isW) stg_once(O1, o0 - rowB, so1);
         };
 #pragma unroll
         for (int s = 0; s < 4; s++) {
@@ -716,8 +724,8 @@ __device__ __forceinline__ void sweep_role(const AtmWsArgs& a, const DevConst& K
         o0 += rowB; o1 += rowB; o2 += rowB; q1 += rowB;
     }
     stg(X, o0 - rowB, limit ? limited<ROLE>(xm1, land_prev) : xm1);  // row jm-2
-    if constexpr (isU) { stg(O1, o0 - rowB, so1); stg(O2, o0 - rowB, so2); }
-    if constexpr (isV || isW) stg(O1, o0 - rowB, so1);
+    if constexpr (isU) { stg_once(O1, o0 - rowB, so1); stg_once(O2, o0 - rowB, so2); }
+    if constexpr (isV || isW) stg_once(O1, o0 - rowB, so1);
 }
 
 template <bool LIMIT, bool LOADLIM = false>
