@@ -109,6 +109,14 @@ __device__ __forceinline__ double gld(const double* base, unsigned off) {
 __device__ __forceinline__ void gst(double* base, unsigned off, double x) {
     *(__attribute__((address_space(1))) double*)((gchar_t)base + off) = x;
 }
+// The same with the non-temporal hint, for what a step touches once (the old-time-level fields and the source terms read,
+// the side outputs written): the last-level cache then keeps the fields the next kernels read again.
+__device__ __forceinline__ double gld_once(const double* base, unsigned off) {
+    return __builtin_nontemporal_load((const __attribute__((address_space(1))) double*)((gcchar_t)base + off));
+}
+__device__ __forceinline__ void gst_once(double* base, unsigned off, double x) {
+    __builtin_nontemporal_store(x, (__attribute__((address_space(1))) double*)((gchar_t)base + off));
+}
 #define PIN(x) asm volatile("" : "+v"(x))
 // A constant of the argument block as a value in scalar registers: without this the compiler may turn a per-lane choice
 // between two such constants into a per-lane choice of ADDRESS and a vector load in the middle of the loop.
@@ -220,18 +228,18 @@ __device__ __forceinline__ void memory_wave(const PipeArgs& a, const DevConst& K
         const unsigned o = o_lev + (unsigned)r * rowB;
         lfl = *(const __attribute__((address_space(1))) uint8_t*)((gcchar_t)a.flags + (o >> 3));
 #pragma unroll
-        for (int n = 0; n < 4; n++) { lx[n] = gld(a.x[VARS[n]], o); lxn[n] = gld(a.xn[VARS[n]], o); }
+        for (int n = 0; n < 4; n++) { lx[n] = gld(a.x[VARS[n]], o); lxn[n] = gld_once(a.xn[VARS[n]], o); }
         if (!geo_lds) { lcos = gld(a.costhe + r, 0u); lirs = gld(a.tab_irm2sin + (size_t)i * jm + r, 0u); }
         ltopo = gld(a.topo, o_sfc + (unsigned)r * rowB);   // (a 2-D field: stays in the L2)
         if constexpr (FORA) {
-            lS[0] = gld(a.S_c, o); lS[1] = gld(a.S_r, o); lS[2] = gld(a.S_i, o); lS[3] = gld(a.S_s, o); lS[4] = gld(a.S_v, o);
+            lS[0] = gld_once(a.S_c, o); lS[1] = gld_once(a.S_r, o); lS[2] = gld_once(a.S_i, o); lS[3] = gld_once(a.S_s, o); lS[4] = gld_once(a.S_v, o);
             if (!geo_lds) lcoefv = gld(a.tab_coefv + (size_t)i * jm + r, 0u);
             lp[0] = r >= 2 ? gld(a.p_dyn, o - 2u * rowB) : 0.;
             lp[1] = gld(a.p_dyn, o - rowB);
             lp[2] = gld(a.p_dyn, o);
             lp[3] = gld(a.p_dyn, o + rowB);
         } else {
-            lS[0] = gld(a.S_c, o); lS[2] = gld(a.S_i, o);
+            lS[0] = gld_once(a.S_c, o); lS[2] = gld_once(a.S_i, o);
         }
         const bool window = r >= 2 && r < jm - 3;
         if (!window) {
@@ -260,9 +268,9 @@ __device__ __forceinline__ void memory_wave(const PipeArgs& a, const DevConst& K
             gst(a.x[V_U], o, LIMIT ? limited<V_U>(u, land) : u);
             gst(a.x[V_C], o, LIMIT ? limited<V_C>(c, land) : c);
             gst(a.x[V_T], o, LIMIT ? limited<V_T>(t, land) : t);
-            gst(a.aux_u, o, land ? 0. : au);
-            gst(a.aux_v, o, land ? 0. : av);
-            gst(a.buoy, o, land ? 0. : bu);
+            gst_once(a.aux_u, o, land ? 0. : au);
+            gst_once(a.aux_v, o, land ? 0. : av);
+            gst_once(a.buoy, o, land ? 0. : bu);
         } else {
             const double (*out)[64] = sh.outB[q];
             const double w = out[0][lane], cl = out[1][lane], ic = out[2][lane], co = out[3][lane], aw = out[4][lane];
@@ -270,7 +278,7 @@ __device__ __forceinline__ void memory_wave(const PipeArgs& a, const DevConst& K
             gst(a.x[V_CLOUD], o, LIMIT ? limited<V_CLOUD>(cl, land) : cl);
             gst(a.x[V_ICE], o, LIMIT ? limited<V_ICE>(ic, land) : ic);
             gst(a.x[V_CO2], o, LIMIT ? limited<V_CO2>(co, land) : co);
-            gst(a.aux_w, o, land ? 0. : aw);
+            gst_once(a.aux_w, o, land ? 0. : aw);
         }
         announce(&ctl->stored, rs, lane);   // (waits until the values have left LDS)
     };

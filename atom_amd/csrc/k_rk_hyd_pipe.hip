@@ -93,6 +93,14 @@ __device__ __forceinline__ double gld(const double* base, unsigned off) {
 __device__ __forceinline__ void gst(double* base, unsigned off, double x) {
     *(__attribute__((address_space(1))) double*)((gchar_t)base + off) = x;
 }
+// The same with the non-temporal hint, for what a step touches once (the old-time-level fields and the source terms read,
+// the side outputs written): the last-level cache then keeps the fields the next kernels read again.
+__device__ __forceinline__ double gld_once(const double* base, unsigned off) {
+    return __builtin_nontemporal_load((const __attribute__((address_space(1))) double*)((gcchar_t)base + off));
+}
+__device__ __forceinline__ void gst_once(double* base, unsigned off, double x) {
+    __builtin_nontemporal_store(x, (__attribute__((address_space(1))) double*)((gchar_t)base + off));
+}
 // device-scope accesses (written through / fetched past the XCD's L2), for the rows that cross workgroups
 __device__ __forceinline__ void gst_agent(double* base, unsigned off, double x) {
     __hip_atomic_store((__attribute__((address_space(1))) double*)((gchar_t)base + off), x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -217,7 +225,7 @@ __device__ __forceinline__ void memory_wave(const PipeArgs& a, const DevConst& K
         lfl = *(const __attribute__((address_space(1))) uint8_t*)((gcchar_t)a.flags + (o >> 3));
 #pragma unroll
         for (int n = 0; n < NV; n++) {
-            lx[n] = gld(a.x[VARS[n]], o); lxn[n] = gld(a.xn[VARS[n]], o);
+            lx[n] = gld(a.x[VARS[n]], o); lxn[n] = gld_once(a.xn[VARS[n]], o);
 #ifdef ATOMDEV_EXP_HP_NOXA  // timing experiment only (results are wrong): the level above is not fetched
             lxa[n] = 0.;
 #else
@@ -228,7 +236,7 @@ __device__ __forceinline__ void memory_wave(const PipeArgs& a, const DevConst& K
         lbathy = gld(a.bathy, oq);
         if constexpr (FORA) {
             if constexpr (!geo_lds) lcoefv = gld(a.tab_coefv + (size_t)i * jm + r, 0u);
-            lrw = gld(a.r_water, o); lrsw = gld(a.r_salt_water, o);
+            lrw = gld_once(a.r_water, o); lrsw = gld_once(a.r_salt_water, o);
             lp[0] = r >= 2 ? gld(a.p_dyn, o - 2u * rowB) : 0.;
             lp[1] = gld(a.p_dyn, o - rowB);
             lp[2] = gld(a.p_dyn, o);
@@ -269,19 +277,19 @@ __device__ __forceinline__ void memory_wave(const PipeArgs& a, const DevConst& K
             if constexpr (FEEDS) gst_agent(a.xo[X_C], o, c); else gst(a.xo[X_C], o, c);
             double sfinger, sdiff;
             if (sb < 0.) { sdiff = sb; sfinger = 0.; } else { sfinger = sb; sdiff = 0.; }
-            gst(a.aux_u, o, land ? 0. : au);
-            gst(a.aux_v, o, land ? 0. : av);
-            gst(a.buoy, o, land ? 0. : bu);
-            gst(a.salt_balance, o, land ? 0. : sb);
-            gst(a.salt_finger, o, land ? 0. : sfinger);
-            gst(a.salt_diffusion, o, land ? 0. : sdiff);
+            gst_once(a.aux_u, o, land ? 0. : au);
+            gst_once(a.aux_v, o, land ? 0. : av);
+            gst_once(a.buoy, o, land ? 0. : bu);
+            gst_once(a.salt_balance, o, land ? 0. : sb);
+            gst_once(a.salt_finger, o, land ? 0. : sfinger);
+            gst_once(a.salt_diffusion, o, land ? 0. : sdiff);
             if (land) { gst(a.r_water, o, 1007.); gst(a.r_salt_water, o, 1032.); }
         } else {
             const double (*out)[64] = sh.outB[q];
             const double t = out[0][lane], w = out[1][lane], aw = out[2][lane];
             gst(a.xo[X_T], o, t);
             gst(a.xo[X_W], o, w);
-            gst(a.aux_w, o, land ? 0. : aw);
+            gst_once(a.aux_w, o, land ? 0. : aw);
         }
         announce(&ctl->stored, rs, lane);   // (waits until the values have left LDS)
     };
