@@ -2,6 +2,7 @@
 # usage (on the GPU box, from the repo root): tools/pmc.sh <tag> <model> [IMxJMxKM] -- one rocprofv3 --pmc pass per counter group
 set -u
 export RUN_RK_MOVE=1
+export ATOMDEV_COPY_ONE_BY_ONE=1   # the calibrating copy moves 8 bytes a lane, like the sweeps
 tag=$1; model=$2; dims=${3:-41x181x361}
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
