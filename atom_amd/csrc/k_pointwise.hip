@@ -57,13 +57,15 @@ __global__ void k_copy_lists(CPtrList src, PtrList dst, int nf, size_t off, size
     if (id >= n) return;
     for (int f = 0; f < nf; f++) dst.p[f][off + id] = 1. * src.p[f][off + id];
 }
-// the same for whole fields (16-byte aligned, as every allocation of the library is), two neighbouring points a thread
+// the same for whole fields (16-byte aligned, as every allocation of the library is), two neighbouring points a thread,
+// the stores with the non-temporal hint
 __global__ void k_copy_lists_pairs(CPtrList src, PtrList dst, int nf, size_t n) {
     const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x, pairs = n >> 1;
     if (id < pairs) {
         for (int f = 0; f < nf; f++) {
             typedef double pair_t __attribute__((ext_vector_type(2)));
-            const pair_t v = __builtin_nontemporal_load(reinterpret_cast<const pair_t*>(src.p[f]) + id);
+            // (plain loads: what is read here is what the kernels after the copy read again; the copies are read once)
+            const pair_t v = reinterpret_cast<const pair_t*>(src.p[f])[id];
             const pair_t w = { 1. * v.x, 1. * v.y };
             __builtin_nontemporal_store(w, reinterpret_cast<pair_t*>(dst.p[f]) + id);
         }
