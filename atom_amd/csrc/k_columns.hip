@@ -31,7 +31,7 @@ __global__ void k_hyd_pressure_density(const double* __restrict__ t, const doubl
         const double cc = c[id], t_Celsius_1 = t_Celsius_0;
         const double alfa_t_p = .0708 * (1. + .068 * t_Celsius_1);
         const double gamma_t_p = .003 * (1. - .012 * t_Celsius_1);
-        p_stat[id] = ps_above;
+        __builtin_nontemporal_store(ps_above, p_stat + id);   // (nothing in the loop reads p_stat: kept out of the last-level cache)
         r_water[id] = rw_above;
         r_salt_water[id] = 999.83 + .808 * cc * c_0 - alfa_t_p * t_Celsius_1 - gamma_t_p * (c_0 - cc * c_0) * t_Celsius_1;
     }
@@ -49,7 +49,7 @@ __global__ void k_hyd_pressure_density(const double* __restrict__ t, const doubl
         const double beta_p = .808 - .0085 * p_km;
         const double alfa_t_p = .0708 * (1. + .351 * p_km + .068 * (1. - .0683 * p_km) * t_Celsius_1);
         const double gamma_t_p = .003 * (1. - .059 * p_km - .012 * (1. - .064 * p_km) * t_Celsius_1);
-        p_stat[id] = ps;
+        __builtin_nontemporal_store(ps, p_stat + id);
         r_water[id] = rw;
         r_salt_water[id] = C_p + beta_p * cc * c_0 - alfa_t_p * t_Celsius_1 - gamma_t_p * (c_0 - cc * c_0) * t_Celsius_1;
         ps_above = ps; rw_above = rw; t_Celsius_0 = t_Celsius_1;

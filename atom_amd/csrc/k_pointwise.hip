@@ -140,7 +140,7 @@ __global__ void k_hyd_solid_ground(PtrList x /* p t c u v w */, PtrList xn, doub
     if (!(flags[id] & FL_LAND)) return;
     const double val[6] = { pa, ta, ca, 0., 0., 0. };
 #pragma unroll
-    for (int f = 0; f < 6; f++) { x.p[f][id] = val[f]; xn.p[f][id] = val[f]; }
+    for (int f = 0; f < 6; f++) { x.p[f][id] = val[f]; __builtin_nontemporal_store(val[f], xn.p[f] + id); }   // (the old-time-level fields are read once a step)
 }
 
 inline unsigned blocks_for(size_t n) { return (unsigned)((n + TPB - 1) / TPB); }

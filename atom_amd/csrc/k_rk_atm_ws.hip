@@ -197,7 +197,11 @@ __device__ __forceinline__ double ldg_once(const double* base, unsigned off) {
     return __builtin_nontemporal_load((const __attribute__((address_space(1))) double*)((gcchar_t)base + off));
 }
 __device__ __forceinline__ void stg_once(double* base, unsigned off, double x) {
+#ifdef ATOMDEV_EXP_PLAIN_AUX   // timing experiment only
+    *(__attribute__((address_space(1))) double*)((gchar_t)base + off) = x;
+#else
     __builtin_nontemporal_store(x, (__attribute__((address_space(1))) double*)((gchar_t)base + off));
+#endif
 }
 
 // 1/b to the accuracy the fp64 division sequence uses: hardware estimate plus two Newton steps.
