@@ -476,7 +476,9 @@ def main():
                          "limiter_on_loads": load_limit,
                          # what a kernel that only moves the sweep's bytes in the sweep's pattern reaches (profiles/r03_stream_pattern.txt)
                          "pattern_bound_note": "35 row-strided streams read and written together by 234 workgroups reach 3.75 TB/s = 0.47 of "
-                                               "peak whatever the kernel does between load and store (tools/ubench/stream_pattern.hip; offline measurement)",
+                                               "peak from HBM whatever the kernel does between load and store (tools/ubench/stream_pattern.hip; offline "
+                                               "measurement); on the 1-degree grid the sweeps get past that because the fields the step reads again "
+                                               "(0.22 GB) stay in the 256 MB last-level cache: everything a step touches once carries the non-temporal hint",
                          "fp64_issue": issue},
             "hydrosphere": hyd_info,
         }
